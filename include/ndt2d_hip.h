@@ -1,0 +1,271 @@
+/*
+ * ndt2d_hip.h -- C-ABI of libndt2d_hip.so: hand-written HIP (gfx950 / MI355X)
+ * kernels for ndt_2d's NDT scan-matching hot path, plus the host-side mirror of
+ * the reference's ndt_2d::ScanMatcher plugin interface for that path.
+ *
+ * Plain C, no torch / Eigen / ROS types: pointers, sizes, doubles.  Every entry
+ * point returns an int status (NDT2D_OK == 0) and never throws.  Citations are
+ * file:line in the reference repository (mikeferguson/ndt_2d @ 2024-12-18).
+ *
+ * Two layers live in the one library:
+ *
+ *  (1) device layer  ndt2d_*         one opaque context per GPU and per plugin
+ *      instance: resident NDT grid, resident beams, search tables, kernel
+ *      launches.  This is what a cgo/JNI/ctypes/pluginlib binding calls.
+ *
+ *  (2) matcher layer ndt2d_matcher_* the reference's ScanMatcherNDT object
+ *      (initialize / addScans / matchScan / scoreScan / scorePoints / reset,
+ *      include/ndt_2d/scan_matcher.hpp:42-91) restated over layer (1), plus the
+ *      additive batched particle path (ParticleFilter::measure,
+ *      src/particle_filter.cpp:78-89).  The pluginlib shim
+ *      (ndt_2d_amd/plugin/scan_matcher_ndt_hip.cpp) is a thin wrapper of it.
+ *
+ * There is NO CPU fallback behind any compute entry point: without a usable
+ * GPU they return NDT2D_ERR_NO_DEVICE / NDT2D_ERR_HIP.
+ */
+#ifndef NDT2D_HIP_H_
+#define NDT2D_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NDT2D_OK 0
+#define NDT2D_ERR_INVALID 1    /* bad argument (NULL, zero size, bad range) */
+#define NDT2D_ERR_NO_GRID 2    /* compute call before ndt2d_set_grid / addScans */
+#define NDT2D_ERR_HIP 3        /* a HIP runtime call failed; see ndt2d_last_error */
+#define NDT2D_ERR_NO_DEVICE 4  /* no GPU visible to this process */
+#define NDT2D_ERR_STATE 5      /* call sequence error (e.g. fetch before launch) */
+
+#define NDT2D_NO_INDEX UINT64_MAX
+
+/* ------------------------------------------------------------------------ */
+/* (1) device layer                                                         */
+/* ------------------------------------------------------------------------ */
+
+typedef struct ndt2d_context * ndt2d_handle;
+
+/* ABI version of this header (bumped on any signature change). */
+int ndt2d_abi_version(void);
+
+/* One context per (plugin instance, GPU).  The reference keeps all state per
+ * ScanMatcherNDT instance (std::unique_ptr<NDT> ndt_,
+ * include/ndt_2d/scan_matcher_ndt.hpp:102) and runs two instances concurrently
+ * on two threads (src/ndt_mapper.cpp:141-142,508-515,634-643): a context owns
+ * its own HIP stream and buffers and holds no process-global mutable state. */
+int ndt2d_create(ndt2d_handle * out, int device_id);
+int ndt2d_destroy(ndt2d_handle h);
+/* Message of the last failure on this context ("" if none).  Never NULL. */
+const char * ndt2d_last_error(ndt2d_handle h);
+/* Launch on a caller-owned hipStream_t instead of the context's own stream
+ * (NULL restores the own stream).  ndt2d_get_stream returns the active one. */
+int ndt2d_set_stream(ndt2d_handle h, void * hip_stream);
+void * ndt2d_get_stream(ndt2d_handle h);
+int ndt2d_device_id(ndt2d_handle h);
+
+/* Upload the NDT cell grid; replaces the NDT object built by
+ * ScanMatcherNDT::addScans (src/scan_matcher_ndt.cpp:66-73).
+ * cells6[i] = {mean_x, mean_y, information(0,0), information(0,1),
+ * information(1,1), n} for cell i = grid_y * size_x + grid_x, i.e. the fields
+ * Cell::score reads (src/ndt_model.cpp:105-116); size/origin/cell_size are
+ * NDT::size_x_, size_y_, origin_x_, origin_y_, cell_size_
+ * (include/ndt_2d/ndt_model.hpp:128-131). */
+int ndt2d_set_grid(ndt2d_handle h, const double * cells6, uint32_t size_x, uint32_t size_y,
+                   double cell_size, double origin_x, double origin_y);
+/* ScanMatcherNDT::reset (src/scan_matcher_ndt.cpp:180-183). */
+int ndt2d_clear_grid(ndt2d_handle h);
+int ndt2d_has_grid(ndt2d_handle h);
+
+/* Upload the beam endpoints of one scan, robot frame, already subsampled to
+ * min(laser_max_beams, points.size()) points by the caller
+ * (src/scan_matcher_ndt.cpp:95-96,110 / :165-166,171). */
+int ndt2d_set_beams(ndt2d_handle h, const double * beams_xy, size_t n_beams);
+
+/* Upload the search lattice of matchScan.  dth[n_th] / dlin[n_lin] are the
+ * values the reference's floating-point loops visit
+ * (`for (dth = -angular_size_; dth < angular_size_; dth += angular_res_)`,
+ * src/scan_matcher_ndt.cpp:103,117,119); cos_th/sin_th[n_th] are
+ * cos/sin(scan_pose.theta + dth[i]) evaluated by the host libm (:106-107);
+ * pose_x/pose_y = scan_pose.x/.y (:112,114). */
+int ndt2d_set_search(ndt2d_handle h, double pose_x, double pose_y, const double * dth,
+                     const double * cos_th, const double * sin_th, size_t n_th,
+                     const double * dlin, size_t n_lin);
+
+/* Result of one (possibly sharded) matchScan search,
+ * src/scan_matcher_ndt.cpp:103-143.  Candidate flat index =
+ * (i_theta * n_lin + i_x) * n_lin + i_y, the reference's loop order. */
+typedef struct ndt2d_match_result
+{
+  double best_score;      /* raw best score = -NDT::likelihood (:127); 0.0 if none < 0 */
+  uint64_t best_index;    /* flat index of the winner, NDT2D_NO_INDEX if none (:128) */
+  double acc[10];         /* k00,k01,k02,k11,k12,k22, u0,u1,u2, s  (:137-140) */
+  uint64_t n_candidates;  /* candidates evaluated by this call */
+} ndt2d_match_result;
+
+/* Number of doubles of the device-resident result record
+ * {best_score, best_index (exact double, -1 if none), acc[10]}. */
+#define NDT2D_MATCH_RECORD_DOUBLES 12
+
+/* Evaluate the theta slab [th_begin, th_end) of the lattice (all n_lin x n_lin
+ * translations of each theta).  Asynchronous on the context's stream.
+ * d_scores (device pointer, optional): receives the raw score of every
+ * candidate of the slab, slab-local flat order.  d_record (device pointer,
+ * optional): receives the NDT2D_MATCH_RECORD_DOUBLES-double result record
+ * (for a device-side all-reduce); the context always keeps its own copy. */
+int ndt2d_match_launch(ndt2d_handle h, size_t th_begin, size_t th_end, double * d_scores,
+                       double * d_record);
+/* Wait for the last ndt2d_match_launch and copy its result to the host. */
+int ndt2d_match_fetch(ndt2d_handle h, ndt2d_match_result * out);
+/* launch + fetch; h_scores (host pointer, optional) receives the slab scores. */
+int ndt2d_match(ndt2d_handle h, size_t th_begin, size_t th_end, double * h_scores,
+                ndt2d_match_result * out);
+
+/* Batched ScanMatcherNDT::scorePoints (src/scan_matcher_ndt.cpp:156-178) =
+ * the body of ParticleFilter::measure's loop (src/particle_filter.cpp:81-87):
+ * scores[i] = sum_k -likelihood(T(pose_i) * beam_k) / n_beams for the beams of
+ * ndt2d_set_beams.  d_* are device pointers; poses are {x, y, theta} triples.
+ * d_stats (optional) receives NDT2D_POSE_STATS_DOUBLES doubles:
+ * {sum w, sum w*x, sum w*y, sum w*cos(theta), sum w*sin(theta), sum w*x*x,
+ *  sum w*x*y, sum w*y*y} with w = scores[i] (un-normalised), the sums
+ * ParticleFilter::updateStatistics needs (src/particle_filter.cpp:166-200). */
+#define NDT2D_POSE_STATS_DOUBLES 8
+int ndt2d_score_poses_launch(ndt2d_handle h, const double * d_poses_xyt, size_t n_poses,
+                             double * d_scores, double * d_stats);
+/* Host-pointer convenience: H2D poses, launch, D2H scores (+ stats). */
+int ndt2d_score_poses(ndt2d_handle h, const double * h_poses_xyt, size_t n_poses,
+                      double * h_scores, double * h_stats);
+
+/* Block until everything launched on the context's stream has finished. */
+int ndt2d_synchronize(ndt2d_handle h);
+/* GPU time (HIP events on the launch stream) of the most recent
+ * ndt2d_match_launch / ndt2d_score_poses_launch, all kernels of that call.
+ * Synchronises.  *n_kernels (optional) = kernels launched by that call. */
+int ndt2d_last_launch_ms(ndt2d_handle h, float * ms, int * n_kernels);
+/* Tuning / introspection: name of the kernel variant the last launch used. */
+const char * ndt2d_last_variant(ndt2d_handle h);
+/* Force a kernel variant (testing): "auto", "lds", "global". */
+int ndt2d_set_variant(ndt2d_handle h, const char * name);
+
+/* ------------------------------------------------------------------------ */
+/* (2) matcher layer: ndt_2d::ScanMatcherNDT restated over the device layer  */
+/* ------------------------------------------------------------------------ */
+
+typedef struct ndt2d_matcher ndt2d_matcher;
+
+int ndt2d_matcher_create(ndt2d_matcher ** out, int device_id);
+int ndt2d_matcher_destroy(ndt2d_matcher * m);
+const char * ndt2d_matcher_last_error(ndt2d_matcher * m);
+/* The device context the matcher drives (for sharded launches / streams). */
+ndt2d_handle ndt2d_matcher_device(ndt2d_matcher * m);
+
+/* ScanMatcherNDT::initialize (src/scan_matcher_ndt.cpp:35-47): the six
+ * declared parameters (defaults 0.25, 0.0025, 0.1, 0.005, 0.05, 100) and
+ * range_max. */
+int ndt2d_matcher_initialize(ndt2d_matcher * m, double ndt_resolution,
+                             double search_angular_resolution, double search_angular_size,
+                             double search_linear_resolution, double search_linear_size,
+                             size_t laser_max_beams, double range_max);
+/* ScanMatcherNDT::addScans (src/scan_matcher_ndt.cpp:49-74): scan k has pose
+ * poses_xyt[3k..3k+2] and robot-frame points
+ * points_xy[2*offsets[k] .. 2*offsets[k+1]).  Builds the NDT on the host with
+ * the reference's incremental formulas (src/ndt_model.cpp:50-103,132-160) and
+ * uploads it. */
+int ndt2d_matcher_add_scans(ndt2d_matcher * m, const double * poses_xyt,
+                            const double * points_xy, const size_t * offsets, size_t n_scans);
+/* ScanMatcherNDT::matchScan (src/scan_matcher_ndt.cpp:76-149).  *score_out =
+ * the function's return value (best_score / scan_points_to_use; 0.0 and
+ * outputs untouched when no NDT, :80).  pose_inout[3] is written only when a
+ * candidate scores < 0 (:128-134); covariance_out[9] row-major (:146). */
+int ndt2d_matcher_match_scan(ndt2d_matcher * m, const double * scan_pose_xyt,
+                             const double * points_xy, size_t n_points, double * pose_inout,
+                             double * covariance_out, double * score_out);
+/* Same search, additionally returning the raw score of every candidate
+ * (all_scores, host, capacity all_scores_cap), the candidate count and the
+ * winner's flat index; any of the extra outputs may be NULL. */
+int ndt2d_matcher_match_scan_ex(ndt2d_matcher * m, const double * scan_pose_xyt,
+                                const double * points_xy, size_t n_points,
+                                double * pose_inout, double * covariance_out,
+                                double * score_out, double * all_scores,
+                                size_t all_scores_cap, size_t * n_candidates_out,
+                                uint64_t * best_index_out);
+/* The two halves of matchScan, for sharded (multi-GPU) searches:
+ * prepare_search subsamples the scan (:95-96,110), builds the offset and
+ * cos/sin tables (:103-107,117,119) and uploads them -- after it,
+ * ndt2d_match_launch(ndt2d_matcher_device(m), th_begin, th_end, ...) evaluates
+ * any theta slab; finish_match turns a (combined) NDT2D_MATCH_RECORD_DOUBLES
+ * record into matchScan's outputs (:128-134,146,148). */
+int ndt2d_matcher_prepare_search(ndt2d_matcher * m, const double * scan_pose_xyt,
+                                 const double * points_xy, size_t n_points, size_t * n_th_out,
+                                 size_t * n_lin_out, size_t * n_beams_out);
+int ndt2d_matcher_finish_match(ndt2d_matcher * m, const double * record, double * pose_inout,
+                               double * covariance_out, double * score_out);
+/* Subsample + upload the beams only (particle path; then
+ * ndt2d_score_poses_launch on ndt2d_matcher_device(m)). */
+int ndt2d_matcher_prepare_beams(ndt2d_matcher * m, const double * points_xy, size_t n_points,
+                                size_t * n_beams_out);
+/* ScanMatcherNDT::scoreScan (:151-154) and scorePoints (:156-178). */
+int ndt2d_matcher_score_scan(ndt2d_matcher * m, const double * scan_pose_xyt,
+                             const double * points_xy, size_t n_points, double * score_out);
+int ndt2d_matcher_score_points(ndt2d_matcher * m, const double * points_xy, size_t n_points,
+                               const double * pose_xyt, double * score_out);
+/* ScanMatcherNDT::reset (:180-183). */
+int ndt2d_matcher_reset(ndt2d_matcher * m);
+int ndt2d_matcher_has_ndt(ndt2d_matcher * m);
+
+/* Additive batched interface (not in the reference's ScanMatcher): scores
+ * n_poses poses in one launch; scores_out[i] == scorePoints(points, pose_i). */
+int ndt2d_matcher_score_poses(ndt2d_matcher * m, const double * points_xy, size_t n_points,
+                              const double * poses_xyt, size_t n_poses, double * scores_out);
+/* ParticleFilter::measure (src/particle_filter.cpp:78-89) incl. its
+ * updateStatistics (:163-218): weights_out[n] = normalised weights,
+ * mean_out[3], cov_inout[9] row-major ((2,2) accumulates onto the previous
+ * value, :216). */
+int ndt2d_matcher_pf_measure(ndt2d_matcher * m, const double * particles_xyt,
+                             size_t n_particles, const double * points_xy, size_t n_points,
+                             double * weights_out, double * mean_out, double * cov_inout);
+
+/* Host NDT introspection (tests compare it bit-for-bit with the oracle). */
+int ndt2d_matcher_grid_info(ndt2d_matcher * m, uint32_t * size_x, uint32_t * size_y,
+                            double * cell_size, double * origin_x, double * origin_y);
+int ndt2d_matcher_grid_cells6(ndt2d_matcher * m, double * cells6_out, size_t capacity_cells);
+/* The search lattice the matcher visits (the reference's FP-accumulated
+ * loops): writes up to cap values, returns the count through *n_out. */
+int ndt2d_search_offsets(double size, double res, double * out, size_t cap, size_t * n_out);
+/* Host-only (no GPU needed) NDT build: the arithmetic of addScans without the
+ * upload, for hosts that only want the packed grid. */
+int ndt2d_host_build_grid(double ndt_resolution, double range_max, const double * poses_xyt,
+                          const double * points_xy, const size_t * offsets, size_t n_scans,
+                          double * cells6_out, size_t capacity_cells, uint32_t * size_x,
+                          uint32_t * size_y, double * origin_x, double * origin_y);
+
+/* ------------------------------------------------------------------------ */
+/* Synthetic workload generator (BASELINE.md section 3 / SURVEY.md 8d)       */
+/* ------------------------------------------------------------------------ */
+
+/* Closed square room [-half, half]^2 with 0.5 m square pillars centred on the
+ * lattice (pitch*i + pitch/2, pitch*j + pitch/2) that fit inside the room. */
+typedef struct ndt2d_world
+{
+  double room_half;
+  double pillar_pitch;
+  double pillar_half;
+} ndt2d_world;
+
+/* Ray-cast one n_beams scan over 2*pi (angle_min = -pi) from pose, range noise
+ * N(0, noise_sigma^2) from splitmix64(seed) + Box-Muller; writes robot-frame
+ * points_xy[2*n_beams]. */
+int ndt2d_synth_scan(const ndt2d_world * world, const double * pose_xyt, size_t n_beams,
+                     double noise_sigma, uint64_t seed, double * points_xy);
+/* 1 if the pose is inside or within `margin` (Chebyshev) of a pillar. */
+int ndt2d_synth_pose_blocked(const ndt2d_world * world, double x, double y, double margin);
+/* n uniforms in [0,1) from splitmix64(seed). */
+int ndt2d_synth_uniform(uint64_t seed, size_t n, double * out);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif  /* NDT2D_HIP_H_ */

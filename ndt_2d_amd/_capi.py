@@ -1,0 +1,124 @@
+"""ctypes binding of include/ndt2d_hip.h (libndt2d_hip.so).
+
+This is the only place the package touches native code.  Importing it fails
+loudly if the HIP extension has not been built -- there is no Python or CPU
+fallback for any compute entry point.
+"""
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libndt2d_hip.so")
+
+OK = 0
+ERR_INVALID = 1
+ERR_NO_GRID = 2
+ERR_HIP = 3
+ERR_NO_DEVICE = 4
+ERR_STATE = 5
+NO_INDEX = (1 << 64) - 1
+MATCH_RECORD_DOUBLES = 12
+POSE_STATS_DOUBLES = 8
+
+_ERR_NAMES = {1: "NDT2D_ERR_INVALID", 2: "NDT2D_ERR_NO_GRID", 3: "NDT2D_ERR_HIP",
+              4: "NDT2D_ERR_NO_DEVICE", 5: "NDT2D_ERR_STATE"}
+
+
+class Ndt2dError(RuntimeError):
+    def __init__(self, code, where, detail=""):
+        self.code = code
+        super().__init__("%s failed: %s%s" % (where, _ERR_NAMES.get(code, str(code)),
+                                               (" (" + detail + ")") if detail else ""))
+
+
+class MatchResult(C.Structure):
+    _fields_ = [("best_score", C.c_double), ("best_index", C.c_uint64),
+                ("acc", C.c_double * 10), ("n_candidates", C.c_uint64)]
+
+
+class World(C.Structure):
+    _fields_ = [("room_half", C.c_double), ("pillar_pitch", C.c_double),
+                ("pillar_half", C.c_double)]
+
+
+_dp = C.POINTER(C.c_double)
+_vp = C.c_void_p
+_d = C.c_double
+_sz = C.c_size_t
+_u32 = C.c_uint32
+_szp = C.POINTER(C.c_size_t)
+
+# name -> (restype, argtypes); one entry per function declared in ndt2d_hip.h
+SIGNATURES = {
+    "ndt2d_abi_version": (C.c_int, []),
+    "ndt2d_create": (C.c_int, [C.POINTER(_vp), C.c_int]),
+    "ndt2d_destroy": (C.c_int, [_vp]),
+    "ndt2d_last_error": (C.c_char_p, [_vp]),
+    "ndt2d_set_stream": (C.c_int, [_vp, _vp]),
+    "ndt2d_get_stream": (_vp, [_vp]),
+    "ndt2d_device_id": (C.c_int, [_vp]),
+    "ndt2d_set_grid": (C.c_int, [_vp, _dp, _u32, _u32, _d, _d, _d]),
+    "ndt2d_clear_grid": (C.c_int, [_vp]),
+    "ndt2d_has_grid": (C.c_int, [_vp]),
+    "ndt2d_set_beams": (C.c_int, [_vp, _dp, _sz]),
+    "ndt2d_set_search": (C.c_int, [_vp, _d, _d, _dp, _dp, _dp, _sz, _dp, _sz]),
+    "ndt2d_match_launch": (C.c_int, [_vp, _sz, _sz, _vp, _vp]),
+    "ndt2d_match_fetch": (C.c_int, [_vp, C.POINTER(MatchResult)]),
+    "ndt2d_match": (C.c_int, [_vp, _sz, _sz, _dp, C.POINTER(MatchResult)]),
+    "ndt2d_score_poses_launch": (C.c_int, [_vp, _vp, _sz, _vp, _vp]),
+    "ndt2d_score_poses": (C.c_int, [_vp, _dp, _sz, _dp, _dp]),
+    "ndt2d_synchronize": (C.c_int, [_vp]),
+    "ndt2d_last_launch_ms": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "ndt2d_last_variant": (C.c_char_p, [_vp]),
+    "ndt2d_set_variant": (C.c_int, [_vp, C.c_char_p]),
+    "ndt2d_matcher_create": (C.c_int, [C.POINTER(_vp), C.c_int]),
+    "ndt2d_matcher_destroy": (C.c_int, [_vp]),
+    "ndt2d_matcher_last_error": (C.c_char_p, [_vp]),
+    "ndt2d_matcher_device": (_vp, [_vp]),
+    "ndt2d_matcher_initialize": (C.c_int, [_vp, _d, _d, _d, _d, _d, _sz, _d]),
+    "ndt2d_matcher_add_scans": (C.c_int, [_vp, _dp, _dp, _szp, _sz]),
+    "ndt2d_matcher_match_scan": (C.c_int, [_vp, _dp, _dp, _sz, _dp, _dp, _dp]),
+    "ndt2d_matcher_match_scan_ex": (C.c_int, [_vp, _dp, _dp, _sz, _dp, _dp, _dp, _dp, _sz,
+                                             _szp, C.POINTER(C.c_uint64)]),
+    "ndt2d_matcher_prepare_search": (C.c_int, [_vp, _dp, _dp, _sz, _szp, _szp, _szp]),
+    "ndt2d_matcher_finish_match": (C.c_int, [_vp, _dp, _dp, _dp, _dp]),
+    "ndt2d_matcher_prepare_beams": (C.c_int, [_vp, _dp, _sz, _szp]),
+    "ndt2d_matcher_score_scan": (C.c_int, [_vp, _dp, _dp, _sz, _dp]),
+    "ndt2d_matcher_score_points": (C.c_int, [_vp, _dp, _sz, _dp, _dp]),
+    "ndt2d_matcher_reset": (C.c_int, [_vp]),
+    "ndt2d_matcher_has_ndt": (C.c_int, [_vp]),
+    "ndt2d_matcher_score_poses": (C.c_int, [_vp, _dp, _sz, _dp, _sz, _dp]),
+    "ndt2d_matcher_pf_measure": (C.c_int, [_vp, _dp, _sz, _dp, _sz, _dp, _dp, _dp]),
+    "ndt2d_matcher_grid_info": (C.c_int, [_vp, C.POINTER(_u32), C.POINTER(_u32), _dp, _dp, _dp]),
+    "ndt2d_matcher_grid_cells6": (C.c_int, [_vp, _dp, _sz]),
+    "ndt2d_search_offsets": (C.c_int, [_d, _d, _dp, _sz, _szp]),
+    "ndt2d_host_build_grid": (C.c_int, [_d, _d, _dp, _dp, _szp, _sz, _dp, _sz,
+                                       C.POINTER(_u32), C.POINTER(_u32), _dp, _dp]),
+    "ndt2d_synth_scan": (C.c_int, [C.POINTER(World), _dp, _sz, _d, C.c_uint64, _dp]),
+    "ndt2d_synth_pose_blocked": (C.c_int, [C.POINTER(World), _d, _d, _d]),
+    "ndt2d_synth_uniform": (C.c_int, [C.c_uint64, _sz, _dp]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library.  Raises ImportError if the extension is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "ndt_2d_amd: %s is missing -- build it with `python -m ndt_2d_amd.build` "
+            "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = args
+    _lib = L
+    return L
+
+
+def dptr(a):
+    return a.ctypes.data_as(_dp)

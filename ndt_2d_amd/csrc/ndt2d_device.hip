@@ -1,0 +1,489 @@
+// Device layer of the C-ABI (include/ndt2d_hip.h, section 1): one context per
+// (plugin instance, GPU) holding the HBM-resident NDT grid, beams and search
+// tables, and launching the kernels of ndt2d_kernels.hip on its own stream.
+// No CPU compute path exists here: every compute entry point needs the GPU.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "ndt2d_hip.h"
+#include "ndt2d_kernels.h"
+
+using ndt2d::GridDesc;
+using ndt2d::kCellDoubles;
+using ndt2d::kCellStrideGlobal;
+
+struct DeviceBuffer
+{
+  double * ptr = nullptr;
+  size_t cap = 0;  // doubles
+};
+
+struct ndt2d_context
+{
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  bool has_grid = false;
+  GridDesc grid{};
+  DeviceBuffer cells_lds_image;
+  DeviceBuffer cells_global;
+
+  DeviceBuffer beams;
+  size_t n_beams = 0;
+
+  DeviceBuffer tables;  // dth | cos | sin | dlin
+  size_t n_th = 0, n_lin = 0;
+  double pose_x = 0.0, pose_y = 0.0;
+  bool has_search = false;
+
+  DeviceBuffer ws_match, ws_poses, record, stats;
+  DeviceBuffer tmp_scores, tmp_poses;
+
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timed = false;
+  int last_kernels = 0;
+  const char * last_variant = "";
+  int force_variant = ndt2d::kVariantAuto;
+
+  bool match_pending = false;
+  uint64_t last_candidates = 0;
+};
+
+namespace
+{
+
+int fail(ndt2d_context * h, int code, const std::string & msg)
+{
+  if (h != nullptr) h->err = msg;
+  return code;
+}
+
+int fail_hip(ndt2d_context * h, hipError_t e, const char * what)
+{
+  std::string msg = std::string(what) + ": " + hipGetErrorString(e);
+  (void)hipGetLastError();  // clear sticky state
+  return fail(h, NDT2D_ERR_HIP, msg);
+}
+
+#define NDT2D_HIP(h, call)                                 \
+  do                                                       \
+  {                                                        \
+    hipError_t e__ = (call);                               \
+    if (e__ != hipSuccess) return fail_hip(h, e__, #call); \
+  } while (0)
+
+int ensure(ndt2d_context * h, DeviceBuffer & b, size_t doubles)
+{
+  if (doubles <= b.cap && b.ptr != nullptr) return NDT2D_OK;
+  if (b.ptr != nullptr)
+  {
+    NDT2D_HIP(h, hipStreamSynchronize(h->stream));
+    NDT2D_HIP(h, hipFree(b.ptr));
+    b.ptr = nullptr;
+    b.cap = 0;
+  }
+  size_t cap = doubles < 64 ? 64 : doubles;
+  NDT2D_HIP(h, hipMalloc(reinterpret_cast<void **>(&b.ptr), cap * sizeof(double)));
+  b.cap = cap;
+  return NDT2D_OK;
+}
+
+void release(DeviceBuffer & b)
+{
+  if (b.ptr != nullptr) (void)hipFree(b.ptr);
+  b.ptr = nullptr;
+  b.cap = 0;
+}
+
+bool is_pow2(double v)
+{
+  if (!(v > 0.0) || !std::isfinite(v)) return false;
+  int e = 0;
+  return std::frexp(v, &e) == 0.5 && std::fpclassify(v) == FP_NORMAL &&
+         std::fpclassify(1.0 / v) == FP_NORMAL;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ndt2d_abi_version(void) { return 1; }
+
+int ndt2d_create(ndt2d_handle * out, int device_id)
+{
+  if (out == nullptr) return NDT2D_ERR_INVALID;
+  *out = nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0)
+  {
+    (void)hipGetLastError();
+    return NDT2D_ERR_NO_DEVICE;
+  }
+  if (device_id < 0 || device_id >= count) return NDT2D_ERR_INVALID;
+  ndt2d_context * h = new (std::nothrow) ndt2d_context();
+  if (h == nullptr) return NDT2D_ERR_INVALID;
+  h->device = device_id;
+  if (hipSetDevice(device_id) != hipSuccess ||
+      hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess)
+  {
+    (void)hipGetLastError();
+    delete h;
+    return NDT2D_ERR_HIP;
+  }
+  h->stream = h->own_stream;
+  *out = h;
+  return NDT2D_OK;
+}
+
+int ndt2d_destroy(ndt2d_handle h)
+{
+  if (h == nullptr) return NDT2D_ERR_INVALID;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  release(h->cells_lds_image);
+  release(h->cells_global);
+  release(h->beams);
+  release(h->tables);
+  release(h->ws_match);
+  release(h->ws_poses);
+  release(h->record);
+  release(h->stats);
+  release(h->tmp_scores);
+  release(h->tmp_poses);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  delete h;
+  return NDT2D_OK;
+}
+
+const char * ndt2d_last_error(ndt2d_handle h)
+{
+  return h != nullptr ? h->err.c_str() : "null handle";
+}
+
+int ndt2d_set_stream(ndt2d_handle h, void * hip_stream)
+{
+  if (h == nullptr) return NDT2D_ERR_INVALID;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  h->stream = hip_stream != nullptr ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
+  return NDT2D_OK;
+}
+
+void * ndt2d_get_stream(ndt2d_handle h) { return h != nullptr ? h->stream : nullptr; }
+
+int ndt2d_device_id(ndt2d_handle h) { return h != nullptr ? h->device : -1; }
+
+int ndt2d_set_grid(ndt2d_handle h, const double * cells6, uint32_t size_x, uint32_t size_y,
+                   double cell_size, double origin_x, double origin_y)
+{
+  if (h == nullptr) return NDT2D_ERR_INVALID;
+  if (cells6 == nullptr || size_x == 0 || size_y == 0 || !(cell_size > 0.0))
+  {
+    return fail(h, NDT2D_ERR_INVALID, "ndt2d_set_grid: bad argument");
+  }
+  const uint64_t ncell64 = static_cast<uint64_t>(size_x) * size_y;
+  if (ncell64 >= (1ull << 31)) return fail(h, NDT2D_ERR_INVALID, "ndt2d_set_grid: grid too large");
+  const uint32_t ncell = static_cast<uint32_t>(ncell64);
+  NDT2D_HIP(h, hipSetDevice(h->device));
+
+  // Pack: h = -0.5 * information (exact); cells with n < 5 cannot score
+  // (reference src/ndt_model.cpp:107) and get the sentinel record.
+  std::vector<double> lds_image(static_cast<size_t>(ncell + 1) * kCellDoubles);
+  std::vector<double> glb(static_cast<size_t>(ncell + 1) * kCellStrideGlobal, 0.0);
+  for (uint32_t i = 0; i <= ncell; ++i)
+  {
+    double rec[kCellDoubles] = {1.0e300, 0.0, -1.0, 0.0, -1.0, 0.0};
+    if (i < ncell && !(cells6[6 * static_cast<size_t>(i) + 5] < 5.0))
+    {
+      const double * c = cells6 + 6 * static_cast<size_t>(i);
+      rec[0] = c[0];
+      rec[1] = c[1];
+      rec[2] = -0.5 * c[2];
+      rec[3] = -0.5 * c[3];
+      rec[4] = -0.5 * c[4];
+      rec[5] = 1.0;
+    }
+    std::memcpy(&lds_image[static_cast<size_t>(i) * kCellDoubles], rec, sizeof(rec));
+    std::memcpy(&glb[static_cast<size_t>(i) * kCellStrideGlobal], rec, sizeof(rec));
+  }
+  int rc = ensure(h, h->cells_lds_image, lds_image.size());
+  if (rc != NDT2D_OK) return rc;
+  rc = ensure(h, h->cells_global, glb.size());
+  if (rc != NDT2D_OK) return rc;
+  NDT2D_HIP(h, hipMemcpyAsync(h->cells_lds_image.ptr, lds_image.data(),
+                              lds_image.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  NDT2D_HIP(h, hipMemcpyAsync(h->cells_global.ptr, glb.data(), glb.size() * sizeof(double),
+                              hipMemcpyHostToDevice, h->stream));
+  NDT2D_HIP(h, hipStreamSynchronize(h->stream));  // host staging vectors go out of scope
+
+  h->grid.cells_lds_image = h->cells_lds_image.ptr;
+  h->grid.cells_global = h->cells_global.ptr;
+  h->grid.size_x = size_x;
+  h->grid.size_y = size_y;
+  h->grid.ncell = ncell;
+  h->grid.cell_size = cell_size;
+  h->grid.pow2 = is_pow2(cell_size) ? 1 : 0;
+  h->grid.inv_cell_size = 1.0 / cell_size;
+  h->grid.origin_x = origin_x;
+  h->grid.origin_y = origin_y;
+  h->has_grid = true;
+  return NDT2D_OK;
+}
+
+int ndt2d_clear_grid(ndt2d_handle h)
+{
+  if (h == nullptr) return NDT2D_ERR_INVALID;
+  h->has_grid = false;
+  return NDT2D_OK;
+}
+
+int ndt2d_has_grid(ndt2d_handle h) { return (h != nullptr && h->has_grid) ? 1 : 0; }
+
+int ndt2d_set_beams(ndt2d_handle h, const double * beams_xy, size_t n_beams)
+{
+  if (h == nullptr) return NDT2D_ERR_INVALID;
+  if (beams_xy == nullptr || n_beams == 0 || n_beams > (1u << 20))
+  {
+    return fail(h, NDT2D_ERR_INVALID, "ndt2d_set_beams: bad argument");
+  }
+  NDT2D_HIP(h, hipSetDevice(h->device));
+  int rc = ensure(h, h->beams, 2 * n_beams + 2);
+  if (rc != NDT2D_OK) return rc;
+  NDT2D_HIP(h, hipMemcpyAsync(h->beams.ptr, beams_xy, 2 * n_beams * sizeof(double),
+                              hipMemcpyHostToDevice, h->stream));
+  NDT2D_HIP(h, hipStreamSynchronize(h->stream));
+  h->n_beams = n_beams;
+  return NDT2D_OK;
+}
+
+int ndt2d_set_search(ndt2d_handle h, double pose_x, double pose_y, const double * dth,
+                     const double * cos_th, const double * sin_th, size_t n_th,
+                     const double * dlin, size_t n_lin)
+{
+  if (h == nullptr) return NDT2D_ERR_INVALID;
+  if (dth == nullptr || cos_th == nullptr || sin_th == nullptr || dlin == nullptr || n_th == 0 ||
+      n_lin == 0 || n_th > (1u << 24) || n_lin > 46340)
+  {
+    return fail(h, NDT2D_ERR_INVALID, "ndt2d_set_search: bad argument");
+  }
+  NDT2D_HIP(h, hipSetDevice(h->device));
+  std::vector<double> t(3 * n_th + n_lin);
+  std::memcpy(&t[0], dth, n_th * sizeof(double));
+  std::memcpy(&t[n_th], cos_th, n_th * sizeof(double));
+  std::memcpy(&t[2 * n_th], sin_th, n_th * sizeof(double));
+  std::memcpy(&t[3 * n_th], dlin, n_lin * sizeof(double));
+  int rc = ensure(h, h->tables, t.size());
+  if (rc != NDT2D_OK) return rc;
+  NDT2D_HIP(h, hipMemcpyAsync(h->tables.ptr, t.data(), t.size() * sizeof(double),
+                              hipMemcpyHostToDevice, h->stream));
+  NDT2D_HIP(h, hipStreamSynchronize(h->stream));
+  h->n_th = n_th;
+  h->n_lin = n_lin;
+  h->pose_x = pose_x;
+  h->pose_y = pose_y;
+  h->has_search = true;
+  return NDT2D_OK;
+}
+
+int ndt2d_match_launch(ndt2d_handle h, size_t th_begin, size_t th_end, double * d_scores,
+                       double * d_record)
+{
+  if (h == nullptr) return NDT2D_ERR_INVALID;
+  if (!h->has_grid) return fail(h, NDT2D_ERR_NO_GRID, "ndt2d_match_launch: no grid");
+  if (!h->has_search || h->n_beams == 0)
+  {
+    return fail(h, NDT2D_ERR_STATE, "ndt2d_match_launch: set_beams/set_search first");
+  }
+  if (th_begin >= th_end || th_end > h->n_th)
+  {
+    return fail(h, NDT2D_ERR_INVALID, "ndt2d_match_launch: bad theta range");
+  }
+  NDT2D_HIP(h, hipSetDevice(h->device));
+  int rc = ensure(h, h->ws_match, ndt2d::match_workspace_doubles());
+  if (rc != NDT2D_OK) return rc;
+  rc = ensure(h, h->record, NDT2D_MATCH_RECORD_DOUBLES);
+  if (rc != NDT2D_OK) return rc;
+
+  ndt2d::MatchArgs a{};
+  a.grid = h->grid;
+  a.beams_xy = h->beams.ptr;
+  a.n_beams = static_cast<uint32_t>(h->n_beams);
+  a.dth = h->tables.ptr;
+  a.cos_th = h->tables.ptr + h->n_th;
+  a.sin_th = h->tables.ptr + 2 * h->n_th;
+  a.dlin = h->tables.ptr + 3 * h->n_th;
+  a.n_th = static_cast<uint32_t>(h->n_th);
+  a.n_lin = static_cast<uint32_t>(h->n_lin);
+  a.th_begin = static_cast<uint32_t>(th_begin);
+  a.th_end = static_cast<uint32_t>(th_end);
+  a.pose_x = h->pose_x;
+  a.pose_y = h->pose_y;
+  a.scores = d_scores;
+
+  ndt2d::LaunchInfo info{"", 0};
+  NDT2D_HIP(h, hipEventRecord(h->ev0, h->stream));
+  hipError_t e = ndt2d::launch_match(a, h->ws_match.ptr, h->record.ptr, d_record,
+                                     h->force_variant, h->stream, &info);
+  if (e != hipSuccess) return fail_hip(h, e, "launch_match");
+  NDT2D_HIP(h, hipEventRecord(h->ev1, h->stream));
+  h->timed = true;
+  h->last_kernels = info.n_kernels;
+  h->last_variant = info.variant;
+  h->match_pending = true;
+  h->last_candidates = static_cast<uint64_t>(th_end - th_begin) * h->n_lin * h->n_lin;
+  return NDT2D_OK;
+}
+
+int ndt2d_match_fetch(ndt2d_handle h, ndt2d_match_result * out)
+{
+  if (h == nullptr || out == nullptr) return NDT2D_ERR_INVALID;
+  if (!h->match_pending) return fail(h, NDT2D_ERR_STATE, "ndt2d_match_fetch: nothing launched");
+  NDT2D_HIP(h, hipSetDevice(h->device));
+  double rec[NDT2D_MATCH_RECORD_DOUBLES];
+  NDT2D_HIP(h, hipMemcpyAsync(rec, h->record.ptr, sizeof(rec), hipMemcpyDeviceToHost, h->stream));
+  NDT2D_HIP(h, hipStreamSynchronize(h->stream));
+  out->best_score = rec[0];
+  out->best_index = rec[1] < 0.0 ? NDT2D_NO_INDEX : static_cast<uint64_t>(rec[1]);
+  for (int k = 0; k < 10; ++k) out->acc[k] = rec[2 + k];
+  out->n_candidates = h->last_candidates;
+  return NDT2D_OK;
+}
+
+int ndt2d_match(ndt2d_handle h, size_t th_begin, size_t th_end, double * h_scores,
+                ndt2d_match_result * out)
+{
+  if (h == nullptr || out == nullptr) return NDT2D_ERR_INVALID;
+  double * d_scores = nullptr;
+  size_t n_scores = 0;
+  if (h_scores != nullptr)
+  {
+    if (th_begin >= th_end || th_end > h->n_th)
+    {
+      return fail(h, NDT2D_ERR_INVALID, "ndt2d_match: bad theta range");
+    }
+    NDT2D_HIP(h, hipSetDevice(h->device));
+    n_scores = (th_end - th_begin) * h->n_lin * h->n_lin;
+    int rc = ensure(h, h->tmp_scores, n_scores);
+    if (rc != NDT2D_OK) return rc;
+    d_scores = h->tmp_scores.ptr;
+  }
+  int rc = ndt2d_match_launch(h, th_begin, th_end, d_scores, nullptr);
+  if (rc != NDT2D_OK) return rc;
+  if (h_scores != nullptr)
+  {
+    NDT2D_HIP(h, hipMemcpyAsync(h_scores, d_scores, n_scores * sizeof(double),
+                                hipMemcpyDeviceToHost, h->stream));
+  }
+  return ndt2d_match_fetch(h, out);
+}
+
+int ndt2d_score_poses_launch(ndt2d_handle h, const double * d_poses_xyt, size_t n_poses,
+                             double * d_scores, double * d_stats)
+{
+  if (h == nullptr) return NDT2D_ERR_INVALID;
+  if (!h->has_grid) return fail(h, NDT2D_ERR_NO_GRID, "ndt2d_score_poses_launch: no grid");
+  if (h->n_beams == 0) return fail(h, NDT2D_ERR_STATE, "ndt2d_score_poses_launch: set_beams first");
+  if (d_poses_xyt == nullptr || d_scores == nullptr || n_poses == 0)
+  {
+    return fail(h, NDT2D_ERR_INVALID, "ndt2d_score_poses_launch: bad argument");
+  }
+  NDT2D_HIP(h, hipSetDevice(h->device));
+  int rc = ensure(h, h->ws_poses, ndt2d::poses_workspace_doubles(n_poses));
+  if (rc != NDT2D_OK) return rc;
+
+  ndt2d::PosesArgs a{};
+  a.grid = h->grid;
+  a.beams_xy = h->beams.ptr;
+  a.n_beams = static_cast<uint32_t>(h->n_beams);
+  a.poses_xyt = d_poses_xyt;
+  a.n_poses = n_poses;
+  a.scores = d_scores;
+
+  ndt2d::LaunchInfo info{"", 0};
+  NDT2D_HIP(h, hipEventRecord(h->ev0, h->stream));
+  hipError_t e = ndt2d::launch_score_poses(a, h->ws_poses.ptr, d_stats, h->force_variant,
+                                           h->stream, &info);
+  if (e != hipSuccess) return fail_hip(h, e, "launch_score_poses");
+  NDT2D_HIP(h, hipEventRecord(h->ev1, h->stream));
+  h->timed = true;
+  h->last_kernels = info.n_kernels;
+  h->last_variant = info.variant;
+  return NDT2D_OK;
+}
+
+int ndt2d_score_poses(ndt2d_handle h, const double * h_poses_xyt, size_t n_poses,
+                      double * h_scores, double * h_stats)
+{
+  if (h == nullptr) return NDT2D_ERR_INVALID;
+  if (h_poses_xyt == nullptr || h_scores == nullptr || n_poses == 0)
+  {
+    return fail(h, NDT2D_ERR_INVALID, "ndt2d_score_poses: bad argument");
+  }
+  if (!h->has_grid) return fail(h, NDT2D_ERR_NO_GRID, "ndt2d_score_poses: no grid");
+  NDT2D_HIP(h, hipSetDevice(h->device));
+  int rc = ensure(h, h->tmp_poses, 3 * n_poses);
+  if (rc != NDT2D_OK) return rc;
+  rc = ensure(h, h->tmp_scores, n_poses);
+  if (rc != NDT2D_OK) return rc;
+  rc = ensure(h, h->stats, NDT2D_POSE_STATS_DOUBLES);
+  if (rc != NDT2D_OK) return rc;
+  NDT2D_HIP(h, hipMemcpyAsync(h->tmp_poses.ptr, h_poses_xyt, 3 * n_poses * sizeof(double),
+                              hipMemcpyHostToDevice, h->stream));
+  rc = ndt2d_score_poses_launch(h, h->tmp_poses.ptr, n_poses, h->tmp_scores.ptr,
+                                h_stats != nullptr ? h->stats.ptr : nullptr);
+  if (rc != NDT2D_OK) return rc;
+  NDT2D_HIP(h, hipMemcpyAsync(h_scores, h->tmp_scores.ptr, n_poses * sizeof(double),
+                              hipMemcpyDeviceToHost, h->stream));
+  if (h_stats != nullptr)
+  {
+    NDT2D_HIP(h, hipMemcpyAsync(h_stats, h->stats.ptr, NDT2D_POSE_STATS_DOUBLES * sizeof(double),
+                                hipMemcpyDeviceToHost, h->stream));
+  }
+  NDT2D_HIP(h, hipStreamSynchronize(h->stream));
+  return NDT2D_OK;
+}
+
+int ndt2d_synchronize(ndt2d_handle h)
+{
+  if (h == nullptr) return NDT2D_ERR_INVALID;
+  NDT2D_HIP(h, hipSetDevice(h->device));
+  NDT2D_HIP(h, hipStreamSynchronize(h->stream));
+  return NDT2D_OK;
+}
+
+int ndt2d_last_launch_ms(ndt2d_handle h, float * ms, int * n_kernels)
+{
+  if (h == nullptr || ms == nullptr) return NDT2D_ERR_INVALID;
+  if (!h->timed) return fail(h, NDT2D_ERR_STATE, "ndt2d_last_launch_ms: nothing launched");
+  NDT2D_HIP(h, hipSetDevice(h->device));
+  NDT2D_HIP(h, hipEventSynchronize(h->ev1));
+  NDT2D_HIP(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
+  if (n_kernels != nullptr) *n_kernels = h->last_kernels;
+  return NDT2D_OK;
+}
+
+const char * ndt2d_last_variant(ndt2d_handle h) { return h != nullptr ? h->last_variant : ""; }
+
+int ndt2d_set_variant(ndt2d_handle h, const char * name)
+{
+  if (h == nullptr || name == nullptr) return NDT2D_ERR_INVALID;
+  if (std::strcmp(name, "auto") == 0) h->force_variant = ndt2d::kVariantAuto;
+  else if (std::strcmp(name, "lds") == 0) h->force_variant = ndt2d::kVariantLds;
+  else if (std::strcmp(name, "global") == 0) h->force_variant = ndt2d::kVariantGlobal;
+  else return fail(h, NDT2D_ERR_INVALID, "ndt2d_set_variant: unknown variant");
+  return NDT2D_OK;
+}
+
+}  // extern "C"

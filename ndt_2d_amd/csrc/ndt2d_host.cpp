@@ -1,0 +1,870 @@
+// Host side of libndt2d_hip.so (include/ndt2d_hip.h, section 2 + generator):
+//   * HostNdt: the NDT build of ScanMatcherNDT::addScans on the host, with the
+//     reference's incremental formulas and point order (it produces the kernels'
+//     input and must be bit-faithful),
+//   * ndt2d_matcher_*: the reference's ScanMatcherNDT object restated over the
+//     device layer -- subsampling, search tables, final covariance formula,
+//   * the batched particle path (ParticleFilter::measure),
+//   * the synthetic workload generator.
+// No scoring arithmetic happens here: every likelihood is evaluated on the GPU.
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "ndt2d_hip.h"
+
+namespace
+{
+
+// ---------------------------------------------------------------------------
+// Host NDT build
+// ---------------------------------------------------------------------------
+
+// One NDT cell; fields as ndt_2d::Cell (reference include/ndt_2d/ndt_model.hpp:43-65).
+// Symmetric 2x2 matrices keep {xx, xy, yy}; correlation(1,0) is never written
+// by the reference and never read.
+struct HostCell
+{
+  bool valid = false;
+  double n = 0.0;
+  double mean_x = 0.0, mean_y = 0.0;
+  double corr_xx = 0.0, corr_xy = 0.0, corr_yy = 0.0;
+  double cov_xx = 0.0, cov_xy = 0.0, cov_yy = 0.0;
+  double info_xx = 0.0, info_xy = 0.0, info_yy = 0.0;
+
+  // Cell::addPoint, reference src/ndt_model.cpp:50-63
+  void add(double x, double y)
+  {
+    const double n1 = n + 1;
+    mean_x = (mean_x * n + x) / n1;
+    mean_y = (mean_y * n + y) / n1;
+    corr_xx = (corr_xx * n + x * x) / n1;
+    corr_xy = (corr_xy * n + x * y) / n1;
+    corr_yy = (corr_yy * n + y * y) / n1;
+    n += 1;
+    valid = false;
+  }
+
+  // Cell::compute, reference src/ndt_model.cpp:65-103
+  void compute()
+  {
+    if (valid || n < 3) return;
+    const double scale = n / (n - 1);
+    cov_xx = (corr_xx - (mean_x * mean_x)) * scale;
+    cov_xy = (corr_xy - (mean_x * mean_y)) * scale;
+    cov_yy = (corr_yy - (mean_y * mean_y)) * scale;
+
+    double small, large;
+    symmetric_eigenvalues(cov_xx, cov_xy, cov_yy, &small, &large);
+    if (small > large) std::swap(small, large);
+    if (small < 0.001 * large)
+    {
+      // eigenvalue clamp (:88-96)
+      const double determinant = (0.001 * large) * large;
+      info_xx = cov_yy / determinant;
+      info_xy = -cov_xy / determinant;
+      info_yy = cov_xx / determinant;
+    }
+    else
+    {
+      // Matrix2d::inverse() (:99): adjugate times 1/det
+      const double det = cov_xx * cov_yy - cov_xy * cov_xy;
+      const double invdet = 1.0 / det;
+      info_xx = cov_yy * invdet;
+      info_xy = -cov_xy * invdet;
+      info_yy = cov_xx * invdet;
+    }
+    valid = true;
+  }
+
+  // Eigenvalues of [[a, b], [b, d]] the way Eigen::EigenSolver's real Schur
+  // form arrives at them for a 2x2 (reference src/ndt_model.cpp:84-85):
+  // negligible off-diagonal -> the diagonal itself, else the 2x2 block split
+  // with p = (a - d) / 2, z = sqrt(p*p + b*b).
+  static void symmetric_eigenvalues(double a, double b, double d, double * e0, double * e1)
+  {
+    const double norm = std::fabs(a) + 2.0 * std::fabs(b) + std::fabs(d);
+    double tiny = norm * (DBL_EPSILON * DBL_EPSILON);
+    if (tiny < DBL_MIN) tiny = DBL_MIN;
+    double thresh = (std::fabs(a) + std::fabs(d)) * DBL_EPSILON;
+    if (thresh < tiny) thresh = tiny;
+    if (norm == 0.0 || std::fabs(b) <= thresh)
+    {
+      *e0 = a;
+      *e1 = d;
+      return;
+    }
+    const double p = 0.5 * (a - d);
+    const double q = p * p + b * b;
+    const double z = std::sqrt(std::fabs(q));
+    *e0 = (d + p) + z;
+    *e1 = (d + p) - z;
+  }
+};
+
+// class NDT (reference include/ndt_2d/ndt_model.hpp:67-134), build side only.
+class HostNdt
+{
+public:
+  // NDT::NDT, reference src/ndt_model.cpp:118-126
+  HostNdt(double cell_size, double size_x, double size_y, double origin_x, double origin_y)
+  : cell_size_(cell_size),
+    size_x_(static_cast<size_t>((size_x / cell_size) + 1)),
+    size_y_(static_cast<size_t>((size_y / cell_size) + 1)),
+    origin_x_(origin_x),
+    origin_y_(origin_y),
+    cells_(size_x_ * size_y_)
+  {
+  }
+
+  // NDT::getIndex, reference src/ndt_model.cpp:203-218
+  long index(double x, double y) const
+  {
+    if (x < origin_x_ || y < origin_y_) return -1;
+    const unsigned int gx = static_cast<unsigned int>(static_cast<long long>((x - origin_x_) / cell_size_));
+    const unsigned int gy = static_cast<unsigned int>(static_cast<long long>((y - origin_y_) / cell_size_));
+    if (gx >= size_x_ || gy >= size_y_) return -1;
+    return static_cast<long>(gy * size_x_ + gx);
+  }
+
+  // NDT::addScan, reference src/ndt_model.cpp:132-152
+  void add_scan(double pose_x, double pose_y, double pose_theta, const double * pts, size_t n)
+  {
+    const double cos_th = std::cos(pose_theta);
+    const double sin_th = std::sin(pose_theta);
+    for (size_t k = 0; k < n; ++k)
+    {
+      const double px = pts[2 * k], py = pts[2 * k + 1];
+      double wx = pose_x;
+      double wy = pose_y;
+      wx += px * cos_th - py * sin_th;
+      wy += px * sin_th + py * cos_th;
+      const long i = index(wx, wy);
+      if (i >= 0) cells_[static_cast<size_t>(i)].add(wx, wy);
+    }
+  }
+
+  // NDT::compute, reference src/ndt_model.cpp:154-160
+  void compute()
+  {
+    for (auto & c : cells_) c.compute();
+  }
+
+  void pack6(double * out) const
+  {
+    for (size_t i = 0; i < cells_.size(); ++i)
+    {
+      const HostCell & c = cells_[i];
+      out[6 * i + 0] = c.mean_x;
+      out[6 * i + 1] = c.mean_y;
+      out[6 * i + 2] = c.info_xx;
+      out[6 * i + 3] = c.info_xy;
+      out[6 * i + 4] = c.info_yy;
+      out[6 * i + 5] = c.n;
+    }
+  }
+
+  double cell_size() const { return cell_size_; }
+  size_t size_x() const { return size_x_; }
+  size_t size_y() const { return size_y_; }
+  double origin_x() const { return origin_x_; }
+  double origin_y() const { return origin_y_; }
+  size_t ncell() const { return cells_.size(); }
+
+private:
+  double cell_size_;
+  size_t size_x_, size_y_;
+  double origin_x_, origin_y_;
+  std::vector<HostCell> cells_;
+};
+
+// ScanMatcherNDT::addScans' extent + NDT build, reference src/scan_matcher_ndt.cpp:49-74.
+// max_x_/max_y_ start at numeric_limits<double>::min(), as the reference has it.
+std::unique_ptr<HostNdt> build_ndt(double resolution, double range_max, const double * poses,
+                                   const double * pts, const size_t * offsets, size_t n_scans)
+{
+  double min_x = std::numeric_limits<double>::max();
+  double max_x = std::numeric_limits<double>::min();
+  double min_y = std::numeric_limits<double>::max();
+  double max_y = std::numeric_limits<double>::min();
+  for (size_t k = 0; k < n_scans; ++k)
+  {
+    min_x = std::min(poses[3 * k] - range_max, min_x);
+    max_x = std::max(poses[3 * k] + range_max, max_x);
+    min_y = std::min(poses[3 * k + 1] - range_max, min_y);
+    max_y = std::max(poses[3 * k + 1] + range_max, max_y);
+  }
+  std::unique_ptr<HostNdt> ndt(
+    new HostNdt(resolution, (max_x - min_x), (max_y - min_y), min_x, min_y));
+  for (size_t k = 0; k < n_scans; ++k)
+  {
+    ndt->add_scan(poses[3 * k], poses[3 * k + 1], poses[3 * k + 2], pts + 2 * offsets[k],
+                  offsets[k + 1] - offsets[k]);
+  }
+  ndt->compute();
+  return ndt;
+}
+
+// The reference's `for (v = -size; v < size; v += res)` (src/scan_matcher_ndt.cpp:103,117,119):
+// the visited values come from repeated floating-point addition.
+std::vector<double> search_offsets(double size, double res)
+{
+  std::vector<double> out;
+  if (!(res > 0.0))
+  {
+    if (-size < size) out.push_back(-size);  // the reference would never terminate
+    return out;
+  }
+  for (double v = -size; v < size; v += res) out.push_back(v);
+  return out;
+}
+
+// Subsampling of matchScan / scorePoints, reference src/scan_matcher_ndt.cpp:95-96,110.
+std::vector<double> subsample(const double * pts, size_t n_points, size_t laser_max_beams)
+{
+  const size_t use = std::min(laser_max_beams, n_points);
+  std::vector<double> out(2 * use);
+  if (use == 0) return out;
+  const double scan_step = static_cast<double>(n_points) / use;
+  for (size_t i = 0; i < use; ++i)
+  {
+    const size_t idx = static_cast<size_t>(i * scan_step);
+    out[2 * i] = pts[2 * idx];
+    out[2 * i + 1] = pts[2 * idx + 1];
+  }
+  return out;
+}
+
+// ROS angles::normalize_angle / shortest_angular_distance (unpinned dependency
+// of the reference, used by updateStatistics src/particle_filter.cpp:215).
+double normalize_angle(double a)
+{
+  const double r = std::fmod(a + M_PI, 2.0 * M_PI);
+  return r <= 0.0 ? r + M_PI : r - M_PI;
+}
+
+}  // namespace
+
+struct ndt2d_matcher
+{
+  ndt2d_handle dev = nullptr;
+  std::string err;
+  // the six declared parameters, reference src/scan_matcher_ndt.cpp:37-44
+  double resolution = 0.25;
+  double angular_res = 0.0025, angular_size = 0.1;
+  double linear_res = 0.005, linear_size = 0.05;
+  size_t laser_max_beams = 100;
+  double range_max = 0.0;
+  std::unique_ptr<HostNdt> ndt;
+  // state of the last prepare_search (subsampled beams + visited offsets)
+  std::vector<double> beams, dth, dlin;
+  bool search_ready = false;
+};
+
+namespace
+{
+
+int mfail(ndt2d_matcher * m, int code, const std::string & msg)
+{
+  if (m != nullptr) m->err = msg;
+  return code;
+}
+
+int dev_fail(ndt2d_matcher * m, int code, const char * what)
+{
+  return mfail(m, code, std::string(what) + ": " + ndt2d_last_error(m->dev));
+}
+
+}  // namespace
+
+extern "C" {
+
+int ndt2d_matcher_create(ndt2d_matcher ** out, int device_id)
+{
+  if (out == nullptr) return NDT2D_ERR_INVALID;
+  *out = nullptr;
+  ndt2d_handle dev = nullptr;
+  int rc = ndt2d_create(&dev, device_id);
+  if (rc != NDT2D_OK) return rc;
+  ndt2d_matcher * m = new (std::nothrow) ndt2d_matcher();
+  if (m == nullptr)
+  {
+    ndt2d_destroy(dev);
+    return NDT2D_ERR_INVALID;
+  }
+  m->dev = dev;
+  *out = m;
+  return NDT2D_OK;
+}
+
+int ndt2d_matcher_destroy(ndt2d_matcher * m)
+{
+  if (m == nullptr) return NDT2D_ERR_INVALID;
+  ndt2d_destroy(m->dev);
+  delete m;
+  return NDT2D_OK;
+}
+
+const char * ndt2d_matcher_last_error(ndt2d_matcher * m)
+{
+  return m != nullptr ? m->err.c_str() : "null matcher";
+}
+
+ndt2d_handle ndt2d_matcher_device(ndt2d_matcher * m) { return m != nullptr ? m->dev : nullptr; }
+
+int ndt2d_matcher_initialize(ndt2d_matcher * m, double ndt_resolution,
+                             double search_angular_resolution, double search_angular_size,
+                             double search_linear_resolution, double search_linear_size,
+                             size_t laser_max_beams, double range_max)
+{
+  if (m == nullptr) return NDT2D_ERR_INVALID;
+  if (!(ndt_resolution > 0.0)) return mfail(m, NDT2D_ERR_INVALID, "ndt_resolution must be > 0");
+  m->resolution = ndt_resolution;
+  m->angular_res = search_angular_resolution;
+  m->angular_size = search_angular_size;
+  m->linear_res = search_linear_resolution;
+  m->linear_size = search_linear_size;
+  m->laser_max_beams = laser_max_beams;
+  m->range_max = range_max;
+  return NDT2D_OK;
+}
+
+int ndt2d_matcher_add_scans(ndt2d_matcher * m, const double * poses_xyt,
+                            const double * points_xy, const size_t * offsets, size_t n_scans)
+{
+  if (m == nullptr) return NDT2D_ERR_INVALID;
+  if (n_scans > 0 && (poses_xyt == nullptr || offsets == nullptr))
+  {
+    return mfail(m, NDT2D_ERR_INVALID, "add_scans: null input");
+  }
+  static const double no_points[2] = {0.0, 0.0};
+  if (points_xy == nullptr) points_xy = no_points;
+  static const size_t no_offsets[1] = {0};
+  if (offsets == nullptr) offsets = no_offsets;
+  m->ndt = build_ndt(m->resolution, m->range_max, poses_xyt, points_xy, offsets, n_scans);
+  const size_t ncell = m->ndt->ncell();
+  if (ncell == 0 || m->ndt->size_x() > 0xffffffffull || m->ndt->size_y() > 0xffffffffull)
+  {
+    m->ndt.reset();
+    ndt2d_clear_grid(m->dev);
+    return mfail(m, NDT2D_ERR_INVALID, "add_scans: degenerate grid extent");
+  }
+  std::vector<double> cells6(6 * ncell);
+  m->ndt->pack6(cells6.data());
+  int rc = ndt2d_set_grid(m->dev, cells6.data(), static_cast<uint32_t>(m->ndt->size_x()),
+                          static_cast<uint32_t>(m->ndt->size_y()), m->ndt->cell_size(),
+                          m->ndt->origin_x(), m->ndt->origin_y());
+  if (rc != NDT2D_OK)
+  {
+    m->ndt.reset();
+    return dev_fail(m, rc, "ndt2d_set_grid");
+  }
+  return NDT2D_OK;
+}
+
+int ndt2d_matcher_reset(ndt2d_matcher * m)
+{
+  if (m == nullptr) return NDT2D_ERR_INVALID;
+  m->ndt.reset();
+  return ndt2d_clear_grid(m->dev);
+}
+
+int ndt2d_matcher_has_ndt(ndt2d_matcher * m) { return (m != nullptr && m->ndt) ? 1 : 0; }
+
+int ndt2d_matcher_prepare_search(ndt2d_matcher * m, const double * scan_pose_xyt,
+                                 const double * points_xy, size_t n_points, size_t * n_th_out,
+                                 size_t * n_lin_out, size_t * n_beams_out)
+{
+  if (m == nullptr || scan_pose_xyt == nullptr) return NDT2D_ERR_INVALID;
+  if (n_points > 0 && points_xy == nullptr) return mfail(m, NDT2D_ERR_INVALID, "null points");
+  m->beams = subsample(points_xy, n_points, m->laser_max_beams);
+  m->dth = search_offsets(m->angular_size, m->angular_res);
+  m->dlin = search_offsets(m->linear_size, m->linear_res);
+  const size_t use = m->beams.size() / 2;
+  const size_t n_th = m->dth.size(), n_lin = m->dlin.size();
+  if (n_th_out != nullptr) *n_th_out = n_th;
+  if (n_lin_out != nullptr) *n_lin_out = n_lin;
+  if (n_beams_out != nullptr) *n_beams_out = use;
+  m->search_ready = false;
+  if (use == 0 || n_th == 0 || n_lin == 0 || !m->ndt) return NDT2D_OK;  // nothing to upload
+
+  std::vector<double> cos_th(n_th), sin_th(n_th);
+  for (size_t i = 0; i < n_th; ++i)
+  {
+    // reference src/scan_matcher_ndt.cpp:106-107
+    cos_th[i] = std::cos(scan_pose_xyt[2] + m->dth[i]);
+    sin_th[i] = std::sin(scan_pose_xyt[2] + m->dth[i]);
+  }
+  int rc = ndt2d_set_beams(m->dev, m->beams.data(), use);
+  if (rc != NDT2D_OK) return dev_fail(m, rc, "ndt2d_set_beams");
+  rc = ndt2d_set_search(m->dev, scan_pose_xyt[0], scan_pose_xyt[1], m->dth.data(), cos_th.data(),
+                        sin_th.data(), n_th, m->dlin.data(), n_lin);
+  if (rc != NDT2D_OK) return dev_fail(m, rc, "ndt2d_set_search");
+  m->search_ready = true;
+  return NDT2D_OK;
+}
+
+int ndt2d_matcher_finish_match(ndt2d_matcher * m, const double * record, double * pose_inout,
+                               double * covariance_out, double * score_out)
+{
+  if (m == nullptr || record == nullptr || score_out == nullptr) return NDT2D_ERR_INVALID;
+  const size_t use = m->beams.size() / 2;
+  const size_t n_lin = m->dlin.size();
+  const double best_score = record[0];
+  if (record[1] >= 0.0 && pose_inout != nullptr && n_lin > 0)
+  {
+    // reference src/scan_matcher_ndt.cpp:128-134: pose = the accumulated
+    // offsets of the winning candidate
+    const uint64_t best_index = static_cast<uint64_t>(record[1]);
+    const uint64_t per_th = static_cast<uint64_t>(n_lin) * n_lin;
+    const uint64_t ith = best_index / per_th;
+    const uint64_t rem = best_index % per_th;
+    if (ith >= m->dth.size()) return mfail(m, NDT2D_ERR_INVALID, "finish_match: index out of range");
+    pose_inout[0] = m->dlin[rem / n_lin];
+    pose_inout[1] = m->dlin[rem % n_lin];
+    pose_inout[2] = m->dth[ith];
+  }
+  // :146 covariance = (1 / s) * k + (1 / (s * s) * u * u^T)
+  if (covariance_out != nullptr)
+  {
+    const double * k = record + 2;
+    const double * u = record + 8;
+    const double s = record[11];
+    const double kk[9] = {k[0], k[1], k[2], k[1], k[3], k[4], k[2], k[4], k[5]};
+    const double inv_s = 1 / s;
+    const double inv_s2 = 1 / (s * s);
+    for (int r = 0; r < 3; ++r)
+    {
+      for (int c = 0; c < 3; ++c)
+      {
+        covariance_out[r * 3 + c] = inv_s * kk[r * 3 + c] + (inv_s2 * u[r]) * u[c];
+      }
+    }
+  }
+  // :148
+  *score_out = best_score / use;
+  return NDT2D_OK;
+}
+
+int ndt2d_matcher_match_scan_ex(ndt2d_matcher * m, const double * scan_pose_xyt,
+                                const double * points_xy, size_t n_points,
+                                double * pose_inout, double * covariance_out,
+                                double * score_out, double * all_scores,
+                                size_t all_scores_cap, size_t * n_candidates_out,
+                                uint64_t * best_index_out)
+{
+  if (m == nullptr || score_out == nullptr || scan_pose_xyt == nullptr)
+  {
+    return NDT2D_ERR_INVALID;
+  }
+  if (n_candidates_out != nullptr) *n_candidates_out = 0;
+  if (best_index_out != nullptr) *best_index_out = NDT2D_NO_INDEX;
+  // `if (!ndt_) return 0.0;` (reference src/scan_matcher_ndt.cpp:80): outputs untouched
+  if (!m->ndt)
+  {
+    *score_out = 0.0;
+    return NDT2D_OK;
+  }
+  size_t n_th = 0, n_lin = 0, use = 0;
+  int rc = ndt2d_matcher_prepare_search(m, scan_pose_xyt, points_xy, n_points, &n_th, &n_lin, &use);
+  if (rc != NDT2D_OK) return rc;
+  const size_t n_cand = n_th * n_lin * n_lin;
+  if (n_candidates_out != nullptr) *n_candidates_out = n_cand;
+
+  // record = {best_score, best_index or -1, k00,k01,k02,k11,k12,k22, u0,u1,u2, s}
+  double record[NDT2D_MATCH_RECORD_DOUBLES] = {0, -1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (!m->search_ready)
+  {
+    // No points: every candidate scores -0.0 and none is < 0 (:127-128); no
+    // candidates: the loops do not run.  Either way k = u = s = 0.
+    if (all_scores != nullptr)
+    {
+      for (size_t i = 0; i < n_cand && i < all_scores_cap; ++i) all_scores[i] = -0.0;
+    }
+  }
+  else
+  {
+    std::vector<double> tmp;
+    double * scores_ptr = nullptr;
+    if (all_scores != nullptr)
+    {
+      if (all_scores_cap >= n_cand)
+      {
+        scores_ptr = all_scores;
+      }
+      else
+      {
+        tmp.resize(n_cand);
+        scores_ptr = tmp.data();
+      }
+    }
+    ndt2d_match_result res;
+    rc = ndt2d_match(m->dev, 0, n_th, scores_ptr, &res);
+    if (rc != NDT2D_OK) return dev_fail(m, rc, "ndt2d_match");
+    if (!tmp.empty()) std::memcpy(all_scores, tmp.data(), all_scores_cap * sizeof(double));
+    record[0] = res.best_score;
+    record[1] = res.best_index == NDT2D_NO_INDEX ? -1.0 : static_cast<double>(res.best_index);
+    for (int i = 0; i < 10; ++i) record[2 + i] = res.acc[i];
+    if (best_index_out != nullptr) *best_index_out = res.best_index;
+  }
+  return ndt2d_matcher_finish_match(m, record, pose_inout, covariance_out, score_out);
+}
+
+int ndt2d_matcher_match_scan(ndt2d_matcher * m, const double * scan_pose_xyt,
+                             const double * points_xy, size_t n_points, double * pose_inout,
+                             double * covariance_out, double * score_out)
+{
+  return ndt2d_matcher_match_scan_ex(m, scan_pose_xyt, points_xy, n_points, pose_inout,
+                                     covariance_out, score_out, nullptr, 0, nullptr, nullptr);
+}
+
+int ndt2d_matcher_score_poses(ndt2d_matcher * m, const double * points_xy, size_t n_points,
+                              const double * poses_xyt, size_t n_poses, double * scores_out)
+{
+  if (m == nullptr || scores_out == nullptr || (n_poses > 0 && poses_xyt == nullptr))
+  {
+    return NDT2D_ERR_INVALID;
+  }
+  if (n_poses == 0) return NDT2D_OK;
+  // `if (!ndt_) return 0.0;` (reference src/scan_matcher_ndt.cpp:159)
+  if (!m->ndt)
+  {
+    for (size_t i = 0; i < n_poses; ++i) scores_out[i] = 0.0;
+    return NDT2D_OK;
+  }
+  if (n_points > 0 && points_xy == nullptr) return mfail(m, NDT2D_ERR_INVALID, "null points");
+  const std::vector<double> beams = subsample(points_xy, n_points, m->laser_max_beams);
+  const size_t use = beams.size() / 2;
+  if (use == 0)
+  {
+    // score = 0.0 / 0 (:177)
+    for (size_t i = 0; i < n_poses; ++i) scores_out[i] = std::numeric_limits<double>::quiet_NaN();
+    return NDT2D_OK;
+  }
+  int rc = ndt2d_set_beams(m->dev, beams.data(), use);
+  if (rc != NDT2D_OK) return dev_fail(m, rc, "ndt2d_set_beams");
+  rc = ndt2d_score_poses(m->dev, poses_xyt, n_poses, scores_out, nullptr);
+  if (rc != NDT2D_OK) return dev_fail(m, rc, "ndt2d_score_poses");
+  return NDT2D_OK;
+}
+
+int ndt2d_matcher_prepare_beams(ndt2d_matcher * m, const double * points_xy, size_t n_points,
+                                size_t * n_beams_out)
+{
+  if (m == nullptr) return NDT2D_ERR_INVALID;
+  if (n_points > 0 && points_xy == nullptr) return mfail(m, NDT2D_ERR_INVALID, "null points");
+  m->beams = subsample(points_xy, n_points, m->laser_max_beams);
+  const size_t use = m->beams.size() / 2;
+  if (n_beams_out != nullptr) *n_beams_out = use;
+  if (use == 0) return NDT2D_OK;
+  int rc = ndt2d_set_beams(m->dev, m->beams.data(), use);
+  if (rc != NDT2D_OK) return dev_fail(m, rc, "ndt2d_set_beams");
+  return NDT2D_OK;
+}
+
+int ndt2d_matcher_score_points(ndt2d_matcher * m, const double * points_xy, size_t n_points,
+                               const double * pose_xyt, double * score_out)
+{
+  if (pose_xyt == nullptr || score_out == nullptr) return NDT2D_ERR_INVALID;
+  return ndt2d_matcher_score_poses(m, points_xy, n_points, pose_xyt, 1, score_out);
+}
+
+int ndt2d_matcher_score_scan(ndt2d_matcher * m, const double * scan_pose_xyt,
+                             const double * points_xy, size_t n_points, double * score_out)
+{
+  // scoreScan(scan) = scorePoints(scan->getPoints(), scan->getPose()) (:151-154)
+  return ndt2d_matcher_score_points(m, points_xy, n_points, scan_pose_xyt, score_out);
+}
+
+int ndt2d_matcher_pf_measure(ndt2d_matcher * m, const double * particles_xyt,
+                             size_t n_particles, const double * points_xy, size_t n_points,
+                             double * weights_out, double * mean_out, double * cov_inout)
+{
+  if (m == nullptr || weights_out == nullptr || mean_out == nullptr || cov_inout == nullptr ||
+      (n_particles > 0 && particles_xyt == nullptr))
+  {
+    return NDT2D_ERR_INVALID;
+  }
+  double stats[NDT2D_POSE_STATS_DOUBLES] = {0, 0, 0, 0, 0, 0, 0, 0};
+  bool have_stats = false;
+  if (n_particles > 0)
+  {
+    if (m->ndt && n_points > 0 && m->laser_max_beams > 0)
+    {
+      if (points_xy == nullptr) return mfail(m, NDT2D_ERR_INVALID, "null points");
+      const std::vector<double> beams = subsample(points_xy, n_points, m->laser_max_beams);
+      int rc = ndt2d_set_beams(m->dev, beams.data(), beams.size() / 2);
+      if (rc != NDT2D_OK) return dev_fail(m, rc, "ndt2d_set_beams");
+      // weights_[i] = scorePoints(points, particle_i) (particle_filter.cpp:81-87)
+      rc = ndt2d_score_poses(m->dev, particles_xyt, n_particles, weights_out, stats);
+      if (rc != NDT2D_OK) return dev_fail(m, rc, "ndt2d_score_poses");
+      have_stats = true;
+    }
+    else
+    {
+      int rc = ndt2d_matcher_score_poses(m, points_xy, n_points, particles_xyt, n_particles,
+                                         weights_out);
+      if (rc != NDT2D_OK) return rc;
+    }
+  }
+  if (!have_stats)
+  {
+    // degenerate inputs (no map / no points): sums of the constant weights
+    for (size_t i = 0; i < n_particles; ++i)
+    {
+      const double w = weights_out[i];
+      const double * p = particles_xyt + 3 * i;
+      stats[0] += w;
+      stats[1] += w * p[0];
+      stats[2] += w * p[1];
+      stats[3] += w * std::cos(p[2]);
+      stats[4] += w * std::sin(p[2]);
+      stats[5] += w * p[0] * p[0];
+      stats[6] += w * p[0] * p[1];
+      stats[7] += w * p[1] * p[1];
+    }
+  }
+
+  // updateStatistics (particle_filter.cpp:163-218) from the device sums:
+  // normalise (:166-174) ...
+  const double sum_weight = stats[0];
+  for (size_t i = 0; i < n_particles; ++i) weights_out[i] /= sum_weight;
+  // ... weighted mean, circular mean of theta (:182-205) ...
+  const double mean_x = stats[1] / sum_weight;
+  const double mean_y = stats[2] / sum_weight;
+  mean_out[0] = mean_x;
+  mean_out[1] = mean_y;
+  mean_out[2] = std::atan2(stats[4] / sum_weight, stats[3] / sum_weight);
+  // ... x/y covariance (:208-215) ...
+  cov_inout[0] = stats[5] / sum_weight - mean_x * mean_x;
+  cov_inout[1] = stats[6] / sum_weight - mean_x * mean_y;
+  cov_inout[3] = cov_inout[1];
+  cov_inout[4] = stats[7] / sum_weight - mean_y * mean_y;
+  // ... theta variance accumulates onto the previous value (:218-222).
+  for (size_t i = 0; i < n_particles; ++i)
+  {
+    const double d = normalize_angle(mean_out[2] - particles_xyt[3 * i + 2]);
+    cov_inout[8] += weights_out[i] * d * d;
+  }
+  return NDT2D_OK;
+}
+
+int ndt2d_matcher_grid_info(ndt2d_matcher * m, uint32_t * size_x, uint32_t * size_y,
+                            double * cell_size, double * origin_x, double * origin_y)
+{
+  if (m == nullptr) return NDT2D_ERR_INVALID;
+  if (!m->ndt) return mfail(m, NDT2D_ERR_NO_GRID, "no NDT");
+  if (size_x) *size_x = static_cast<uint32_t>(m->ndt->size_x());
+  if (size_y) *size_y = static_cast<uint32_t>(m->ndt->size_y());
+  if (cell_size) *cell_size = m->ndt->cell_size();
+  if (origin_x) *origin_x = m->ndt->origin_x();
+  if (origin_y) *origin_y = m->ndt->origin_y();
+  return NDT2D_OK;
+}
+
+int ndt2d_matcher_grid_cells6(ndt2d_matcher * m, double * cells6_out, size_t capacity_cells)
+{
+  if (m == nullptr || cells6_out == nullptr) return NDT2D_ERR_INVALID;
+  if (!m->ndt) return mfail(m, NDT2D_ERR_NO_GRID, "no NDT");
+  if (capacity_cells < m->ndt->ncell()) return mfail(m, NDT2D_ERR_INVALID, "capacity too small");
+  m->ndt->pack6(cells6_out);
+  return NDT2D_OK;
+}
+
+int ndt2d_search_offsets(double size, double res, double * out, size_t cap, size_t * n_out)
+{
+  const std::vector<double> v = search_offsets(size, res);
+  if (n_out != nullptr) *n_out = v.size();
+  if (out != nullptr)
+  {
+    for (size_t i = 0; i < v.size() && i < cap; ++i) out[i] = v[i];
+  }
+  return NDT2D_OK;
+}
+
+int ndt2d_host_build_grid(double ndt_resolution, double range_max, const double * poses_xyt,
+                          const double * points_xy, const size_t * offsets, size_t n_scans,
+                          double * cells6_out, size_t capacity_cells, uint32_t * size_x,
+                          uint32_t * size_y, double * origin_x, double * origin_y)
+{
+  if (!(ndt_resolution > 0.0) || (n_scans > 0 && (poses_xyt == nullptr || offsets == nullptr)))
+  {
+    return NDT2D_ERR_INVALID;
+  }
+  static const double no_points[2] = {0.0, 0.0};
+  static const size_t no_offsets[1] = {0};
+  std::unique_ptr<HostNdt> ndt = build_ndt(ndt_resolution, range_max, poses_xyt,
+                                           points_xy ? points_xy : no_points,
+                                           offsets ? offsets : no_offsets, n_scans);
+  if (size_x) *size_x = static_cast<uint32_t>(ndt->size_x());
+  if (size_y) *size_y = static_cast<uint32_t>(ndt->size_y());
+  if (origin_x) *origin_x = ndt->origin_x();
+  if (origin_y) *origin_y = ndt->origin_y();
+  if (cells6_out != nullptr)
+  {
+    if (capacity_cells < ndt->ncell()) return NDT2D_ERR_INVALID;
+    ndt->pack6(cells6_out);
+  }
+  return NDT2D_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Synthetic workload generator
+// ---------------------------------------------------------------------------
+
+}  // extern "C"
+
+namespace
+{
+
+struct SplitMix64
+{
+  uint64_t s;
+  explicit SplitMix64(uint64_t seed) : s(seed) {}
+  uint64_t next()
+  {
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+  }
+  double uniform() { return static_cast<double>(next() >> 11) * (1.0 / 9007199254740992.0); }
+  double normal()
+  {
+    // Box-Muller, one value per two uniforms
+    const double u1 = 1.0 - uniform();
+    const double u2 = uniform();
+    return std::sqrt(-2.0 * std::log(u1)) * std::cos(2.0 * M_PI * u2);
+  }
+};
+
+bool pillar_in_cell(const ndt2d_world & w, long ci, long cj, double * cx, double * cy)
+{
+  *cx = w.pillar_pitch * static_cast<double>(ci) + 0.5 * w.pillar_pitch;
+  *cy = w.pillar_pitch * static_cast<double>(cj) + 0.5 * w.pillar_pitch;
+  return std::fabs(*cx) + w.pillar_half < w.room_half && std::fabs(*cy) + w.pillar_half < w.room_half;
+}
+
+// Distance along (dx, dy) from (ox, oy) to the nearest surface.
+double raycast(const ndt2d_world & w, double ox, double oy, double dx, double dy)
+{
+  const double inf = std::numeric_limits<double>::infinity();
+  // room walls (origin inside the room)
+  double t_wall = inf;
+  if (dx > 0) t_wall = std::min(t_wall, (w.room_half - ox) / dx);
+  if (dx < 0) t_wall = std::min(t_wall, (-w.room_half - ox) / dx);
+  if (dy > 0) t_wall = std::min(t_wall, (w.room_half - oy) / dy);
+  if (dy < 0) t_wall = std::min(t_wall, (-w.room_half - oy) / dy);
+  if (!(w.pillar_pitch > 0.0) || !(w.pillar_half > 0.0)) return t_wall;
+
+  // walk the pillar lattice cells the ray crosses (one pillar per cell)
+  const double pitch = w.pillar_pitch;
+  long ci = static_cast<long>(std::floor(ox / pitch));
+  long cj = static_cast<long>(std::floor(oy / pitch));
+  const long step_i = dx > 0 ? 1 : -1, step_j = dy > 0 ? 1 : -1;
+  double t_max_x = dx != 0 ? ((dx > 0 ? (ci + 1) * pitch : ci * pitch) - ox) / dx : inf;
+  double t_max_y = dy != 0 ? ((dy > 0 ? (cj + 1) * pitch : cj * pitch) - oy) / dy : inf;
+  const double t_dx = dx != 0 ? pitch / std::fabs(dx) : inf;
+  const double t_dy = dy != 0 ? pitch / std::fabs(dy) : inf;
+  double t_enter = 0.0;
+  while (t_enter <= t_wall)
+  {
+    double cx, cy;
+    if (pillar_in_cell(w, ci, cj, &cx, &cy))
+    {
+      // slab test against [cx - h, cx + h] x [cy - h, cy + h]
+      double t0 = 0.0, t1 = inf;
+      bool hit = true;
+      const double lo[2] = {cx - w.pillar_half, cy - w.pillar_half};
+      const double hi[2] = {cx + w.pillar_half, cy + w.pillar_half};
+      const double o[2] = {ox, oy}, d[2] = {dx, dy};
+      for (int a = 0; a < 2 && hit; ++a)
+      {
+        if (d[a] == 0.0)
+        {
+          if (o[a] < lo[a] || o[a] > hi[a]) hit = false;
+        }
+        else
+        {
+          double ta = (lo[a] - o[a]) / d[a], tb = (hi[a] - o[a]) / d[a];
+          if (ta > tb) std::swap(ta, tb);
+          t0 = std::max(t0, ta);
+          t1 = std::min(t1, tb);
+          if (t0 > t1) hit = false;
+        }
+      }
+      if (hit && t0 > 0.0 && t0 < t_wall) return t0;
+    }
+    if (t_max_x < t_max_y)
+    {
+      t_enter = t_max_x;
+      t_max_x += t_dx;
+      ci += step_i;
+    }
+    else
+    {
+      t_enter = t_max_y;
+      t_max_y += t_dy;
+      cj += step_j;
+    }
+  }
+  return t_wall;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ndt2d_synth_scan(const ndt2d_world * world, const double * pose_xyt, size_t n_beams,
+                     double noise_sigma, uint64_t seed, double * points_xy)
+{
+  if (world == nullptr || pose_xyt == nullptr || points_xy == nullptr || n_beams == 0)
+  {
+    return NDT2D_ERR_INVALID;
+  }
+  if (std::fabs(pose_xyt[0]) >= world->room_half || std::fabs(pose_xyt[1]) >= world->room_half)
+  {
+    return NDT2D_ERR_INVALID;
+  }
+  SplitMix64 rng(seed);
+  const double step = 2.0 * M_PI / static_cast<double>(n_beams);
+  for (size_t k = 0; k < n_beams; ++k)
+  {
+    const double ang = -M_PI + static_cast<double>(k) * step;
+    const double wa = pose_xyt[2] + ang;
+    double r = raycast(*world, pose_xyt[0], pose_xyt[1], std::cos(wa), std::sin(wa));
+    r += noise_sigma * rng.normal();
+    points_xy[2 * k] = r * std::cos(ang);
+    points_xy[2 * k + 1] = r * std::sin(ang);
+  }
+  return NDT2D_OK;
+}
+
+int ndt2d_synth_pose_blocked(const ndt2d_world * world, double x, double y, double margin)
+{
+  if (world == nullptr || !(world->pillar_pitch > 0.0)) return 0;
+  const long ci = static_cast<long>(std::floor(x / world->pillar_pitch));
+  const long cj = static_cast<long>(std::floor(y / world->pillar_pitch));
+  double cx, cy;
+  if (!pillar_in_cell(*world, ci, cj, &cx, &cy)) return 0;
+  return (std::fabs(x - cx) <= world->pillar_half + margin &&
+          std::fabs(y - cy) <= world->pillar_half + margin)
+           ? 1
+           : 0;
+}
+
+int ndt2d_synth_uniform(uint64_t seed, size_t n, double * out)
+{
+  if (out == nullptr) return NDT2D_ERR_INVALID;
+  SplitMix64 rng(seed);
+  for (size_t i = 0; i < n; ++i) out[i] = rng.uniform();
+  return NDT2D_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,87 @@
+// Internal interface between the HIP kernels (ndt2d_kernels.hip) and the
+// device-layer C-ABI (ndt2d_device.hip).  Not installed; the public boundary is
+// include/ndt2d_hip.h.
+#ifndef NDT2D_KERNELS_H_
+#define NDT2D_KERNELS_H_
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace ndt2d
+{
+
+// Doubles per packed device cell record.  {mean_x, mean_y, h00, h01, h11, occ}
+// with h = -0.5 * information (exact scaling) and occ = 1.0 for cells that can
+// score (n >= 5, reference src/ndt_model.cpp:107), 0.0 otherwise.  Cells that
+// cannot score carry a sentinel mean so their exponent is -inf and exp() gives
+// the reference's exact 0.0 without a branch.  Record ncell is such a sentinel
+// and stands for "outside the grid" (src/ndt_model.cpp:165-169,205-208,212-215).
+constexpr int kCellDoubles = 6;
+// Stride (doubles) of the HBM-resident copy used when the grid does not fit in
+// LDS: one 64-byte line per cell, so a gather touches exactly one line.
+constexpr int kCellStrideGlobal = 8;
+
+struct GridDesc
+{
+  const double * cells_lds_image;  // [ncell + 1][kCellDoubles], source of the LDS fill
+  const double * cells_global;     // [ncell + 1][kCellStrideGlobal]
+  uint32_t size_x, size_y, ncell;
+  double cell_size;
+  double inv_cell_size;  // exact iff pow2
+  int pow2;              // cell_size is a power of two: t * inv == t / cell_size bit-for-bit
+  double origin_x, origin_y;
+};
+
+struct MatchArgs
+{
+  GridDesc grid;
+  const double * beams_xy;  // [n_beams][2] robot frame
+  uint32_t n_beams;
+  const double * dth;       // [n_th]
+  const double * cos_th;    // [n_th]
+  const double * sin_th;    // [n_th]
+  const double * dlin;      // [n_lin]
+  uint32_t n_th, n_lin;
+  uint32_t th_begin, th_end;
+  double pose_x, pose_y;
+  double * scores;          // optional, slab-local flat order
+  double * partials;        // [n_workers][NDT2D_MATCH_RECORD_DOUBLES]
+  uint32_t chunk;           // candidates per work item
+};
+
+struct PosesArgs
+{
+  GridDesc grid;
+  const double * beams_xy;
+  uint32_t n_beams;
+  const double * poses_xyt;  // [n_poses][3]
+  uint64_t n_poses;
+  double * scores;           // [n_poses]
+  double * partials;         // [n_blocks][8]  (may be null)
+};
+
+struct LaunchInfo
+{
+  const char * variant;
+  int n_kernels;
+};
+
+// Launch the match search + its final reduction.  record_out: device,
+// 12 doubles.  workspace: device scratch for per-wave partials, at least
+// match_workspace_doubles() doubles.
+size_t match_workspace_doubles();
+hipError_t launch_match(const MatchArgs & args, double * workspace, double * record_out,
+                        double * record_out2, int force_variant, hipStream_t stream,
+                        LaunchInfo * info);
+
+size_t poses_workspace_doubles(uint64_t n_poses);
+hipError_t launch_score_poses(const PosesArgs & args, double * workspace, double * stats_out,
+                              int force_variant, hipStream_t stream, LaunchInfo * info);
+
+// force_variant values
+enum { kVariantAuto = 0, kVariantLds = 1, kVariantGlobal = 2 };
+
+}  // namespace ndt2d
+
+#endif  // NDT2D_KERNELS_H_

@@ -1,0 +1,657 @@
+// Hand-written HIP kernels for ndt_2d's NDT scoring hot path, gfx950 (MI355X).
+//
+//   match_kernel        ScanMatcherNDT::matchScan's exhaustive (theta, x, y)
+//                       search, reference src/scan_matcher_ndt.cpp:103-143:
+//                       one 64-lane wavefront per candidate pose, lanes stride
+//                       the beams, wave-level reduction of the per-point
+//                       likelihoods (NDT::likelihood, src/ndt_model.cpp:178-187).
+//   score_poses_kernel  ScanMatcherNDT::scorePoints for a batch of poses
+//                       (src/scan_matcher_ndt.cpp:156-178), i.e. the loop body
+//                       of ParticleFilter::measure (src/particle_filter.cpp:81-87):
+//                       one candidate pose (particle) per lane, beams in order.
+//
+// All arithmetic is IEEE double in the reference's operation order; this file
+// is compiled with -ffp-contract=off so no multiply-add is fused that the
+// reference's x86-64 build keeps separate.  No MFMA: there is no dense
+// contraction on this path.
+#include "ndt2d_kernels.h"
+
+#include <math.h>
+
+namespace ndt2d
+{
+
+namespace
+{
+
+constexpr int kWave = 64;
+constexpr int kMatchThreads = 512;
+constexpr int kMatchWaves = kMatchThreads / kWave;
+constexpr int kRecord = 12;  // NDT2D_MATCH_RECORD_DOUBLES
+constexpr double kNoIndex = 1.0e308;
+// Coordinate given to padding beams (lane index >= n_beams): far left of any
+// grid, so they select the sentinel record and contribute exp(-inf) = +0.0.
+constexpr double kPadCoord = -1.0e300;
+
+// NDT::getIndex, reference src/ndt_model.cpp:203-218.
+//   x < origin_x_ || y < origin_y_            -> outside
+//   grid = (unsigned)((x - origin) / cell)    -> truncation toward zero
+//   grid >= size                               -> outside
+// `fx < size_x` on the un-truncated quotient is equivalent to
+// `trunc(fx) < size_x` for fx >= 0 and keeps the conversion in range.
+// Returns ncell (the sentinel record) for "outside".
+template <bool POW2>
+__device__ __forceinline__ uint32_t cell_index(const GridDesc & g, double px, double py)
+{
+  const double tx = px - g.origin_x;
+  const double ty = py - g.origin_y;
+  double fx, fy;
+  if (POW2)
+  {
+    // cell_size is a power of two: multiplying by its exact reciprocal gives
+    // the correctly rounded quotient, bit-identical to the reference's divide.
+    fx = tx * g.inv_cell_size;
+    fy = ty * g.inv_cell_size;
+  }
+  else
+  {
+    fx = tx / g.cell_size;
+    fy = ty / g.cell_size;
+  }
+  const bool inside = (tx >= 0.0) & (ty >= 0.0) & (fx < static_cast<double>(g.size_x)) &
+                      (fy < static_cast<double>(g.size_y));
+  const uint32_t gx = static_cast<uint32_t>(fx);
+  const uint32_t gy = static_cast<uint32_t>(fy);
+  return inside ? gy * g.size_x + gx : g.ncell;
+}
+
+// Cell::score, reference src/ndt_model.cpp:105-116, on a packed record with
+// h = -0.5 * information:  exponent = ((-0.5 q^T) I) q
+//   = (q0*h00 + q1*h01) * q0 + (q0*h01 + q1*h11) * q1   (same roundings).
+__device__ __forceinline__ double record_likelihood(double mx, double my, double h00,
+                                                    double h01, double h11, double px,
+                                                    double py)
+{
+  const double q0 = px - mx;
+  const double q1 = py - my;
+  const double r0 = q0 * h00 + q1 * h01;
+  const double r1 = q0 * h01 + q1 * h11;
+  const double e = r0 * q0 + r1 * q1;
+  return exp(e);
+}
+
+// NDT::likelihood(Vector2d), reference src/ndt_model.cpp:162-170.
+template <bool LDS_GRID, bool POW2>
+__device__ __forceinline__ double point_likelihood(const GridDesc & g, const double * lds_cells,
+                                                   double px, double py)
+{
+  const uint32_t idx = cell_index<POW2>(g, px, py);
+  double2 a, b, c;
+  if (LDS_GRID)
+  {
+    const double2 * rec = reinterpret_cast<const double2 *>(lds_cells + idx * kCellDoubles);
+    a = rec[0];
+    b = rec[1];
+    c = rec[2];
+  }
+  else
+  {
+    const double2 * rec =
+      reinterpret_cast<const double2 *>(g.cells_global + static_cast<size_t>(idx) * kCellStrideGlobal);
+    a = rec[0];
+    b = rec[1];
+    c = rec[2];
+  }
+  return record_likelihood(a.x, a.y, b.x, b.y, c.x, px, py);
+}
+
+__device__ __forceinline__ void stage_grid_to_lds(const GridDesc & g, double * lds_cells)
+{
+  const uint32_t n2 = (g.ncell + 1) * kCellDoubles / 2;  // kCellDoubles is even
+  const double2 * src = reinterpret_cast<const double2 *>(g.cells_lds_image);
+  double2 * dst = reinterpret_cast<double2 *>(lds_cells);
+  for (uint32_t i = threadIdx.x; i < n2; i += blockDim.x)
+  {
+    dst[i] = src[i];
+  }
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1)
+  {
+    v += __shfl_xor(v, off, kWave);
+  }
+  return v;
+}
+
+// (score, index) ordering of the reference's `if (score < best_score)` scan in
+// loop order (src/scan_matcher_ndt.cpp:128): lower score wins, ties go to the
+// lower flat index.
+__device__ __forceinline__ bool better(double s_a, double i_a, double s_b, double i_b)
+{
+  return (s_a < s_b) | ((s_a == s_b) & (i_a < i_b));
+}
+
+// ---------------------------------------------------------------------------
+// matchScan search: one wavefront per candidate pose.
+//
+// A work item is `chunk` consecutive (ix, iy) candidates of one theta; wave w of
+// the whole launch takes items w, w + W, ...  Per item the wave rotates its
+// NBL beams per lane into registers (points_outer, :108-115), then per
+// candidate shifts them (:121-125), gathers the cell records from the LDS copy
+// of the grid and reduces the likelihoods across the wave.
+// ---------------------------------------------------------------------------
+template <int NBL, bool LDS_GRID, bool POW2>
+__global__ void __launch_bounds__(kMatchThreads) match_kernel(const MatchArgs a)
+{
+  extern __shared__ __align__(16) double lds_cells[];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x >> 6;
+
+  if (LDS_GRID)
+  {
+    stage_grid_to_lds(a.grid, lds_cells);
+    __syncthreads();
+  }
+
+  const uint32_t n_lin = a.n_lin;
+  const uint32_t m = n_lin * n_lin;                       // candidates per theta
+  const uint32_t cps = (m + a.chunk - 1) / a.chunk;       // chunks per theta
+  const uint64_t n_items = static_cast<uint64_t>(a.th_end - a.th_begin) * cps;
+  const uint32_t n_workers = gridDim.x * kMatchWaves;
+  const uint32_t worker = wave * gridDim.x + blockIdx.x;  // interleave CUs
+
+  // Lane L < 10 owns covariance accumulator L of {k00,k01,k02,k11,k12,k22,u0,u1,u2,s}
+  // (src/scan_matcher_ndt.cpp:137-140): acc += (xa * xb) * score with
+  // xa, xb in {dx, dy, dth, 1}; (x * 1) * score == x * score exactly.
+  int sel_a = 4, sel_b = 4;  // 0: dx, 1: dy, 2: dth, 3: 1.0, 4: 0.0
+  switch (lane)
+  {
+    case 0: sel_a = 0; sel_b = 0; break;
+    case 1: sel_a = 0; sel_b = 1; break;
+    case 2: sel_a = 0; sel_b = 2; break;
+    case 3: sel_a = 1; sel_b = 1; break;
+    case 4: sel_a = 1; sel_b = 2; break;
+    case 5: sel_a = 2; sel_b = 2; break;
+    case 6: sel_a = 0; sel_b = 3; break;
+    case 7: sel_a = 1; sel_b = 3; break;
+    case 8: sel_a = 2; sel_b = 3; break;
+    case 9: sel_a = 3; sel_b = 3; break;
+    default: break;
+  }
+
+  double best_s = 0.0;       // `double best_score = 0;` (:83)
+  double best_i = kNoIndex;
+  double acc = 0.0;
+
+  for (uint64_t item = worker; item < n_items; item += n_workers)
+  {
+    const uint32_t ith = a.th_begin + static_cast<uint32_t>(item / cps);
+    const uint32_t c = static_cast<uint32_t>(item % cps);
+    const double ct = a.cos_th[ith];
+    const double st = a.sin_th[ith];
+    const double dt = a.dth[ith];
+
+    // points_outer (:108-115)
+    double ox[NBL], oy[NBL];
+#pragma unroll
+    for (int j = 0; j < NBL; ++j)
+    {
+      const uint32_t b = lane + kWave * j;
+      if (b < a.n_beams)
+      {
+        const double2 p = reinterpret_cast<const double2 *>(a.beams_xy)[b];
+        ox[j] = p.x * ct - p.y * st + a.pose_x;
+        oy[j] = p.x * st + p.y * ct + a.pose_y;
+      }
+      else
+      {
+        ox[j] = kPadCoord;
+        oy[j] = kPadCoord;
+      }
+    }
+
+    const uint32_t f0 = c * a.chunk;
+    const uint32_t f1 = min(f0 + a.chunk, m);
+    uint32_t ix = f0 / n_lin;
+    uint32_t iy = f0 - ix * n_lin;
+    for (uint32_t f = f0; f < f1; ++f)
+    {
+      const double dx = a.dlin[ix];
+      const double dy = a.dlin[iy];
+
+      // points_inner + NDT::likelihood(points_inner) (:121-127)
+      double sum = 0.0;
+#pragma unroll
+      for (int j = 0; j < NBL; ++j)
+      {
+        const double px = ox[j] + dx;
+        const double py = oy[j] + dy;
+        sum += point_likelihood<LDS_GRID, POW2>(a.grid, lds_cells, px, py);
+      }
+      sum = wave_sum(sum);
+      const double score = -sum;
+
+      const double flat = static_cast<double>(static_cast<uint64_t>(ith) * m + f);
+      if (score < best_s)
+      {
+        best_s = score;
+        best_i = flat;
+      }
+
+      const double xa = sel_a == 0 ? dx : (sel_a == 1 ? dy : (sel_a == 2 ? dt : (sel_a == 3 ? 1.0 : 0.0)));
+      const double xb = sel_b == 0 ? dx : (sel_b == 1 ? dy : (sel_b == 2 ? dt : (sel_b == 3 ? 1.0 : 0.0)));
+      acc += (xa * xb) * score;
+
+      if (a.scores != nullptr && lane == 0)
+      {
+        a.scores[static_cast<uint64_t>(ith - a.th_begin) * m + f] = score;
+      }
+
+      if (++iy == n_lin)
+      {
+        iy = 0;
+        ++ix;
+      }
+    }
+  }
+
+  double * out = a.partials + static_cast<size_t>(worker) * kRecord;
+  if (lane == 0)
+  {
+    out[0] = best_s;
+    out[1] = best_i;
+  }
+  if (lane < 10)
+  {
+    out[2 + lane] = acc;
+  }
+}
+
+// Final reduction of the per-wave partial records, fixed order (deterministic).
+// record = {best_score, best_index (exact double, -1 if none), acc[10]}.
+__global__ void __launch_bounds__(256) match_reduce_kernel(const double * partials,
+                                                           uint32_t n_workers, double * record,
+                                                           double * record2)
+{
+  __shared__ double sh[256 * kRecord];
+  const int t = threadIdx.x;
+  double v[kRecord];
+  v[0] = 0.0;
+  v[1] = kNoIndex;
+#pragma unroll
+  for (int k = 2; k < kRecord; ++k) v[k] = 0.0;
+  for (uint32_t w = t; w < n_workers; w += 256)
+  {
+    const double * p = partials + static_cast<size_t>(w) * kRecord;
+    if (better(p[0], p[1], v[0], v[1]))
+    {
+      v[0] = p[0];
+      v[1] = p[1];
+    }
+#pragma unroll
+    for (int k = 2; k < kRecord; ++k) v[k] += p[k];
+  }
+#pragma unroll
+  for (int k = 0; k < kRecord; ++k) sh[t * kRecord + k] = v[k];
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1)
+  {
+    if (t < s)
+    {
+      double * mine = sh + t * kRecord;
+      const double * other = sh + (t + s) * kRecord;
+      if (better(other[0], other[1], mine[0], mine[1]))
+      {
+        mine[0] = other[0];
+        mine[1] = other[1];
+      }
+#pragma unroll
+      for (int k = 2; k < kRecord; ++k) mine[k] += other[k];
+    }
+    __syncthreads();
+  }
+  if (t < kRecord)
+  {
+    double val = sh[t];
+    if (t == 1 && !(sh[0] < 0.0)) val = -1.0;
+    record[t] = val;
+    if (record2 != nullptr) record2[t] = val;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Batched scorePoints: one pose (particle) per lane; beams are walked in order,
+// so each lane's sum has exactly the reference's sequential order (:168-175).
+// ---------------------------------------------------------------------------
+template <int THREADS, bool LDS_GRID, bool POW2>
+__global__ void __launch_bounds__(THREADS) score_poses_kernel(const PosesArgs a)
+{
+  // One dynamic LDS region (keeps its base 16-byte aligned):
+  // [per-wave statistics][beams][grid records]
+  extern __shared__ __align__(16) double lds[];
+  double * sh_stats = lds;                                    // [THREADS/64][8]
+  double * lds_beams = lds + (THREADS / kWave) * 8;           // [n_beams][2]
+  double * lds_cells = lds_beams + 2 * ((a.n_beams + 1) & ~1u);
+
+  for (uint32_t i = threadIdx.x; i < 2 * a.n_beams; i += THREADS)
+  {
+    lds_beams[i] = a.beams_xy[i];
+  }
+  if (LDS_GRID)
+  {
+    stage_grid_to_lds(a.grid, lds_cells);
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x >> 6;
+  double st[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) st[k] = 0.0;
+
+  const uint64_t stride = static_cast<uint64_t>(gridDim.x) * THREADS;
+  const uint64_t n_round = (a.n_poses + stride - 1) / stride * stride;
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * THREADS + threadIdx.x; i < n_round;
+       i += stride)
+  {
+    const bool valid = i < a.n_poses;
+    double x = 0.0, y = 0.0, th = 0.0;
+    if (valid)
+    {
+      x = a.poses_xyt[3 * i];
+      y = a.poses_xyt[3 * i + 1];
+      th = a.poses_xyt[3 * i + 2];
+    }
+    // toEigen(pose): AngleAxisd(theta, Z) -> [[c,-s],[s,c]] (conversions.hpp:64-68)
+    double s, c;
+    sincos(th, &s, &c);
+
+    double sum = 0.0;
+    for (uint32_t k = 0; k < a.n_beams; ++k)
+    {
+      const double2 p = reinterpret_cast<const double2 *>(lds_beams)[k];
+      // p = t * (x, y, 1) (:172-173): translation + (c*x + (-s)*y), (s*x + c*y)
+      const double px = x + (c * p.x - s * p.y);
+      const double py = y + (s * p.x + c * p.y);
+      sum += point_likelihood<LDS_GRID, POW2>(a.grid, lds_cells, px, py);
+    }
+    // score += -likelihood  ==  -(sum of likelihoods), bit-for-bit; (:177)
+    const double score = -sum / static_cast<double>(a.n_beams);
+    if (valid)
+    {
+      a.scores[i] = score;
+      // sums for ParticleFilter::updateStatistics (particle_filter.cpp:166-200)
+      const double w = score;
+      st[0] += w;
+      st[1] += w * x;
+      st[2] += w * y;
+      st[3] += w * c;
+      st[4] += w * s;
+      st[5] += w * x * x;
+      st[6] += w * x * y;
+      st[7] += w * y * y;
+    }
+  }
+
+  if (a.partials != nullptr)
+  {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) st[k] = wave_sum(st[k]);
+    if (lane == 0)
+    {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) sh_stats[wave * 8 + k] = st[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 8)
+    {
+      double v = 0.0;
+      for (int w = 0; w < THREADS / kWave; ++w) v += sh_stats[w * 8 + threadIdx.x];
+      a.partials[static_cast<size_t>(blockIdx.x) * 8 + threadIdx.x] = v;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) poses_reduce_kernel(const double * partials,
+                                                           uint32_t n_blocks, double * stats)
+{
+  __shared__ double sh[256 * 8];
+  const int t = threadIdx.x;
+  double v[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] = 0.0;
+  for (uint32_t b = t; b < n_blocks; b += 256)
+  {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] += partials[static_cast<size_t>(b) * 8 + k];
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) sh[t * 8 + k] = v[k];
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1)
+  {
+    if (t < s)
+    {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) sh[t * 8 + k] += sh[(t + s) * 8 + k];
+    }
+    __syncthreads();
+  }
+  if (t < 8) stats[t] = sh[t];
+}
+
+constexpr uint32_t kMaxMatchBlocks = 512;   // 2 blocks per CU on 256 CUs
+constexpr uint32_t kMaxPosesBlocks = 4096;
+constexpr size_t kLdsPerCu = 160 * 1024;
+
+struct DeviceLimits
+{
+  int cus;
+  size_t lds_per_block;
+};
+
+DeviceLimits device_limits()
+{
+  DeviceLimits lim{256, kLdsPerCu};
+  int dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess)
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess)
+    {
+      lim.cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+      int v = 0;
+      if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess &&
+          v > 0)
+      {
+        lim.lds_per_block = static_cast<size_t>(v);
+      }
+    }
+  }
+  return lim;
+}
+
+template <int NBL, bool LDS_GRID, bool POW2>
+hipError_t launch_match_variant(const MatchArgs & args, uint32_t blocks, size_t lds_bytes,
+                                hipStream_t stream)
+{
+  auto kernel = match_kernel<NBL, LDS_GRID, POW2>;
+  if (lds_bytes > 48 * 1024)
+  {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(lds_bytes));
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kMatchThreads), lds_bytes, stream, args);
+  return hipGetLastError();
+}
+
+template <bool LDS_GRID, bool POW2>
+hipError_t dispatch_match_nbl(const MatchArgs & args, uint32_t blocks, size_t lds_bytes,
+                              hipStream_t stream)
+{
+  const uint32_t nbl = (args.n_beams + kWave - 1) / kWave;
+  if (nbl <= 2) return launch_match_variant<2, LDS_GRID, POW2>(args, blocks, lds_bytes, stream);
+  if (nbl <= 4) return launch_match_variant<4, LDS_GRID, POW2>(args, blocks, lds_bytes, stream);
+  if (nbl <= 8) return launch_match_variant<8, LDS_GRID, POW2>(args, blocks, lds_bytes, stream);
+  if (nbl <= 12) return launch_match_variant<12, LDS_GRID, POW2>(args, blocks, lds_bytes, stream);
+  if (nbl <= 16) return launch_match_variant<16, LDS_GRID, POW2>(args, blocks, lds_bytes, stream);
+  return hipErrorInvalidValue;
+}
+
+}  // namespace
+
+size_t match_workspace_doubles()
+{
+  return static_cast<size_t>(kMaxMatchBlocks) * kMatchWaves * kRecord;
+}
+
+hipError_t launch_match(const MatchArgs & args_in, double * workspace, double * record_out,
+                        double * record_out2, int force_variant, hipStream_t stream,
+                        LaunchInfo * info)
+{
+  MatchArgs args = args_in;
+  if (args.n_beams == 0 || args.n_beams > 16 * kWave) return hipErrorInvalidValue;
+  const DeviceLimits lim = device_limits();
+
+  const size_t grid_bytes = static_cast<size_t>(args.grid.ncell + 1) * kCellDoubles * sizeof(double);
+  bool use_lds = grid_bytes <= lim.lds_per_block;
+  if (force_variant == kVariantGlobal) use_lds = false;
+  if (force_variant == kVariantLds && !use_lds) return hipErrorInvalidValue;
+
+  // Blocks: persistent, at most 2 per CU (2 x 80 KB grid copies fill the 160 KB LDS).
+  uint32_t blocks_per_cu = 2;
+  if (use_lds && grid_bytes * 2 > kLdsPerCu) blocks_per_cu = 1;
+  uint32_t max_blocks = static_cast<uint32_t>(lim.cus) * blocks_per_cu;
+  if (max_blocks > kMaxMatchBlocks) max_blocks = kMaxMatchBlocks;
+
+  const uint64_t m = static_cast<uint64_t>(args.n_lin) * args.n_lin;
+  const uint64_t total = m * (args.th_end - args.th_begin);
+  // Work item size: aim for >= 8 items per wave, between 8 and 128 candidates.
+  uint64_t chunk = total / (static_cast<uint64_t>(max_blocks) * kMatchWaves * 8);
+  if (chunk < 8) chunk = 8;
+  if (chunk > 128) chunk = 128;
+  if (chunk > m) chunk = m;
+  args.chunk = static_cast<uint32_t>(chunk);
+  const uint64_t cps = (m + chunk - 1) / chunk;
+  const uint64_t n_items = cps * (args.th_end - args.th_begin);
+  uint32_t blocks = static_cast<uint32_t>((n_items + kMatchWaves - 1) / kMatchWaves);
+  if (blocks > max_blocks) blocks = max_blocks;
+  if (blocks == 0) blocks = 1;
+  args.partials = workspace;
+
+  hipError_t e;
+  const bool pow2 = args.grid.pow2 != 0;
+  if (use_lds)
+  {
+    e = pow2 ? dispatch_match_nbl<true, true>(args, blocks, grid_bytes, stream)
+             : dispatch_match_nbl<true, false>(args, blocks, grid_bytes, stream);
+  }
+  else
+  {
+    e = pow2 ? dispatch_match_nbl<false, true>(args, blocks, 0, stream)
+             : dispatch_match_nbl<false, false>(args, blocks, 0, stream);
+  }
+  if (e != hipSuccess) return e;
+
+  hipLaunchKernelGGL(match_reduce_kernel, dim3(1), dim3(256), 0, stream, workspace,
+                     blocks * kMatchWaves, record_out, record_out2);
+  e = hipGetLastError();
+  if (info != nullptr)
+  {
+    info->variant = use_lds ? (pow2 ? "match/wave-per-candidate/lds-grid/pow2"
+                                    : "match/wave-per-candidate/lds-grid/div")
+                            : (pow2 ? "match/wave-per-candidate/global-grid/pow2"
+                                    : "match/wave-per-candidate/global-grid/div");
+    info->n_kernels = 2;
+  }
+  return e;
+}
+
+size_t poses_workspace_doubles(uint64_t)
+{
+  return static_cast<size_t>(kMaxPosesBlocks) * 8;
+}
+
+namespace
+{
+
+template <int THREADS, bool LDS_GRID, bool POW2>
+hipError_t launch_poses_variant(const PosesArgs & args, uint32_t blocks, size_t lds_bytes,
+                                hipStream_t stream)
+{
+  auto kernel = score_poses_kernel<THREADS, LDS_GRID, POW2>;
+  if (lds_bytes > 48 * 1024)
+  {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(lds_bytes));
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(kernel, dim3(blocks), dim3(THREADS), lds_bytes, stream, args);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_score_poses(const PosesArgs & args_in, double * workspace, double * stats_out,
+                              int force_variant, hipStream_t stream, LaunchInfo * info)
+{
+  PosesArgs args = args_in;
+  if (args.n_beams == 0 || args.n_poses == 0) return hipErrorInvalidValue;
+  const DeviceLimits lim = device_limits();
+  // beams + the per-wave statistics slots (64 B per wave, 16 waves at most)
+  const size_t beams_bytes =
+    static_cast<size_t>(2) * ((args.n_beams + 1) & ~1u) * sizeof(double) + 16 * 8 * sizeof(double);
+  const size_t grid_bytes = static_cast<size_t>(args.grid.ncell + 1) * kCellDoubles * sizeof(double);
+  bool use_lds = beams_bytes + grid_bytes <= lim.lds_per_block;
+  if (force_variant == kVariantGlobal) use_lds = false;
+  if (force_variant == kVariantLds && !use_lds) return hipErrorInvalidValue;
+  if (beams_bytes > lim.lds_per_block) return hipErrorInvalidValue;
+
+  args.partials = stats_out != nullptr ? workspace : nullptr;
+  const bool pow2 = args.grid.pow2 != 0;
+  hipError_t e;
+  uint32_t blocks;
+  if (use_lds)
+  {
+    constexpr int T = 1024;  // one block per CU owns the LDS grid copy: make it 16 waves
+    uint64_t need = (args.n_poses + T - 1) / T;
+    blocks = static_cast<uint32_t>(need < static_cast<uint64_t>(lim.cus) ? need : lim.cus);
+    const size_t lds_bytes = beams_bytes + grid_bytes;
+    e = pow2 ? launch_poses_variant<T, true, true>(args, blocks, lds_bytes, stream)
+             : launch_poses_variant<T, true, false>(args, blocks, lds_bytes, stream);
+  }
+  else
+  {
+    constexpr int T = 256;
+    uint64_t need = (args.n_poses + T - 1) / T;
+    blocks = static_cast<uint32_t>(need < kMaxPosesBlocks ? need : kMaxPosesBlocks);
+    e = pow2 ? launch_poses_variant<T, false, true>(args, blocks, beams_bytes, stream)
+             : launch_poses_variant<T, false, false>(args, blocks, beams_bytes, stream);
+  }
+  if (e != hipSuccess) return e;
+  int n_kernels = 1;
+  if (stats_out != nullptr)
+  {
+    hipLaunchKernelGGL(poses_reduce_kernel, dim3(1), dim3(256), 0, stream, workspace, blocks,
+                       stats_out);
+    e = hipGetLastError();
+    n_kernels = 2;
+  }
+  if (info != nullptr)
+  {
+    info->variant = use_lds ? (pow2 ? "poses/lane-per-pose/lds-grid/pow2"
+                                    : "poses/lane-per-pose/lds-grid/div")
+                            : (pow2 ? "poses/lane-per-pose/global-grid/pow2"
+                                    : "poses/lane-per-pose/global-grid/div");
+    info->n_kernels = n_kernels;
+  }
+  return e;
+}
+
+}  // namespace ndt2d

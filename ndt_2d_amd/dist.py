@@ -1,0 +1,109 @@
+"""Multi-GPU sharding of the hot path: one process per GPU, torch.distributed
+(backend "nccl" = RCCL over xGMI on MI355X; "gloo" in the CPU tests).
+
+matchScan: the candidate lattice is split into contiguous theta slabs (theta is
+the outer loop of the reference, src/scan_matcher_ndt.cpp:103, so lower rank =
+earlier in the reference's visiting order, which is what breaks score ties).
+Every rank reduces its slab on its own GPU to one 12-double record
+{best_score, best_index, k00,k01,k02,k11,k12,k22, u0,u1,u2, s}; the records are
+exchanged by ONE all-reduce(sum) of a [world, 12] buffer in which each rank
+fills only its own row (x + 0 is exact, so the exchange is bit-deterministic),
+then combined in rank order with the reference's strict `<`.
+
+ParticleFilter::measure: particles are split into contiguous ranges; each rank
+scores its range and reduces {sum w, sum w*x, ...} (8 doubles); one
+all-reduce(sum) of a [world, 8] buffer gives every rank the total particle
+weight (reference src/particle_filter.cpp:166-174) and the moment sums.
+"""
+import math
+
+import numpy as np
+
+MATCH_RECORD = 12
+POSE_STATS = 8
+
+
+def shard_range(n, rank, world):
+    """Contiguous [begin, end) share of n items for `rank` (sizes differ by <= 1)."""
+    base, rem = divmod(n, world)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+def combine_match_records(records):
+    """records[world][12] in rank order -> (best_score, best_index or None, acc[10]).
+
+    Strict `<` in rank order reproduces the reference's first-wins rule
+    (src/scan_matcher_ndt.cpp:128): a later slab only wins with a lower score.
+    The accumulators are summed in rank order."""
+    records = np.asarray(records, dtype=np.float64).reshape(-1, MATCH_RECORD)
+    best_score, best_index = 0.0, None
+    acc = np.zeros(10, dtype=np.float64)
+    for rec in records:
+        if rec[1] >= 0.0 and rec[0] < best_score:
+            best_score, best_index = float(rec[0]), int(rec[1])
+        acc += rec[2:]
+    return best_score, best_index, acc
+
+
+def covariance_from_acc(acc):
+    """covariance = (1/s) k + (1/(s*s)) u u^T (reference src/scan_matcher_ndt.cpp:146)."""
+    k = np.array([[acc[0], acc[1], acc[2]], [acc[1], acc[3], acc[4]], [acc[2], acc[4], acc[5]]])
+    u = np.array(acc[6:9])
+    s = acc[9]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        inv_s = np.float64(1.0) / np.float64(s)
+        inv_s2 = np.float64(1.0) / (np.float64(s) * np.float64(s))
+        return inv_s * k + np.outer(inv_s2 * u, u)
+
+
+def decode_index(best_index, n_lin):
+    """flat index -> (i_theta, i_x, i_y), the reference's loop nesting."""
+    per_th = n_lin * n_lin
+    ith, rem = divmod(best_index, per_th)
+    return ith, rem // n_lin, rem % n_lin
+
+
+def allreduce_rows(row, rank, world, dist, device=None):
+    """Exchange one row per rank with a single all-reduce(sum).
+
+    `row` is a 1-D float64 torch tensor (this rank's record, already on the
+    device the backend wants).  Returns the [world, len(row)] table."""
+    import torch
+    table = torch.zeros((world, row.numel()), dtype=torch.float64,
+                        device=row.device if device is None else device)
+    table[rank].copy_(row)
+    if world > 1:
+        dist.all_reduce(table, op=dist.ReduceOp.SUM)
+    return table
+
+
+def finish_particle_statistics(stats_table, weights_local, particles_local, cov22_prev=0.0,
+                               dist=None):
+    """updateStatistics (reference src/particle_filter.cpp:163-218) from the
+    all-reduced moment sums.  stats_table[world][8] un-normalised sums per rank.
+    Returns (normalised local weights, mean[3], cov[3,3]).  The theta variance
+    (second pass, :218-222) is summed over ranks with a second tiny all-reduce
+    when `dist` is given."""
+    st = np.asarray(stats_table, dtype=np.float64).reshape(-1, POSE_STATS).sum(axis=0)
+    sum_w = st[0]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        w = np.asarray(weights_local, dtype=np.float64) / sum_w
+        mean_x, mean_y = st[1] / sum_w, st[2] / sum_w
+        mean_th = math.atan2(st[4] / sum_w, st[3] / sum_w)
+        cov = np.zeros((3, 3))
+        cov[0, 0] = st[5] / sum_w - mean_x * mean_x
+        cov[0, 1] = cov[1, 0] = st[6] / sum_w - mean_x * mean_y
+        cov[1, 1] = st[7] / sum_w - mean_y * mean_y
+    th = np.asarray(particles_local, dtype=np.float64).reshape(-1, 3)[:, 2]
+    # angles::shortest_angular_distance(theta_i, mean_theta)
+    r = np.fmod((mean_th - th) + math.pi, 2.0 * math.pi)
+    d = np.where(r <= 0.0, r + math.pi, r - math.pi)
+    local = float(np.sum(w * d * d))
+    if dist is not None:
+        import torch
+        t = torch.tensor([local], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        local = float(t[0])
+    cov[2, 2] = cov22_prev + local
+    return w, np.array([mean_x, mean_y, mean_th]), cov

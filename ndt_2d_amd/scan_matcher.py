@@ -1,0 +1,298 @@
+"""Python-side handle on the matcher layer of libndt2d_hip.so.
+
+`ScanMatcherNDT` mirrors the reference's ndt_2d::ScanMatcherNDT plugin object
+(reference include/ndt_2d/scan_matcher_ndt.hpp:42-105): the same six methods
+with the same argument meaning and error behaviour, so the parity tests read
+like tests of the reference.  Every score is computed by the HIP kernels
+through the C-ABI; nothing here evaluates a likelihood.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import Ndt2dError, dptr
+
+# defaults of the declared parameters, reference src/scan_matcher_ndt.cpp:37-44
+DEFAULT_PARAMS = dict(ndt_resolution=0.25, search_angular_resolution=0.0025,
+                      search_angular_size=0.1, search_linear_resolution=0.005,
+                      search_linear_size=0.05, laser_max_beams=100)
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a.reshape(shape) if shape is not None else a
+
+
+def search_offsets(size, res):
+    """Values visited by the reference's `for (v = -size; v < size; v += res)`."""
+    L = _capi.lib()
+    n = C.c_size_t(0)
+    L.ndt2d_search_offsets(size, res, None, 0, C.byref(n))
+    out = np.zeros(n.value, dtype=np.float64)
+    if n.value:
+        L.ndt2d_search_offsets(size, res, dptr(out), n.value, C.byref(n))
+    return out
+
+
+def _pack_scans(scans):
+    poses = _f64([s[0] for s in scans], (-1, 3)) if scans else np.zeros((0, 3))
+    pts = [_f64(s[1], (-1, 2)) for s in scans]
+    offsets = np.zeros(len(scans) + 1, dtype=np.uint64)
+    if scans:
+        offsets[1:] = np.cumsum([len(p) for p in pts])
+    allpts = _f64(np.concatenate(pts) if pts else np.zeros((0, 2)))
+    return poses, allpts, offsets
+
+
+def host_build_grid(ndt_resolution, range_max, scans):
+    """addScans' NDT build on the host only (no GPU): (cells6, size_x, size_y, ox, oy)."""
+    L = _capi.lib()
+    poses, allpts, offsets = _pack_scans(scans)
+    sx, sy = C.c_uint32(0), C.c_uint32(0)
+    ox, oy = C.c_double(0), C.c_double(0)
+    off_p = offsets.ctypes.data_as(C.POINTER(C.c_size_t))
+    rc = L.ndt2d_host_build_grid(ndt_resolution, range_max, dptr(poses), dptr(allpts), off_p,
+                                 len(scans), None, 0, C.byref(sx), C.byref(sy), C.byref(ox),
+                                 C.byref(oy))
+    if rc != _capi.OK:
+        raise Ndt2dError(rc, "ndt2d_host_build_grid")
+    cells = np.zeros((sx.value * sy.value, 6), dtype=np.float64)
+    rc = L.ndt2d_host_build_grid(ndt_resolution, range_max, dptr(poses), dptr(allpts), off_p,
+                                 len(scans), dptr(cells), len(cells), C.byref(sx), C.byref(sy),
+                                 C.byref(ox), C.byref(oy))
+    if rc != _capi.OK:
+        raise Ndt2dError(rc, "ndt2d_host_build_grid")
+    return cells, sx.value, sy.value, ox.value, oy.value
+
+
+class ScanMatcherNDT:
+    """ndt_2d::ScanMatcherNDT over the MI355X kernels."""
+
+    def __init__(self, device_id=0):
+        self._L = _capi.lib()
+        self._m = C.c_void_p()
+        rc = self._L.ndt2d_matcher_create(C.byref(self._m), int(device_id))
+        if rc != _capi.OK:
+            self._m = None
+            raise Ndt2dError(rc, "ndt2d_matcher_create",
+                             "no usable GPU; this library has no CPU fallback")
+        self.params = dict(DEFAULT_PARAMS, range_max=0.0)
+
+    def close(self):
+        if getattr(self, "_m", None):
+            self._L.ndt2d_matcher_destroy(self._m)
+            self._m = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, where):
+        if rc != _capi.OK:
+            msg = self._L.ndt2d_matcher_last_error(self._m)
+            raise Ndt2dError(rc, where, msg.decode() if msg else "")
+
+    @property
+    def device_handle(self):
+        """The ndt2d_handle of the device layer (for sharded / device-pointer launches)."""
+        return C.c_void_p(self._L.ndt2d_matcher_device(self._m))
+
+    # -- ScanMatcher interface (reference include/ndt_2d/scan_matcher.hpp:42-91) --
+
+    def initialize(self, name="scan_matcher", range_max=0.0, **params):
+        """initialize(name, node, range_max): `params` stands for the node's parameters
+        `<name>.ndt_resolution` etc. (reference src/scan_matcher_ndt.cpp:35-47)."""
+        unknown = set(params) - set(DEFAULT_PARAMS)
+        if unknown:
+            raise KeyError("undeclared parameter(s): %s" % sorted(unknown))
+        p = dict(DEFAULT_PARAMS)
+        p.update(params)
+        p["range_max"] = float(range_max)
+        self.name = name
+        self.params = p
+        self._check(self._L.ndt2d_matcher_initialize(
+            self._m, p["ndt_resolution"], p["search_angular_resolution"],
+            p["search_angular_size"], p["search_linear_resolution"], p["search_linear_size"],
+            int(p["laser_max_beams"]), p["range_max"]), "initialize")
+
+    def addScans(self, scans):
+        """scans: iterable of (pose_xyt, points[n, 2]) -- the [begin, end) range."""
+        scans = list(scans)
+        poses, allpts, offsets = _pack_scans(scans)
+        self._check(self._L.ndt2d_matcher_add_scans(
+            self._m, dptr(poses), dptr(allpts),
+            offsets.ctypes.data_as(C.POINTER(C.c_size_t)), len(scans)), "addScans")
+
+    def matchScan(self, scan_pose, points, pose=None, want_scores=False):
+        """Returns dict(score, pose, covariance, n_candidates, best_index[, scores]).
+        `pose` is the caller's pre-initialised out-parameter (default (0,0,0)); it is
+        returned untouched when no candidate scores below 0, and covariance is
+        None when there is no NDT (the reference leaves both untouched then)."""
+        sp = _f64(scan_pose, (3,))
+        pts = _f64(points, (-1, 2))
+        pose_io = np.array([0.0, 0.0, 0.0] if pose is None else pose, dtype=np.float64)
+        cov = np.full(9, np.nan)
+        score = C.c_double(0.0)
+        ncand = C.c_size_t(0)
+        best = C.c_uint64(0)
+        scores, sp_ptr, cap = None, None, 0
+        if want_scores:
+            p = self.params
+            n_th = len(search_offsets(p["search_angular_size"], p["search_angular_resolution"]))
+            n_lin = len(search_offsets(p["search_linear_size"], p["search_linear_resolution"]))
+            cap = n_th * n_lin * n_lin
+            scores = np.zeros(cap, dtype=np.float64)
+            sp_ptr = dptr(scores)
+        self._check(self._L.ndt2d_matcher_match_scan_ex(
+            self._m, dptr(sp), dptr(pts), len(pts), dptr(pose_io), dptr(cov), C.byref(score),
+            sp_ptr, cap, C.byref(ncand), C.byref(best)), "matchScan")
+        has = bool(self._L.ndt2d_matcher_has_ndt(self._m))
+        return dict(score=score.value, pose=pose_io,
+                    covariance=cov.reshape(3, 3) if has else None,
+                    n_candidates=ncand.value, best_index=best.value, scores=scores)
+
+    def scoreScan(self, scan_pose, points):
+        sp = _f64(scan_pose, (3,))
+        pts = _f64(points, (-1, 2))
+        out = C.c_double(0.0)
+        self._check(self._L.ndt2d_matcher_score_scan(self._m, dptr(sp), dptr(pts), len(pts),
+                                                     C.byref(out)), "scoreScan")
+        return out.value
+
+    def scorePoints(self, points, pose):
+        pts = _f64(points, (-1, 2))
+        ps = _f64(pose, (3,))
+        out = C.c_double(0.0)
+        self._check(self._L.ndt2d_matcher_score_points(self._m, dptr(pts), len(pts), dptr(ps),
+                                                       C.byref(out)), "scorePoints")
+        return out.value
+
+    def reset(self):
+        self._check(self._L.ndt2d_matcher_reset(self._m), "reset")
+
+    # -- additive batched interface ------------------------------------------------
+
+    def scorePoses(self, points, poses):
+        """scores[i] == scorePoints(points, poses[i]), one launch."""
+        pts = _f64(points, (-1, 2))
+        ps = _f64(poses, (-1, 3))
+        out = np.zeros(len(ps), dtype=np.float64)
+        self._check(self._L.ndt2d_matcher_score_poses(self._m, dptr(pts), len(pts), dptr(ps),
+                                                      len(ps), dptr(out)), "scorePoses")
+        return out
+
+    # -- split matchScan / device-pointer launches (multi-GPU sharding, bench) ---------
+
+    def prepare_search(self, scan_pose, points):
+        """Subsample + build/upload the search tables.  Returns (n_th, n_lin, n_beams)."""
+        sp = _f64(scan_pose, (3,))
+        pts = _f64(points, (-1, 2))
+        n_th, n_lin, n_b = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+        self._check(self._L.ndt2d_matcher_prepare_search(
+            self._m, dptr(sp), dptr(pts), len(pts), C.byref(n_th), C.byref(n_lin),
+            C.byref(n_b)), "prepare_search")
+        return n_th.value, n_lin.value, n_b.value
+
+    def prepare_beams(self, points):
+        pts = _f64(points, (-1, 2))
+        n_b = C.c_size_t(0)
+        self._check(self._L.ndt2d_matcher_prepare_beams(self._m, dptr(pts), len(pts),
+                                                        C.byref(n_b)), "prepare_beams")
+        return n_b.value
+
+    def _dev_check(self, rc, where):
+        if rc != _capi.OK:
+            msg = self._L.ndt2d_last_error(self.device_handle)
+            raise Ndt2dError(rc, where, msg.decode() if msg else "")
+
+    def match_launch(self, th_begin, th_end, record_ptr=None, scores_ptr=None):
+        """Asynchronous slab search; record_ptr / scores_ptr are DEVICE addresses
+        (e.g. torch tensor .data_ptr()) or None."""
+        self._dev_check(self._L.ndt2d_match_launch(self.device_handle, th_begin, th_end,
+                                                   scores_ptr, record_ptr), "ndt2d_match_launch")
+
+    def match_fetch(self):
+        res = _capi.MatchResult()
+        self._dev_check(self._L.ndt2d_match_fetch(self.device_handle, C.byref(res)),
+                        "ndt2d_match_fetch")
+        rec = np.zeros(_capi.MATCH_RECORD_DOUBLES)
+        rec[0] = res.best_score
+        rec[1] = -1.0 if res.best_index == _capi.NO_INDEX else float(res.best_index)
+        rec[2:] = res.acc[:]
+        return rec
+
+    def finish_match(self, record, pose=None):
+        """matchScan's outputs from a (combined) 12-double record."""
+        rec = _f64(record, (_capi.MATCH_RECORD_DOUBLES,))
+        pose_io = np.array([0.0, 0.0, 0.0] if pose is None else pose, dtype=np.float64)
+        cov = np.zeros(9)
+        score = C.c_double(0.0)
+        self._check(self._L.ndt2d_matcher_finish_match(self._m, dptr(rec), dptr(pose_io),
+                                                       dptr(cov), C.byref(score)), "finish_match")
+        return dict(score=score.value, pose=pose_io, covariance=cov.reshape(3, 3))
+
+    def score_poses_launch(self, poses_ptr, n_poses, scores_ptr, stats_ptr=None):
+        """Asynchronous batched scorePoints on DEVICE pointers."""
+        self._dev_check(self._L.ndt2d_score_poses_launch(self.device_handle, poses_ptr, n_poses,
+                                                         scores_ptr, stats_ptr),
+                        "ndt2d_score_poses_launch")
+
+    def set_stream(self, stream_ptr):
+        self._dev_check(self._L.ndt2d_set_stream(self.device_handle, stream_ptr),
+                        "ndt2d_set_stream")
+
+    def synchronize(self):
+        self._dev_check(self._L.ndt2d_synchronize(self.device_handle), "ndt2d_synchronize")
+
+    # -- introspection ---------------------------------------------------------------
+
+    def has_ndt(self):
+        return bool(self._L.ndt2d_matcher_has_ndt(self._m))
+
+    def grid(self):
+        """(cells6[ncell, 6], size_x, size_y, cell_size, origin_x, origin_y) of the host NDT."""
+        sx, sy = C.c_uint32(0), C.c_uint32(0)
+        cs, ox, oy = C.c_double(0), C.c_double(0), C.c_double(0)
+        self._check(self._L.ndt2d_matcher_grid_info(self._m, C.byref(sx), C.byref(sy),
+                                                    C.byref(cs), C.byref(ox), C.byref(oy)),
+                    "grid_info")
+        cells = np.zeros((sx.value * sy.value, 6), dtype=np.float64)
+        self._check(self._L.ndt2d_matcher_grid_cells6(self._m, dptr(cells), len(cells)),
+                    "grid_cells6")
+        return cells, sx.value, sy.value, cs.value, ox.value, oy.value
+
+    def last_launch_ms(self):
+        ms = C.c_float(0)
+        nk = C.c_int(0)
+        rc = self._L.ndt2d_last_launch_ms(self.device_handle, C.byref(ms), C.byref(nk))
+        if rc != _capi.OK:
+            raise Ndt2dError(rc, "ndt2d_last_launch_ms")
+        return ms.value, nk.value
+
+    def last_variant(self):
+        v = self._L.ndt2d_last_variant(self.device_handle)
+        return v.decode() if v else ""
+
+    def set_variant(self, name):
+        rc = self._L.ndt2d_set_variant(self.device_handle, name.encode())
+        if rc != _capi.OK:
+            raise Ndt2dError(rc, "ndt2d_set_variant")
+
+
+def pf_measure(matcher, particles, points, cov_prev=None):
+    """ParticleFilter::measure (reference src/particle_filter.cpp:78-89) including its
+    updateStatistics (:163-218).  Returns (normalised weights, mean[3], cov[3, 3]);
+    cov_prev carries cov_(2,2), which the reference accumulates across calls."""
+    L = _capi.lib()
+    pa = _f64(particles, (-1, 3))
+    pts = _f64(points, (-1, 2))
+    w = np.zeros(len(pa), dtype=np.float64)
+    mean = np.zeros(3)
+    cov = np.zeros(9) if cov_prev is None else np.array(cov_prev, dtype=np.float64).reshape(9)
+    matcher._check(L.ndt2d_matcher_pf_measure(matcher._m, dptr(pa), len(pa), dptr(pts),
+                                              len(pts), dptr(w), dptr(mean), dptr(cov)),
+                   "pf_measure")
+    return w, mean, cov.reshape(3, 3)
