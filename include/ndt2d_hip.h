@@ -140,9 +140,10 @@ int ndt2d_score_poses(ndt2d_handle h, const double * h_poses_xyt, size_t n_poses
 
 /* Block until everything launched on the context's stream has finished. */
 int ndt2d_synchronize(ndt2d_handle h);
-/* GPU time (HIP events on the launch stream) of the most recent
- * ndt2d_match_launch / ndt2d_score_poses_launch, all kernels of that call.
- * Synchronises.  *n_kernels (optional) = kernels launched by that call. */
+/* GPU time (HIP events on the launch stream) of the dominant kernel -- the
+ * search / scoring kernel, without the few-microsecond final reduction -- of the
+ * most recent ndt2d_match_launch / ndt2d_score_poses_launch.  Synchronises.
+ * *n_kernels (optional) = kernels launched by that call. */
 int ndt2d_last_launch_ms(ndt2d_handle h, float * ms, int * n_kernels);
 /* Tuning / introspection: name of the kernel variant the last launch used. */
 const char * ndt2d_last_variant(ndt2d_handle h);

@@ -335,9 +335,8 @@ int ndt2d_match_launch(ndt2d_handle h, size_t th_begin, size_t th_end, double * 
   ndt2d::LaunchInfo info{"", 0};
   NDT2D_HIP(h, hipEventRecord(h->ev0, h->stream));
   hipError_t e = ndt2d::launch_match(a, h->ws_match.ptr, h->record.ptr, d_record,
-                                     h->force_variant, h->stream, &info);
+                                     h->force_variant, h->stream, h->ev1, &info);
   if (e != hipSuccess) return fail_hip(h, e, "launch_match");
-  NDT2D_HIP(h, hipEventRecord(h->ev1, h->stream));
   h->timed = true;
   h->last_kernels = info.n_kernels;
   h->last_variant = info.variant;
@@ -414,9 +413,8 @@ int ndt2d_score_poses_launch(ndt2d_handle h, const double * d_poses_xyt, size_t 
   ndt2d::LaunchInfo info{"", 0};
   NDT2D_HIP(h, hipEventRecord(h->ev0, h->stream));
   hipError_t e = ndt2d::launch_score_poses(a, h->ws_poses.ptr, d_stats, h->force_variant,
-                                           h->stream, &info);
+                                           h->stream, h->ev1, &info);
   if (e != hipSuccess) return fail_hip(h, e, "launch_score_poses");
-  NDT2D_HIP(h, hipEventRecord(h->ev1, h->stream));
   h->timed = true;
   h->last_kernels = info.n_kernels;
   h->last_variant = info.variant;

@@ -71,13 +71,16 @@ struct LaunchInfo
 // 12 doubles.  workspace: device scratch for per-wave partials, at least
 // match_workspace_doubles() doubles.
 size_t match_workspace_doubles();
+// ev_main_done (optional) is recorded right after the search kernel, before the
+// tiny final reduction, so the caller can time the dominant kernel alone.
 hipError_t launch_match(const MatchArgs & args, double * workspace, double * record_out,
                         double * record_out2, int force_variant, hipStream_t stream,
-                        LaunchInfo * info);
+                        hipEvent_t ev_main_done, LaunchInfo * info);
 
 size_t poses_workspace_doubles(uint64_t n_poses);
 hipError_t launch_score_poses(const PosesArgs & args, double * workspace, double * stats_out,
-                              int force_variant, hipStream_t stream, LaunchInfo * info);
+                              int force_variant, hipStream_t stream, hipEvent_t ev_main_done,
+                              LaunchInfo * info);
 
 // force_variant values
 enum { kVariantAuto = 0, kVariantLds = 1, kVariantGlobal = 2 };

@@ -194,8 +194,10 @@ __global__ void __launch_bounds__(kMatchThreads) match_kernel(const MatchArgs a)
     const double st = a.sin_th[ith];
     const double dt = a.dth[ith];
 
-    // points_outer (:108-115)
-    double ox[NBL], oy[NBL];
+    // points_outer (:108-115); NBL == 0 is the any-beam-count variant that
+    // rotates on the fly instead of keeping points_outer in registers.
+    constexpr int kRegs = NBL > 0 ? NBL : 1;
+    double ox[kRegs], oy[kRegs];
 #pragma unroll
     for (int j = 0; j < NBL; ++j)
     {
@@ -224,12 +226,25 @@ __global__ void __launch_bounds__(kMatchThreads) match_kernel(const MatchArgs a)
 
       // points_inner + NDT::likelihood(points_inner) (:121-127)
       double sum = 0.0;
-#pragma unroll
-      for (int j = 0; j < NBL; ++j)
+      if (NBL > 0)
       {
-        const double px = ox[j] + dx;
-        const double py = oy[j] + dy;
-        sum += point_likelihood<LDS_GRID, POW2>(a.grid, lds_cells, px, py);
+#pragma unroll
+        for (int j = 0; j < NBL; ++j)
+        {
+          const double px = ox[j] + dx;
+          const double py = oy[j] + dy;
+          sum += point_likelihood<LDS_GRID, POW2>(a.grid, lds_cells, px, py);
+        }
+      }
+      else
+      {
+        for (uint32_t b = lane; b < a.n_beams; b += kWave)
+        {
+          const double2 p = reinterpret_cast<const double2 *>(a.beams_xy)[b];
+          const double px = (p.x * ct - p.y * st + a.pose_x) + dx;
+          const double py = (p.x * st + p.y * ct + a.pose_y) + dy;
+          sum += point_likelihood<LDS_GRID, POW2>(a.grid, lds_cells, px, py);
+        }
       }
       sum = wave_sum(sum);
       const double score = -sum;
@@ -500,7 +515,7 @@ hipError_t dispatch_match_nbl(const MatchArgs & args, uint32_t blocks, size_t ld
   if (nbl <= 8) return launch_match_variant<8, LDS_GRID, POW2>(args, blocks, lds_bytes, stream);
   if (nbl <= 12) return launch_match_variant<12, LDS_GRID, POW2>(args, blocks, lds_bytes, stream);
   if (nbl <= 16) return launch_match_variant<16, LDS_GRID, POW2>(args, blocks, lds_bytes, stream);
-  return hipErrorInvalidValue;
+  return launch_match_variant<0, LDS_GRID, POW2>(args, blocks, lds_bytes, stream);
 }
 
 }  // namespace
@@ -512,10 +527,10 @@ size_t match_workspace_doubles()
 
 hipError_t launch_match(const MatchArgs & args_in, double * workspace, double * record_out,
                         double * record_out2, int force_variant, hipStream_t stream,
-                        LaunchInfo * info)
+                        hipEvent_t ev_main_done, LaunchInfo * info)
 {
   MatchArgs args = args_in;
-  if (args.n_beams == 0 || args.n_beams > 16 * kWave) return hipErrorInvalidValue;
+  if (args.n_beams == 0) return hipErrorInvalidValue;
   const DeviceLimits lim = device_limits();
 
   const size_t grid_bytes = static_cast<size_t>(args.grid.ncell + 1) * kCellDoubles * sizeof(double);
@@ -557,6 +572,11 @@ hipError_t launch_match(const MatchArgs & args_in, double * workspace, double * 
              : dispatch_match_nbl<false, false>(args, blocks, 0, stream);
   }
   if (e != hipSuccess) return e;
+  if (ev_main_done != nullptr)
+  {
+    e = hipEventRecord(ev_main_done, stream);
+    if (e != hipSuccess) return e;
+  }
 
   hipLaunchKernelGGL(match_reduce_kernel, dim3(1), dim3(256), 0, stream, workspace,
                      blocks * kMatchWaves, record_out, record_out2);
@@ -599,7 +619,8 @@ hipError_t launch_poses_variant(const PosesArgs & args, uint32_t blocks, size_t 
 }  // namespace
 
 hipError_t launch_score_poses(const PosesArgs & args_in, double * workspace, double * stats_out,
-                              int force_variant, hipStream_t stream, LaunchInfo * info)
+                              int force_variant, hipStream_t stream, hipEvent_t ev_main_done,
+                              LaunchInfo * info)
 {
   PosesArgs args = args_in;
   if (args.n_beams == 0 || args.n_poses == 0) return hipErrorInvalidValue;
@@ -635,6 +656,11 @@ hipError_t launch_score_poses(const PosesArgs & args_in, double * workspace, dou
              : launch_poses_variant<T, false, false>(args, blocks, beams_bytes, stream);
   }
   if (e != hipSuccess) return e;
+  if (ev_main_done != nullptr)
+  {
+    e = hipEventRecord(ev_main_done, stream);
+    if (e != hipSuccess) return e;
+  }
   int n_kernels = 1;
   if (stats_out != nullptr)
   {

@@ -1,0 +1,468 @@
+"""Parity tests proper: the HIP path, called through the C-ABI, against the oracle
+on the same seeded inputs and against the committed golden fixtures.
+
+Tolerances: BASELINE.json asks for scores within 1e-5 and the same best pose.
+The kernels keep the reference's operation order, so what is actually observed
+is ~1e-13 (wave-tree vs sequential summation, exp() ulps); the tests assert
+both the contractual 1e-5 and a tighter 1e-9 regression bound."""
+import ctypes as C
+import json
+import math
+import os
+import threading
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from ndt_2d_amd import ScanMatcherNDT, _capi, pf_measure, synth
+from ndt_2d_amd import dist as shard
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL_CONTRACT = 1e-5   # BASELINE.json north_star
+TOL_TIGHT = 1e-9      # regression bound on raw (un-normalised) scores
+
+
+def _pair(cfg, **override):
+    """(gpu matcher, oracle matcher, scans, guess, points) for a synthetic config."""
+    scans = synth.map_scans(cfg)
+    params = synth.matcher_params(cfg, **override)
+    gpu = ScanMatcherNDT(0)
+    gpu.initialize("test", **params)
+    gpu.addScans(scans)
+    ref = O.ScanMatcherNDT()
+    ref.initialize(**params)
+    ref.addScans(scans)
+    guess, pts, _ = synth.query_scan(cfg)
+    return gpu, ref, scans, guess, pts
+
+
+def _check_match(got, exp, n_beams):
+    assert got["n_candidates"] == exp["n_candidates"]
+    assert got["best_index"] == exp["best_index"]
+    assert np.array_equal(got["pose"], exp["pose"])
+    assert abs(got["score"] - exp["score"]) < TOL_CONTRACT
+    assert abs(got["score"] - exp["score"]) < TOL_TIGHT
+    assert np.allclose(got["covariance"], exp["covariance"], rtol=1e-9, atol=0, equal_nan=True)
+    if got.get("scores") is not None and exp.get("scores") is not None:
+        err = np.max(np.abs(got["scores"] - exp["scores"]))
+        assert err < TOL_CONTRACT and err < TOL_TIGHT
+        assert np.max(np.abs(got["scores"] - exp["scores"]) / n_beams) < TOL_CONTRACT
+
+
+@pytest.fixture(scope="module")
+def cfg1():
+    return _pair(1)
+
+
+def test_extension_is_loaded_in_tree():
+    # the native library this process uses is the in-tree build
+    assert os.path.samefile(os.path.dirname(_capi.LIB_PATH),
+                            os.path.join(os.path.dirname(GOLDEN), "..", "ndt_2d_amd"))
+    maps = open("/proc/self/maps").read()
+    _capi.lib()
+    maps = open("/proc/self/maps").read()
+    assert "libndt2d_hip.so" in maps
+
+
+def test_cfg1_match_vs_oracle_and_golden(cfg1):
+    gpu, ref, _, guess, pts = cfg1
+    got = gpu.matchScan(guess, pts, want_scores=True)
+    exp = ref.matchScan(guess, pts, want_scores=True)
+    _check_match(got, exp, 720)
+    g = np.load(os.path.join(GOLDEN, "cfg1_match.npz"))
+    assert np.array_equal(gpu.grid()[0], g["cells6"])          # host NDT build, bit-exact
+    assert np.max(np.abs(got["scores"] - g["scores"])) < TOL_TIGHT
+    assert got["best_index"] == int(g["best_index"])
+    assert np.array_equal(got["pose"], g["pose"])
+    assert abs(got["score"] - float(g["score"])) < TOL_TIGHT
+    assert np.allclose(got["covariance"], g["covariance"], rtol=1e-9, atol=0)
+    assert "lds-grid" in gpu.last_variant()
+
+
+def test_score_scan_and_score_points(cfg1):
+    gpu, ref, _, guess, pts = cfg1
+    assert abs(gpu.scoreScan(guess, pts) - ref.scoreScan(guess, pts)) < TOL_TIGHT
+    for pose in [(0.13, -0.07, 0.031), (-1.2, 0.8, 2.5), (3.9, 3.9, -3.1), (50.0, 50.0, 0.0)]:
+        assert abs(gpu.scorePoints(pts, pose) - ref.scorePoints(pts, pose)) < TOL_TIGHT
+    # a matching pose scores lower (better) than a displaced one
+    assert gpu.scorePoints(pts, (0.13, -0.07, 0.031)) < gpu.scorePoints(pts, (0.5, 0.5, 0.3))
+
+
+def test_plugin_default_parameters_subsample(cfg1):
+    # laser_max_beams = 100 of 720 beams, 21 x 21 x 80 lattice (reference defaults)
+    _, _, scans, _, pts = cfg1
+    g = np.load(os.path.join(GOLDEN, "cfg1_match.npz"))
+    p = json.loads(str(g["default_params_json"]))
+    gpu = ScanMatcherNDT(0)
+    gpu.initialize("local_scan_matcher", **p)
+    gpu.addScans(scans)
+    got = gpu.matchScan(g["default_scan_pose"], pts, want_scores=True)
+    assert got["n_candidates"] == 21 * 21 * 80
+    assert np.max(np.abs(got["scores"] - g["default_scores"])) < TOL_TIGHT
+    assert got["best_index"] == int(g["default_best_index"])
+    assert np.array_equal(got["pose"], g["default_pose"])
+    assert abs(got["score"] - float(g["default_score"])) < TOL_TIGHT
+    assert np.allclose(got["covariance"], g["default_covariance"], rtol=1e-9, atol=0)
+
+
+def test_device_layer_direct_and_theta_sharding(cfg1):
+    """ndt2d_set_grid / set_beams / set_search / match on the raw device layer with
+    the golden grid; the slab records combine to the unsharded result."""
+    g = np.load(os.path.join(GOLDEN, "cfg1_match.npz"))
+    p = json.loads(str(g["params_json"]))
+    L = _capi.lib()
+    h = C.c_void_p()
+    assert L.ndt2d_create(C.byref(h), 0) == 0
+    try:
+        cells = np.ascontiguousarray(g["cells6"])
+        assert L.ndt2d_set_grid(h, _capi.dptr(cells), int(g["size_x"]), int(g["size_y"]),
+                                float(g["cell_size"]), float(g["origin"][0]),
+                                float(g["origin"][1])) == 0
+        pts = np.ascontiguousarray(g["points"])
+        assert L.ndt2d_set_beams(h, _capi.dptr(pts), len(pts)) == 0
+        dth = O.search_offsets(p["search_angular_size"], p["search_angular_resolution"])
+        dlin = O.search_offsets(p["search_linear_size"], p["search_linear_resolution"])
+        sp = g["scan_pose"]
+        cos_t = np.array([math.cos(sp[2] + d) for d in dth])
+        sin_t = np.array([math.sin(sp[2] + d) for d in dth])
+        assert L.ndt2d_set_search(h, sp[0], sp[1], _capi.dptr(dth), _capi.dptr(cos_t),
+                                  _capi.dptr(sin_t), len(dth), _capi.dptr(dlin), len(dlin)) == 0
+        per = len(dlin) ** 2
+
+        def run(b, e):
+            res = _capi.MatchResult()
+            sc = np.zeros((e - b) * per)
+            assert L.ndt2d_match(h, b, e, _capi.dptr(sc), C.byref(res)) == 0, L.ndt2d_last_error(h)
+            rec = np.zeros(12)
+            rec[0] = res.best_score
+            rec[1] = -1.0 if res.best_index == _capi.NO_INDEX else float(res.best_index)
+            rec[2:] = res.acc[:]
+            assert res.n_candidates == (e - b) * per
+            return rec, sc
+
+        full, sc_full = run(0, len(dth))
+        assert np.max(np.abs(sc_full - g["scores"])) < TOL_TIGHT
+        assert int(full[1]) == int(g["best_index"])
+        for world in (2, 3, 8):
+            recs, scs = zip(*[run(*shard.shard_range(len(dth), r, world)) for r in range(world)])
+            assert np.array_equal(np.concatenate(scs), sc_full)  # per-candidate scores: bitwise
+            s, i, acc = shard.combine_match_records(recs)
+            assert (s, i) == (full[0], int(full[1]))
+            assert np.allclose(acc, full[2:], rtol=1e-12, atol=0)
+            assert np.allclose(shard.covariance_from_acc(acc), g["covariance"], rtol=1e-9, atol=0)
+        # bad ranges are rejected
+        res = _capi.MatchResult()
+        assert L.ndt2d_match(h, 5, 5, None, C.byref(res)) == _capi.ERR_INVALID
+        assert L.ndt2d_match(h, 0, len(dth) + 1, None, C.byref(res)) == _capi.ERR_INVALID
+    finally:
+        L.ndt2d_destroy(h)
+
+
+def test_lds_and_global_grid_variants_agree_bitwise(cfg1):
+    gpu, _, _, guess, pts = cfg1
+    a = gpu.matchScan(guess, pts, want_scores=True)
+    gpu.set_variant("global")
+    try:
+        b = gpu.matchScan(guess, pts, want_scores=True)
+        assert "global-grid" in gpu.last_variant()
+    finally:
+        gpu.set_variant("auto")
+    assert np.array_equal(a["scores"], b["scores"])
+    assert a["best_index"] == b["best_index"]
+
+
+def test_runs_are_deterministic(cfg1):
+    gpu, _, _, guess, pts = cfg1
+    a = gpu.matchScan(guess, pts, want_scores=True)
+    b = gpu.matchScan(guess, pts, want_scores=True)
+    assert np.array_equal(a["scores"], b["scores"])
+    assert np.array_equal(a["covariance"], b["covariance"]) and a["score"] == b["score"]
+
+
+def test_non_power_of_two_cell_size_uses_true_division():
+    # ndt_resolution 0.1: t * (1/0.1) != t / 0.1 in general (reference ndt_model.cpp:210-211)
+    gpu, ref, _, guess, pts = _pair(1, ndt_resolution=0.1, search_linear_size=0.3,
+                                    search_angular_size=0.1)
+    got = gpu.matchScan(guess, pts, want_scores=True)
+    exp = ref.matchScan(guess, pts, want_scores=True)
+    assert "/div" in gpu.last_variant()
+    _check_match(got, exp, 720)
+    parts = synth.particles(3, 2048)
+    parts[:, :2] *= 4.5 / 23.0
+    assert np.max(np.abs(gpu.scorePoses(pts, parts) - O.pf_measure(ref, parts, pts))) < TOL_TIGHT
+
+
+@pytest.mark.parametrize("n_beams", [1, 63, 64, 65, 100, 129, 719, 1500])
+def test_ragged_beam_counts(cfg1, n_beams):
+    # tail lanes / every beams-per-lane specialisation incl. the > 1024-beam variant
+    _, _, scans, guess, _ = cfg1
+    w = synth.world_of(1)
+    pts = synth.scan(w, (0.13, -0.07, 0.031), 900 + n_beams, n_beams=n_beams)
+    params = synth.matcher_params(1, laser_max_beams=4000, search_linear_size=0.2,
+                                  search_angular_size=0.05)
+    gpu = ScanMatcherNDT(0)
+    gpu.initialize("t", **params)
+    gpu.addScans(scans)
+    ref = O.ScanMatcherNDT()
+    ref.initialize(**params)
+    ref.addScans(scans)
+    _check_match(gpu.matchScan(guess, pts, want_scores=True),
+                 ref.matchScan(guess, pts, want_scores=True), n_beams)
+    poses = synth.particles(3, 300)
+    poses[:, :2] *= 4.0 / 23.0
+    assert np.max(np.abs(gpu.scorePoses(pts, poses) - O.pf_measure(ref, poses, pts))) < TOL_TIGHT
+
+
+def test_cfg2_full_size():
+    """BASELINE.json configs[1]: 2,000,000 candidates x 720 beams on one GPU."""
+    gpu, ref, _, guess, pts = _pair(2)
+    got = gpu.matchScan(guess, pts, want_scores=True)
+    assert got["n_candidates"] == 2000000
+    exp = ref.matchScan(guess, pts, omp_threads=os.cpu_count())
+    assert np.array_equal(got["pose"], exp["pose"])
+    assert abs(got["score"] - exp["score"]) < TOL_TIGHT
+    assert np.allclose(got["covariance"], exp["covariance"], rtol=1e-9, atol=0)
+    # sampled candidates against the oracle's NDT::likelihood on the reference's
+    # points_outer / points_inner construction (scan_matcher_ndt.cpp:106-125)
+    p = gpu.params
+    dth = O.search_offsets(p["search_angular_size"], p["search_angular_resolution"])
+    dlin = O.search_offsets(p["search_linear_size"], p["search_linear_resolution"])
+    rng = np.random.default_rng(7)
+    idx = np.unique(np.concatenate([rng.integers(0, 2000000, 1500), [0, 1999999, got["best_index"]]]))
+    for flat in idx:
+        ith, ix, iy = shard.decode_index(int(flat), len(dlin))
+        c, s = math.cos(guess[2] + dth[ith]), math.sin(guess[2] + dth[ith])
+        ox = pts[:, 0] * c - pts[:, 1] * s + guess[0]
+        oy = pts[:, 0] * s + pts[:, 1] * c + guess[1]
+        inner = np.stack([ox + dlin[ix], oy + dlin[iy]], axis=1)
+        assert abs(got["scores"][flat] + ref.ndt.likelihood(inner)) < TOL_TIGHT
+    # the winner is the global minimum, ties to the lowest flat index
+    assert got["best_index"] == int(np.argmin(got["scores"]))
+    assert got["score"] * 720 == got["scores"].min()
+    # accumulators against a float64 recomputation from the GPU's own scores
+    sc = got["scores"]
+    assert got["covariance"][2, 2] > 0
+    s_sum = math.fsum(sc)
+    k22 = math.fsum(np.repeat(dth, len(dlin) ** 2) ** 2 * sc)
+    u2 = math.fsum(np.repeat(dth, len(dlin) ** 2) * sc)
+    assert got["covariance"][2, 2] == pytest.approx(k22 / s_sum + (u2 / s_sum) ** 2, rel=1e-9)
+
+
+def test_cfg4_sized_lattice_properties():
+    """BASELINE.json configs[3] lattice (501 x 501 x 1257 = 315.5M candidates) on one GPU
+    through size-independent properties: slab sharding invariance, in-slab sampled
+    parity, and consistency with the cfg-2 search it contains."""
+    gpu, ref, _, guess, pts = _pair(4)
+    n_th, n_lin, n_beams = gpu.prepare_search(guess, pts)
+    assert (n_th, n_lin, n_beams) == (1257, 501, 720)
+    gpu.match_launch(0, n_th)
+    full = gpu.match_fetch()
+    recs = []
+    for r in range(8):
+        gpu.match_launch(*shard.shard_range(n_th, r, 8))
+        recs.append(gpu.match_fetch())
+    s, i, acc = shard.combine_match_records(recs)
+    assert (s, i) == (full[0], int(full[1]))
+    assert np.allclose(acc, full[2:], rtol=1e-11, atol=0)
+    out = gpu.finish_match(full)
+    # The synthetic room is 4-fold symmetric, so over +-pi the winner may sit in any
+    # of the four rotated basins (noise decides); it must be one of them.
+    k = round((out["pose"][2] - 0.031) / (math.pi / 2))
+    assert abs(out["pose"][2] - (0.031 + k * math.pi / 2)) <= 0.005 + 1e-9
+    assert np.hypot(out["pose"][0], out["pose"][1]) < 0.3
+    # the winner's score against the oracle's likelihood of that candidate
+    p = gpu.params
+    dth = O.search_offsets(p["search_angular_size"], p["search_angular_resolution"])
+    dlin = O.search_offsets(p["search_linear_size"], p["search_linear_resolution"])
+    ith, ix, iy = shard.decode_index(i, n_lin)
+    assert (dlin[ix], dlin[iy], dth[ith]) == tuple(out["pose"])
+    c, sn = math.cos(guess[2] + dth[ith]), math.sin(guess[2] + dth[ith])
+    inner = np.stack([pts[:, 0] * c - pts[:, 1] * sn + guess[0] + dlin[ix],
+                      pts[:, 0] * sn + pts[:, 1] * c + guess[1] + dlin[iy]], axis=1)
+    assert abs(full[0] + ref.ndt.likelihood(inner)) < TOL_TIGHT
+    # one whole theta slab against the oracle restricted to that theta (angular loop of 1)
+    t = 700
+    import torch
+    d_scores = torch.zeros(n_lin * n_lin, dtype=torch.float64, device="cuda:0")
+    gpu.match_launch(t, t + 1, scores_ptr=d_scores.data_ptr())
+    gpu.synchronize()
+    slab = d_scores.cpu().numpy()
+    c, sn = math.cos(guess[2] + dth[t]), math.sin(guess[2] + dth[t])
+    ox = pts[:, 0] * c - pts[:, 1] * sn + guess[0]
+    oy = pts[:, 0] * sn + pts[:, 1] * c + guess[1]
+    rng = np.random.default_rng(11)
+    for f in rng.integers(0, n_lin * n_lin, 400):
+        inner = np.stack([ox + dlin[f // n_lin], oy + dlin[f % n_lin]], axis=1)
+        assert abs(slab[f] + ref.ndt.likelihood(inner)) < TOL_TIGHT
+
+
+def test_cfg3_particles_golden_through_device_layer():
+    g = np.load(os.path.join(GOLDEN, "cfg3_poses256.npz"))
+    ncell = int(g["size_x"]) * int(g["size_y"])
+    cells = np.zeros((ncell, 6))
+    cells[g["occupied_index"]] = g["occupied_cells6"]
+    L = _capi.lib()
+    h = C.c_void_p()
+    assert L.ndt2d_create(C.byref(h), 0) == 0
+    try:
+        assert L.ndt2d_set_grid(h, _capi.dptr(cells), int(g["size_x"]), int(g["size_y"]),
+                                float(g["cell_size"]), float(g["origin"][0]),
+                                float(g["origin"][1])) == 0
+        pts = np.ascontiguousarray(g["points"])
+        assert L.ndt2d_set_beams(h, _capi.dptr(pts), len(pts)) == 0
+        parts = np.ascontiguousarray(g["particles"])
+        w = np.zeros(len(parts))
+        st = np.zeros(8)
+        assert L.ndt2d_score_poses(h, _capi.dptr(parts), len(parts), _capi.dptr(w),
+                                   _capi.dptr(st)) == 0, L.ndt2d_last_error(h)
+        assert np.max(np.abs(w - g["weights_raw"])) < TOL_TIGHT
+        assert st[0] == pytest.approx(g["weights_raw"].sum(), rel=1e-12)
+        assert st[1] == pytest.approx((g["weights_raw"] * parts[:, 0]).sum(), rel=1e-10)
+        assert b"global-grid" in L.ndt2d_last_variant(h)   # 201 x 201 grid does not fit in LDS
+    finally:
+        L.ndt2d_destroy(h)
+
+
+def test_cfg3_full_particle_filter_measure():
+    """BASELINE.json configs[2]: 100,000 particles x 720 beams, 201 x 201 NDT."""
+    gpu, ref, _, _, pts = _pair(3)
+    parts = synth.particles(3)
+    parts[:5000, 0] = 1.0 + (parts[:5000, 0] / 23.0) * 0.2   # a cluster near the true pose
+    parts[:5000, 1] = 0.5 + (parts[:5000, 1] / 23.0) * 0.2
+    parts[:5000, 2] = 0.3 + (parts[:5000, 2] / math.pi) * 0.05
+    w_raw = gpu.scorePoses(pts, parts)
+    w_ref = O.pf_measure(ref, parts, pts, omp_threads=os.cpu_count())
+    assert np.max(np.abs(w_raw - w_ref)) < TOL_CONTRACT
+    assert np.max(np.abs(w_raw - w_ref)) < TOL_TIGHT
+    cov_prev = np.zeros((3, 3))
+    cov_prev[2, 2] = 0.125                                   # cov_(2,2) accumulates (:216)
+    w, mean, cov = pf_measure(gpu, parts, pts, cov_prev=cov_prev)
+    w_n, mean_ref, cov_ref = O.pf_update_statistics(parts, w_ref, cov_prev=cov_prev)
+    assert np.allclose(w, w_n, rtol=1e-9, atol=1e-18)
+    assert abs(w.sum() - 1.0) < 1e-12
+    assert np.allclose(mean, mean_ref, rtol=1e-9, atol=1e-12)
+    assert np.allclose(cov, cov_ref, rtol=1e-8, atol=1e-12)
+    assert np.argmax(w) < 5000
+
+
+def test_cfg5_sized_particle_set():
+    """BASELINE.json configs[4] on one GPU: 1,000,000 particles, 801 x 801 NDT."""
+    gpu, ref, _, _, pts = _pair(5)
+    assert gpu.grid()[1:3] == (801, 801)
+    parts = synth.particles(5)
+    w = gpu.scorePoses(pts, parts)
+    w_ref = O.pf_measure(ref, parts, pts, omp_threads=os.cpu_count())
+    assert np.max(np.abs(w - w_ref)) < TOL_TIGHT
+    # sharding the particle set leaves every weight bit-identical
+    halves = np.concatenate([gpu.scorePoses(pts, parts[:400001]), gpu.scorePoses(pts, parts[400001:])])
+    assert np.array_equal(halves, w)
+
+
+def test_no_ndt_returns_zero_and_leaves_outputs():
+    # reference src/scan_matcher_ndt.cpp:80,159
+    gpu = ScanMatcherNDT(0)
+    gpu.initialize("t", range_max=5.0)
+    r = gpu.matchScan((0, 0, 0), [(1.0, 1.0)], pose=(7.0, 8.0, 9.0))
+    assert r["score"] == 0.0 and np.array_equal(r["pose"], [7.0, 8.0, 9.0])
+    assert r["covariance"] is None
+    assert gpu.scorePoints([(1.0, 1.0)], (0, 0, 0)) == 0.0
+    assert gpu.scoreScan((0, 0, 0), [(1.0, 1.0)]) == 0.0
+    assert np.array_equal(gpu.scorePoses([(1.0, 1.0)], [(0, 0, 0), (1, 1, 1)]), [0.0, 0.0])
+    gpu.addScans([((0, 0, 0), [(1.1, 1.1), (1.11, 1.1), (1.1, 1.11), (1.09, 1.1), (1.1, 1.09)])])
+    assert gpu.has_ndt() and gpu.scorePoints([(1.1, 1.1)], (0, 0, 0)) < 0.0
+    gpu.reset()
+    assert not gpu.has_ndt() and gpu.scorePoints([(1.1, 1.1)], (0, 0, 0)) == 0.0
+    # device layer: compute before set_grid is an error, not a silent zero
+    L = _capi.lib()
+    h = C.c_void_p()
+    assert L.ndt2d_create(C.byref(h), 0) == 0
+    assert L.ndt2d_match_launch(h, 0, 1, None, None) == _capi.ERR_NO_GRID
+    L.ndt2d_destroy(h)
+
+
+def test_all_out_of_grid_scan(cfg1):
+    gpu, ref, _, guess, pts = cfg1
+    far = pts + 100.0
+    got = gpu.matchScan(guess, far, pose=(1.0, 2.0, 3.0), want_scores=True)
+    exp = ref.matchScan(guess, far, pose=(1.0, 2.0, 3.0))
+    assert got["score"] == exp["score"] == 0.0
+    assert got["best_index"] == _capi.NO_INDEX
+    assert np.array_equal(got["pose"], [1.0, 2.0, 3.0])
+    assert np.isnan(got["covariance"]).all() and np.isnan(exp["covariance"]).all()
+    assert not got["scores"].any()
+
+
+def test_cell_population_and_grid_edges():
+    # n < 5 cells score exactly 0 (ndt_model.cpp:107); a point exactly on origin_x is
+    # inside, one ulp below is outside; the last column [size-1] is inside (:203-218)
+    pts4 = [(0.5, 0.5), (0.6, 0.5), (0.5, 0.6), (0.4, 0.45)]
+    edge = [(-5.0, -5.0), (-4.99, -4.98), (-4.97, -4.99), (-4.98, -4.96), (-4.96, -4.97)]
+    top = [(5.9, 5.9), (5.95, 5.9), (5.9, 5.95), (5.85, 5.92), (5.93, 5.86)]
+    for cells_pts in (pts4, pts4 + [(0.55, 0.52)], edge, top):
+        gpu = ScanMatcherNDT(0)
+        gpu.initialize("t", ndt_resolution=1.0, range_max=5.0, laser_max_beams=10)
+        gpu.addScans([((0.0, 0.0, 0.0), cells_pts)])
+        ref = O.ScanMatcherNDT()
+        ref.initialize(ndt_resolution=1.0, range_max=5.0, laser_max_beams=10)
+        ref.addScans([((0.0, 0.0, 0.0), cells_pts)])
+        assert gpu.grid()[1:3] == (11, 11)
+        probes = [cells_pts[0], (-5.0, -5.0), (np.nextafter(-5.0, -6.0), -5.0),
+                  (-5.0, np.nextafter(-5.0, -6.0)), (5.999, 5.999), (6.0, 5.5), (5.5, 6.0),
+                  (np.nextafter(6.0, 0.0), 5.9)]
+        for q in probes:
+            got = gpu.scorePoints([q], (0.0, 0.0, 0.0))
+            exp = ref.scorePoints([q], (0.0, 0.0, 0.0))
+            assert abs(got - exp) < 1e-12, (cells_pts[0], q, got, exp)
+    ref4 = O.ScanMatcherNDT()
+    ref4.initialize(ndt_resolution=1.0, range_max=5.0)
+    ref4.addScans([((0.0, 0.0, 0.0), pts4)])
+    assert ref4.scorePoints([(0.5, 0.5)], (0, 0, 0)) == 0.0
+
+
+def test_reference_known_answer_through_the_gpu():
+    # reference test/ndt_model_tests.cpp:191-230: likelihood((3.5, 3.5)) = 0.7659 +- 1e-3
+    v = json.load(open(os.path.join(GOLDEN, "reference_ndt_model_tests.json")))["test_ndt"]
+    gpu = ScanMatcherNDT(0)
+    gpu.initialize("t", ndt_resolution=1.0, range_max=5.0)
+    gpu.addScans([(v["scan_pose"], v["scan_points"])])
+    got = -gpu.scorePoints(v["query"], (0.0, 0.0, 0.0))
+    assert got == pytest.approx(v["likelihood"], abs=v["tol"])
+    assert got == pytest.approx(0.76592833836492369, rel=1e-12)   # SURVEY.md section 4 digits
+
+
+def test_empty_scan_gives_nan(cfg1):
+    gpu, ref, _, guess, _ = cfg1
+    empty = np.zeros((0, 2))
+    assert math.isnan(gpu.scorePoints(empty, (0, 0, 0))) and math.isnan(ref.scorePoints(empty, (0, 0, 0)))
+    r = gpu.matchScan(guess, empty, pose=(1.0, 1.0, 1.0))
+    assert math.isnan(r["score"]) and np.isnan(r["covariance"]).all()
+    assert np.array_equal(r["pose"], [1.0, 1.0, 1.0])
+
+
+def test_two_instances_on_two_threads(cfg1):
+    """The node runs a local and a global matcher concurrently on two threads
+    (reference src/ndt_mapper.cpp:141-142,508-515,634-643)."""
+    _, ref, scans, guess, pts = cfg1
+    exp = ref.matchScan(guess, pts)
+    results, errors = {}, []
+
+    def work(name):
+        try:
+            m = ScanMatcherNDT(0)
+            m.initialize(name, **synth.matcher_params(1))
+            for _ in range(3):
+                m.reset()
+                m.addScans(scans)
+                results[name] = m.matchScan(guess, pts)
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(n,)) for n in ("local", "global")]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errors, errors
+    for r in results.values():
+        assert np.array_equal(r["pose"], exp["pose"]) and abs(r["score"] - exp["score"]) < TOL_TIGHT
