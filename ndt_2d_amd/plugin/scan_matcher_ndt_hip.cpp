@@ -1,0 +1,149 @@
+// pluginlib shim over libndt2d_hip.so; see scan_matcher_ndt_hip.hpp.
+//
+// ndt_2d::Point is {double x, y} (include/ndt_2d/point.hpp:35-51), so a
+// std::vector<Point> is already the interleaved xy array the C-ABI takes.
+// There is no CPU fallback: if the device call fails the method logs the error
+// and returns the reference's "no map" value 0.0 with the outputs untouched
+// (src/scan_matcher_ndt.cpp:80,159); nothing is thrown across the boundary.
+#include "scan_matcher_ndt_hip.hpp"
+
+#include <cstddef>
+
+namespace ndt_2d_hip
+{
+
+static_assert(sizeof(ndt_2d::Point) == 2 * sizeof(double), "Point must be {double x, y}");
+
+ScanMatcherNDTHip::~ScanMatcherNDTHip()
+{
+  if (matcher_) ndt2d_matcher_destroy(matcher_);
+}
+
+bool ScanMatcherNDTHip::ok(int rc, const char * what) const
+{
+  if (rc == NDT2D_OK) return true;
+  if (node_)
+  {
+    RCLCPP_ERROR(node_->get_logger(), "%s: %s failed (%d): %s", name_.c_str(), what, rc,
+                 matcher_ ? ndt2d_matcher_last_error(matcher_) : "no device context");
+  }
+  return false;
+}
+
+void ScanMatcherNDTHip::initialize(const std::string & name, rclcpp::Node * node,
+                                   double range_max)
+{
+  node_ = node;
+  name_ = name;
+  // the reference's six parameters, same names and defaults (src/scan_matcher_ndt.cpp:37-44)
+  const double resolution = node->declare_parameter<double>(name + ".ndt_resolution", 0.25);
+  const double angular_res =
+    node->declare_parameter<double>(name + ".search_angular_resolution", 0.0025);
+  const double angular_size = node->declare_parameter<double>(name + ".search_angular_size", 0.1);
+  const double linear_res =
+    node->declare_parameter<double>(name + ".search_linear_resolution", 0.005);
+  const double linear_size = node->declare_parameter<double>(name + ".search_linear_size", 0.05);
+  const int laser_max_beams = node->declare_parameter<int>(name + ".laser_max_beams", 100);
+  // new, additive: which GPU this instance runs on
+  const int device_id = node->declare_parameter<int>(name + ".device_id", 0);
+
+  if (!ok(ndt2d_matcher_create(&matcher_, device_id), "ndt2d_matcher_create"))
+  {
+    matcher_ = nullptr;
+    return;
+  }
+  ok(ndt2d_matcher_initialize(matcher_, resolution, angular_res, angular_size, linear_res,
+                              linear_size, static_cast<std::size_t>(laser_max_beams), range_max),
+     "ndt2d_matcher_initialize");
+}
+
+void ScanMatcherNDTHip::addScans(const std::vector<ndt_2d::ScanPtr>::const_iterator & begin,
+                                 const std::vector<ndt_2d::ScanPtr>::const_iterator & end)
+{
+  if (!matcher_) return;
+  std::vector<double> poses;
+  std::vector<double> points;
+  std::vector<std::size_t> offsets(1, 0);
+  for (auto scan = begin; scan != end; ++scan)
+  {
+    const ndt_2d::Pose2d pose = (*scan)->getPose();
+    poses.push_back(pose.x);
+    poses.push_back(pose.y);
+    poses.push_back(pose.theta);
+    for (const auto & p : (*scan)->getPoints())
+    {
+      points.push_back(p.x);
+      points.push_back(p.y);
+    }
+    offsets.push_back(points.size() / 2);
+  }
+  ok(ndt2d_matcher_add_scans(matcher_, poses.data(), points.data(), offsets.data(),
+                             offsets.size() - 1),
+     "ndt2d_matcher_add_scans");
+}
+
+double ScanMatcherNDTHip::matchScan(const ndt_2d::ScanPtr & scan, ndt_2d::Pose2d & pose,
+                                    Eigen::Matrix3d & covariance) const
+{
+  if (!matcher_ || !ndt2d_matcher_has_ndt(matcher_)) return 0.0;
+  const ndt_2d::Pose2d scan_pose = scan->getPose();
+  const std::vector<ndt_2d::Point> points = scan->getPoints();
+  const double sp[3] = {scan_pose.x, scan_pose.y, scan_pose.theta};
+  double pose_io[3] = {pose.x, pose.y, pose.theta};
+  double cov[9];
+  double score = 0.0;
+  if (!ok(ndt2d_matcher_match_scan(matcher_, sp, reinterpret_cast<const double *>(points.data()),
+                                   points.size(), pose_io, cov, &score),
+          "ndt2d_matcher_match_scan"))
+  {
+    return 0.0;
+  }
+  pose.x = pose_io[0];
+  pose.y = pose_io[1];
+  pose.theta = pose_io[2];
+  for (int r = 0; r < 3; ++r)
+  {
+    for (int c = 0; c < 3; ++c) covariance(r, c) = cov[r * 3 + c];
+  }
+  return score;
+}
+
+double ScanMatcherNDTHip::scoreScan(const ndt_2d::ScanPtr & scan) const
+{
+  return scorePoints(scan->getPoints(), scan->getPose());
+}
+
+double ScanMatcherNDTHip::scorePoints(const std::vector<ndt_2d::Point> & points,
+                                      const ndt_2d::Pose2d & pose) const
+{
+  if (!matcher_) return 0.0;
+  const double p[3] = {pose.x, pose.y, pose.theta};
+  double score = 0.0;
+  if (!ok(ndt2d_matcher_score_points(matcher_, reinterpret_cast<const double *>(points.data()),
+                                     points.size(), p, &score),
+          "ndt2d_matcher_score_points"))
+  {
+    return 0.0;
+  }
+  return score;
+}
+
+void ScanMatcherNDTHip::reset()
+{
+  if (matcher_) ok(ndt2d_matcher_reset(matcher_), "ndt2d_matcher_reset");
+}
+
+bool ScanMatcherNDTHip::scorePoses(const std::vector<ndt_2d::Point> & points,
+                                   const double * poses_xyt, std::size_t n,
+                                   double * scores) const
+{
+  if (!matcher_) return false;
+  return ok(ndt2d_matcher_score_poses(matcher_, reinterpret_cast<const double *>(points.data()),
+                                      points.size(), poses_xyt, n, scores),
+            "ndt2d_matcher_score_poses");
+}
+
+}  // namespace ndt_2d_hip
+
+#include <pluginlib/class_list_macros.hpp>
+PLUGINLIB_EXPORT_CLASS(ndt_2d_hip::ScanMatcherNDTHip, ndt_2d::ScanMatcher)
