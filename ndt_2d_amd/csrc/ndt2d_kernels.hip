@@ -25,7 +25,7 @@ namespace
 {
 
 constexpr int kWave = 64;
-constexpr int kMatchThreads = 512;
+constexpr int kMatchThreads = 1024;
 constexpr int kMatchWaves = kMatchThreads / kWave;
 constexpr int kRecord = 12;  // NDT2D_MATCH_RECORD_DOUBLES
 constexpr double kNoIndex = 1.0e308;
@@ -539,7 +539,7 @@ hipError_t launch_match(const MatchArgs & args_in, double * workspace, double * 
   if (force_variant == kVariantLds && !use_lds) return hipErrorInvalidValue;
 
   // Blocks: persistent, at most 2 per CU (2 x 80 KB grid copies fill the 160 KB LDS).
-  uint32_t blocks_per_cu = 2;
+  uint32_t blocks_per_cu = 1;
   if (use_lds && grid_bytes * 2 > kLdsPerCu) blocks_per_cu = 1;
   uint32_t max_blocks = static_cast<uint32_t>(lim.cus) * blocks_per_cu;
   if (max_blocks > kMaxMatchBlocks) max_blocks = kMaxMatchBlocks;
