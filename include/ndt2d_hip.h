@@ -147,7 +147,9 @@ int ndt2d_synchronize(ndt2d_handle h);
 int ndt2d_last_launch_ms(ndt2d_handle h, float * ms, int * n_kernels);
 /* Tuning / introspection: name of the kernel variant the last launch used. */
 const char * ndt2d_last_variant(ndt2d_handle h);
-/* Force a kernel variant (testing): "auto", "lds", "global". */
+/* Force a kernel variant (testing / A-B measurement): "auto", "lds", "global"
+ * (grid placement), "wave", "wave-lds", "wave-global", "lane" (candidate mapping
+ * of the match search). */
 int ndt2d_set_variant(ndt2d_handle h, const char * name);
 
 /* ------------------------------------------------------------------------ */

@@ -42,9 +42,10 @@ struct ndt2d_context
   DeviceBuffer tables;  // dth | cos | sin | dlin
   size_t n_th = 0, n_lin = 0;
   double pose_x = 0.0, pose_y = 0.0;
+  double dlin_absmax = 0.0;
   bool has_search = false;
 
-  DeviceBuffer ws_match, ws_poses, record, stats;
+  DeviceBuffer ws_match, ws_poses, record, stats, outer;
   DeviceBuffer tmp_scores, tmp_poses;
 
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -155,6 +156,7 @@ int ndt2d_destroy(ndt2d_handle h)
   release(h->beams);
   release(h->tables);
   release(h->ws_match);
+  release(h->outer);
   release(h->ws_poses);
   release(h->record);
   release(h->stats);
@@ -291,6 +293,11 @@ int ndt2d_set_search(ndt2d_handle h, double pose_x, double pose_y, const double 
   NDT2D_HIP(h, hipStreamSynchronize(h->stream));
   h->n_th = n_th;
   h->n_lin = n_lin;
+  h->dlin_absmax = 0.0;
+  for (size_t i = 0; i < n_lin; ++i)
+  {
+    if (std::fabs(dlin[i]) > h->dlin_absmax) h->dlin_absmax = std::fabs(dlin[i]);
+  }
   h->pose_x = pose_x;
   h->pose_y = pose_y;
   h->has_search = true;
@@ -324,6 +331,7 @@ int ndt2d_match_launch(ndt2d_handle h, size_t th_begin, size_t th_end, double * 
   a.cos_th = h->tables.ptr + h->n_th;
   a.sin_th = h->tables.ptr + 2 * h->n_th;
   a.dlin = h->tables.ptr + 3 * h->n_th;
+  a.dlin_absmax = h->dlin_absmax;
   a.n_th = static_cast<uint32_t>(h->n_th);
   a.n_lin = static_cast<uint32_t>(h->n_lin);
   a.th_begin = static_cast<uint32_t>(th_begin);
@@ -332,9 +340,18 @@ int ndt2d_match_launch(ndt2d_handle h, size_t th_begin, size_t th_end, double * 
   a.pose_y = h->pose_y;
   a.scores = d_scores;
 
+  // scratch for the rotated-beam table of the lane-per-candidate mapping
+  double * outer = nullptr;
+  if (!(h->force_variant & ndt2d::kVariantWave))
+  {
+    rc = ensure(h, h->outer, ndt2d::match_lane_outer_doubles(a));
+    if (rc != NDT2D_OK) return rc;
+    outer = h->outer.ptr;
+  }
+
   ndt2d::LaunchInfo info{"", 0};
   NDT2D_HIP(h, hipEventRecord(h->ev0, h->stream));
-  hipError_t e = ndt2d::launch_match(a, h->ws_match.ptr, h->record.ptr, d_record,
+  hipError_t e = ndt2d::launch_match(a, h->ws_match.ptr, outer, h->record.ptr, d_record,
                                      h->force_variant, h->stream, h->ev1, &info);
   if (e != hipSuccess) return fail_hip(h, e, "launch_match");
   h->timed = true;
@@ -480,6 +497,10 @@ int ndt2d_set_variant(ndt2d_handle h, const char * name)
   if (std::strcmp(name, "auto") == 0) h->force_variant = ndt2d::kVariantAuto;
   else if (std::strcmp(name, "lds") == 0) h->force_variant = ndt2d::kVariantLds;
   else if (std::strcmp(name, "global") == 0) h->force_variant = ndt2d::kVariantGlobal;
+  else if (std::strcmp(name, "wave") == 0) h->force_variant = ndt2d::kVariantWave;
+  else if (std::strcmp(name, "wave-lds") == 0) h->force_variant = ndt2d::kVariantWave | ndt2d::kVariantLds;
+  else if (std::strcmp(name, "wave-global") == 0) h->force_variant = ndt2d::kVariantWave | ndt2d::kVariantGlobal;
+  else if (std::strcmp(name, "lane") == 0) h->force_variant = ndt2d::kVariantLane;
   else return fail(h, NDT2D_ERR_INVALID, "ndt2d_set_variant: unknown variant");
   return NDT2D_OK;
 }

@@ -1,0 +1,133 @@
+// Device-side building blocks shared by the kernels: NDT::getIndex, Cell::score,
+// the LDS staging of the grid and the wave reductions.  Included by the .hip
+// translation units only.  All double arithmetic keeps the reference's operation
+// order; the translation units are compiled with -ffp-contract=off.
+#ifndef NDT2D_DEVICE_FN_H_
+#define NDT2D_DEVICE_FN_H_
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "ndt2d_kernels.h"
+
+namespace ndt2d
+{
+
+constexpr int kWave = 64;
+constexpr int kRecord = 12;  // NDT2D_MATCH_RECORD_DOUBLES
+constexpr double kNoIndex = 1.0e308;
+// Coordinate given to padding beams (lane index >= n_beams): far left of any
+// grid, so they select the sentinel record and contribute exp(-inf) = +0.0.
+constexpr double kPadCoord = -1.0e300;
+
+// NDT::getIndex, reference src/ndt_model.cpp:203-218.
+//   x < origin_x_ || y < origin_y_            -> outside
+//   grid = (unsigned)((x - origin) / cell)    -> truncation toward zero
+//   grid >= size                               -> outside
+// `fx < size_x` on the un-truncated quotient is equivalent to
+// `trunc(fx) < size_x` for fx >= 0 and keeps the conversion in range.
+// Returns ncell (the sentinel record) for "outside".
+template <bool POW2>
+__device__ __forceinline__ uint32_t cell_index(const GridDesc & g, double px, double py)
+{
+  const double tx = px - g.origin_x;
+  const double ty = py - g.origin_y;
+  double fx, fy;
+  if (POW2)
+  {
+    // cell_size is a power of two: multiplying by its exact reciprocal gives
+    // the correctly rounded quotient, bit-identical to the reference's divide.
+    fx = tx * g.inv_cell_size;
+    fy = ty * g.inv_cell_size;
+  }
+  else
+  {
+    fx = tx / g.cell_size;
+    fy = ty / g.cell_size;
+  }
+  const bool inside = (tx >= 0.0) & (ty >= 0.0) & (fx < static_cast<double>(g.size_x)) &
+                      (fy < static_cast<double>(g.size_y));
+  const uint32_t gx = static_cast<uint32_t>(fx);
+  const uint32_t gy = static_cast<uint32_t>(fy);
+  return inside ? gy * g.size_x + gx : g.ncell;
+}
+
+// Cell::score, reference src/ndt_model.cpp:105-116, on a packed record with
+// h = -0.5 * information:  exponent = ((-0.5 q^T) I) q
+//   = (q0*h00 + q1*h01) * q0 + (q0*h01 + q1*h11) * q1   (same roundings).
+__device__ __forceinline__ double record_likelihood(double mx, double my, double h00,
+                                                    double h01, double h11, double px,
+                                                    double py)
+{
+  const double q0 = px - mx;
+  const double q1 = py - my;
+  const double r0 = q0 * h00 + q1 * h01;
+  const double r1 = q0 * h01 + q1 * h11;
+  const double e = r0 * q0 + r1 * q1;
+  return exp(e);
+}
+
+// Likelihood of (px, py) against the packed record idx of the LDS / HBM grid copy.
+template <bool LDS_GRID>
+__device__ __forceinline__ double indexed_likelihood(const GridDesc & g, const double * lds_cells,
+                                                     uint32_t idx, double px, double py)
+{
+  double2 a, b, c;
+  if (LDS_GRID)
+  {
+    const double2 * rec = reinterpret_cast<const double2 *>(lds_cells + idx * kCellDoubles);
+    a = rec[0];
+    b = rec[1];
+    c = rec[2];
+  }
+  else
+  {
+    const double2 * rec =
+      reinterpret_cast<const double2 *>(g.cells_global + static_cast<size_t>(idx) * kCellStrideGlobal);
+    a = rec[0];
+    b = rec[1];
+    c = rec[2];
+  }
+  return record_likelihood(a.x, a.y, b.x, b.y, c.x, px, py);
+}
+
+// NDT::likelihood(Vector2d), reference src/ndt_model.cpp:162-170.
+template <bool LDS_GRID, bool POW2>
+__device__ __forceinline__ double point_likelihood(const GridDesc & g, const double * lds_cells,
+                                                   double px, double py)
+{
+  return indexed_likelihood<LDS_GRID>(g, lds_cells, cell_index<POW2>(g, px, py), px, py);
+}
+
+__device__ __forceinline__ void stage_grid_to_lds(const GridDesc & g, double * lds_cells)
+{
+  const uint32_t n2 = (g.ncell + 1) * kCellDoubles / 2;  // kCellDoubles is even
+  const double2 * src = reinterpret_cast<const double2 *>(g.cells_lds_image);
+  double2 * dst = reinterpret_cast<double2 *>(lds_cells);
+  for (uint32_t i = threadIdx.x; i < n2; i += blockDim.x)
+  {
+    dst[i] = src[i];
+  }
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1)
+  {
+    v += __shfl_xor(v, off, kWave);
+  }
+  return v;
+}
+
+// (score, index) ordering of the reference's `if (score < best_score)` scan in
+// loop order (src/scan_matcher_ndt.cpp:128): lower score wins, ties go to the
+// lower flat index.
+__device__ __forceinline__ bool better(double s_a, double i_a, double s_b, double i_b)
+{
+  return (s_a < s_b) | ((s_a == s_b) & (i_a < i_b));
+}
+
+}  // namespace ndt2d
+
+#endif  // NDT2D_DEVICE_FN_H_

@@ -42,6 +42,7 @@ struct MatchArgs
   const double * cos_th;    // [n_th]
   const double * sin_th;    // [n_th]
   const double * dlin;      // [n_lin]
+  double dlin_absmax;       // max |dlin[i]| (host side copy of the search extent)
   uint32_t n_th, n_lin;
   uint32_t th_begin, th_end;
   double pose_x, pose_y;
@@ -73,17 +74,29 @@ struct LaunchInfo
 size_t match_workspace_doubles();
 // ev_main_done (optional) is recorded right after the search kernel, before the
 // tiny final reduction, so the caller can time the dominant kernel alone.
-hipError_t launch_match(const MatchArgs & args, double * workspace, double * record_out,
-                        double * record_out2, int force_variant, hipStream_t stream,
-                        hipEvent_t ev_main_done, LaunchInfo * info);
+// outer (optional): scratch of match_lane_outer_doubles() doubles; without it the
+// lane-per-candidate mapping is not available.
+hipError_t launch_match(const MatchArgs & args, double * workspace, double * outer,
+                        double * record_out, double * record_out2, int force_variant,
+                        hipStream_t stream, hipEvent_t ev_main_done, LaunchInfo * info);
 
 size_t poses_workspace_doubles(uint64_t n_poses);
 hipError_t launch_score_poses(const PosesArgs & args, double * workspace, double * stats_out,
                               int force_variant, hipStream_t stream, hipEvent_t ev_main_done,
                               LaunchInfo * info);
 
-// force_variant values
-enum { kVariantAuto = 0, kVariantLds = 1, kVariantGlobal = 2 };
+// Lane-per-candidate search (ndt2d_match_lane.hip).  outer: device scratch of
+// match_lane_outer_doubles() doubles for the rotated-beam table; workspace
+// receives one partial record per wave (*n_workers_out of them).
+size_t match_lane_outer_doubles(const MatchArgs & args);
+bool match_lane_supported(const MatchArgs & args, size_t lds_per_block);
+hipError_t launch_match_lane(const MatchArgs & args, double * outer, double * workspace,
+                             uint32_t max_workers, int cus, hipStream_t stream,
+                             uint32_t * n_workers_out);
+
+// force_variant: grid placement in the low bits, candidate mapping above them
+enum { kVariantAuto = 0, kVariantLds = 1, kVariantGlobal = 2, kVariantGridMask = 3,
+       kVariantWave = 4, kVariantLane = 8 };
 
 }  // namespace ndt2d
 

@@ -14,9 +14,7 @@
 // is compiled with -ffp-contract=off so no multiply-add is fused that the
 // reference's x86-64 build keeps separate.  No MFMA: there is no dense
 // contraction on this path.
-#include "ndt2d_kernels.h"
-
-#include <math.h>
+#include "ndt2d_device_fn.h"
 
 namespace ndt2d
 {
@@ -24,115 +22,8 @@ namespace ndt2d
 namespace
 {
 
-constexpr int kWave = 64;
 constexpr int kMatchThreads = 1024;
 constexpr int kMatchWaves = kMatchThreads / kWave;
-constexpr int kRecord = 12;  // NDT2D_MATCH_RECORD_DOUBLES
-constexpr double kNoIndex = 1.0e308;
-// Coordinate given to padding beams (lane index >= n_beams): far left of any
-// grid, so they select the sentinel record and contribute exp(-inf) = +0.0.
-constexpr double kPadCoord = -1.0e300;
-
-// NDT::getIndex, reference src/ndt_model.cpp:203-218.
-//   x < origin_x_ || y < origin_y_            -> outside
-//   grid = (unsigned)((x - origin) / cell)    -> truncation toward zero
-//   grid >= size                               -> outside
-// `fx < size_x` on the un-truncated quotient is equivalent to
-// `trunc(fx) < size_x` for fx >= 0 and keeps the conversion in range.
-// Returns ncell (the sentinel record) for "outside".
-template <bool POW2>
-__device__ __forceinline__ uint32_t cell_index(const GridDesc & g, double px, double py)
-{
-  const double tx = px - g.origin_x;
-  const double ty = py - g.origin_y;
-  double fx, fy;
-  if (POW2)
-  {
-    // cell_size is a power of two: multiplying by its exact reciprocal gives
-    // the correctly rounded quotient, bit-identical to the reference's divide.
-    fx = tx * g.inv_cell_size;
-    fy = ty * g.inv_cell_size;
-  }
-  else
-  {
-    fx = tx / g.cell_size;
-    fy = ty / g.cell_size;
-  }
-  const bool inside = (tx >= 0.0) & (ty >= 0.0) & (fx < static_cast<double>(g.size_x)) &
-                      (fy < static_cast<double>(g.size_y));
-  const uint32_t gx = static_cast<uint32_t>(fx);
-  const uint32_t gy = static_cast<uint32_t>(fy);
-  return inside ? gy * g.size_x + gx : g.ncell;
-}
-
-// Cell::score, reference src/ndt_model.cpp:105-116, on a packed record with
-// h = -0.5 * information:  exponent = ((-0.5 q^T) I) q
-//   = (q0*h00 + q1*h01) * q0 + (q0*h01 + q1*h11) * q1   (same roundings).
-__device__ __forceinline__ double record_likelihood(double mx, double my, double h00,
-                                                    double h01, double h11, double px,
-                                                    double py)
-{
-  const double q0 = px - mx;
-  const double q1 = py - my;
-  const double r0 = q0 * h00 + q1 * h01;
-  const double r1 = q0 * h01 + q1 * h11;
-  const double e = r0 * q0 + r1 * q1;
-  return exp(e);
-}
-
-// NDT::likelihood(Vector2d), reference src/ndt_model.cpp:162-170.
-template <bool LDS_GRID, bool POW2>
-__device__ __forceinline__ double point_likelihood(const GridDesc & g, const double * lds_cells,
-                                                   double px, double py)
-{
-  const uint32_t idx = cell_index<POW2>(g, px, py);
-  double2 a, b, c;
-  if (LDS_GRID)
-  {
-    const double2 * rec = reinterpret_cast<const double2 *>(lds_cells + idx * kCellDoubles);
-    a = rec[0];
-    b = rec[1];
-    c = rec[2];
-  }
-  else
-  {
-    const double2 * rec =
-      reinterpret_cast<const double2 *>(g.cells_global + static_cast<size_t>(idx) * kCellStrideGlobal);
-    a = rec[0];
-    b = rec[1];
-    c = rec[2];
-  }
-  return record_likelihood(a.x, a.y, b.x, b.y, c.x, px, py);
-}
-
-__device__ __forceinline__ void stage_grid_to_lds(const GridDesc & g, double * lds_cells)
-{
-  const uint32_t n2 = (g.ncell + 1) * kCellDoubles / 2;  // kCellDoubles is even
-  const double2 * src = reinterpret_cast<const double2 *>(g.cells_lds_image);
-  double2 * dst = reinterpret_cast<double2 *>(lds_cells);
-  for (uint32_t i = threadIdx.x; i < n2; i += blockDim.x)
-  {
-    dst[i] = src[i];
-  }
-}
-
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-  for (int off = kWave / 2; off > 0; off >>= 1)
-  {
-    v += __shfl_xor(v, off, kWave);
-  }
-  return v;
-}
-
-// (score, index) ordering of the reference's `if (score < best_score)` scan in
-// loop order (src/scan_matcher_ndt.cpp:128): lower score wins, ties go to the
-// lower flat index.
-__device__ __forceinline__ bool better(double s_a, double i_a, double s_b, double i_b)
-{
-  return (s_a < s_b) | ((s_a == s_b) & (i_a < i_b));
-}
 
 // ---------------------------------------------------------------------------
 // matchScan search: one wavefront per candidate pose.
@@ -458,7 +349,7 @@ __global__ void __launch_bounds__(256) poses_reduce_kernel(const double * partia
   if (t < 8) stats[t] = sh[t];
 }
 
-constexpr uint32_t kMaxMatchBlocks = 512;   // 2 blocks per CU on 256 CUs
+constexpr uint32_t kMaxMatchBlocks = 512;
 constexpr uint32_t kMaxPosesBlocks = 4096;
 constexpr size_t kLdsPerCu = 160 * 1024;
 
@@ -525,69 +416,95 @@ size_t match_workspace_doubles()
   return static_cast<size_t>(kMaxMatchBlocks) * kMatchWaves * kRecord;
 }
 
-hipError_t launch_match(const MatchArgs & args_in, double * workspace, double * record_out,
-                        double * record_out2, int force_variant, hipStream_t stream,
-                        hipEvent_t ev_main_done, LaunchInfo * info)
+hipError_t launch_match(const MatchArgs & args_in, double * workspace, double * outer,
+                        double * record_out, double * record_out2, int force_variant,
+                        hipStream_t stream, hipEvent_t ev_main_done, LaunchInfo * info)
 {
   MatchArgs args = args_in;
   if (args.n_beams == 0) return hipErrorInvalidValue;
   const DeviceLimits lim = device_limits();
+  const int force_grid = force_variant & kVariantGridMask;
+  const bool pow2 = args.grid.pow2 != 0;
 
   const size_t grid_bytes = static_cast<size_t>(args.grid.ncell + 1) * kCellDoubles * sizeof(double);
   bool use_lds = grid_bytes <= lim.lds_per_block;
-  if (force_variant == kVariantGlobal) use_lds = false;
-  if (force_variant == kVariantLds && !use_lds) return hipErrorInvalidValue;
+  if (force_grid == kVariantGlobal) use_lds = false;
+  if (force_grid == kVariantLds && !use_lds) return hipErrorInvalidValue;
 
-  // Blocks: persistent, at most 2 per CU (2 x 80 KB grid copies fill the 160 KB LDS).
-  uint32_t blocks_per_cu = 1;
-  if (use_lds && grid_bytes * 2 > kLdsPerCu) blocks_per_cu = 1;
-  uint32_t max_blocks = static_cast<uint32_t>(lim.cus) * blocks_per_cu;
-  if (max_blocks > kMaxMatchBlocks) max_blocks = kMaxMatchBlocks;
-
-  const uint64_t m = static_cast<uint64_t>(args.n_lin) * args.n_lin;
-  const uint64_t total = m * (args.th_end - args.th_begin);
-  // Work item size: aim for >= 8 items per wave, between 8 and 128 candidates.
-  uint64_t chunk = total / (static_cast<uint64_t>(max_blocks) * kMatchWaves * 8);
-  if (chunk < 8) chunk = 8;
-  if (chunk > 128) chunk = 128;
-  if (chunk > m) chunk = m;
-  args.chunk = static_cast<uint32_t>(chunk);
-  const uint64_t cps = (m + chunk - 1) / chunk;
-  const uint64_t n_items = cps * (args.th_end - args.th_begin);
-  uint32_t blocks = static_cast<uint32_t>((n_items + kMatchWaves - 1) / kMatchWaves);
-  if (blocks > max_blocks) blocks = max_blocks;
-  if (blocks == 0) blocks = 1;
-  args.partials = workspace;
+  // Candidate mapping: lane-per-candidate (8 x 8 patch per wave, occupancy
+  // early-out) whenever its LDS image fits, else wave-per-candidate.
+  bool use_lane = outer != nullptr && force_grid != kVariantGlobal &&
+                  match_lane_supported(args, lim.lds_per_block);
+  if (force_variant & kVariantWave) use_lane = false;
+  if ((force_variant & kVariantLane) && !use_lane) return hipErrorInvalidValue;
 
   hipError_t e;
-  const bool pow2 = args.grid.pow2 != 0;
-  if (use_lds)
+  uint32_t n_workers = 0;
+  if (use_lane)
   {
-    e = pow2 ? dispatch_match_nbl<true, true>(args, blocks, grid_bytes, stream)
-             : dispatch_match_nbl<true, false>(args, blocks, grid_bytes, stream);
+    e = launch_match_lane(args, outer, workspace, kMaxMatchBlocks * kMatchWaves, lim.cus, stream,
+                          &n_workers);
+    if (e != hipSuccess) return e;
   }
   else
   {
-    e = pow2 ? dispatch_match_nbl<false, true>(args, blocks, 0, stream)
-             : dispatch_match_nbl<false, false>(args, blocks, 0, stream);
+    // Blocks: persistent, one 1024-thread block per CU (one LDS grid copy per CU).
+    uint32_t max_blocks = static_cast<uint32_t>(lim.cus);
+    if (max_blocks > kMaxMatchBlocks) max_blocks = kMaxMatchBlocks;
+
+    const uint64_t m = static_cast<uint64_t>(args.n_lin) * args.n_lin;
+    const uint64_t total = m * (args.th_end - args.th_begin);
+    // Work item size: aim for >= 8 items per wave, between 8 and 128 candidates.
+    uint64_t chunk = total / (static_cast<uint64_t>(max_blocks) * kMatchWaves * 8);
+    if (chunk < 8) chunk = 8;
+    if (chunk > 128) chunk = 128;
+    if (chunk > m) chunk = m;
+    args.chunk = static_cast<uint32_t>(chunk);
+    const uint64_t cps = (m + chunk - 1) / chunk;
+    const uint64_t n_items = cps * (args.th_end - args.th_begin);
+    uint32_t blocks = static_cast<uint32_t>((n_items + kMatchWaves - 1) / kMatchWaves);
+    if (blocks > max_blocks) blocks = max_blocks;
+    if (blocks == 0) blocks = 1;
+    args.partials = workspace;
+    n_workers = blocks * kMatchWaves;
+
+    if (use_lds)
+    {
+      e = pow2 ? dispatch_match_nbl<true, true>(args, blocks, grid_bytes, stream)
+               : dispatch_match_nbl<true, false>(args, blocks, grid_bytes, stream);
+    }
+    else
+    {
+      e = pow2 ? dispatch_match_nbl<false, true>(args, blocks, 0, stream)
+               : dispatch_match_nbl<false, false>(args, blocks, 0, stream);
+    }
+    if (e != hipSuccess) return e;
   }
-  if (e != hipSuccess) return e;
   if (ev_main_done != nullptr)
   {
     e = hipEventRecord(ev_main_done, stream);
     if (e != hipSuccess) return e;
   }
 
-  hipLaunchKernelGGL(match_reduce_kernel, dim3(1), dim3(256), 0, stream, workspace,
-                     blocks * kMatchWaves, record_out, record_out2);
+  hipLaunchKernelGGL(match_reduce_kernel, dim3(1), dim3(256), 0, stream, workspace, n_workers,
+                     record_out, record_out2);
   e = hipGetLastError();
   if (info != nullptr)
   {
-    info->variant = use_lds ? (pow2 ? "match/wave-per-candidate/lds-grid/pow2"
-                                    : "match/wave-per-candidate/lds-grid/div")
-                            : (pow2 ? "match/wave-per-candidate/global-grid/pow2"
-                                    : "match/wave-per-candidate/global-grid/div");
-    info->n_kernels = 2;
+    if (use_lane)
+    {
+      info->variant = pow2 ? "match/lane-per-candidate/lds-grid/pow2"
+                           : "match/lane-per-candidate/lds-grid/div";
+      info->n_kernels = 3;
+    }
+    else
+    {
+      info->variant = use_lds ? (pow2 ? "match/wave-per-candidate/lds-grid/pow2"
+                                      : "match/wave-per-candidate/lds-grid/div")
+                              : (pow2 ? "match/wave-per-candidate/global-grid/pow2"
+                                      : "match/wave-per-candidate/global-grid/div");
+      info->n_kernels = 2;
+    }
   }
   return e;
 }
@@ -630,8 +547,8 @@ hipError_t launch_score_poses(const PosesArgs & args_in, double * workspace, dou
     static_cast<size_t>(2) * ((args.n_beams + 1) & ~1u) * sizeof(double) + 16 * 8 * sizeof(double);
   const size_t grid_bytes = static_cast<size_t>(args.grid.ncell + 1) * kCellDoubles * sizeof(double);
   bool use_lds = beams_bytes + grid_bytes <= lim.lds_per_block;
-  if (force_variant == kVariantGlobal) use_lds = false;
-  if (force_variant == kVariantLds && !use_lds) return hipErrorInvalidValue;
+  if ((force_variant & kVariantGridMask) == kVariantGlobal) use_lds = false;
+  if ((force_variant & kVariantGridMask) == kVariantLds && !use_lds) return hipErrorInvalidValue;
   if (beams_bytes > lim.lds_per_block) return hipErrorInvalidValue;
 
   args.partials = stats_out != nullptr ? workspace : nullptr;

@@ -161,17 +161,28 @@ def test_device_layer_direct_and_theta_sharding(cfg1):
         L.ndt2d_destroy(h)
 
 
-def test_lds_and_global_grid_variants_agree_bitwise(cfg1):
-    gpu, _, _, guess, pts = cfg1
-    a = gpu.matchScan(guess, pts, want_scores=True)
-    gpu.set_variant("global")
+def test_kernel_variants_agree(cfg1):
+    """Every candidate mapping / grid placement against the oracle; the two grid
+    placements of one mapping agree bitwise (same arithmetic, different memory)."""
+    gpu, ref, _, guess, pts = cfg1
+    exp = ref.matchScan(guess, pts, want_scores=True)
+    got = {}
     try:
-        b = gpu.matchScan(guess, pts, want_scores=True)
-        assert "global-grid" in gpu.last_variant()
+        for name, tag in [("lane", "lane-per-candidate/lds-grid"),
+                          ("wave-lds", "wave-per-candidate/lds-grid"),
+                          ("wave-global", "wave-per-candidate/global-grid")]:
+            gpu.set_variant(name)
+            got[name] = gpu.matchScan(guess, pts, want_scores=True)
+            assert tag in gpu.last_variant(), gpu.last_variant()
+            _check_match(got[name], exp, 720)
     finally:
         gpu.set_variant("auto")
-    assert np.array_equal(a["scores"], b["scores"])
-    assert a["best_index"] == b["best_index"]
+    assert np.array_equal(got["wave-lds"]["scores"], got["wave-global"]["scores"])
+    # the lane mapping sums the beams in the reference's order: only exp() ulps remain
+    d_lane = np.abs(got["lane"]["scores"] - exp["scores"])
+    d_wave = np.abs(got["wave-lds"]["scores"] - exp["scores"])
+    assert d_lane.max() <= d_wave.max() + 1e-13
+    assert d_lane.max() < 1e-12
 
 
 def test_runs_are_deterministic(cfg1):
