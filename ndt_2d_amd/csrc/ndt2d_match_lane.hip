@@ -13,23 +13,28 @@
 // The 64 points of a patch for one beam lie within 0.16 m of each other, so
 // they fall into one to four NDT cells, and four cells out of five hold no
 // distribution (n < 5: likelihood exactly 0, src/ndt_model.cpp:107).  The kernel
-// is VALU-issue bound, so each beam first takes a 9-instruction look-up:
+// is VALU-issue bound, so each beam first takes a two-instruction look-up into
+// an occupancy map of the grid held in LDS:
 //
-//   fixed-point cell coordinate  f = int(k + d)      k: per beam (scalar),
-//                                                    d: per lane (register)
-//   map byte                     m = lds_map[(fy >> ..) | (fx >> F)]
+//   map coordinates are 8.16 fixed point (cell . fraction), x and y packed into
+//   ONE double:  K = 2^52 + ky * 2^24 + kx  per beam (wave-uniform, SGPR),
+//                D =        dy * 2^24 + dx  per lane (register).
+//   K + D is exact integer arithmetic in the f64 mantissa (v_add_f64); the low
+//   48 mantissa bits of the sum are {fy, fx}, so the map address
+//   (cell_y << 8) | cell_x is two bytes of the sum picked by one v_perm_b32.
 //
-// lds_map is the occupancy of the grid, padded so that no clamping is needed:
-// bit 0 = the cell holds a distribution, bit 1 = the cell or one of its eight
-// neighbours does.  If no lane of the wave sees bit 1 the beam contributes
-// exactly +0.0 to all 64 sums and is skipped -- even a coordinate that the
-// fixed-point arithmetic puts on the wrong side of a cell boundary lands in a
-// neighbour, which bit 1 covers.  Otherwise the wave checks which lanes are
-// within 4 fixed-point units of a boundary ("near"); if any lane is occupied or
-// near it runs the exact reference arithmetic (points_inner :121-125,
-// NDT::getIndex src/ndt_model.cpp:203-218 for near lanes, Cell::score :105-116).
-// Every skipped term is an exact zero, so the sums are bit-identical to the
-// unskipped evaluation.
+// The map is padded by more cells than any offset reaches and beams are
+// pre-clamped, so no per-lane range check exists.  Map byte: bit 0 = the cell
+// holds a distribution, bit 1 = the cell or one of its eight neighbours does.
+// If no lane of the wave sees bit 1 the beam adds exactly +0.0 to all 64 sums
+// and is skipped -- the fixed-point coordinate may sit on the wrong side of a
+// cell boundary (it is rounded), but then the true cell is a neighbour, which
+// bit 1 covers.  Otherwise lanes within 4 fixed-point units (2^-14 cell) of a
+// boundary are "near"; if any lane is occupied or near, the wave runs the exact
+// reference arithmetic (points_inner :121-125, NDT::getIndex
+// src/ndt_model.cpp:203-218 for near lanes, Cell::score :105-116).  Every
+// skipped term is an exact zero, so the sums are bit-identical to the unskipped
+// evaluation.
 #include "ndt2d_device_fn.h"
 
 namespace ndt2d
@@ -40,26 +45,30 @@ namespace
 
 constexpr int kLaneThreads = 1024;
 constexpr int kLaneWaves = kLaneThreads / kWave;
-constexpr int kPatch = 8;          // patch is kPatch x kPatch candidates = one wave
-constexpr int kNearUnits = 4;      // fixed-point guard band around cell boundaries
-constexpr int kUnroll = 4;
+constexpr int kPatch = 8;            // patch is kPatch x kPatch candidates = one wave
+constexpr int kUnroll = 8;           // beams per look-up group
+// map coordinates are 8.16 fixed point
+constexpr double kFracScale = 65536.0;
+constexpr int kMapStride = 256;      // map row stride in bytes = 2^8 cells
+constexpr int kMaxMapCells = 256;    // cell coordinate is one byte
+constexpr uint32_t kNearUnits = 4;   // guard band around cell boundaries, in 2^-16 cells
+constexpr double kTwo24 = 16777216.0;
+constexpr double kTwo52 = 4503599627370496.0;
 
 struct LaneGeom
 {
-  int32_t pad;        // border cells on every side of the grid in the map
-  int32_t map_w_log2; // map row stride = 2^map_w_log2 >= size_x + 2 * pad
-  int32_t map_h;      // size_y + 2 * pad
-  int32_t fbits;      // fixed-point fraction bits
-  double scale;       // 2^fbits
+  int32_t pad;     // border cells on every side of the grid in the map
+  int32_t map_h;   // size_y + 2 * pad rows of kMapStride bytes
   double k_min, k_max_x, k_max_y;  // clamp of the per-beam fixed-point coordinate
 };
 
-// points_outer for the slab (reference :106-115) plus the fixed-point map
-// coordinate of each rotated beam:
-//   outer[t][b] = {ox, oy, kx, ky},  k = ((o - origin) * inv_cell + pad) * 2^fbits
-// clamped so that k + d stays inside the map for every lane offset d; a clamped
-// beam is further outside the grid than any offset can bring back, so it stays
-// in the (empty) border.
+// points_outer for the slab (reference :106-115) plus the packed fixed-point
+// map coordinate of each rotated beam:
+//   outer[t][b] = {ox, oy, K, 0},   K = 2^52 + ky * 2^24 + kx,
+//   k = rint(((o - origin) * inv_cell + pad) * 2^16) clamped to [k_min, k_max]
+// so that k + d stays inside the map for every lane offset d.  A clamped beam
+// is further outside the grid than any offset can bring back; it stays in the
+// empty border.
 __global__ void __launch_bounds__(256) outer_table_kernel(const MatchArgs a, double4 * outer,
                                                           const LaneGeom geo)
 {
@@ -76,11 +85,13 @@ __global__ void __launch_bounds__(256) outer_table_kernel(const MatchArgs a, dou
     double4 o;
     o.x = p.x * ct - p.y * st + a.pose_x;
     o.y = p.x * st + p.y * ct + a.pose_y;
-    const double kx = ((o.x - a.grid.origin_x) * a.grid.inv_cell_size + geo.pad) * geo.scale;
-    const double ky = ((o.y - a.grid.origin_y) * a.grid.inv_cell_size + geo.pad) * geo.scale;
+    double kx = ((o.x - a.grid.origin_x) * a.grid.inv_cell_size + geo.pad) * kFracScale;
+    double ky = ((o.y - a.grid.origin_y) * a.grid.inv_cell_size + geo.pad) * kFracScale;
     // !(k >= min) also catches NaN
-    o.z = !(kx >= geo.k_min) ? geo.k_min : (kx > geo.k_max_x ? geo.k_max_x : kx);
-    o.w = !(ky >= geo.k_min) ? geo.k_min : (ky > geo.k_max_y ? geo.k_max_y : ky);
+    kx = !(kx >= geo.k_min) ? geo.k_min : (kx > geo.k_max_x ? geo.k_max_x : kx);
+    ky = !(ky >= geo.k_min) ? geo.k_min : (ky > geo.k_max_y ? geo.k_max_y : ky);
+    o.z = kTwo52 + (rint(ky) * kTwo24 + rint(kx));
+    o.w = 0.0;
     outer[i] = o;
   }
 }
@@ -89,33 +100,27 @@ struct LaneCtx
 {
   const double * lds_cells;
   const uint8_t * lds_map;
-  int32_t fbits;
-  int32_t row_shift;   // fbits - map_w_log2
-  int32_t row_mask;    // ~(2^map_w_log2 - 1)
-  int32_t frac_mask;   // 2^fbits - 1
   int32_t pad;
   int32_t size_x;
 };
 
-// U consecutive beams of one patch.
+// U consecutive beams of one patch; o[] holds their table rows, dxy the lane's
+// packed fixed-point offset.
 template <int U, bool POW2>
 __device__ __forceinline__ void lane_beams(const GridDesc & g, const LaneCtx & c,
-                                           const double4 * __restrict__ row, double dx, double dy,
-                                           double dxs, double dys, double & sum)
+                                           const double4 (&o)[U], double dx, double dy,
+                                           double dxy, double & sum)
 {
-  double4 o[U];
-  int32_t fx[U], fy[U];
-  uint32_t m[U];
+  uint32_t lo[U], hi[U], m[U];
   uint32_t any_bits = 0;
-#pragma unroll
-  for (int u = 0; u < U; ++u) o[u] = row[u];
 #pragma unroll
   for (int u = 0; u < U; ++u)
   {
-    fx[u] = __double2int_rz(o[u].z + dxs);
-    fy[u] = __double2int_rz(o[u].w + dys);
-    const int32_t idx = ((fy[u] >> c.row_shift) & c.row_mask) | (fx[u] >> c.fbits);
-    m[u] = c.lds_map[idx];
+    const double s = o[u].z + dxy;  // exact: integers below 2^53
+    lo[u] = static_cast<uint32_t>(__double2loint(s));
+    hi[u] = static_cast<uint32_t>(__double2hiint(s));
+    // byte 0 <- lo.byte2 (cell x), byte 1 <- hi.byte1 (cell y), bytes 2,3 <- 0
+    m[u] = c.lds_map[__builtin_amdgcn_perm(hi[u], lo[u], 0x0c0c0502u)];
     any_bits |= m[u];
   }
   if (__any(any_bits & 2u))
@@ -125,9 +130,10 @@ __device__ __forceinline__ void lane_beams(const GridDesc & g, const LaneCtx & c
     {
       if (__any(m[u] & 2u))
       {
-        const bool near =
-          (static_cast<uint32_t>((fx[u] + kNearUnits) & c.frac_mask) < 2u * kNearUnits) |
-          (static_cast<uint32_t>((fy[u] + kNearUnits) & c.frac_mask) < 2u * kNearUnits);
+        const uint32_t frac_x = lo[u] & 0xffffu;
+        const uint32_t frac_y = __builtin_amdgcn_alignbit(hi[u], lo[u], 24) & 0xffffu;
+        const bool near = (((frac_x + kNearUnits) & 0xffffu) < 2u * kNearUnits) |
+                          (((frac_y + kNearUnits) & 0xffffu) < 2u * kNearUnits);
         const bool occ = (m[u] & 1u) != 0;
         if (__any(occ | near))
         {
@@ -142,8 +148,8 @@ __device__ __forceinline__ void lane_beams(const GridDesc & g, const LaneCtx & c
           else
           {
             // interior of a cell: the look-up cell is the reference's cell
-            const int32_t cx = (fx[u] >> c.fbits) - c.pad;
-            const int32_t cy = (fy[u] >> c.fbits) - c.pad;
+            const int32_t cx = static_cast<int32_t>((lo[u] >> 16) & 0xffu) - c.pad;
+            const int32_t cy = static_cast<int32_t>((hi[u] >> 8) & 0xffu) - c.pad;
             idx = occ ? static_cast<uint32_t>(cy * c.size_x + cx) : g.ncell;
           }
           sum += indexed_likelihood<true>(g, c.lds_cells, idx, px, py);
@@ -157,19 +163,19 @@ template <bool POW2>
 __global__ void __launch_bounds__(kLaneThreads) match_lane_kernel(
   const MatchArgs a, const double4 * __restrict__ outer, const LaneGeom geo)
 {
+  // LDS image: padded occupancy map (at offset 0, so the packed cell bytes are
+  // the LDS address) followed by the packed cell records.
   extern __shared__ __align__(16) double lds[];
   const GridDesc & g = a.grid;
-  double * lds_cells = lds;
-  uint8_t * lds_map = reinterpret_cast<uint8_t *>(lds + static_cast<size_t>(g.ncell + 1) * kCellDoubles);
+  uint8_t * lds_map = reinterpret_cast<uint8_t *>(lds);
+  double * lds_cells = lds + (static_cast<size_t>(geo.map_h) * kMapStride) / sizeof(double);
 
-  // LDS image: packed cell records + padded occupancy map
   stage_grid_to_lds(g, lds_cells);
   {
-    const int32_t w = 1 << geo.map_w_log2;
     const int32_t sx = static_cast<int32_t>(g.size_x), sy = static_cast<int32_t>(g.size_y);
-    for (int32_t i = threadIdx.x; i < w * geo.map_h; i += kLaneThreads)
+    for (int32_t i = threadIdx.x; i < kMapStride * geo.map_h; i += kLaneThreads)
     {
-      const int32_t cx = (i & (w - 1)) - geo.pad, cy = (i >> geo.map_w_log2) - geo.pad;
+      const int32_t cx = (i & (kMapStride - 1)) - geo.pad, cy = (i >> 8) - geo.pad;
       uint32_t self = 0, around = 0;
       for (int32_t ny = cy - 1; ny <= cy + 1; ++ny)
       {
@@ -192,10 +198,6 @@ __global__ void __launch_bounds__(kLaneThreads) match_lane_kernel(
   LaneCtx c;
   c.lds_cells = lds_cells;
   c.lds_map = lds_map;
-  c.fbits = geo.fbits;
-  c.row_shift = geo.fbits - geo.map_w_log2;
-  c.row_mask = ~((1 << geo.map_w_log2) - 1);
-  c.frac_mask = (1 << geo.fbits) - 1;
   c.pad = geo.pad;
   c.size_x = static_cast<int32_t>(g.size_x);
 
@@ -209,7 +211,7 @@ __global__ void __launch_bounds__(kLaneThreads) match_lane_kernel(
   const uint32_t n_workers = gridDim.x * kLaneWaves;
   const uint32_t worker = wave * gridDim.x + blockIdx.x;
   const uint64_t per_theta = static_cast<uint64_t>(n_lin) * n_lin;
-  const double inv_scaled = g.inv_cell_size * geo.scale;
+  const double inv_scaled = g.inv_cell_size * kFracScale;
 
   double best_s = 0.0;       // `double best_score = 0;` (:83)
   double best_i = kNoIndex;
@@ -229,19 +231,22 @@ __global__ void __launch_bounds__(kLaneThreads) match_lane_kernel(
     // lanes beyond the lattice edge shadow the edge candidate and are dropped below
     const double dx = a.dlin[min(ix, n_lin - 1)];
     const double dy = a.dlin[min(iy, n_lin - 1)];
-    const double dxs = dx * inv_scaled;
-    const double dys = dy * inv_scaled;
+    const double dxy = rint(dy * inv_scaled) * kTwo24 + rint(dx * inv_scaled);
     const double4 * __restrict__ row = outer + static_cast<size_t>(t) * a.n_beams;
 
     double sum = 0.0;
     uint32_t b = 0;
     for (; b + kUnroll <= a.n_beams; b += kUnroll)
     {
-      lane_beams<kUnroll, POW2>(g, c, row + b, dx, dy, dxs, dys, sum);
+      double4 o[kUnroll];
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) o[u] = row[b + u];
+      lane_beams<kUnroll, POW2>(g, c, o, dx, dy, dxy, sum);
     }
     for (; b < a.n_beams; ++b)
     {
-      lane_beams<1, POW2>(g, c, row + b, dx, dy, dxs, dys, sum);
+      const double4 one[1] = {row[b]};
+      lane_beams<1, POW2>(g, c, one, dx, dy, dxy, sum);
     }
 
     if (valid)
@@ -295,33 +300,24 @@ __global__ void __launch_bounds__(kLaneThreads) match_lane_kernel(
   }
 }
 
-// Map geometry for a search; false if the fixed-point range cannot hold it.
+// Map geometry for a search; false if the byte-per-axis cell coordinate cannot
+// hold the padded grid.
 bool lane_geometry(const MatchArgs & args, LaneGeom * geo, size_t * map_bytes)
 {
   const double lin_cells = args.dlin_absmax * args.grid.inv_cell_size;
-  if (!(lin_cells >= 0.0) || lin_cells > 4096.0) return false;
+  if (!(lin_cells >= 0.0) || lin_cells > kMaxMapCells) return false;
   const int32_t pad = static_cast<int32_t>(2.0 * lin_cells) + 3;
   const uint64_t need_w = static_cast<uint64_t>(args.grid.size_x) + 2 * pad;
   const uint64_t need_h = static_cast<uint64_t>(args.grid.size_y) + 2 * pad;
-  int w_log2 = 0;
-  while ((1ull << w_log2) < need_w) ++w_log2;
-  // coordinates up to max(need_w, need_h) cells must fit a positive int32
-  int c_log2 = w_log2;
-  while ((1ull << c_log2) < need_h) ++c_log2;
-  int fbits = 30 - c_log2;
-  if (fbits > 24) fbits = 24;
-  if (fbits < 8 || fbits < w_log2) return false;
+  if (need_w > kMaxMapCells || need_h > kMaxMapCells) return false;
   geo->pad = pad;
-  geo->map_w_log2 = w_log2;
   geo->map_h = static_cast<int32_t>(need_h);
-  geo->fbits = fbits;
-  geo->scale = static_cast<double>(1u << fbits);
-  // lanes add |d| <= lin_cells * scale; keep one cell of margin on both sides
-  const double reach = (lin_cells + 1.0) * geo->scale;
+  // lanes add |d| <= lin_cells * 2^16 (+0.5 rounding); one cell of margin each side
+  const double reach = (lin_cells + 1.0) * kFracScale;
   geo->k_min = reach;
-  geo->k_max_x = static_cast<double>(need_w - 1) * geo->scale - reach;
-  geo->k_max_y = static_cast<double>(need_h - 1) * geo->scale - reach;
-  *map_bytes = (static_cast<size_t>(1u << w_log2) * need_h + 15) & ~size_t(15);
+  geo->k_max_x = static_cast<double>(need_w - 1) * kFracScale - reach;
+  geo->k_max_y = static_cast<double>(need_h - 1) * kFracScale - reach;
+  *map_bytes = static_cast<size_t>(kMapStride) * need_h;
   return true;
 }
 
