@@ -55,22 +55,41 @@ __device__ __forceinline__ uint32_t cell_index(const GridDesc & g, double px, do
 // Cell::score, reference src/ndt_model.cpp:105-116, on a packed record with
 // h = -0.5 * information:  exponent = ((-0.5 q^T) I) q
 //   = (q0*h00 + q1*h01) * q0 + (q0*h01 + q1*h11) * q1   (same roundings).
-__device__ __forceinline__ double record_likelihood(double mx, double my, double h00,
-                                                    double h01, double h11, double px,
-                                                    double py)
+__device__ __forceinline__ double record_exponent(double mx, double my, double h00,
+                                                  double h01, double h11, double px, double py)
 {
   const double q0 = px - mx;
   const double q1 = py - my;
   const double r0 = q0 * h00 + q1 * h01;
   const double r1 = q0 * h01 + q1 * h11;
-  const double e = r0 * q0 + r1 * q1;
-  return exp(e);
+  return r0 * q0 + r1 * q1;
 }
 
-// Likelihood of (px, py) against the packed record idx of the LDS / HBM grid copy.
+__device__ __forceinline__ double record_likelihood(double mx, double my, double h00,
+                                                    double h01, double h11, double px,
+                                                    double py)
+{
+  return exp(record_exponent(mx, my, h00, h01, h11, px, py));
+}
+
+// A non-negative term t = exp(e) leaves a running sum s > 0 unchanged,
+// RN(s + t) == s, whenever t < 2^-54 * s (less than half an ulp of s), i.e.
+// e < ln(s) - 37.43.  negligible_below(s) returns a conservative such bound
+// (ln(s) >= (frexp_exp(s) - 1) * ln 2); for s == 0 only the exp() underflow
+// range (exp(e) == +0.0 for e < -745.14) qualifies.  Terms only grow the sum, so
+// a bound taken earlier stays valid.
+__device__ __forceinline__ double negligible_below(double s)
+{
+  const double from_sum =
+    fma(static_cast<double>(__builtin_amdgcn_frexp_exp(s) - 1), 0.6931471805599453, -38.0);
+  return (s > 0.0 && from_sum > -746.0) ? from_sum : -746.0;
+}
+
+// Exponent of Cell::score for (px, py) against the packed record idx of the
+// LDS / HBM grid copy.
 template <bool LDS_GRID>
-__device__ __forceinline__ double indexed_likelihood(const GridDesc & g, const double * lds_cells,
-                                                     uint32_t idx, double px, double py)
+__device__ __forceinline__ double indexed_exponent(const GridDesc & g, const double * lds_cells,
+                                                   uint32_t idx, double px, double py)
 {
   double2 a, b, c;
   if (LDS_GRID)
@@ -88,7 +107,14 @@ __device__ __forceinline__ double indexed_likelihood(const GridDesc & g, const d
     b = rec[1];
     c = rec[2];
   }
-  return record_likelihood(a.x, a.y, b.x, b.y, c.x, px, py);
+  return record_exponent(a.x, a.y, b.x, b.y, c.x, px, py);
+}
+
+template <bool LDS_GRID>
+__device__ __forceinline__ double indexed_likelihood(const GridDesc & g, const double * lds_cells,
+                                                     uint32_t idx, double px, double py)
+{
+  return exp(indexed_exponent<LDS_GRID>(g, lds_cells, idx, px, py));
 }
 
 // NDT::likelihood(Vector2d), reference src/ndt_model.cpp:162-170.

@@ -111,6 +111,8 @@ __device__ __forceinline__ void lane_beams(const GridDesc & g, const LaneCtx & c
                                            const double4 (&o)[U], double dx, double dy,
                                            double dxy, double & sum)
 {
+  // terms below this exponent cannot change this lane's sum (bit-exact skip)
+  const double skip_below = negligible_below(sum);
   uint32_t lo[U], hi[U], m[U];
   uint32_t any_bits = 0;
 #pragma unroll
@@ -152,7 +154,12 @@ __device__ __forceinline__ void lane_beams(const GridDesc & g, const LaneCtx & c
             const int32_t cy = static_cast<int32_t>((hi[u] >> 8) & 0xffu) - c.pad;
             idx = occ ? static_cast<uint32_t>(cy * c.size_x + cx) : g.ncell;
           }
-          sum += indexed_likelihood<true>(g, c.lds_cells, idx, px, py);
+          const double e = indexed_exponent<true>(g, c.lds_cells, idx, px, py);
+          // !(e < bound) also keeps NaN exponents (degenerate cells) on the exact path
+          if (__any(!(e < skip_below)))
+          {
+            sum += exp(e);
+          }
         }
       }
     }
