@@ -70,6 +70,19 @@ def cpu_baseline(params, scans, guess, pts, seconds_hint=20.0):
     }
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC
+    passes (profiles/r01_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in
+    separate --pmc runs of this same command, corrected as MI355X_MICROARCH.md
+    prescribes).  None if the file is absent."""
+    path = os.path.join(_ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["match"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def particle_bench(matcher_cls, synth, torch, device_index, reps=5):
     """Secondary figure (not the headline): ParticleFilter::measure's scoring on
     BASELINE.json configs[2] ("cfg-3"): 100k particles x 720 beams, 201x201 NDT."""
@@ -93,11 +106,18 @@ def particle_bench(matcher_cls, synth, torch, device_index, reps=5):
             ms.append(t)
     units = len(parts) * n_beams
     avg = sum(ms) / len(ms)
+    m.set_stream(None)
+    # PCIe-inclusive: host particles in, host weights out (ndt2d_matcher_score_poses)
+    e2e = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        m.scorePoses(pts, parts)
+        e2e.append(time.perf_counter() - t0)
     out = {"workload": "cfg-3: 100000 particles x 720 beams, 201x201 NDT @0.25 m",
+           "host_call_ms": min(e2e) * 1e3, "host_call_value": units / min(e2e),
            "units_per_launch": units, "kernel_ms": avg, "value": units / (avg * 1e-3),
            "unit": "candidate-beams/s", "variant": m.last_variant(),
            "achieved_GBps": units * BYTES_PER_UNIT / (avg * 1e-3) / 1e9}
-    m.set_stream(None)
     m.close()
     return out
 
@@ -210,7 +230,9 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                "kernel": "match_kernel", "kernel_ms_avg": avg_kernel_ms,
+                "kernel": "match_lane_kernel (+ its 7 us rotated-beam table pre-pass)"
+                          if "lane" in variant else "match_kernel",
+                "kernel_ms_avg": avg_kernel_ms,
                 "algorithmic_bytes_per_launch": my_units * BYTES_PER_UNIT,
                 "note": "algorithmic 64 B/unit; compulsory HBM traffic is ~0.02 B/unit "
                         "(grid + beams are LDS/register resident) -- see DESIGN.md",
@@ -218,6 +240,21 @@ def main():
             "match_result": {"score": result["score"], "pose": [float(v) for v in result["pose"]],
                              "best_index": best_index},
         }
+        traffic = pmc_traffic()
+        if traffic is not None:
+            line["roofline"]["traffic"] = traffic["bytes_per_launch"]
+            line["roofline"]["traffic_source"] = traffic["source"]
+        if world == 1:
+            # PCIe-inclusive figure (never `value`): the whole matchScan call with host
+            # buffers in and out (subsample, tables, H2D, search, D2H of the 12-double record)
+            m.set_stream(None)
+            e2e = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                m.matchScan(guess, pts)
+                e2e.append(time.perf_counter() - t0)
+            line["host_call"] = {"ms": min(e2e) * 1e3, "value": total_units / min(e2e),
+                                 "what": "ndt2d_matcher_match_scan, host buffers in/out"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(synth.matcher_params(2), scans, guess, pts)
         if world == 1 and not args.no_particles:
