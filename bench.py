@@ -96,7 +96,11 @@ def particle_bench(matcher_cls, synth, torch, device_index, reps=5):
     d_parts = torch.from_numpy(parts).to(dev)
     d_scores = torch.zeros(len(parts), dtype=torch.float64, device=dev)
     d_stats = torch.zeros(8, dtype=torch.float64, device=dev)
-    m.set_stream(torch.cuda.current_stream().cuda_stream)
+    # an explicit (non-null) torch stream shared with the library: torch ops and
+    # the kernels are ordered on it
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize(dev)
+    m.set_stream(stream.cuda_stream)
     ms = []
     for i in range(reps + 1):
         m.score_poses_launch(d_parts.data_ptr(), len(parts), d_scores.data_ptr(),
@@ -146,13 +150,30 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # NDT2D_BENCH_BACKEND=gloo is a debugging aid only (several ranks sharing one
+    # GPU on a 1-GPU box, records exchanged through host memory); the driver's
+    # runs use the default: one GPU per rank, RCCL.
+    backend = os.environ.get("NDT2D_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    local_rank = dev_index
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "gloo":
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+
+    def all_reduce(tensor, op):
+        if backend == "gloo":
+            host = tensor.cpu()
+            dist.all_reduce(host, op=op)
+            tensor.copy_(host)
+        else:
+            dist.all_reduce(tensor, op=op)
 
     from ndt_2d_amd import ScanMatcherNDT, synth
     from ndt_2d_amd import dist as shard
@@ -171,7 +192,12 @@ def main():
     my_units = (th_end - th_begin) * n_lin * n_lin * n_beams
     total_units = n_th * n_lin * n_lin * n_beams
 
-    m.set_stream(torch.cuda.current_stream().cuda_stream)
+    # One explicit (non-null) torch stream carries everything: torch ops, the
+    # library's kernels (ndt2d_set_stream) and, through torch.distributed's
+    # current-stream hand-off, the RCCL all-reduce.
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    m.set_stream(stream.cuda_stream)
     table = torch.zeros((world, shard.MATCH_RECORD), dtype=torch.float64, device=dev)
 
     def step():
@@ -179,7 +205,7 @@ def main():
             table.zero_()
         m.match_launch(th_begin, th_end, record_ptr=table[rank].data_ptr())
         if world > 1:
-            dist.all_reduce(table, op=dist.ReduceOp.SUM)
+            all_reduce(table, dist.ReduceOp.SUM)
 
     def fence():
         if world > 1:
@@ -198,7 +224,7 @@ def main():
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        all_reduce(t, dist.ReduceOp.MAX)
     elapsed = float(t[0])
     ms_per_step = elapsed / args.steps * 1e3
 
