@@ -35,6 +35,7 @@ struct ndt2d_context
   GridDesc grid{};
   DeviceBuffer cells_lds_image;
   DeviceBuffer cells_global;
+  DeviceBuffer occ_bits;  // uint32 words stored in a double buffer
 
   DeviceBuffer beams;
   size_t n_beams = 0;
@@ -153,6 +154,7 @@ int ndt2d_destroy(ndt2d_handle h)
   (void)hipStreamSynchronize(h->stream);
   release(h->cells_lds_image);
   release(h->cells_global);
+  release(h->occ_bits);
   release(h->beams);
   release(h->tables);
   release(h->ws_match);
@@ -204,11 +206,14 @@ int ndt2d_set_grid(ndt2d_handle h, const double * cells6, uint32_t size_x, uint3
   // (reference src/ndt_model.cpp:107) and get the sentinel record.
   std::vector<double> lds_image(static_cast<size_t>(ncell + 1) * kCellDoubles);
   std::vector<double> glb(static_cast<size_t>(ncell + 1) * kCellStrideGlobal, 0.0);
+  // occupancy bitmap: bit i = cell i can score; ncell + 1 bits, padded to whole doubles
+  std::vector<uint32_t> bits(((static_cast<size_t>(ncell) + 1 + 31) / 32 + 1) & ~size_t(1), 0u);
   for (uint32_t i = 0; i <= ncell; ++i)
   {
     double rec[kCellDoubles] = {1.0e300, 0.0, -1.0, 0.0, -1.0, 0.0};
     if (i < ncell && !(cells6[6 * static_cast<size_t>(i) + 5] < 5.0))
     {
+      bits[i >> 5] |= 1u << (i & 31u);
       const double * c = cells6 + 6 * static_cast<size_t>(i);
       rec[0] = c[0];
       rec[1] = c[1];
@@ -228,10 +233,15 @@ int ndt2d_set_grid(ndt2d_handle h, const double * cells6, uint32_t size_x, uint3
                               lds_image.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
   NDT2D_HIP(h, hipMemcpyAsync(h->cells_global.ptr, glb.data(), glb.size() * sizeof(double),
                               hipMemcpyHostToDevice, h->stream));
+  rc = ensure(h, h->occ_bits, bits.size() / 2);
+  if (rc != NDT2D_OK) return rc;
+  NDT2D_HIP(h, hipMemcpyAsync(h->occ_bits.ptr, bits.data(), bits.size() * sizeof(uint32_t),
+                              hipMemcpyHostToDevice, h->stream));
   NDT2D_HIP(h, hipStreamSynchronize(h->stream));  // host staging vectors go out of scope
 
   h->grid.cells_lds_image = h->cells_lds_image.ptr;
   h->grid.cells_global = h->cells_global.ptr;
+  h->grid.occ_bits = reinterpret_cast<const uint32_t *>(h->occ_bits.ptr);
   h->grid.size_x = size_x;
   h->grid.size_y = size_y;
   h->grid.ncell = ncell;
@@ -501,6 +511,7 @@ int ndt2d_set_variant(ndt2d_handle h, const char * name)
   else if (std::strcmp(name, "wave-lds") == 0) h->force_variant = ndt2d::kVariantWave | ndt2d::kVariantLds;
   else if (std::strcmp(name, "wave-global") == 0) h->force_variant = ndt2d::kVariantWave | ndt2d::kVariantGlobal;
   else if (std::strcmp(name, "lane") == 0) h->force_variant = ndt2d::kVariantLane;
+  else if (std::strcmp(name, "dense") == 0) h->force_variant = ndt2d::kVariantDense;
   else return fail(h, NDT2D_ERR_INVALID, "ndt2d_set_variant: unknown variant");
   return NDT2D_OK;
 }

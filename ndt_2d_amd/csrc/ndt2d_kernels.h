@@ -26,6 +26,7 @@ struct GridDesc
 {
   const double * cells_lds_image;  // [ncell + 1][kCellDoubles], source of the LDS fill
   const double * cells_global;     // [ncell + 1][kCellStrideGlobal]
+  const uint32_t * occ_bits;       // bit i = cell i holds a distribution; ncell + 1 bits (last = 0)
   uint32_t size_x, size_y, ncell;
   double cell_size;
   double inv_cell_size;  // exact iff pow2
@@ -94,9 +95,15 @@ hipError_t launch_match_lane(const MatchArgs & args, double * outer, double * wo
                              uint32_t max_workers, int cus, hipStream_t stream,
                              uint32_t * n_workers_out);
 
+// Particle scoring with per-wave compaction of the occupied (pose, beam) pairs
+// (ndt2d_poses_compact.hip).
+bool poses_compact_supported(const PosesArgs & args, size_t lds_per_block);
+hipError_t launch_poses_compact(const PosesArgs & args, int cus, hipStream_t stream,
+                                uint32_t * blocks_out);
+
 // force_variant: grid placement in the low bits, candidate mapping above them
 enum { kVariantAuto = 0, kVariantLds = 1, kVariantGlobal = 2, kVariantGridMask = 3,
-       kVariantWave = 4, kVariantLane = 8 };
+       kVariantWave = 4, kVariantLane = 8, kVariantDense = 16 };
 
 }  // namespace ndt2d
 

@@ -555,7 +555,17 @@ hipError_t launch_score_poses(const PosesArgs & args_in, double * workspace, dou
   const bool pow2 = args.grid.pow2 != 0;
   hipError_t e;
   uint32_t blocks;
-  if (use_lds)
+  // Default: per-wave compaction of the occupied (pose, beam) pairs; the dense
+  // kernels remain for grids whose occupancy bitmap does not fit in LDS and for
+  // A/B measurement ("dense", "lds", "global").
+  const bool use_compact = force_variant == kVariantAuto &&
+                           poses_compact_supported(args, lim.lds_per_block);
+  if (use_compact)
+  {
+    e = launch_poses_compact(args, lim.cus, stream, &blocks);
+  }
+  else if (use_lds)
+
   {
     constexpr int T = 1024;  // one block per CU owns the LDS grid copy: make it 16 waves
     uint64_t need = (args.n_poses + T - 1) / T;
@@ -588,10 +598,12 @@ hipError_t launch_score_poses(const PosesArgs & args_in, double * workspace, dou
   }
   if (info != nullptr)
   {
-    info->variant = use_lds ? (pow2 ? "poses/lane-per-pose/lds-grid/pow2"
-                                    : "poses/lane-per-pose/lds-grid/div")
-                            : (pow2 ? "poses/lane-per-pose/global-grid/pow2"
-                                    : "poses/lane-per-pose/global-grid/div");
+    info->variant = use_compact ? (pow2 ? "poses/lane-per-pose/compact/pow2"
+                                        : "poses/lane-per-pose/compact/div")
+                    : use_lds   ? (pow2 ? "poses/lane-per-pose/lds-grid/pow2"
+                                        : "poses/lane-per-pose/lds-grid/div")
+                                : (pow2 ? "poses/lane-per-pose/global-grid/pow2"
+                                        : "poses/lane-per-pose/global-grid/div");
     info->n_kernels = n_kernels;
   }
   return e;

@@ -1,0 +1,276 @@
+// Batched ScanMatcherNDT::scorePoints (reference src/scan_matcher_ndt.cpp:156-178),
+// the loop body of ParticleFilter::measure (src/particle_filter.cpp:81-87), with
+// per-wave compaction of the work that is not an exact zero.
+//
+// One pose (particle) per lane.  For random poses only a few percent of the
+// (pose, beam) pairs land in a cell that holds a distribution; every other pair
+// contributes exactly 0.0 (src/ndt_model.cpp:107,165-169).  Evaluating the
+// Gaussian for all 64 lanes whenever one lane needs it wastes the VALU, and
+// gathering a 48-byte record per lane from 64 different cache lines saturates
+// the texture-addresser.  So each wave runs two phases:
+//
+//   A (dense, per beam)   transform the beam by the lane's pose (:171-173), exact
+//                         NDT::getIndex (src/ndt_model.cpp:203-218), look the cell up
+//                         in an occupancy bitmap held in LDS; occupied lanes append
+//                         {px, py, cell | lane} to the wave's LDS queue (ballot +
+//                         mbcnt prefix).
+//   B (every 64 items)    lane j takes queue item j: gathers the cell record (one
+//                         64-byte line), evaluates Cell::score (:105-116) and adds it
+//                         to its owner's running sum with an LDS f64 atomic.
+//
+// The queue is FIFO in beam order and a (pose, beam) pair appears at most once, so
+// each owner's terms arrive in the reference's beam order; only exact zeros are
+// left out of the sums.
+#include "ndt2d_device_fn.h"
+
+namespace ndt2d
+{
+
+namespace
+{
+
+constexpr int kQueueCap = 128;          // items per wave (ring); < 64 pending + <= 64 pushed
+constexpr uint32_t kCellBits = 26;      // queue meta word = cell index | lane << 26
+constexpr uint32_t kCellMask = (1u << kCellBits) - 1;
+// The beams are cut into kChunks contiguous chunks.  A lane's score is
+//   ((c_0 + c_1) + c_2) + ... + c_7,   c_j = in-order sum of the terms of chunk j,
+// whatever number of waves (1, 2, 4 or 8) shares the 64 poses of a group, so the
+// result does not depend on the launch geometry or on how a particle set is
+// sharded.  (It differs from the reference's single running sum by a few ulps.)
+constexpr int kChunks = 8;
+
+template <int THREADS>
+struct CompactLayout
+{
+  static constexpr int kWaves = THREADS / kWave;
+  // doubles: [stats kWaves*8][sums THREADS][chunk sums kWaves*kChunks*64 (at most)]
+  //          [q_px kWaves*cap][q_py kWaves*cap][q_meta (u32) kWaves*cap/2]
+  static constexpr size_t kFixedDoubles =
+    static_cast<size_t>(kWaves) * 8 + THREADS + static_cast<size_t>(kWaves) * kChunks * kWave +
+    2 * static_cast<size_t>(kWaves) * kQueueCap + static_cast<size_t>(kWaves) * kQueueCap / 2;
+};
+
+// SPLIT waves share the 64 poses of a group; each takes kChunks / SPLIT chunks.
+template <int THREADS, bool POW2>
+__global__ void __launch_bounds__(THREADS) score_poses_compact_kernel(const PosesArgs a,
+                                                                      const uint32_t split)
+{
+  using L = CompactLayout<THREADS>;
+  extern __shared__ __align__(16) double lds[];
+  double * sh_stats = lds;
+  double * sh_sum = sh_stats + L::kWaves * 8;
+  double * sh_chunk = sh_sum + THREADS;                       // [group][chunk][lane]
+  double * q_px_all = sh_chunk + L::kWaves * kChunks * kWave;
+  double * q_py_all = q_px_all + L::kWaves * kQueueCap;
+  uint32_t * q_meta_all = reinterpret_cast<uint32_t *>(q_py_all + L::kWaves * kQueueCap);
+  double * lds_beams = reinterpret_cast<double *>(q_meta_all + L::kWaves * kQueueCap);
+  uint32_t * lds_bits = reinterpret_cast<uint32_t *>(lds_beams + 2 * ((a.n_beams + 1) & ~1u));
+
+  const GridDesc & g = a.grid;
+  for (uint32_t i = threadIdx.x; i < 2 * a.n_beams; i += THREADS) lds_beams[i] = a.beams_xy[i];
+  const uint32_t n_words = (g.ncell + 1 + 31) / 32;
+  for (uint32_t i = threadIdx.x; i < n_words; i += THREADS) lds_bits[i] = g.occ_bits[i];
+  __syncthreads();
+
+  const uint32_t lane = threadIdx.x & (kWave - 1);
+  const uint32_t wave = threadIdx.x >> 6;
+  const uint32_t group = wave / split;          // group of 64 poses inside the block
+  const uint32_t part = wave - group * split;   // which share of the chunks
+  const uint32_t groups_per_block = L::kWaves / split;
+  double * q_px = q_px_all + wave * kQueueCap;
+  double * q_py = q_py_all + wave * kQueueCap;
+  uint32_t * q_meta = q_meta_all + wave * kQueueCap;
+  double * my_sums = sh_sum + wave * kWave;
+  double * my_chunks = sh_chunk + static_cast<size_t>(group) * kChunks * kWave;
+  const uint64_t lanes_below = (1ull << lane) - 1ull;
+  const uint32_t chunk_len = (a.n_beams + kChunks - 1) / kChunks;
+  const uint32_t chunks_per_part = kChunks / split;
+
+  double st[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) st[k] = 0.0;
+
+  // Phase B: lanes [0, n) each evaluate one queued item
+  auto drain = [&](uint32_t head, uint32_t n) {
+    if (lane < n)
+    {
+      const uint32_t slot = (head + lane) & (kQueueCap - 1);
+      const double px = q_px[slot];
+      const double py = q_py[slot];
+      const uint32_t meta = q_meta[slot];
+      const double e = indexed_exponent<false>(g, nullptr, meta & kCellMask, px, py);
+      atomicAdd(&my_sums[meta >> kCellBits], exp(e));
+    }
+  };
+
+  const uint64_t poses_per_block = static_cast<uint64_t>(groups_per_block) * kWave;
+  const uint64_t stride = static_cast<uint64_t>(gridDim.x) * poses_per_block;
+  const uint64_t n_round = (a.n_poses + stride - 1) / stride * stride;
+  for (uint64_t base = static_cast<uint64_t>(blockIdx.x) * poses_per_block; base < n_round;
+       base += stride)
+  {
+    const uint64_t i = base + static_cast<uint64_t>(group) * kWave + lane;
+    const bool valid = i < a.n_poses;
+    double x = kPadCoord, y = kPadCoord, th = 0.0;  // padding lanes: every beam is outside
+    if (valid)
+    {
+      x = a.poses_xyt[3 * i];
+      y = a.poses_xyt[3 * i + 1];
+      th = a.poses_xyt[3 * i + 2];
+    }
+    // toEigen(pose): AngleAxisd(theta, Z) -> [[c,-s],[s,c]] (conversions.hpp:64-68)
+    double s, c;
+    sincos(th, &s, &c);
+
+    for (uint32_t cj = 0; cj < chunks_per_part; ++cj)
+    {
+      const uint32_t chunk = part * chunks_per_part + cj;
+      const uint32_t k0 = min(chunk * chunk_len, a.n_beams);
+      const uint32_t k1 = min(k0 + chunk_len, a.n_beams);
+      my_sums[lane] = 0.0;
+      uint32_t head = 0, count = 0;
+      for (uint32_t k = k0; k < k1; ++k)
+      {
+        const double2 p = reinterpret_cast<const double2 *>(lds_beams)[k];
+        // p = t * (x, y, 1) (:172-173): translation + (c*x + (-s)*y), (s*x + c*y)
+        const double px = x + (c * p.x - s * p.y);
+        const double py = y + (s * p.x + c * p.y);
+        const uint32_t idx = cell_index<POW2>(g, px, py);
+        const bool occ = ((lds_bits[idx >> 5] >> (idx & 31u)) & 1u) != 0;
+        const uint64_t mask = __ballot(occ);
+        if (mask != 0)
+        {
+          if (occ)
+          {
+            const uint32_t slot =
+              (head + count + static_cast<uint32_t>(__popcll(mask & lanes_below))) & (kQueueCap - 1);
+            q_px[slot] = px;
+            q_py[slot] = py;
+            q_meta[slot] = idx | (lane << kCellBits);
+          }
+          count += static_cast<uint32_t>(__popcll(mask));
+          if (count >= kWave)
+          {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            drain(head, kWave);
+            head = (head + kWave) & (kQueueCap - 1);
+            count -= kWave;
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      drain(head, count);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      my_chunks[chunk * kWave + lane] = my_sums[lane];
+    }
+    __syncthreads();
+
+    if (part == 0)
+    {
+      double sum = my_chunks[lane];
+#pragma unroll
+      for (int j = 1; j < kChunks; ++j) sum += my_chunks[j * kWave + lane];
+      // score = sum of (-likelihood) / n  ==  -(sum) / n (:175-177)
+      const double score = -sum / static_cast<double>(a.n_beams);
+      if (valid)
+      {
+        a.scores[i] = score;
+        // sums for ParticleFilter::updateStatistics (particle_filter.cpp:166-200)
+        const double w = score;
+        st[0] += w;
+        st[1] += w * x;
+        st[2] += w * y;
+        st[3] += w * c;
+        st[4] += w * s;
+        st[5] += w * x * x;
+        st[6] += w * x * y;
+        st[7] += w * y * y;
+      }
+    }
+    __syncthreads();
+  }
+
+  if (a.partials != nullptr)
+  {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) st[k] = wave_sum(st[k]);
+    if (lane == 0)
+    {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) sh_stats[wave * 8 + k] = st[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 8)
+    {
+      double v = 0.0;
+      for (int w = 0; w < L::kWaves; ++w) v += sh_stats[w * 8 + threadIdx.x];
+      a.partials[static_cast<size_t>(blockIdx.x) * 8 + threadIdx.x] = v;
+    }
+  }
+}
+
+size_t compact_lds_bytes(const PosesArgs & args, int threads)
+{
+  const size_t fixed = threads == 1024 ? CompactLayout<1024>::kFixedDoubles
+                                       : CompactLayout<256>::kFixedDoubles;
+  const size_t beams = static_cast<size_t>(2) * ((args.n_beams + 1) & ~1u);
+  const size_t words = (static_cast<size_t>(args.grid.ncell) + 1 + 31) / 32;
+  return (fixed + beams) * sizeof(double) + ((words * 4 + 15) & ~size_t(15));
+}
+
+template <int THREADS>
+hipError_t launch_compact(const PosesArgs & args, uint32_t blocks, uint32_t split,
+                          size_t lds_bytes, hipStream_t stream)
+{
+  auto launch = [&](auto kernel) -> hipError_t {
+    if (lds_bytes > 48 * 1024)
+    {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         static_cast<int>(lds_bytes));
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(THREADS), lds_bytes, stream, args, split);
+    return hipGetLastError();
+  };
+  return args.grid.pow2 ? launch(score_poses_compact_kernel<THREADS, true>)
+                        : launch(score_poses_compact_kernel<THREADS, false>);
+}
+
+}  // namespace
+
+bool poses_compact_supported(const PosesArgs & args, size_t lds_per_block)
+{
+  return args.grid.occ_bits != nullptr && args.grid.ncell < kCellMask &&
+         compact_lds_bytes(args, 1024) <= lds_per_block;
+}
+
+hipError_t launch_poses_compact(const PosesArgs & args, int cus, hipStream_t stream,
+                                uint32_t * blocks_out)
+{
+  // Small LDS image: 256-thread blocks, several per CU.  Large occupancy bitmap:
+  // one 1024-thread block per CU shares it.
+  const size_t small = compact_lds_bytes(args, 256);
+  const bool use_small = small <= 48 * 1024;
+  const int threads = use_small ? 256 : 1024;
+  const uint32_t waves_per_block = static_cast<uint32_t>(threads / kWave);
+  // Waves sharing one group of 64 poses: enough to put >= ~8 waves on every SIMD
+  // (the gathers of phase B are latency bound), at most kChunks and one block.
+  const uint64_t groups = (args.n_poses + kWave - 1) / kWave;
+  const uint64_t want_waves = static_cast<uint64_t>(cus) * 4 * 8;
+  uint32_t split = 1;
+  while (split < static_cast<uint32_t>(kChunks) && split < waves_per_block &&
+         groups * split < want_waves)
+  {
+    split *= 2;
+  }
+  const uint64_t groups_per_block = waves_per_block / split;
+  const uint64_t need = (groups + groups_per_block - 1) / groups_per_block;
+  const uint64_t cap = use_small ? 4096 : static_cast<uint64_t>(cus);
+  const uint32_t blocks = static_cast<uint32_t>(need < cap ? need : cap);
+  if (blocks_out != nullptr) *blocks_out = blocks;
+  return use_small ? launch_compact<256>(args, blocks, split, small, stream)
+                   : launch_compact<1024>(args, blocks, split, compact_lds_bytes(args, 1024), stream);
+}
+
+}  // namespace ndt2d

@@ -332,7 +332,14 @@ def test_cfg3_particles_golden_through_device_layer():
         assert np.max(np.abs(w - g["weights_raw"])) < TOL_TIGHT
         assert st[0] == pytest.approx(g["weights_raw"].sum(), rel=1e-12)
         assert st[1] == pytest.approx((g["weights_raw"] * parts[:, 0]).sum(), rel=1e-10)
-        assert b"global-grid" in L.ndt2d_last_variant(h)   # 201 x 201 grid does not fit in LDS
+        assert b"compact" in L.ndt2d_last_variant(h)
+        # the dense kernels (records gathered per lane; 201 x 201 grid does not fit in LDS)
+        assert L.ndt2d_set_variant(h, b"dense") == 0
+        w2 = np.zeros(len(parts))
+        assert L.ndt2d_score_poses(h, _capi.dptr(parts), len(parts), _capi.dptr(w2), None) == 0
+        assert b"global-grid" in L.ndt2d_last_variant(h)
+        assert np.max(np.abs(w2 - g["weights_raw"])) < TOL_TIGHT
+        assert np.max(np.abs(w2 - w)) < 1e-13
     finally:
         L.ndt2d_destroy(h)
 
@@ -367,9 +374,12 @@ def test_cfg5_sized_particle_set():
     w = gpu.scorePoses(pts, parts)
     w_ref = O.pf_measure(ref, parts, pts, omp_threads=os.cpu_count())
     assert np.max(np.abs(w - w_ref)) < TOL_TIGHT
-    # sharding the particle set leaves every weight bit-identical
+    # sharding the particle set leaves every weight bit-identical, whatever the
+    # launch geometry each shard size selects
     halves = np.concatenate([gpu.scorePoses(pts, parts[:400001]), gpu.scorePoses(pts, parts[400001:])])
     assert np.array_equal(halves, w)
+    small = np.concatenate([gpu.scorePoses(pts, parts[i:i + 7777]) for i in range(0, 70000, 7777)])
+    assert np.array_equal(small, w[:len(small)])
 
 
 def test_no_ndt_returns_zero_and_leaves_outputs():
