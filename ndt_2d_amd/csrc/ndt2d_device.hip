@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <limits>
 #include <new>
 #include <string>
 #include <vector>
@@ -44,6 +45,7 @@ struct ndt2d_context
   size_t n_th = 0, n_lin = 0;
   double pose_x = 0.0, pose_y = 0.0;
   double dlin_absmax = 0.0;
+  double beam_rmax = 0.0;
   bool has_search = false;
 
   DeviceBuffer ws_match, ws_poses, record, stats, outer;
@@ -277,6 +279,14 @@ int ndt2d_set_beams(ndt2d_handle h, const double * beams_xy, size_t n_beams)
                               hipMemcpyHostToDevice, h->stream));
   NDT2D_HIP(h, hipStreamSynchronize(h->stream));
   h->n_beams = n_beams;
+  h->beam_rmax = 0.0;
+  for (size_t i = 0; i < n_beams; ++i)
+  {
+    const double r = std::hypot(beams_xy[2 * i], beams_xy[2 * i + 1]);
+    if (r > h->beam_rmax) h->beam_rmax = r;
+    if (std::isnan(r)) h->beam_rmax = std::numeric_limits<double>::infinity();
+  }
+  // an infinite reach (NaN / inf beam) disables the windowed lane mapping
   return NDT2D_OK;
 }
 
@@ -342,6 +352,7 @@ int ndt2d_match_launch(ndt2d_handle h, size_t th_begin, size_t th_end, double * 
   a.sin_th = h->tables.ptr + 2 * h->n_th;
   a.dlin = h->tables.ptr + 3 * h->n_th;
   a.dlin_absmax = h->dlin_absmax;
+  a.beam_rmax = h->beam_rmax;
   a.n_th = static_cast<uint32_t>(h->n_th);
   a.n_lin = static_cast<uint32_t>(h->n_lin);
   a.th_begin = static_cast<uint32_t>(th_begin);

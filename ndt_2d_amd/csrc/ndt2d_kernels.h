@@ -44,6 +44,7 @@ struct MatchArgs
   const double * sin_th;    // [n_th]
   const double * dlin;      // [n_lin]
   double dlin_absmax;       // max |dlin[i]| (host side copy of the search extent)
+  double beam_rmax;         // max |beam| (host side copy of the scan's reach)
   uint32_t n_th, n_lin;
   uint32_t th_begin, th_end;
   double pose_x, pose_y;
@@ -92,8 +93,8 @@ hipError_t launch_score_poses(const PosesArgs & args, double * workspace, double
 size_t match_lane_outer_doubles(const MatchArgs & args);
 bool match_lane_supported(const MatchArgs & args, size_t lds_per_block);
 hipError_t launch_match_lane(const MatchArgs & args, double * outer, double * workspace,
-                             uint32_t max_workers, int cus, hipStream_t stream,
-                             uint32_t * n_workers_out);
+                             uint32_t max_workers, int cus, size_t lds_per_block,
+                             hipStream_t stream, uint32_t * n_workers_out, bool * lds_records_out);
 
 // Particle scoring with per-wave compaction of the occupied (pose, beam) pairs
 // (ndt2d_poses_compact.hip).

@@ -440,10 +440,11 @@ hipError_t launch_match(const MatchArgs & args_in, double * workspace, double * 
 
   hipError_t e;
   uint32_t n_workers = 0;
+  bool lane_lds_records = true;
   if (use_lane)
   {
-    e = launch_match_lane(args, outer, workspace, kMaxMatchBlocks * kMatchWaves, lim.cus, stream,
-                          &n_workers);
+    e = launch_match_lane(args, outer, workspace, kMaxMatchBlocks * kMatchWaves, lim.cus,
+                          lim.lds_per_block, stream, &n_workers, &lane_lds_records);
     if (e != hipSuccess) return e;
   }
   else
@@ -493,8 +494,10 @@ hipError_t launch_match(const MatchArgs & args_in, double * workspace, double * 
   {
     if (use_lane)
     {
-      info->variant = pow2 ? "match/lane-per-candidate/lds-grid/pow2"
-                           : "match/lane-per-candidate/lds-grid/div";
+      info->variant = lane_lds_records ? (pow2 ? "match/lane-per-candidate/lds-grid/pow2"
+                                               : "match/lane-per-candidate/lds-grid/div")
+                                       : (pow2 ? "match/lane-per-candidate/lds-map+global-records/pow2"
+                                               : "match/lane-per-candidate/lds-map+global-records/div");
       info->n_kernels = 3;
     }
     else

@@ -35,6 +35,8 @@
 // src/ndt_model.cpp:203-218 for near lanes, Cell::score :105-116).  Every
 // skipped term is an exact zero, so the sums are bit-identical to the unskipped
 // evaluation.
+#include <cmath>
+
 #include "ndt2d_device_fn.h"
 
 namespace ndt2d
@@ -57,15 +59,19 @@ constexpr double kTwo52 = 4503599627370496.0;
 
 struct LaneGeom
 {
-  int32_t pad;     // border cells on every side of the grid in the map
-  int32_t map_h;   // size_y + 2 * pad rows of kMapStride bytes
+  int32_t pad;     // border cells on every side of the window in the map
+  int32_t map_h;   // win_h + 2 * pad rows of kMapStride bytes
+  // Window of grid cells the map covers: every point this search can produce
+  // (scan pose +- (longest beam + largest offset)) lies inside it or outside the
+  // grid.  For small grids it is the whole grid.
+  int32_t win_x0, win_y0, win_w, win_h;
   double k_min, k_max_x, k_max_y;  // clamp of the per-beam fixed-point coordinate
 };
 
 // points_outer for the slab (reference :106-115) plus the packed fixed-point
 // map coordinate of each rotated beam:
 //   outer[t][b] = {ox, oy, K, 0},   K = 2^52 + ky * 2^24 + kx,
-//   k = rint(((o - origin) * inv_cell + pad) * 2^16) clamped to [k_min, k_max]
+//   k = rint(((o - origin) * inv_cell - window_origin + pad) * 2^16) clamped to [k_min, k_max]
 // so that k + d stays inside the map for every lane offset d.  A clamped beam
 // is further outside the grid than any offset can bring back; it stays in the
 // empty border.
@@ -85,8 +91,8 @@ __global__ void __launch_bounds__(256) outer_table_kernel(const MatchArgs a, dou
     double4 o;
     o.x = p.x * ct - p.y * st + a.pose_x;
     o.y = p.x * st + p.y * ct + a.pose_y;
-    double kx = ((o.x - a.grid.origin_x) * a.grid.inv_cell_size + geo.pad) * kFracScale;
-    double ky = ((o.y - a.grid.origin_y) * a.grid.inv_cell_size + geo.pad) * kFracScale;
+    double kx = ((o.x - a.grid.origin_x) * a.grid.inv_cell_size + (geo.pad - geo.win_x0)) * kFracScale;
+    double ky = ((o.y - a.grid.origin_y) * a.grid.inv_cell_size + (geo.pad - geo.win_y0)) * kFracScale;
     // !(k >= min) also catches NaN
     kx = !(kx >= geo.k_min) ? geo.k_min : (kx > geo.k_max_x ? geo.k_max_x : kx);
     ky = !(ky >= geo.k_min) ? geo.k_min : (ky > geo.k_max_y ? geo.k_max_y : ky);
@@ -100,13 +106,13 @@ struct LaneCtx
 {
   const double * lds_cells;
   const uint8_t * lds_map;
-  int32_t pad;
+  int32_t off_x, off_y;   // map cell -> grid cell: subtract (pad - win_x0), (pad - win_y0)
   int32_t size_x;
 };
 
 // U consecutive beams of one patch; o[] holds their table rows, dxy the lane's
 // packed fixed-point offset.
-template <int U, bool POW2>
+template <int U, bool POW2, bool LDS_RECORDS>
 __device__ __forceinline__ void lane_beams(const GridDesc & g, const LaneCtx & c,
                                            const double4 (&o)[U], double dx, double dy,
                                            double dxy, double & sum)
@@ -150,11 +156,11 @@ __device__ __forceinline__ void lane_beams(const GridDesc & g, const LaneCtx & c
           else
           {
             // interior of a cell: the look-up cell is the reference's cell
-            const int32_t cx = static_cast<int32_t>((lo[u] >> 16) & 0xffu) - c.pad;
-            const int32_t cy = static_cast<int32_t>((hi[u] >> 8) & 0xffu) - c.pad;
+            const int32_t cx = static_cast<int32_t>((lo[u] >> 16) & 0xffu) - c.off_x;
+            const int32_t cy = static_cast<int32_t>((hi[u] >> 8) & 0xffu) - c.off_y;
             idx = occ ? static_cast<uint32_t>(cy * c.size_x + cx) : g.ncell;
           }
-          const double e = indexed_exponent<true>(g, c.lds_cells, idx, px, py);
+          const double e = indexed_exponent<LDS_RECORDS>(g, c.lds_cells, idx, px, py);
           // !(e < bound) also keeps NaN exponents (degenerate cells) on the exact path
           if (__any(!(e < skip_below)))
           {
@@ -166,23 +172,27 @@ __device__ __forceinline__ void lane_beams(const GridDesc & g, const LaneCtx & c
   }
 }
 
-template <bool POW2>
+template <bool POW2, bool LDS_RECORDS>
 __global__ void __launch_bounds__(kLaneThreads) match_lane_kernel(
   const MatchArgs a, const double4 * __restrict__ outer, const LaneGeom geo)
 {
-  // LDS image: padded occupancy map (at offset 0, so the packed cell bytes are
-  // the LDS address) followed by the packed cell records.
+  // LDS image: padded occupancy map of the window (at offset 0, so the packed
+  // cell bytes are the LDS address) followed, if they fit (LDS_RECORDS), by the
+  // packed cell records of the whole grid; otherwise records are gathered from
+  // the 64-byte-stride HBM copy (a patch touches 1-4 lines).
   extern __shared__ __align__(16) double lds[];
   const GridDesc & g = a.grid;
   uint8_t * lds_map = reinterpret_cast<uint8_t *>(lds);
   double * lds_cells = lds + (static_cast<size_t>(geo.map_h) * kMapStride) / sizeof(double);
 
-  stage_grid_to_lds(g, lds_cells);
+  if (LDS_RECORDS) stage_grid_to_lds(g, lds_cells);
   {
     const int32_t sx = static_cast<int32_t>(g.size_x), sy = static_cast<int32_t>(g.size_y);
     for (int32_t i = threadIdx.x; i < kMapStride * geo.map_h; i += kLaneThreads)
     {
-      const int32_t cx = (i & (kMapStride - 1)) - geo.pad, cy = (i >> 8) - geo.pad;
+      // map cell -> grid cell
+      const int32_t cx = (i & (kMapStride - 1)) - geo.pad + geo.win_x0;
+      const int32_t cy = (i >> 8) - geo.pad + geo.win_y0;
       uint32_t self = 0, around = 0;
       for (int32_t ny = cy - 1; ny <= cy + 1; ++ny)
       {
@@ -190,10 +200,10 @@ __global__ void __launch_bounds__(kLaneThreads) match_lane_kernel(
         {
           if (nx >= 0 && nx < sx && ny >= 0 && ny < sy)
           {
-            const bool o =
-              g.cells_lds_image[static_cast<size_t>(ny * sx + nx) * kCellDoubles + 5] != 0.0;
-            around |= o ? 1u : 0u;
-            if (nx == cx && ny == cy) self = o ? 1u : 0u;
+            const uint32_t cell = static_cast<uint32_t>(ny * sx + nx);
+            const uint32_t o = (g.occ_bits[cell >> 5] >> (cell & 31u)) & 1u;
+            around |= o;
+            if (nx == cx && ny == cy) self = o;
           }
         }
       }
@@ -205,7 +215,8 @@ __global__ void __launch_bounds__(kLaneThreads) match_lane_kernel(
   LaneCtx c;
   c.lds_cells = lds_cells;
   c.lds_map = lds_map;
-  c.pad = geo.pad;
+  c.off_x = geo.pad - geo.win_x0;
+  c.off_y = geo.pad - geo.win_y0;
   c.size_x = static_cast<int32_t>(g.size_x);
 
   const uint32_t lane = threadIdx.x & (kWave - 1);
@@ -248,12 +259,12 @@ __global__ void __launch_bounds__(kLaneThreads) match_lane_kernel(
       double4 o[kUnroll];
 #pragma unroll
       for (int u = 0; u < kUnroll; ++u) o[u] = row[b + u];
-      lane_beams<kUnroll, POW2>(g, c, o, dx, dy, dxy, sum);
+      lane_beams<kUnroll, POW2, LDS_RECORDS>(g, c, o, dx, dy, dxy, sum);
     }
     for (; b < a.n_beams; ++b)
     {
       const double4 one[1] = {row[b]};
-      lane_beams<1, POW2>(g, c, one, dx, dy, dxy, sum);
+      lane_beams<1, POW2, LDS_RECORDS>(g, c, one, dx, dy, dxy, sum);
     }
 
     if (valid)
@@ -307,25 +318,60 @@ __global__ void __launch_bounds__(kLaneThreads) match_lane_kernel(
   }
 }
 
+// Window of grid cells [lo, hi] reachable along one axis, clipped to the grid.
+bool axis_window(double pose, double reach, double origin, double inv_cell, uint32_t size,
+                 int32_t * lo, int32_t * n)
+{
+  const double a = std::floor((pose - reach - origin) * inv_cell) - 1.0;
+  const double b = std::floor((pose + reach - origin) * inv_cell) + 1.0;
+  if (!(a == a) || !(b == b)) return false;  // NaN
+  double lo_c = a < 0.0 ? 0.0 : a;
+  double hi_c = b > static_cast<double>(size) - 1.0 ? static_cast<double>(size) - 1.0 : b;
+  if (lo_c > hi_c)
+  {
+    // nothing of the grid is reachable: any one-cell window will do
+    lo_c = hi_c = (a < 0.0 ? 0.0 : static_cast<double>(size) - 1.0);
+  }
+  *lo = static_cast<int32_t>(lo_c);
+  *n = static_cast<int32_t>(hi_c - lo_c) + 1;
+  return true;
+}
+
 // Map geometry for a search; false if the byte-per-axis cell coordinate cannot
-// hold the padded grid.
+// hold the padded window.
 bool lane_geometry(const MatchArgs & args, LaneGeom * geo, size_t * map_bytes)
 {
   const double lin_cells = args.dlin_absmax * args.grid.inv_cell_size;
   if (!(lin_cells >= 0.0) || lin_cells > kMaxMapCells) return false;
+  if (!(args.beam_rmax >= 0.0) || !std::isfinite(args.beam_rmax)) return false;
   const int32_t pad = static_cast<int32_t>(2.0 * lin_cells) + 3;
-  const uint64_t need_w = static_cast<uint64_t>(args.grid.size_x) + 2 * pad;
-  const uint64_t need_h = static_cast<uint64_t>(args.grid.size_y) + 2 * pad;
+  // points_inner = R * beam + pose + (dx, dy): within beam_rmax + |d|max of the pose per axis
+  const double reach = args.beam_rmax + args.dlin_absmax;
+  if (!axis_window(args.pose_x, reach, args.grid.origin_x, args.grid.inv_cell_size,
+                   args.grid.size_x, &geo->win_x0, &geo->win_w) ||
+      !axis_window(args.pose_y, reach, args.grid.origin_y, args.grid.inv_cell_size,
+                   args.grid.size_y, &geo->win_y0, &geo->win_h))
+  {
+    return false;
+  }
+  const uint64_t need_w = static_cast<uint64_t>(geo->win_w) + 2 * pad;
+  const uint64_t need_h = static_cast<uint64_t>(geo->win_h) + 2 * pad;
   if (need_w > kMaxMapCells || need_h > kMaxMapCells) return false;
   geo->pad = pad;
   geo->map_h = static_cast<int32_t>(need_h);
   // lanes add |d| <= lin_cells * 2^16 (+0.5 rounding); one cell of margin each side
-  const double reach = (lin_cells + 1.0) * kFracScale;
-  geo->k_min = reach;
-  geo->k_max_x = static_cast<double>(need_w - 1) * kFracScale - reach;
-  geo->k_max_y = static_cast<double>(need_h - 1) * kFracScale - reach;
+  const double reach_units = (lin_cells + 1.0) * kFracScale;
+  geo->k_min = reach_units;
+  geo->k_max_x = static_cast<double>(need_w - 1) * kFracScale - reach_units;
+  geo->k_max_y = static_cast<double>(need_h - 1) * kFracScale - reach_units;
   *map_bytes = static_cast<size_t>(kMapStride) * need_h;
   return true;
+}
+
+bool lane_records_in_lds(const MatchArgs & args, size_t map_bytes, size_t lds_per_block)
+{
+  const size_t grid_bytes = static_cast<size_t>(args.grid.ncell + 1) * kCellDoubles * sizeof(double);
+  return grid_bytes + map_bytes <= lds_per_block;
 }
 
 }  // namespace
@@ -339,16 +385,15 @@ bool match_lane_supported(const MatchArgs & args, size_t lds_per_block)
 {
   LaneGeom geo;
   size_t map_bytes = 0;
-  if (!lane_geometry(args, &geo, &map_bytes)) return false;
-  const size_t grid_bytes = static_cast<size_t>(args.grid.ncell + 1) * kCellDoubles * sizeof(double);
+  if (args.grid.occ_bits == nullptr || !lane_geometry(args, &geo, &map_bytes)) return false;
   const uint64_t p1 = (args.n_lin + kPatch - 1) / kPatch;
   const uint64_t items = static_cast<uint64_t>(args.th_end - args.th_begin) * p1 * p1;
-  return grid_bytes + map_bytes <= lds_per_block && items < (1ull << 32);
+  return map_bytes <= lds_per_block && items < (1ull << 32);
 }
 
 hipError_t launch_match_lane(const MatchArgs & args_in, double * outer, double * workspace,
-                             uint32_t max_workers, int cus, hipStream_t stream,
-                             uint32_t * n_workers_out)
+                             uint32_t max_workers, int cus, size_t lds_per_block,
+                             hipStream_t stream, uint32_t * n_workers_out, bool * lds_records_out)
 {
   MatchArgs args = args_in;
   args.partials = workspace;
@@ -372,8 +417,11 @@ hipError_t launch_match_lane(const MatchArgs & args_in, double * outer, double *
   if (blocks > max_blocks) blocks = max_blocks;
   if (blocks == 0) blocks = 1;
 
+  const bool lds_records = lane_records_in_lds(args, map_bytes, lds_per_block);
+  if (lds_records_out != nullptr) *lds_records_out = lds_records;
   const size_t lds_bytes =
-    static_cast<size_t>(args.grid.ncell + 1) * kCellDoubles * sizeof(double) + map_bytes;
+    map_bytes +
+    (lds_records ? static_cast<size_t>(args.grid.ncell + 1) * kCellDoubles * sizeof(double) : 0);
   auto launch = [&](auto kernel) -> hipError_t {
     if (lds_bytes > 48 * 1024)
     {
@@ -386,7 +434,14 @@ hipError_t launch_match_lane(const MatchArgs & args_in, double * outer, double *
                        reinterpret_cast<const double4 *>(outer), geo);
     return hipGetLastError();
   };
-  e = args.grid.pow2 ? launch(match_lane_kernel<true>) : launch(match_lane_kernel<false>);
+  if (lds_records)
+  {
+    e = args.grid.pow2 ? launch(match_lane_kernel<true, true>) : launch(match_lane_kernel<false, true>);
+  }
+  else
+  {
+    e = args.grid.pow2 ? launch(match_lane_kernel<true, false>) : launch(match_lane_kernel<false, false>);
+  }
   if (n_workers_out != nullptr) *n_workers_out = blocks * kLaneWaves;
   return e;
 }

@@ -310,6 +310,33 @@ def test_cfg4_sized_lattice_properties():
         assert abs(slab[f] + ref.ndt.likelihood(inner)) < TOL_TIGHT
 
 
+def test_match_scan_on_a_large_map_uses_the_windowed_lane_kernel():
+    """matchScan against the 201 x 201 global map (scan-match localisation,
+    reference src/ndt_mapper.cpp:547-566): the grid does not fit in LDS, the
+    search window does."""
+    gpu, ref, _, guess, pts = _pair(3, search_linear_size=0.5, search_linear_resolution=0.05,
+                                    search_angular_size=0.1, search_angular_resolution=0.01)
+    wrong = guess + np.array([0.21, -0.13, 0.04])          # start off the true pose
+    got = gpu.matchScan(wrong, pts, want_scores=True)
+    assert "lane-per-candidate/lds-map+global-records" in gpu.last_variant(), gpu.last_variant()
+    exp = ref.matchScan(wrong, pts, want_scores=True)
+    _check_match(got, exp, 720)
+    assert np.all(np.abs(wrong + got["pose"] - guess) <= [0.05, 0.05, 0.01])
+    # same search through the wave-per-candidate kernel (records gathered from HBM)
+    gpu.set_variant("wave")
+    try:
+        alt = gpu.matchScan(wrong, pts, want_scores=True)
+        assert "wave-per-candidate/global-grid" in gpu.last_variant()
+    finally:
+        gpu.set_variant("auto")
+    _check_match(alt, exp, 720)
+    # a scan pose near the map edge and one outside the map
+    for pose in [(-24.0, 20.0, 0.5), (60.0, 60.0, 0.0)]:
+        a = gpu.matchScan(pose, pts, want_scores=True)
+        b = ref.matchScan(pose, pts, want_scores=True)
+        _check_match(a, b, 720)
+
+
 def test_cfg3_particles_golden_through_device_layer():
     g = np.load(os.path.join(GOLDEN, "cfg3_poses256.npz"))
     ncell = int(g["size_x"]) * int(g["size_y"])
