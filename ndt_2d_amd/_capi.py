@@ -111,6 +111,14 @@ def lib():
         raise ImportError(
             "ndt_2d_amd: %s is missing -- build it with `python -m ndt_2d_amd.build` "
             "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+    # PyTorch-ROCm wheels bundle their own HIP runtime.  If this library pulled in
+    # the system libamdhip64 first, a later `import torch` would bring a second
+    # runtime into the process and find no GPUs; loading torch's first makes both
+    # share one.  (Pure C/C++ hosts, e.g. the ROS plugin, never see torch.)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         f = getattr(L, name)

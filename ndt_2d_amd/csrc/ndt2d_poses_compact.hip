@@ -38,16 +38,18 @@ constexpr uint32_t kCellMask = (1u << kCellBits) - 1;
 // result does not depend on the launch geometry or on how a particle set is
 // sharded.  (It differs from the reference's single running sum by a few ulps.)
 constexpr int kChunks = 8;
+constexpr size_t kLdsBudget = 160 * 1024;
 
 template <int THREADS>
 struct CompactLayout
 {
   static constexpr int kWaves = THREADS / kWave;
-  // doubles: [stats kWaves*8][sums THREADS][chunk sums kWaves*kChunks*64 (at most)]
-  //          [q_px kWaves*cap][q_py kWaves*cap][q_meta (u32) kWaves*cap/2]
+  // doubles: [stats kWaves*8][sums THREADS][q_px kWaves*cap][q_py kWaves*cap]
+  //          [q_meta (u32) kWaves*cap/2]; then beams, occupancy bitmap and, when
+  //          several waves share a group, the chunk sums [groups][kChunks][64]
   static constexpr size_t kFixedDoubles =
-    static_cast<size_t>(kWaves) * 8 + THREADS + static_cast<size_t>(kWaves) * kChunks * kWave +
-    2 * static_cast<size_t>(kWaves) * kQueueCap + static_cast<size_t>(kWaves) * kQueueCap / 2;
+    static_cast<size_t>(kWaves) * 8 + THREADS + 2 * static_cast<size_t>(kWaves) * kQueueCap +
+    static_cast<size_t>(kWaves) * kQueueCap / 2;
 };
 
 // SPLIT waves share the 64 poses of a group; each takes kChunks / SPLIT chunks.
@@ -59,8 +61,7 @@ __global__ void __launch_bounds__(THREADS) score_poses_compact_kernel(const Pose
   extern __shared__ __align__(16) double lds[];
   double * sh_stats = lds;
   double * sh_sum = sh_stats + L::kWaves * 8;
-  double * sh_chunk = sh_sum + THREADS;                       // [group][chunk][lane]
-  double * q_px_all = sh_chunk + L::kWaves * kChunks * kWave;
+  double * q_px_all = sh_sum + THREADS;
   double * q_py_all = q_px_all + L::kWaves * kQueueCap;
   uint32_t * q_meta_all = reinterpret_cast<uint32_t *>(q_py_all + L::kWaves * kQueueCap);
   double * lds_beams = reinterpret_cast<double *>(q_meta_all + L::kWaves * kQueueCap);
@@ -69,6 +70,8 @@ __global__ void __launch_bounds__(THREADS) score_poses_compact_kernel(const Pose
   const GridDesc & g = a.grid;
   for (uint32_t i = threadIdx.x; i < 2 * a.n_beams; i += THREADS) lds_beams[i] = a.beams_xy[i];
   const uint32_t n_words = (g.ncell + 1 + 31) / 32;
+  // chunk sums [group][chunk][lane], only used (and allocated) when split > 1
+  double * sh_chunk = reinterpret_cast<double *>(lds_bits + ((n_words + 3) & ~3u));
   for (uint32_t i = threadIdx.x; i < n_words; i += THREADS) lds_bits[i] = g.occ_bits[i];
   __syncthreads();
 
@@ -122,6 +125,7 @@ __global__ void __launch_bounds__(THREADS) score_poses_compact_kernel(const Pose
     double s, c;
     sincos(th, &s, &c);
 
+    double total = 0.0;
     for (uint32_t cj = 0; cj < chunks_per_part; ++cj)
     {
       const uint32_t chunk = part * chunks_per_part + cj;
@@ -161,15 +165,27 @@ __global__ void __launch_bounds__(THREADS) score_poses_compact_kernel(const Pose
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       drain(head, count);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      my_chunks[chunk * kWave + lane] = my_sums[lane];
+      const double csum = my_sums[lane];
+      if (split > 1)
+      {
+        my_chunks[chunk * kWave + lane] = csum;
+      }
+      else
+      {
+        total = chunk == 0 ? csum : total + csum;  // ((c_0 + c_1) + c_2) + ...
+      }
     }
-    __syncthreads();
+    if (split > 1) __syncthreads();
 
     if (part == 0)
     {
-      double sum = my_chunks[lane];
+      double sum = total;
+      if (split > 1)
+      {
+        sum = my_chunks[lane];
 #pragma unroll
-      for (int j = 1; j < kChunks; ++j) sum += my_chunks[j * kWave + lane];
+        for (int j = 1; j < kChunks; ++j) sum += my_chunks[j * kWave + lane];
+      }
       // score = sum of (-likelihood) / n  ==  -(sum) / n (:175-177)
       const double score = -sum / static_cast<double>(a.n_beams);
       if (valid)
@@ -187,7 +203,7 @@ __global__ void __launch_bounds__(THREADS) score_poses_compact_kernel(const Pose
         st[7] += w * y * y;
       }
     }
-    __syncthreads();
+    if (split > 1) __syncthreads();
   }
 
   if (a.partials != nullptr)
@@ -209,13 +225,30 @@ __global__ void __launch_bounds__(THREADS) score_poses_compact_kernel(const Pose
   }
 }
 
-size_t compact_lds_bytes(const PosesArgs & args, int threads)
+size_t compact_lds_bytes(const PosesArgs & args, int threads, uint32_t split)
 {
   const size_t fixed = threads == 1024 ? CompactLayout<1024>::kFixedDoubles
                                        : CompactLayout<256>::kFixedDoubles;
   const size_t beams = static_cast<size_t>(2) * ((args.n_beams + 1) & ~1u);
   const size_t words = (static_cast<size_t>(args.grid.ncell) + 1 + 31) / 32;
-  return (fixed + beams) * sizeof(double) + ((words * 4 + 15) & ~size_t(15));
+  const size_t chunk_sums =
+    split > 1 ? static_cast<size_t>(threads / kWave / split) * kChunks * kWave : 0;
+  return (fixed + beams + chunk_sums) * sizeof(double) + ((words + 3) & ~size_t(3)) * 4;
+}
+
+// Waves sharing one group of 64 poses: enough to put ~8 waves on every SIMD (the
+// gathers of phase B are latency bound), at most kChunks and one block.
+uint32_t choose_split(const PosesArgs & args, int cus, uint32_t waves_per_block)
+{
+  const uint64_t groups = (args.n_poses + kWave - 1) / kWave;
+  const uint64_t want_waves = static_cast<uint64_t>(cus) * 4 * 8;
+  uint32_t split = 1;
+  while (split < static_cast<uint32_t>(kChunks) && split < waves_per_block &&
+         groups * split < want_waves)
+  {
+    split *= 2;
+  }
+  return split;
 }
 
 template <int THREADS>
@@ -242,7 +275,7 @@ hipError_t launch_compact(const PosesArgs & args, uint32_t blocks, uint32_t spli
 bool poses_compact_supported(const PosesArgs & args, size_t lds_per_block)
 {
   return args.grid.occ_bits != nullptr && args.grid.ncell < kCellMask &&
-         compact_lds_bytes(args, 1024) <= lds_per_block;
+         compact_lds_bytes(args, 1024, 1) <= lds_per_block;
 }
 
 hipError_t launch_poses_compact(const PosesArgs & args, int cus, hipStream_t stream,
@@ -250,27 +283,30 @@ hipError_t launch_poses_compact(const PosesArgs & args, int cus, hipStream_t str
 {
   // Small LDS image: 256-thread blocks, several per CU.  Large occupancy bitmap:
   // one 1024-thread block per CU shares it.
-  const size_t small = compact_lds_bytes(args, 256);
+  uint32_t split = choose_split(args, cus, 4);
+  const size_t small = compact_lds_bytes(args, 256, split);
   const bool use_small = small <= 48 * 1024;
   const int threads = use_small ? 256 : 1024;
   const uint32_t waves_per_block = static_cast<uint32_t>(threads / kWave);
-  // Waves sharing one group of 64 poses: enough to put >= ~8 waves on every SIMD
-  // (the gathers of phase B are latency bound), at most kChunks and one block.
-  const uint64_t groups = (args.n_poses + kWave - 1) / kWave;
-  const uint64_t want_waves = static_cast<uint64_t>(cus) * 4 * 8;
-  uint32_t split = 1;
-  while (split < static_cast<uint32_t>(kChunks) && split < waves_per_block &&
-         groups * split < want_waves)
+  size_t lds_bytes = small;
+  if (!use_small)
   {
-    split *= 2;
+    split = choose_split(args, cus, waves_per_block);
+    lds_bytes = compact_lds_bytes(args, 1024, split);
+    while (split > 1 && lds_bytes > kLdsBudget)
+    {
+      split /= 2;
+      lds_bytes = compact_lds_bytes(args, 1024, split);
+    }
   }
+  const uint64_t groups = (args.n_poses + kWave - 1) / kWave;
   const uint64_t groups_per_block = waves_per_block / split;
   const uint64_t need = (groups + groups_per_block - 1) / groups_per_block;
   const uint64_t cap = use_small ? 4096 : static_cast<uint64_t>(cus);
   const uint32_t blocks = static_cast<uint32_t>(need < cap ? need : cap);
   if (blocks_out != nullptr) *blocks_out = blocks;
-  return use_small ? launch_compact<256>(args, blocks, split, small, stream)
-                   : launch_compact<1024>(args, blocks, split, compact_lds_bytes(args, 1024), stream);
+  return use_small ? launch_compact<256>(args, blocks, split, lds_bytes, stream)
+                   : launch_compact<1024>(args, blocks, split, lds_bytes, stream);
 }
 
 }  // namespace ndt2d
