@@ -94,6 +94,43 @@ def particles_case(cfg, variants):
     return out
 
 
+def build_case(cfg):
+    """N1: ScanMatcherNDT::addScans, host build + upload vs build on the device."""
+    scans = synth.map_scans(cfg)
+    params = synth.matcher_params(cfg)
+    n_points = sum(len(s[1]) for s in scans)
+    out = {"scans": len(scans), "points": n_points}
+    for mode in ("host", "device"):
+        m = ScanMatcherNDT(0)
+        m.initialize("bench", **params)
+        m.set_build_mode(mode)
+        wall, dev = [], []
+        for i in range(6):
+            t0 = time.perf_counter()
+            m.addScans(scans)
+            m.synchronize()
+            t1 = time.perf_counter()
+            if i:
+                wall.append(t1 - t0)
+                if mode == "device":
+                    dev.append(m.last_launch_ms()[0])
+        out[mode] = {"add_scans_ms": float(np.median(wall)) * 1e3}
+        if dev:
+            out[mode]["device_pipeline_ms"] = float(np.median(dev))
+        m.close()
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    ref = O.ScanMatcherNDT()
+    ref.initialize(**params)
+    t = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        ref.addScans(scans)
+        t.append(time.perf_counter() - t0)
+    out["cpu_oracle_ms"] = float(np.median(t)) * 1e3
+    return out
+
+
 if __name__ == "__main__":
     res = {
         "cfg2_match": match_case(2, ["auto", "wave"]),
@@ -104,5 +141,8 @@ if __name__ == "__main__":
         "default_plugin_latency": default_latency(),
         "cfg3_particles": particles_case(3, ["auto", "dense"]),
         "cfg5_particles": particles_case(5, ["auto", "dense"]),
+        "ndt_build_cfg1": build_case(1),
+        "ndt_build_cfg3": build_case(3),
+        "ndt_build_cfg5": build_case(5),
     }
     print(json.dumps(res, indent=1))

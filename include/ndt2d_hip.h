@@ -75,6 +75,21 @@ int ndt2d_device_id(ndt2d_handle h);
  * (include/ndt_2d/ndt_model.hpp:128-131). */
 int ndt2d_set_grid(ndt2d_handle h, const double * cells6, uint32_t size_x, uint32_t size_y,
                    double cell_size, double origin_x, double origin_y);
+/* Build the NDT on the device from the scans themselves and install it: the
+ * whole of ScanMatcherNDT::addScans (src/scan_matcher_ndt.cpp:49-74) --
+ * bounding box of the scan poses +- range_max, NDT::addScan for every scan in
+ * order (src/ndt_model.cpp:132-152), NDT::compute (:154-160).  Scan k has pose
+ * poses_xyt[3k..3k+2] and robot-frame points points_xy[2*offsets[k] ..
+ * 2*offsets[k+1]).  Every cell sees its points in the reference's order (stable
+ * sort by cell), so the result is bit-identical to the host build.  Asynchronous
+ * on the context's stream. */
+int ndt2d_build_grid(ndt2d_handle h, double ndt_resolution, double range_max,
+                     const double * poses_xyt, const double * points_xy, const size_t * offsets,
+                     size_t n_scans);
+/* Geometry and (optionally) the cells6 records of the installed grid, copied
+ * back from the device.  Any output may be NULL. */
+int ndt2d_get_grid(ndt2d_handle h, double * cells6_out, size_t capacity_cells, uint32_t * size_x,
+                   uint32_t * size_y, double * cell_size, double * origin_x, double * origin_y);
 /* ScanMatcherNDT::reset (src/scan_matcher_ndt.cpp:180-183). */
 int ndt2d_clear_grid(ndt2d_handle h);
 int ndt2d_has_grid(ndt2d_handle h);
@@ -178,6 +193,10 @@ int ndt2d_matcher_initialize(ndt2d_matcher * m, double ndt_resolution,
  * uploads it. */
 int ndt2d_matcher_add_scans(ndt2d_matcher * m, const double * poses_xyt,
                             const double * points_xy, const size_t * offsets, size_t n_scans);
+/* Where addScans builds the NDT: "host" (C++ on the host, then upload), "device"
+ * (ndt2d_build_grid) or "auto" (device from 32768 map points up).  Both give
+ * bit-identical grids. */
+int ndt2d_matcher_set_build_mode(ndt2d_matcher * m, const char * mode);
 /* ScanMatcherNDT::matchScan (src/scan_matcher_ndt.cpp:76-149).  *score_out =
  * the function's return value (best_score / scan_points_to_use; 0.0 and
  * outputs untouched when no NDT, :80).  pose_inout[3] is written only when a

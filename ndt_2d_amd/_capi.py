@@ -58,6 +58,8 @@ SIGNATURES = {
     "ndt2d_get_stream": (_vp, [_vp]),
     "ndt2d_device_id": (C.c_int, [_vp]),
     "ndt2d_set_grid": (C.c_int, [_vp, _dp, _u32, _u32, _d, _d, _d]),
+    "ndt2d_build_grid": (C.c_int, [_vp, _d, _d, _dp, _dp, _szp, _sz]),
+    "ndt2d_get_grid": (C.c_int, [_vp, _dp, _sz, C.POINTER(_u32), C.POINTER(_u32), _dp, _dp, _dp]),
     "ndt2d_clear_grid": (C.c_int, [_vp]),
     "ndt2d_has_grid": (C.c_int, [_vp]),
     "ndt2d_set_beams": (C.c_int, [_vp, _dp, _sz]),
@@ -77,6 +79,7 @@ SIGNATURES = {
     "ndt2d_matcher_device": (_vp, [_vp]),
     "ndt2d_matcher_initialize": (C.c_int, [_vp, _d, _d, _d, _d, _d, _sz, _d]),
     "ndt2d_matcher_add_scans": (C.c_int, [_vp, _dp, _dp, _szp, _sz]),
+    "ndt2d_matcher_set_build_mode": (C.c_int, [_vp, C.c_char_p]),
     "ndt2d_matcher_match_scan": (C.c_int, [_vp, _dp, _dp, _sz, _dp, _dp, _dp]),
     "ndt2d_matcher_match_scan_ex": (C.c_int, [_vp, _dp, _dp, _sz, _dp, _dp, _dp, _dp, _sz,
                                              _szp, C.POINTER(C.c_uint64)]),

@@ -1,0 +1,252 @@
+// NDT build on the device: ScanMatcherNDT::addScans' NDT::addScan + NDT::compute
+// (reference src/scan_matcher_ndt.cpp:67-73, src/ndt_model.cpp:50-103,132-160).
+//
+// Cell::addPoint is an order-dependent recurrence (incremental mean and second
+// moment, src/ndt_model.cpp:52-57) whose later `correlation - mean^2`
+// (src/ndt_model.cpp:78) cancels catastrophically, so bit parity needs every cell to see its
+// points in the reference's order (scan by scan, point by point).  Pipeline:
+//
+//   1. points_kernel   one thread per point: transform by its scan's pose
+//                      (:139-141, cos/sin from the host libm as in :135-136),
+//                      NDT::getIndex (:203-218) -> sort key = cell (ncell = outside)
+//   2. stable radix sort of (cell, point index)  [hipcub::DeviceRadixSort]: points
+//                      of one cell stay in their original order
+//   3. segments_kernel first / one-past-last sorted position of every cell
+//   4. cells_kernel    one thread per cell walks its points in order: addPoint,
+//                      then Cell::compute (:65-103), and writes the cell in all the
+//                      layouts the scorers read (cells6, LDS image, 64-byte gather
+//                      copy)
+//   5. bits_kernel     occupancy bitmap, one thread per 32 cells
+//
+// Everything is IEEE double with the reference's operation order (file compiled
+// with -ffp-contract=off; '/' and sqrt are correctly rounded).
+#include <hipcub/hipcub.hpp>
+
+#include "ndt2d_device_fn.h"
+
+namespace ndt2d
+{
+
+namespace
+{
+
+struct ScanRec
+{
+  double x, y, c, s;  // pose translation, cos / sin of pose theta
+};
+
+__global__ void __launch_bounds__(256) points_kernel(const BuildArgs a)
+{
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n_points) return;
+  // which scan does point i belong to: last k with offsets[k] <= i
+  uint32_t lo = 0, hi = a.n_scans;
+  while (hi - lo > 1)
+  {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (a.offsets[mid] <= i) lo = mid; else hi = mid;
+  }
+  const ScanRec sc = reinterpret_cast<const ScanRec *>(a.scans)[lo];
+  const double2 p = reinterpret_cast<const double2 *>(a.points_xy)[i];
+  // p(0) = pose.x; p(0) += point.x * cos_th - point.y * sin_th (:139-141)
+  const double wx = sc.x + (p.x * sc.c - p.y * sc.s);
+  const double wy = sc.y + (p.x * sc.s + p.y * sc.c);
+  a.world_xy[2 * static_cast<size_t>(i)] = wx;
+  a.world_xy[2 * static_cast<size_t>(i) + 1] = wy;
+  a.keys_in[i] = a.grid.pow2 ? cell_index<true>(a.grid, wx, wy) : cell_index<false>(a.grid, wx, wy);
+  a.vals_in[i] = i;
+}
+
+__global__ void __launch_bounds__(256) segments_kernel(const uint32_t * keys, uint32_t n,
+                                                       uint32_t * seg_begin, uint32_t * seg_end)
+{
+  const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  const uint32_t k = keys[j];
+  if (j == 0 || keys[j - 1] != k) seg_begin[k] = j;
+  if (j == n - 1 || keys[j + 1] != k) seg_end[k] = j + 1;
+}
+
+// Eigenvalues of the symmetric 2x2 [[a, b], [b, d]] the way
+// Eigen::EigenSolver's real Schur form arrives at them (src/ndt_model.cpp:84-85);
+// same restatement as the host builder (csrc/ndt2d_host.cpp).
+__device__ __forceinline__ void symmetric_eigenvalues(double a, double b, double d, double * e0,
+                                                      double * e1)
+{
+  const double eps = 2.220446049250313e-16;
+  const double tiny_min = 2.2250738585072014e-308;
+  const double norm = fabs(a) + 2.0 * fabs(b) + fabs(d);
+  double tiny = norm * (eps * eps);
+  if (tiny < tiny_min) tiny = tiny_min;
+  double thresh = (fabs(a) + fabs(d)) * eps;
+  if (thresh < tiny) thresh = tiny;
+  if (norm == 0.0 || fabs(b) <= thresh)
+  {
+    *e0 = a;
+    *e1 = d;
+    return;
+  }
+  const double p = 0.5 * (a - d);
+  const double q = p * p + b * b;
+  const double z = sqrt(fabs(q));
+  *e0 = (d + p) + z;
+  *e1 = (d + p) - z;
+}
+
+__global__ void __launch_bounds__(256) cells_kernel(const BuildArgs a, const uint32_t * sorted_vals,
+                                                    const uint32_t * seg_begin,
+                                                    const uint32_t * seg_end)
+{
+  const uint32_t cell = blockIdx.x * 256 + threadIdx.x;
+  if (cell > a.grid.ncell) return;
+
+  double n = 0.0, mean_x = 0.0, mean_y = 0.0, cxx = 0.0, cxy = 0.0, cyy = 0.0;
+  double ixx = 0.0, ixy = 0.0, iyy = 0.0;
+  if (cell < a.grid.ncell)
+  {
+    // Cell::addPoint in the reference's point order (src/ndt_model.cpp:50-63)
+    const uint32_t b = seg_begin[cell], e = seg_end[cell];
+    for (uint32_t j = b; j < e; ++j)
+    {
+      const size_t i = sorted_vals[j];
+      const double x = a.world_xy[2 * i], y = a.world_xy[2 * i + 1];
+      const double n1 = n + 1;
+      mean_x = (mean_x * n + x) / n1;
+      mean_y = (mean_y * n + y) / n1;
+      cxx = (cxx * n + x * x) / n1;
+      cxy = (cxy * n + x * y) / n1;
+      cyy = (cyy * n + y * y) / n1;
+      n += 1;
+    }
+    // Cell::compute (src/ndt_model.cpp:65-103)
+    if (!(n < 3))
+    {
+      const double scale = n / (n - 1);
+      const double vxx = (cxx - (mean_x * mean_x)) * scale;
+      const double vxy = (cxy - (mean_x * mean_y)) * scale;
+      const double vyy = (cyy - (mean_y * mean_y)) * scale;
+      double small, large;
+      symmetric_eigenvalues(vxx, vxy, vyy, &small, &large);
+      if (small > large)
+      {
+        const double t = small;
+        small = large;
+        large = t;
+      }
+      if (small < 0.001 * large)
+      {
+        const double determinant = (0.001 * large) * large;
+        ixx = vyy / determinant;
+        ixy = -vxy / determinant;
+        iyy = vxx / determinant;
+      }
+      else
+      {
+        const double det = vxx * vyy - vxy * vxy;
+        const double invdet = 1.0 / det;
+        ixx = vyy * invdet;
+        ixy = -vxy * invdet;
+        iyy = vxx * invdet;
+      }
+    }
+    double * c6 = a.cells6 + static_cast<size_t>(cell) * 6;
+    c6[0] = mean_x;
+    c6[1] = mean_y;
+    c6[2] = ixx;
+    c6[3] = ixy;
+    c6[4] = iyy;
+    c6[5] = n;
+  }
+
+  // scorer layouts: h = -0.5 * information; sentinel for cells that cannot score
+  // (n < 5, src/ndt_model.cpp:107) and for record ncell ("outside")
+  double rec[kCellDoubles] = {1.0e300, 0.0, -1.0, 0.0, -1.0, 0.0};
+  if (cell < a.grid.ncell && !(n < 5.0))
+  {
+    rec[0] = mean_x;
+    rec[1] = mean_y;
+    rec[2] = -0.5 * ixx;
+    rec[3] = -0.5 * ixy;
+    rec[4] = -0.5 * iyy;
+    rec[5] = 1.0;
+  }
+  double * l = a.cells_lds_image + static_cast<size_t>(cell) * kCellDoubles;
+  double * gl = a.cells_global + static_cast<size_t>(cell) * kCellStrideGlobal;
+#pragma unroll
+  for (int k = 0; k < kCellDoubles; ++k)
+  {
+    l[k] = rec[k];
+    gl[k] = rec[k];
+  }
+  gl[6] = 0.0;
+  gl[7] = 0.0;
+}
+
+__global__ void __launch_bounds__(256) bits_kernel(const double * cells_lds_image, uint32_t ncell,
+                                                   uint32_t n_words, uint32_t * bits)
+{
+  const uint32_t w = blockIdx.x * 256 + threadIdx.x;
+  if (w >= n_words) return;
+  uint32_t v = 0;
+  for (uint32_t k = 0; k < 32; ++k)
+  {
+    const uint32_t cell = w * 32 + k;
+    if (cell < ncell && cells_lds_image[static_cast<size_t>(cell) * kCellDoubles + 5] != 0.0)
+    {
+      v |= 1u << k;
+    }
+  }
+  bits[w] = v;
+}
+
+int key_bits(uint32_t ncell)
+{
+  int b = 1;
+  while (b < 32 && (1ull << b) <= ncell) ++b;
+  return b;
+}
+
+}  // namespace
+
+size_t build_sort_temp_bytes(uint32_t n_points, uint32_t ncell)
+{
+  size_t bytes = 0;
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, static_cast<const uint32_t *>(nullptr),
+                                     static_cast<uint32_t *>(nullptr),
+                                     static_cast<const uint32_t *>(nullptr),
+                                     static_cast<uint32_t *>(nullptr), n_points, 0, key_bits(ncell));
+  return bytes;
+}
+
+hipError_t launch_build_grid(const BuildArgs & a, hipStream_t stream)
+{
+  hipError_t e;
+  const uint32_t ncell = a.grid.ncell;
+  e = hipMemsetAsync(a.seg_begin, 0, static_cast<size_t>(ncell + 1) * 2 * sizeof(uint32_t), stream);
+  if (e != hipSuccess) return e;
+  if (a.n_points > 0)
+  {
+    const uint32_t pb = (a.n_points + 255) / 256;
+    hipLaunchKernelGGL(points_kernel, dim3(pb), dim3(256), 0, stream, a);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    size_t temp = a.sort_temp_bytes;
+    e = hipcub::DeviceRadixSort::SortPairs(a.sort_temp, temp, a.keys_in, a.keys_out, a.vals_in,
+                                           a.vals_out, a.n_points, 0, key_bits(ncell), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(segments_kernel, dim3(pb), dim3(256), 0, stream, a.keys_out, a.n_points,
+                       a.seg_begin, a.seg_begin + (ncell + 1));
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(cells_kernel, dim3((ncell + 1 + 255) / 256), dim3(256), 0, stream, a,
+                     a.vals_out, a.seg_begin, a.seg_begin + (ncell + 1));
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  const uint32_t n_words = (ncell + 1 + 31) / 32;
+  hipLaunchKernelGGL(bits_kernel, dim3((n_words + 255) / 256), dim3(256), 0, stream,
+                     a.cells_lds_image, ncell, n_words, a.occ_bits);
+  return hipGetLastError();
+}
+
+}  // namespace ndt2d

@@ -4,6 +4,7 @@
 // No CPU compute path exists here: every compute entry point needs the GPU.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -37,6 +38,11 @@ struct ndt2d_context
   DeviceBuffer cells_lds_image;
   DeviceBuffer cells_global;
   DeviceBuffer occ_bits;  // uint32 words stored in a double buffer
+  DeviceBuffer cells6;    // raw {mean, information, n} records (introspection)
+  // device NDT build scratch + host staging that must outlive the async copies
+  DeviceBuffer b_points, b_scans, b_offsets, b_world, b_keys, b_vals, b_temp, b_seg;
+  std::vector<double> stage_scans;
+  std::vector<uint32_t> stage_offsets;
 
   DeviceBuffer beams;
   size_t n_beams = 0;
@@ -157,6 +163,15 @@ int ndt2d_destroy(ndt2d_handle h)
   release(h->cells_lds_image);
   release(h->cells_global);
   release(h->occ_bits);
+  release(h->cells6);
+  release(h->b_points);
+  release(h->b_scans);
+  release(h->b_offsets);
+  release(h->b_world);
+  release(h->b_keys);
+  release(h->b_vals);
+  release(h->b_temp);
+  release(h->b_seg);
   release(h->beams);
   release(h->tables);
   release(h->ws_match);
@@ -239,6 +254,10 @@ int ndt2d_set_grid(ndt2d_handle h, const double * cells6, uint32_t size_x, uint3
   if (rc != NDT2D_OK) return rc;
   NDT2D_HIP(h, hipMemcpyAsync(h->occ_bits.ptr, bits.data(), bits.size() * sizeof(uint32_t),
                               hipMemcpyHostToDevice, h->stream));
+  rc = ensure(h, h->cells6, static_cast<size_t>(ncell) * 6);
+  if (rc != NDT2D_OK) return rc;
+  NDT2D_HIP(h, hipMemcpyAsync(h->cells6.ptr, cells6, static_cast<size_t>(ncell) * 6 * sizeof(double),
+                              hipMemcpyHostToDevice, h->stream));
   NDT2D_HIP(h, hipStreamSynchronize(h->stream));  // host staging vectors go out of scope
 
   h->grid.cells_lds_image = h->cells_lds_image.ptr;
@@ -253,6 +272,150 @@ int ndt2d_set_grid(ndt2d_handle h, const double * cells6, uint32_t size_x, uint3
   h->grid.origin_x = origin_x;
   h->grid.origin_y = origin_y;
   h->has_grid = true;
+  return NDT2D_OK;
+}
+
+int ndt2d_build_grid(ndt2d_handle h, double ndt_resolution, double range_max,
+                     const double * poses_xyt, const double * points_xy, const size_t * offsets,
+                     size_t n_scans)
+{
+  if (h == nullptr) return NDT2D_ERR_INVALID;
+  if (!(ndt_resolution > 0.0) || n_scans == 0 || poses_xyt == nullptr || offsets == nullptr ||
+      n_scans > (1u << 30))
+  {
+    return fail(h, NDT2D_ERR_INVALID, "ndt2d_build_grid: bad argument");
+  }
+  const size_t n_points = offsets[n_scans];
+  if (n_points >= (1ull << 31) || (n_points > 0 && points_xy == nullptr))
+  {
+    return fail(h, NDT2D_ERR_INVALID, "ndt2d_build_grid: bad points");
+  }
+  // Extent: ScanMatcherNDT::addScans (reference src/scan_matcher_ndt.cpp:52-66); max_x_ /
+  // max_y_ start at numeric_limits<double>::min() as the reference has it.
+  double min_x = std::numeric_limits<double>::max(), max_x = std::numeric_limits<double>::min();
+  double min_y = std::numeric_limits<double>::max(), max_y = std::numeric_limits<double>::min();
+  for (size_t k = 0; k < n_scans; ++k)
+  {
+    min_x = std::min(poses_xyt[3 * k] - range_max, min_x);
+    max_x = std::max(poses_xyt[3 * k] + range_max, max_x);
+    min_y = std::min(poses_xyt[3 * k + 1] - range_max, min_y);
+    max_y = std::max(poses_xyt[3 * k + 1] + range_max, max_y);
+  }
+  // NDT::NDT (src/ndt_model.cpp:118-126): size_x_ = (size_t)(size_x / cell_size + 1)
+  const double fsx = ((max_x - min_x) / ndt_resolution) + 1;
+  const double fsy = ((max_y - min_y) / ndt_resolution) + 1;
+  if (!(fsx >= 1.0) || !(fsy >= 1.0) || fsx * fsy >= 2147483648.0)
+  {
+    return fail(h, NDT2D_ERR_INVALID, "ndt2d_build_grid: degenerate grid extent");
+  }
+  const uint32_t size_x = static_cast<uint32_t>(static_cast<size_t>(fsx));
+  const uint32_t size_y = static_cast<uint32_t>(static_cast<size_t>(fsy));
+  const uint32_t ncell = size_x * size_y;
+  NDT2D_HIP(h, hipSetDevice(h->device));
+
+  // staging that must stay alive until the copies are done: kept in the context
+  NDT2D_HIP(h, hipStreamSynchronize(h->stream));
+  h->stage_scans.resize(4 * n_scans);
+  h->stage_offsets.resize(((n_scans + 1) + 1) & ~size_t(1));
+  for (size_t k = 0; k < n_scans; ++k)
+  {
+    h->stage_scans[4 * k] = poses_xyt[3 * k];
+    h->stage_scans[4 * k + 1] = poses_xyt[3 * k + 1];
+    h->stage_scans[4 * k + 2] = std::cos(poses_xyt[3 * k + 2]);  // :135-136, host libm
+    h->stage_scans[4 * k + 3] = std::sin(poses_xyt[3 * k + 2]);
+    h->stage_offsets[k] = static_cast<uint32_t>(offsets[k]);
+  }
+  h->stage_offsets[n_scans] = static_cast<uint32_t>(n_points);
+
+  const size_t temp_bytes = ndt2d::build_sort_temp_bytes(static_cast<uint32_t>(n_points), ncell);
+  int rc;
+  if ((rc = ensure(h, h->b_points, 2 * n_points + 2)) != NDT2D_OK) return rc;
+  if ((rc = ensure(h, h->b_scans, 4 * n_scans)) != NDT2D_OK) return rc;
+  if ((rc = ensure(h, h->b_offsets, h->stage_offsets.size() / 2)) != NDT2D_OK) return rc;
+  if ((rc = ensure(h, h->b_world, 2 * n_points + 2)) != NDT2D_OK) return rc;
+  if ((rc = ensure(h, h->b_keys, n_points + 2)) != NDT2D_OK) return rc;   // 2 x u32 arrays
+  if ((rc = ensure(h, h->b_vals, n_points + 2)) != NDT2D_OK) return rc;
+  if ((rc = ensure(h, h->b_temp, temp_bytes / 8 + 2)) != NDT2D_OK) return rc;
+  if ((rc = ensure(h, h->b_seg, static_cast<size_t>(ncell) + 2)) != NDT2D_OK) return rc;
+  if ((rc = ensure(h, h->cells6, static_cast<size_t>(ncell) * 6)) != NDT2D_OK) return rc;
+  if ((rc = ensure(h, h->cells_lds_image, static_cast<size_t>(ncell + 1) * kCellDoubles)) != NDT2D_OK) return rc;
+  if ((rc = ensure(h, h->cells_global, static_cast<size_t>(ncell + 1) * kCellStrideGlobal)) != NDT2D_OK) return rc;
+  if ((rc = ensure(h, h->occ_bits, ((static_cast<size_t>(ncell) + 1 + 31) / 32 + 2) / 2)) != NDT2D_OK) return rc;
+
+  if (n_points > 0)
+  {
+    NDT2D_HIP(h, hipMemcpyAsync(h->b_points.ptr, points_xy, 2 * n_points * sizeof(double),
+                                hipMemcpyHostToDevice, h->stream));
+  }
+  NDT2D_HIP(h, hipMemcpyAsync(h->b_scans.ptr, h->stage_scans.data(), 4 * n_scans * sizeof(double),
+                              hipMemcpyHostToDevice, h->stream));
+  NDT2D_HIP(h, hipMemcpyAsync(h->b_offsets.ptr, h->stage_offsets.data(),
+                              (n_scans + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+
+  GridDesc g{};
+  g.size_x = size_x;
+  g.size_y = size_y;
+  g.ncell = ncell;
+  g.cell_size = ndt_resolution;
+  g.pow2 = is_pow2(ndt_resolution) ? 1 : 0;
+  g.inv_cell_size = 1.0 / ndt_resolution;
+  g.origin_x = min_x;
+  g.origin_y = min_y;
+
+  ndt2d::BuildArgs a{};
+  a.grid = g;
+  a.points_xy = h->b_points.ptr;
+  a.n_points = static_cast<uint32_t>(n_points);
+  a.scans = h->b_scans.ptr;
+  a.offsets = reinterpret_cast<const uint32_t *>(h->b_offsets.ptr);
+  a.n_scans = static_cast<uint32_t>(n_scans);
+  a.world_xy = h->b_world.ptr;
+  a.keys_in = reinterpret_cast<uint32_t *>(h->b_keys.ptr);
+  a.keys_out = a.keys_in + n_points + 1;
+  a.vals_in = reinterpret_cast<uint32_t *>(h->b_vals.ptr);
+  a.vals_out = a.vals_in + n_points + 1;
+  a.sort_temp = h->b_temp.ptr;
+  a.sort_temp_bytes = temp_bytes;
+  a.seg_begin = reinterpret_cast<uint32_t *>(h->b_seg.ptr);
+  a.cells6 = h->cells6.ptr;
+  a.cells_lds_image = h->cells_lds_image.ptr;
+  a.cells_global = h->cells_global.ptr;
+  a.occ_bits = reinterpret_cast<uint32_t *>(h->occ_bits.ptr);
+  NDT2D_HIP(h, hipEventRecord(h->ev0, h->stream));
+  hipError_t e = ndt2d::launch_build_grid(a, h->stream);
+  if (e != hipSuccess) return fail_hip(h, e, "launch_build_grid");
+  NDT2D_HIP(h, hipEventRecord(h->ev1, h->stream));
+  h->timed = true;
+  h->last_kernels = 7;
+  h->last_variant = "build/sort-by-cell+in-order-recurrence";
+
+  g.cells_lds_image = h->cells_lds_image.ptr;
+  g.cells_global = h->cells_global.ptr;
+  g.occ_bits = reinterpret_cast<const uint32_t *>(h->occ_bits.ptr);
+  h->grid = g;
+  h->has_grid = true;
+  return NDT2D_OK;
+}
+
+int ndt2d_get_grid(ndt2d_handle h, double * cells6_out, size_t capacity_cells, uint32_t * size_x,
+                   uint32_t * size_y, double * cell_size, double * origin_x, double * origin_y)
+{
+  if (h == nullptr) return NDT2D_ERR_INVALID;
+  if (!h->has_grid) return fail(h, NDT2D_ERR_NO_GRID, "ndt2d_get_grid: no grid");
+  if (size_x) *size_x = h->grid.size_x;
+  if (size_y) *size_y = h->grid.size_y;
+  if (cell_size) *cell_size = h->grid.cell_size;
+  if (origin_x) *origin_x = h->grid.origin_x;
+  if (origin_y) *origin_y = h->grid.origin_y;
+  if (cells6_out != nullptr)
+  {
+    if (capacity_cells < h->grid.ncell) return fail(h, NDT2D_ERR_INVALID, "ndt2d_get_grid: capacity");
+    NDT2D_HIP(h, hipSetDevice(h->device));
+    NDT2D_HIP(h, hipMemcpyAsync(cells6_out, h->cells6.ptr,
+                                static_cast<size_t>(h->grid.ncell) * 6 * sizeof(double),
+                                hipMemcpyDeviceToHost, h->stream));
+    NDT2D_HIP(h, hipStreamSynchronize(h->stream));
+  }
   return NDT2D_OK;
 }
 

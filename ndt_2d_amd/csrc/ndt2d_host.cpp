@@ -261,7 +261,9 @@ struct ndt2d_matcher
   double linear_res = 0.005, linear_size = 0.05;
   size_t laser_max_beams = 100;
   double range_max = 0.0;
-  std::unique_ptr<HostNdt> ndt;
+  std::unique_ptr<HostNdt> ndt;   // host copy; empty when the NDT was built on the device
+  bool have_ndt = false;          // `ndt_` is set (reference scan_matcher_ndt.hpp:102)
+  int build_mode = 0;             // 0 auto, 1 host, 2 device
   // state of the last prepare_search (subsampled beams + visited offsets)
   std::vector<double> beams, dth, dlin;
   bool search_ready = false;
@@ -347,6 +349,26 @@ int ndt2d_matcher_add_scans(ndt2d_matcher * m, const double * poses_xyt,
   if (points_xy == nullptr) points_xy = no_points;
   static const size_t no_offsets[1] = {0};
   if (offsets == nullptr) offsets = no_offsets;
+  m->have_ndt = false;
+  // Device build (N1): the whole of addScans on the GPU, bit-identical to the host
+  // build; "auto" uses it from 32768 map points up, where it beats the host build
+  // (measured: 0.12 vs 0.14 ms at 6.5 k points, 2.7 vs 1.0 ms at 378 k, 58.6 vs 2.1 ms at 1.1 M).
+  const size_t n_map_points = n_scans > 0 ? offsets[n_scans] : 0;
+  const bool on_device =
+    n_scans > 0 && (m->build_mode == 2 || (m->build_mode == 0 && n_map_points >= 32768));
+  if (on_device)
+  {
+    m->ndt.reset();
+    int rc = ndt2d_build_grid(m->dev, m->resolution, m->range_max, poses_xyt, points_xy, offsets,
+                              n_scans);
+    if (rc != NDT2D_OK)
+    {
+      ndt2d_clear_grid(m->dev);
+      return dev_fail(m, rc, "ndt2d_build_grid");
+    }
+    m->have_ndt = true;
+    return NDT2D_OK;
+  }
   m->ndt = build_ndt(m->resolution, m->range_max, poses_xyt, points_xy, offsets, n_scans);
   const size_t ncell = m->ndt->ncell();
   if (ncell == 0 || m->ndt->size_x() > 0xffffffffull || m->ndt->size_y() > 0xffffffffull)
@@ -365,6 +387,17 @@ int ndt2d_matcher_add_scans(ndt2d_matcher * m, const double * poses_xyt,
     m->ndt.reset();
     return dev_fail(m, rc, "ndt2d_set_grid");
   }
+  m->have_ndt = true;
+  return NDT2D_OK;
+}
+
+int ndt2d_matcher_set_build_mode(ndt2d_matcher * m, const char * mode)
+{
+  if (m == nullptr || mode == nullptr) return NDT2D_ERR_INVALID;
+  if (std::strcmp(mode, "auto") == 0) m->build_mode = 0;
+  else if (std::strcmp(mode, "host") == 0) m->build_mode = 1;
+  else if (std::strcmp(mode, "device") == 0) m->build_mode = 2;
+  else return mfail(m, NDT2D_ERR_INVALID, "set_build_mode: unknown mode");
   return NDT2D_OK;
 }
 
@@ -372,10 +405,11 @@ int ndt2d_matcher_reset(ndt2d_matcher * m)
 {
   if (m == nullptr) return NDT2D_ERR_INVALID;
   m->ndt.reset();
+  m->have_ndt = false;
   return ndt2d_clear_grid(m->dev);
 }
 
-int ndt2d_matcher_has_ndt(ndt2d_matcher * m) { return (m != nullptr && m->ndt) ? 1 : 0; }
+int ndt2d_matcher_has_ndt(ndt2d_matcher * m) { return (m != nullptr && m->have_ndt) ? 1 : 0; }
 
 int ndt2d_matcher_prepare_search(ndt2d_matcher * m, const double * scan_pose_xyt,
                                  const double * points_xy, size_t n_points, size_t * n_th_out,
@@ -392,7 +426,7 @@ int ndt2d_matcher_prepare_search(ndt2d_matcher * m, const double * scan_pose_xyt
   if (n_lin_out != nullptr) *n_lin_out = n_lin;
   if (n_beams_out != nullptr) *n_beams_out = use;
   m->search_ready = false;
-  if (use == 0 || n_th == 0 || n_lin == 0 || !m->ndt) return NDT2D_OK;  // nothing to upload
+  if (use == 0 || n_th == 0 || n_lin == 0 || !m->have_ndt) return NDT2D_OK;  // nothing to upload
 
   std::vector<double> cos_th(n_th), sin_th(n_th);
   for (size_t i = 0; i < n_th; ++i)
@@ -466,7 +500,7 @@ int ndt2d_matcher_match_scan_ex(ndt2d_matcher * m, const double * scan_pose_xyt,
   if (n_candidates_out != nullptr) *n_candidates_out = 0;
   if (best_index_out != nullptr) *best_index_out = NDT2D_NO_INDEX;
   // `if (!ndt_) return 0.0;` (reference src/scan_matcher_ndt.cpp:80): outputs untouched
-  if (!m->ndt)
+  if (!m->have_ndt)
   {
     *score_out = 0.0;
     return NDT2D_OK;
@@ -533,7 +567,7 @@ int ndt2d_matcher_score_poses(ndt2d_matcher * m, const double * points_xy, size_
   }
   if (n_poses == 0) return NDT2D_OK;
   // `if (!ndt_) return 0.0;` (reference src/scan_matcher_ndt.cpp:159)
-  if (!m->ndt)
+  if (!m->have_ndt)
   {
     for (size_t i = 0; i < n_poses; ++i) scores_out[i] = 0.0;
     return NDT2D_OK;
@@ -595,7 +629,7 @@ int ndt2d_matcher_pf_measure(ndt2d_matcher * m, const double * particles_xyt,
   bool have_stats = false;
   if (n_particles > 0)
   {
-    if (m->ndt && n_points > 0 && m->laser_max_beams > 0)
+    if (m->have_ndt && n_points > 0 && m->laser_max_beams > 0)
     {
       if (points_xy == nullptr) return mfail(m, NDT2D_ERR_INVALID, "null points");
       const std::vector<double> beams = subsample(points_xy, n_points, m->laser_max_beams);
@@ -659,22 +693,24 @@ int ndt2d_matcher_grid_info(ndt2d_matcher * m, uint32_t * size_x, uint32_t * siz
                             double * cell_size, double * origin_x, double * origin_y)
 {
   if (m == nullptr) return NDT2D_ERR_INVALID;
-  if (!m->ndt) return mfail(m, NDT2D_ERR_NO_GRID, "no NDT");
-  if (size_x) *size_x = static_cast<uint32_t>(m->ndt->size_x());
-  if (size_y) *size_y = static_cast<uint32_t>(m->ndt->size_y());
-  if (cell_size) *cell_size = m->ndt->cell_size();
-  if (origin_x) *origin_x = m->ndt->origin_x();
-  if (origin_y) *origin_y = m->ndt->origin_y();
-  return NDT2D_OK;
+  if (!m->have_ndt) return mfail(m, NDT2D_ERR_NO_GRID, "no NDT");
+  int rc = ndt2d_get_grid(m->dev, nullptr, 0, size_x, size_y, cell_size, origin_x, origin_y);
+  return rc == NDT2D_OK ? rc : dev_fail(m, rc, "ndt2d_get_grid");
 }
 
 int ndt2d_matcher_grid_cells6(ndt2d_matcher * m, double * cells6_out, size_t capacity_cells)
 {
   if (m == nullptr || cells6_out == nullptr) return NDT2D_ERR_INVALID;
-  if (!m->ndt) return mfail(m, NDT2D_ERR_NO_GRID, "no NDT");
-  if (capacity_cells < m->ndt->ncell()) return mfail(m, NDT2D_ERR_INVALID, "capacity too small");
-  m->ndt->pack6(cells6_out);
-  return NDT2D_OK;
+  if (!m->have_ndt) return mfail(m, NDT2D_ERR_NO_GRID, "no NDT");
+  if (m->ndt)
+  {
+    if (capacity_cells < m->ndt->ncell()) return mfail(m, NDT2D_ERR_INVALID, "capacity too small");
+    m->ndt->pack6(cells6_out);
+    return NDT2D_OK;
+  }
+  int rc = ndt2d_get_grid(m->dev, cells6_out, capacity_cells, nullptr, nullptr, nullptr, nullptr,
+                          nullptr);
+  return rc == NDT2D_OK ? rc : dev_fail(m, rc, "ndt2d_get_grid");
 }
 
 int ndt2d_search_offsets(double size, double res, double * out, size_t cap, size_t * n_out)

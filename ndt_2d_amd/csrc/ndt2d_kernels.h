@@ -64,6 +64,28 @@ struct PosesArgs
   double * partials;         // [n_blocks][8]  (may be null)
 };
 
+// NDT build on the device (ndt2d_build.hip).  `grid` carries the geometry only.
+struct BuildArgs
+{
+  GridDesc grid;
+  const double * points_xy;   // [n_points][2] robot frame, scans concatenated
+  uint32_t n_points;
+  const double * scans;       // [n_scans][4] {pose_x, pose_y, cos(theta), sin(theta)}
+  const uint32_t * offsets;   // [n_scans + 1] first point of every scan
+  uint32_t n_scans;
+  double * world_xy;          // [n_points][2] scratch
+  uint32_t * keys_in, * keys_out, * vals_in, * vals_out;  // [n_points] scratch
+  void * sort_temp;
+  size_t sort_temp_bytes;
+  uint32_t * seg_begin;       // [2 * (ncell + 1)] scratch: begin | end
+  double * cells6;            // [ncell][6] out: {mean_x, mean_y, i00, i01, i11, n}
+  double * cells_lds_image;   // [ncell + 1][kCellDoubles] out
+  double * cells_global;      // [ncell + 1][kCellStrideGlobal] out
+  uint32_t * occ_bits;        // out
+};
+size_t build_sort_temp_bytes(uint32_t n_points, uint32_t ncell);
+hipError_t launch_build_grid(const BuildArgs & args, hipStream_t stream);
+
 struct LaunchInfo
 {
   const char * variant;

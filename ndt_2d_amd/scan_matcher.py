@@ -173,6 +173,10 @@ class ScanMatcherNDT:
     def reset(self):
         self._check(self._L.ndt2d_matcher_reset(self._m), "reset")
 
+    def set_build_mode(self, mode):
+        """Where addScans builds the NDT: "host", "device" or "auto" (bit-identical grids)."""
+        self._check(self._L.ndt2d_matcher_set_build_mode(self._m, mode.encode()), "set_build_mode")
+
     # -- additive batched interface ------------------------------------------------
 
     def scorePoses(self, points, poses):

@@ -337,6 +337,63 @@ def test_match_scan_on_a_large_map_uses_the_windowed_lane_kernel():
         _check_match(a, b, 720)
 
 
+@pytest.mark.parametrize("cfg", [1, 3, 5])
+def test_device_ndt_build_is_bit_identical(cfg):
+    """N1: addScans on the GPU (stable sort by cell + in-order per-cell recurrence)
+    against the oracle's NDT, bit for bit, and against the host build."""
+    scans = synth.map_scans(cfg)
+    params = synth.matcher_params(cfg)
+    ref = O.ScanMatcherNDT()
+    ref.initialize(**params)
+    ref.addScans(scans)
+    exp = ref.ndt.cells6()
+    got = {}
+    for mode in ("device", "host"):
+        gpu = ScanMatcherNDT(0)
+        gpu.initialize("t", **params)
+        gpu.set_build_mode(mode)
+        gpu.addScans(scans)
+        cells, sx, sy, cs, ox, oy = gpu.grid()
+        assert (sx, sy) == synth.CONFIGS[cfg]["grid"] == (ref.ndt.size_x, ref.ndt.size_y)
+        assert (ox, oy) == ref.ndt.origin and cs == 0.25
+        assert np.array_equal(cells, exp), mode
+        got[mode] = gpu
+    # scoring against the device-built grid equals scoring against the host-built one
+    _, pts, _ = synth.query_scan(cfg)
+    poses = synth.particles(3, 2000)
+    poses[:, :2] *= synth.CONFIGS[cfg]["world"][0] / 23.0
+    assert np.array_equal(got["device"].scorePoses(pts, poses), got["host"].scorePoses(pts, poses))
+
+
+def test_device_ndt_build_edge_cases():
+    rng = np.random.default_rng(5)
+    w = synth.world_of(1)
+    # rotated scan poses, an empty scan, a scan entirely outside the extent, 0.1 m cells
+    scans = []
+    for k in range(12):
+        pose = (rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(-3.1, 3.1))
+        scans.append((pose, synth.scan(w, pose, 7000 + k, n_beams=300 + 17 * k)))
+    scans.insert(3, ((0.2, 0.1, 1.0), np.zeros((0, 2))))
+    scans.append(((0.0, 0.0, 0.0), np.full((40, 2), 500.0)))
+    for res in (0.25, 0.1, 1.0):
+        ref = O.ScanMatcherNDT()
+        ref.initialize(ndt_resolution=res, range_max=4.75)
+        ref.addScans(scans)
+        gpu = ScanMatcherNDT(0)
+        gpu.initialize("t", ndt_resolution=res, range_max=4.75)
+        gpu.set_build_mode("device")
+        gpu.addScans(scans)
+        cells, sx, sy, cs, ox, oy = gpu.grid()
+        assert (sx, sy, ox, oy) == (ref.ndt.size_x, ref.ndt.size_y) + ref.ndt.origin
+        assert np.array_equal(cells, ref.ndt.cells6()), res
+    # re-building with a different map replaces the grid; reset clears it
+    gpu.addScans(scans[:2])
+    ref.addScans(scans[:2])
+    assert np.array_equal(gpu.grid()[0], ref.ndt.cells6())
+    gpu.reset()
+    assert not gpu.has_ndt()
+
+
 def test_cfg3_particles_golden_through_device_layer():
     g = np.load(os.path.join(GOLDEN, "cfg3_poses256.npz"))
     ncell = int(g["size_x"]) * int(g["size_y"])
