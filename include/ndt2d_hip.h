@@ -153,6 +153,23 @@ int ndt2d_score_poses_launch(ndt2d_handle h, const double * d_poses_xyt, size_t 
 int ndt2d_score_poses(ndt2d_handle h, const double * h_poses_xyt, size_t n_poses,
                       double * h_scores, double * h_stats);
 
+/* ParticleFilter::updateStatistics (src/particle_filter.cpp:163-218) on the
+ * device, from the (all-reduced) moment sums d_stats of ndt2d_score_poses_launch:
+ * d_weights[n] are divided by the total weight in place (:171-174) and d_out
+ * receives NDT2D_PF_RESULT_DOUBLES doubles {sum w, mean x, mean y, mean theta
+ * (circular, :205), cov xx, cov xy, cov yy (:208-215), sum_i w_i *
+ * shortest_angular_distance(theta_i, mean theta)^2 (:213-217, to be ADDED to the
+ * caller's cov(2,2), which the reference never zeroes)}.  Device pointers,
+ * asynchronous. */
+#define NDT2D_PF_RESULT_DOUBLES 8
+int ndt2d_pf_finalize_launch(ndt2d_handle h, const double * d_poses_xyt, size_t n_poses,
+                             double * d_weights, const double * d_stats, double * d_out);
+/* Host-pointer convenience = ParticleFilter::measure for the beams of
+ * ndt2d_set_beams: H2D particles, score, statistics, D2H normalised weights and
+ * the NDT2D_PF_RESULT_DOUBLES result. */
+int ndt2d_pf_measure(ndt2d_handle h, const double * h_poses_xyt, size_t n_poses,
+                     double * h_weights, double * h_out);
+
 /* Block until everything launched on the context's stream has finished. */
 int ndt2d_synchronize(ndt2d_handle h);
 /* GPU time (HIP events on the launch stream) of the dominant kernel -- the

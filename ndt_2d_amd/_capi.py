@@ -69,6 +69,8 @@ SIGNATURES = {
     "ndt2d_match": (C.c_int, [_vp, _sz, _sz, _dp, C.POINTER(MatchResult)]),
     "ndt2d_score_poses_launch": (C.c_int, [_vp, _vp, _sz, _vp, _vp]),
     "ndt2d_score_poses": (C.c_int, [_vp, _dp, _sz, _dp, _dp]),
+    "ndt2d_pf_finalize_launch": (C.c_int, [_vp, _vp, _sz, _vp, _vp, _vp]),
+    "ndt2d_pf_measure": (C.c_int, [_vp, _dp, _sz, _dp, _dp]),
     "ndt2d_synchronize": (C.c_int, [_vp]),
     "ndt2d_last_launch_ms": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "ndt2d_last_variant": (C.c_char_p, [_vp]),

@@ -654,6 +654,55 @@ int ndt2d_score_poses(ndt2d_handle h, const double * h_poses_xyt, size_t n_poses
   return NDT2D_OK;
 }
 
+int ndt2d_pf_finalize_launch(ndt2d_handle h, const double * d_poses_xyt, size_t n_poses,
+                             double * d_weights, const double * d_stats, double * d_out)
+{
+  if (h == nullptr) return NDT2D_ERR_INVALID;
+  if (d_poses_xyt == nullptr || d_weights == nullptr || d_stats == nullptr || d_out == nullptr ||
+      n_poses == 0)
+  {
+    return fail(h, NDT2D_ERR_INVALID, "ndt2d_pf_finalize_launch: bad argument");
+  }
+  NDT2D_HIP(h, hipSetDevice(h->device));
+  int rc = ensure(h, h->ws_poses, ndt2d::poses_workspace_doubles(n_poses));
+  if (rc != NDT2D_OK) return rc;
+  hipError_t e = ndt2d::launch_pf_finalize(d_poses_xyt, n_poses, d_weights, d_stats,
+                                           h->ws_poses.ptr, d_out, h->stream);
+  if (e != hipSuccess) return fail_hip(h, e, "launch_pf_finalize");
+  return NDT2D_OK;
+}
+
+int ndt2d_pf_measure(ndt2d_handle h, const double * h_poses_xyt, size_t n_poses,
+                     double * h_weights, double * h_out)
+{
+  if (h == nullptr) return NDT2D_ERR_INVALID;
+  if (h_poses_xyt == nullptr || h_weights == nullptr || h_out == nullptr || n_poses == 0)
+  {
+    return fail(h, NDT2D_ERR_INVALID, "ndt2d_pf_measure: bad argument");
+  }
+  if (!h->has_grid) return fail(h, NDT2D_ERR_NO_GRID, "ndt2d_pf_measure: no grid");
+  NDT2D_HIP(h, hipSetDevice(h->device));
+  int rc = ensure(h, h->tmp_poses, 3 * n_poses);
+  if (rc != NDT2D_OK) return rc;
+  rc = ensure(h, h->tmp_scores, n_poses);
+  if (rc != NDT2D_OK) return rc;
+  rc = ensure(h, h->stats, NDT2D_POSE_STATS_DOUBLES + NDT2D_PF_RESULT_DOUBLES);
+  if (rc != NDT2D_OK) return rc;
+  NDT2D_HIP(h, hipMemcpyAsync(h->tmp_poses.ptr, h_poses_xyt, 3 * n_poses * sizeof(double),
+                              hipMemcpyHostToDevice, h->stream));
+  rc = ndt2d_score_poses_launch(h, h->tmp_poses.ptr, n_poses, h->tmp_scores.ptr, h->stats.ptr);
+  if (rc != NDT2D_OK) return rc;
+  double * d_out = h->stats.ptr + NDT2D_POSE_STATS_DOUBLES;
+  rc = ndt2d_pf_finalize_launch(h, h->tmp_poses.ptr, n_poses, h->tmp_scores.ptr, h->stats.ptr, d_out);
+  if (rc != NDT2D_OK) return rc;
+  NDT2D_HIP(h, hipMemcpyAsync(h_weights, h->tmp_scores.ptr, n_poses * sizeof(double),
+                              hipMemcpyDeviceToHost, h->stream));
+  NDT2D_HIP(h, hipMemcpyAsync(h_out, d_out, NDT2D_PF_RESULT_DOUBLES * sizeof(double),
+                              hipMemcpyDeviceToHost, h->stream));
+  NDT2D_HIP(h, hipStreamSynchronize(h->stream));
+  return NDT2D_OK;
+}
+
 int ndt2d_synchronize(ndt2d_handle h)
 {
   if (h == nullptr) return NDT2D_ERR_INVALID;

@@ -625,62 +625,61 @@ int ndt2d_matcher_pf_measure(ndt2d_matcher * m, const double * particles_xyt,
   {
     return NDT2D_ERR_INVALID;
   }
-  double stats[NDT2D_POSE_STATS_DOUBLES] = {0, 0, 0, 0, 0, 0, 0, 0};
-  bool have_stats = false;
-  if (n_particles > 0)
+  if (n_particles > 0 && m->have_ndt && n_points > 0 && m->laser_max_beams > 0)
   {
-    if (m->have_ndt && n_points > 0 && m->laser_max_beams > 0)
-    {
-      if (points_xy == nullptr) return mfail(m, NDT2D_ERR_INVALID, "null points");
-      const std::vector<double> beams = subsample(points_xy, n_points, m->laser_max_beams);
-      int rc = ndt2d_set_beams(m->dev, beams.data(), beams.size() / 2);
-      if (rc != NDT2D_OK) return dev_fail(m, rc, "ndt2d_set_beams");
-      // weights_[i] = scorePoints(points, particle_i) (particle_filter.cpp:81-87)
-      rc = ndt2d_score_poses(m->dev, particles_xyt, n_particles, weights_out, stats);
-      if (rc != NDT2D_OK) return dev_fail(m, rc, "ndt2d_score_poses");
-      have_stats = true;
-    }
-    else
-    {
-      int rc = ndt2d_matcher_score_poses(m, points_xy, n_points, particles_xyt, n_particles,
-                                         weights_out);
-      if (rc != NDT2D_OK) return rc;
-    }
-  }
-  if (!have_stats)
-  {
-    // degenerate inputs (no map / no points): sums of the constant weights
-    for (size_t i = 0; i < n_particles; ++i)
-    {
-      const double w = weights_out[i];
-      const double * p = particles_xyt + 3 * i;
-      stats[0] += w;
-      stats[1] += w * p[0];
-      stats[2] += w * p[1];
-      stats[3] += w * std::cos(p[2]);
-      stats[4] += w * std::sin(p[2]);
-      stats[5] += w * p[0] * p[0];
-      stats[6] += w * p[0] * p[1];
-      stats[7] += w * p[1] * p[1];
-    }
+    // weights_[i] = scorePoints(points, particle_i) (particle_filter.cpp:81-87), then
+    // updateStatistics (:163-218), all on the device
+    if (points_xy == nullptr) return mfail(m, NDT2D_ERR_INVALID, "null points");
+    const std::vector<double> beams = subsample(points_xy, n_points, m->laser_max_beams);
+    int rc = ndt2d_set_beams(m->dev, beams.data(), beams.size() / 2);
+    if (rc != NDT2D_OK) return dev_fail(m, rc, "ndt2d_set_beams");
+    double out[NDT2D_PF_RESULT_DOUBLES];
+    rc = ndt2d_pf_measure(m->dev, particles_xyt, n_particles, weights_out, out);
+    if (rc != NDT2D_OK) return dev_fail(m, rc, "ndt2d_pf_measure");
+    mean_out[0] = out[1];
+    mean_out[1] = out[2];
+    mean_out[2] = out[3];
+    cov_inout[0] = out[4];
+    cov_inout[1] = out[5];
+    cov_inout[3] = out[5];
+    cov_inout[4] = out[6];
+    cov_inout[8] += out[7];  // cov_(2,2) accumulates (:216)
+    return NDT2D_OK;
   }
 
-  // updateStatistics (particle_filter.cpp:163-218) from the device sums:
-  // normalise (:166-174) ...
+  // Degenerate inputs (no map / no points / no particles): every weight is the
+  // constant scorePoints returns (0.0 or NaN); the statistics of those constants.
+  if (n_particles > 0)
+  {
+    int rc = ndt2d_matcher_score_poses(m, points_xy, n_points, particles_xyt, n_particles,
+                                       weights_out);
+    if (rc != NDT2D_OK) return rc;
+  }
+  double stats[NDT2D_POSE_STATS_DOUBLES] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (size_t i = 0; i < n_particles; ++i)
+  {
+    const double w = weights_out[i];
+    const double * p = particles_xyt + 3 * i;
+    stats[0] += w;
+    stats[1] += w * p[0];
+    stats[2] += w * p[1];
+    stats[3] += w * std::cos(p[2]);
+    stats[4] += w * std::sin(p[2]);
+    stats[5] += w * p[0] * p[0];
+    stats[6] += w * p[0] * p[1];
+    stats[7] += w * p[1] * p[1];
+  }
   const double sum_weight = stats[0];
   for (size_t i = 0; i < n_particles; ++i) weights_out[i] /= sum_weight;
-  // ... weighted mean, circular mean of theta (:182-205) ...
   const double mean_x = stats[1] / sum_weight;
   const double mean_y = stats[2] / sum_weight;
   mean_out[0] = mean_x;
   mean_out[1] = mean_y;
   mean_out[2] = std::atan2(stats[4] / sum_weight, stats[3] / sum_weight);
-  // ... x/y covariance (:208-215) ...
   cov_inout[0] = stats[5] / sum_weight - mean_x * mean_x;
   cov_inout[1] = stats[6] / sum_weight - mean_x * mean_y;
   cov_inout[3] = cov_inout[1];
   cov_inout[4] = stats[7] / sum_weight - mean_y * mean_y;
-  // ... theta variance accumulates onto the previous value (:218-222).
   for (size_t i = 0; i < n_particles; ++i)
   {
     const double d = normalize_angle(mean_out[2] - particles_xyt[3 * i + 2]);

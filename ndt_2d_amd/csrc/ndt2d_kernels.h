@@ -109,6 +109,13 @@ hipError_t launch_score_poses(const PosesArgs & args, double * workspace, double
                               int force_variant, hipStream_t stream, hipEvent_t ev_main_done,
                               LaunchInfo * info);
 
+// ParticleFilter::updateStatistics from the moment sums: normalises weights in
+// place and writes out = {sum w, mean x, mean y, mean theta, cov xx, cov xy, cov yy,
+// theta-variance increment}.  workspace: poses_workspace_doubles() doubles.
+hipError_t launch_pf_finalize(const double * poses_xyt, uint64_t n_poses, double * weights,
+                              const double * stats, double * workspace, double * out,
+                              hipStream_t stream);
+
 // Lane-per-candidate search (ndt2d_match_lane.hip).  outer: device scratch of
 // match_lane_outer_doubles() doubles for the rotated-beam table; workspace
 // receives one partial record per wave (*n_workers_out of them).

@@ -512,6 +512,94 @@ hipError_t launch_match(const MatchArgs & args_in, double * workspace, double * 
   return e;
 }
 
+namespace
+{
+
+// angles::shortest_angular_distance(from, to) = normalize_angle(to - from),
+// normalize_angle(a) = fmod(a + pi, 2 pi) -/+ pi  (ROS `angles`, used at
+// reference src/particle_filter.cpp:215)
+__device__ __forceinline__ double shortest_angular_distance(double from, double to)
+{
+  const double kPi = 3.14159265358979323846;
+  const double r = fmod((to - from) + kPi, 2.0 * kPi);
+  return r <= 0.0 ? r + kPi : r - kPi;
+}
+
+// ParticleFilter::updateStatistics on the device (reference
+// src/particle_filter.cpp:163-218) from the (all-reduced) moment sums
+//   stats = {sum w, sum w x, sum w y, sum w cos, sum w sin, sum w xx, sum w xy, sum w yy}:
+// every weight is normalised in place (:171-174) and the weighted squared angular
+// distance to the circular mean (:213-217) is reduced per block.
+__global__ void __launch_bounds__(256) pf_finalize_kernel(const double * poses_xyt, uint64_t n,
+                                                          double * weights, const double * stats,
+                                                          double * partials)
+{
+  __shared__ double sh[4];
+  const double sum_w = stats[0];
+  const double mean_th = atan2(stats[4] / sum_w, stats[3] / sum_w);
+  double acc = 0.0;
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x; i < n;
+       i += static_cast<uint64_t>(gridDim.x) * 256)
+  {
+    const double w = weights[i] / sum_w;
+    weights[i] = w;
+    const double d = shortest_angular_distance(poses_xyt[3 * i + 2], mean_th);
+    acc += w * d * d;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & (kWave - 1)) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+}
+
+// out = {sum w, mean x, mean y, mean theta, cov xx, cov xy, cov yy, theta variance increment}
+__global__ void __launch_bounds__(256) pf_finalize_reduce_kernel(const double * partials,
+                                                                 uint32_t n_blocks,
+                                                                 const double * stats, double * out)
+{
+  __shared__ double sh[256];
+  double v = 0.0;
+  for (uint32_t b = threadIdx.x; b < n_blocks; b += 256) v += partials[b];
+  sh[threadIdx.x] = v;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1)
+  {
+    if (static_cast<int>(threadIdx.x) < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0)
+  {
+    const double sum_w = stats[0];
+    const double mean_x = stats[1] / sum_w, mean_y = stats[2] / sum_w;
+    out[0] = sum_w;
+    out[1] = mean_x;
+    out[2] = mean_y;
+    out[3] = atan2(stats[4] / sum_w, stats[3] / sum_w);
+    out[4] = stats[5] / sum_w - mean_x * mean_x;
+    out[5] = stats[6] / sum_w - mean_x * mean_y;
+    out[6] = stats[7] / sum_w - mean_y * mean_y;
+    out[7] = sh[0];
+  }
+}
+
+}  // namespace
+
+hipError_t launch_pf_finalize(const double * poses_xyt, uint64_t n_poses, double * weights,
+                              const double * stats, double * workspace, double * out,
+                              hipStream_t stream)
+{
+  if (n_poses == 0) return hipErrorInvalidValue;
+  uint64_t need = (n_poses + 255) / 256;
+  const uint32_t blocks = static_cast<uint32_t>(need < kMaxPosesBlocks ? need : kMaxPosesBlocks);
+  hipLaunchKernelGGL(pf_finalize_kernel, dim3(blocks), dim3(256), 0, stream, poses_xyt, n_poses,
+                     weights, stats, workspace);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(pf_finalize_reduce_kernel, dim3(1), dim3(256), 0, stream, workspace, blocks,
+                     stats, out);
+  return hipGetLastError();
+}
+
 size_t poses_workspace_doubles(uint64_t)
 {
   return static_cast<size_t>(kMaxPosesBlocks) * 8;

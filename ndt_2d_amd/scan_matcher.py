@@ -244,6 +244,14 @@ class ScanMatcherNDT:
                                                          scores_ptr, stats_ptr),
                         "ndt2d_score_poses_launch")
 
+    def pf_finalize_launch(self, poses_ptr, n_poses, weights_ptr, stats_ptr, out_ptr):
+        """updateStatistics on DEVICE pointers: weights normalised in place by the
+        total weight in stats (all-reduced over ranks when sharded), out[8] =
+        {sum w, mean x, mean y, mean theta, cov xx, cov xy, cov yy, theta-variance part}."""
+        self._dev_check(self._L.ndt2d_pf_finalize_launch(self.device_handle, poses_ptr, n_poses,
+                                                         weights_ptr, stats_ptr, out_ptr),
+                        "ndt2d_pf_finalize_launch")
+
     def set_stream(self, stream_ptr):
         self._dev_check(self._L.ndt2d_set_stream(self.device_handle, stream_ptr),
                         "ndt2d_set_stream")

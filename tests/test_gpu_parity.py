@@ -450,6 +450,51 @@ def test_cfg3_full_particle_filter_measure():
     assert np.argmax(w) < 5000
 
 
+def test_sharded_particle_statistics_on_device():
+    """The multi-GPU particle flow on one GPU: two shards score their particles, the
+    [2, 8] moment table is summed (the all-reduce), each shard finalises with the
+    global sums; weights, mean and covariance equal the unsharded result."""
+    import torch
+    gpu, ref, _, _, pts = _pair(3)
+    parts = synth.particles(3, 50000)
+    parts[:3000, 0] = 1.0 + (parts[:3000, 0] / 23.0) * 0.2
+    parts[:3000, 1] = 0.5 + (parts[:3000, 1] / 23.0) * 0.2
+    parts[:3000, 2] = 0.3 + (parts[:3000, 2] / math.pi) * 0.05
+    w_full, mean_full, cov_full = pf_measure(gpu, parts, pts)
+    w_ref = O.pf_measure(ref, parts, pts, omp_threads=os.cpu_count())
+    w_n, mean_ref, cov_ref = O.pf_update_statistics(parts, w_ref)
+    assert np.allclose(w_full, w_n, rtol=1e-9, atol=1e-18)
+    assert np.allclose(mean_full, mean_ref, rtol=1e-9, atol=1e-12)
+    assert np.allclose(cov_full, cov_ref, rtol=1e-8, atol=1e-12)
+
+    gpu.prepare_beams(pts)
+    dev = torch.device("cuda:0")
+    shards = [parts[:20001], parts[20001:]]
+    d_parts = [torch.from_numpy(np.ascontiguousarray(s)).to(dev) for s in shards]
+    d_w = [torch.zeros(len(s), dtype=torch.float64, device=dev) for s in shards]
+    table = torch.zeros((2, 8), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    for r in range(2):
+        gpu.score_poses_launch(d_parts[r].data_ptr(), len(shards[r]), d_w[r].data_ptr(),
+                               table[r].data_ptr())
+    gpu.synchronize()
+    total = table.sum(dim=0).contiguous()          # what the all-reduce leaves on every rank
+    outs = torch.zeros((2, 8), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    for r in range(2):
+        gpu.pf_finalize_launch(d_parts[r].data_ptr(), len(shards[r]), d_w[r].data_ptr(),
+                               total.data_ptr(), outs[r].data_ptr())
+    gpu.synchronize()
+    w = np.concatenate([t.cpu().numpy() for t in d_w])
+    o = outs.cpu().numpy()
+    assert np.allclose(w, w_full, rtol=1e-12, atol=0)
+    assert np.allclose(o[0, :7], o[1, :7], rtol=0, atol=0)               # same global sums
+    assert np.allclose(o[0, 1:4], mean_full, rtol=1e-12, atol=1e-15)
+    assert np.allclose([o[0, 4], o[0, 5], o[0, 6]],
+                       [cov_full[0, 0], cov_full[0, 1], cov_full[1, 1]], rtol=1e-9, atol=1e-15)
+    assert o[:, 7].sum() == pytest.approx(cov_full[2, 2], rel=1e-10)
+
+
 def test_cfg5_sized_particle_set():
     """BASELINE.json configs[4] on one GPU: 1,000,000 particles, 801 x 801 NDT."""
     gpu, ref, _, _, pts = _pair(5)
