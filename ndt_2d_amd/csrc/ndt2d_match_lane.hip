@@ -75,9 +75,40 @@ struct LaneGeom
 // so that k + d stays inside the map for every lane offset d.  A clamped beam
 // is further outside the grid than any offset can bring back; it stays in the
 // empty border.
+//
+// The same launch builds the occupancy map of the window (one byte per map
+// cell, see the file header) once, in HBM; every search block then copies the
+// finished image into its LDS.
 __global__ void __launch_bounds__(256) outer_table_kernel(const MatchArgs a, double4 * outer,
-                                                          const LaneGeom geo)
+                                                          uint8_t * map_out, const LaneGeom geo)
 {
+  {
+    const GridDesc & g = a.grid;
+    const int32_t sx = static_cast<int32_t>(g.size_x), sy = static_cast<int32_t>(g.size_y);
+    const uint32_t n_map = static_cast<uint32_t>(kMapStride) * geo.map_h;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_map; i += gridDim.x * 256)
+    {
+      // map cell -> grid cell
+      const int32_t cx = static_cast<int32_t>(i & (kMapStride - 1)) - geo.pad + geo.win_x0;
+      const int32_t cy = static_cast<int32_t>(i >> 8) - geo.pad + geo.win_y0;
+      uint32_t self = 0, around = 0;
+      for (int32_t ny = cy - 1; ny <= cy + 1; ++ny)
+      {
+        for (int32_t nx = cx - 1; nx <= cx + 1; ++nx)
+        {
+          if (nx >= 0 && nx < sx && ny >= 0 && ny < sy)
+          {
+            const uint32_t cell = static_cast<uint32_t>(ny * sx + nx);
+            const uint32_t o = (g.occ_bits[cell >> 5] >> (cell & 31u)) & 1u;
+            around |= o;
+            if (nx == cx && ny == cy) self = o;
+          }
+        }
+      }
+      map_out[i] = static_cast<uint8_t>(self | (around << 1));
+    }
+  }
+
   const uint64_t n = static_cast<uint64_t>(a.th_end - a.th_begin) * a.n_beams;
   for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x; i < n;
        i += static_cast<uint64_t>(gridDim.x) * 256)
@@ -174,7 +205,8 @@ __device__ __forceinline__ void lane_beams(const GridDesc & g, const LaneCtx & c
 
 template <bool POW2, bool LDS_RECORDS>
 __global__ void __launch_bounds__(kLaneThreads) match_lane_kernel(
-  const MatchArgs a, const double4 * __restrict__ outer, const LaneGeom geo)
+  const MatchArgs a, const double4 * __restrict__ outer, const uint8_t * __restrict__ map_image,
+  const LaneGeom geo)
 {
   // LDS image: padded occupancy map of the window (at offset 0, so the packed
   // cell bytes are the LDS address) followed, if they fit (LDS_RECORDS), by the
@@ -187,28 +219,11 @@ __global__ void __launch_bounds__(kLaneThreads) match_lane_kernel(
 
   if (LDS_RECORDS) stage_grid_to_lds(g, lds_cells);
   {
-    const int32_t sx = static_cast<int32_t>(g.size_x), sy = static_cast<int32_t>(g.size_y);
-    for (int32_t i = threadIdx.x; i < kMapStride * geo.map_h; i += kLaneThreads)
-    {
-      // map cell -> grid cell
-      const int32_t cx = (i & (kMapStride - 1)) - geo.pad + geo.win_x0;
-      const int32_t cy = (i >> 8) - geo.pad + geo.win_y0;
-      uint32_t self = 0, around = 0;
-      for (int32_t ny = cy - 1; ny <= cy + 1; ++ny)
-      {
-        for (int32_t nx = cx - 1; nx <= cx + 1; ++nx)
-        {
-          if (nx >= 0 && nx < sx && ny >= 0 && ny < sy)
-          {
-            const uint32_t cell = static_cast<uint32_t>(ny * sx + nx);
-            const uint32_t o = (g.occ_bits[cell >> 5] >> (cell & 31u)) & 1u;
-            around |= o;
-            if (nx == cx && ny == cy) self = o;
-          }
-        }
-      }
-      lds_map[i] = static_cast<uint8_t>(self | (around << 1));
-    }
+    // the map image was built by the pre-kernel; kMapStride * map_h is a multiple of 16
+    const uint32_t n16 = static_cast<uint32_t>(kMapStride) * geo.map_h / 16;
+    const uint4 * src = reinterpret_cast<const uint4 *>(map_image);
+    uint4 * dst = reinterpret_cast<uint4 *>(lds_map);
+    for (uint32_t i = threadIdx.x; i < n16; i += kLaneThreads) dst[i] = src[i];
   }
   __syncthreads();
 
@@ -378,7 +393,9 @@ bool lane_records_in_lds(const MatchArgs & args, size_t map_bytes, size_t lds_pe
 
 size_t match_lane_outer_doubles(const MatchArgs & args)
 {
-  return static_cast<size_t>(args.th_end - args.th_begin) * args.n_beams * 4;
+  // rotated-beam table + the occupancy-map image (at most 256 x 256 bytes)
+  return static_cast<size_t>(args.th_end - args.th_begin) * args.n_beams * 4 +
+         static_cast<size_t>(kMapStride) * kMaxMapCells / sizeof(double);
 }
 
 bool match_lane_supported(const MatchArgs & args, size_t lds_per_block)
@@ -404,8 +421,10 @@ hipError_t launch_match_lane(const MatchArgs & args_in, double * outer, double *
   const uint64_t n_outer = static_cast<uint64_t>(args.th_end - args.th_begin) * args.n_beams;
   uint32_t oblocks = static_cast<uint32_t>((n_outer + 255) / 256);
   if (oblocks > 4096) oblocks = 4096;
+  if (oblocks < 64) oblocks = 64;  // the map build wants a few thousand threads as well
+  uint8_t * map_image = reinterpret_cast<uint8_t *>(outer + n_outer * 4);
   hipLaunchKernelGGL(outer_table_kernel, dim3(oblocks), dim3(256), 0, stream, args,
-                     reinterpret_cast<double4 *>(outer), geo);
+                     reinterpret_cast<double4 *>(outer), map_image, geo);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
 
@@ -431,7 +450,8 @@ hipError_t launch_match_lane(const MatchArgs & args_in, double * outer, double *
       if (e2 != hipSuccess) return e2;
     }
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kLaneThreads), lds_bytes, stream, args,
-                       reinterpret_cast<const double4 *>(outer), geo);
+                       reinterpret_cast<const double4 *>(outer),
+                       static_cast<const uint8_t *>(map_image), geo);
     return hipGetLastError();
   };
   if (lds_records)
