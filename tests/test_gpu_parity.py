@@ -572,6 +572,45 @@ def test_cell_population_and_grid_edges():
     assert ref4.scorePoints([(0.5, 0.5)], (0, 0, 0)) == 0.0
 
 
+def test_degenerate_cell_propagates_nan_like_the_reference(cfg1):
+    """Five identical points give a zero covariance; Matrix2d::inverse() of it is
+    inf/NaN (reference src/ndt_model.cpp:99) and every point scored against that cell
+    is NaN.  The NaN must reach the same candidates, leave the argmin to the others
+    and poison the covariance exactly as in the reference."""
+    _, _, scans, guess, pts = cfg1
+    bad = ((0.0, 0.0, 0.0), np.tile([[3.625, 0.625]], (6, 1)))  # binary-exact, in an otherwise empty cell inside the east wall
+    params = synth.matcher_params(1, search_linear_size=0.3, search_angular_size=0.06)
+    ref = O.ScanMatcherNDT()
+    ref.initialize(**params)
+    ref.addScans([bad])
+    assert np.isnan(ref.ndt.cells6()).any()
+    gpu = ScanMatcherNDT(0)
+    gpu.initialize("t", **params)
+    for mode in ("host", "device"):
+        gpu.set_build_mode(mode)
+        gpu.addScans([bad])
+        assert np.array_equal(gpu.grid()[0], ref.ndt.cells6(), equal_nan=True)
+    poses = np.array([(0.0, 0.0, 0.0), (0.05, 0.02, 0.0), (2.0, 2.0, 1.0)])
+    probe = np.array([(3.6, 0.6), (1.0, 1.0), (3.7, 0.7)])
+    a, b = gpu.scorePoses(probe, poses), O.pf_measure(ref, poses, probe)
+    assert np.array_equal(np.isnan(a), np.isnan(b)) and np.isnan(a).any() and not np.isnan(a).all()
+    assert np.allclose(a, b, rtol=0, atol=1e-12, equal_nan=True)
+    # the same cell inside a healthy map
+    ref.addScans(scans + [bad])
+    exp = ref.matchScan(guess, pts, want_scores=True)
+    assert np.isnan(exp["scores"]).any() and not np.isnan(exp["scores"]).all()
+    for variant in ("lane", "wave"):
+        gpu.set_variant(variant)
+        gpu.addScans(scans + [bad])
+        got = gpu.matchScan(guess, pts, want_scores=True)
+        assert np.array_equal(np.isnan(got["scores"]), np.isnan(exp["scores"])), variant
+        assert np.allclose(got["scores"], exp["scores"], rtol=0, atol=1e-9, equal_nan=True)
+        assert got["best_index"] == exp["best_index"] and got["score"] == pytest.approx(exp["score"], abs=1e-12)
+        assert np.array_equal(got["pose"], exp["pose"])
+        assert np.isnan(got["covariance"]).all() and np.isnan(exp["covariance"]).all()
+    gpu.set_variant("auto")
+
+
 def test_reference_known_answer_through_the_gpu():
     # reference test/ndt_model_tests.cpp:191-230: likelihood((3.5, 3.5)) = 0.7659 +- 1e-3
     v = json.load(open(os.path.join(GOLDEN, "reference_ndt_model_tests.json")))["test_ndt"]
