@@ -14,6 +14,8 @@
 // is compiled with -ffp-contract=off so no multiply-add is fused that the
 // reference's x86-64 build keeps separate.  No MFMA: there is no dense
 // contraction on this path.
+#include <mutex>
+
 #include "ndt2d_device_fn.h"
 
 namespace ndt2d
@@ -359,25 +361,38 @@ struct DeviceLimits
   size_t lds_per_block;
 };
 
+// Immutable per-device facts, queried once per device (hipGetDeviceProperties is
+// far too slow for the launch path of a 100-microsecond search).
 DeviceLimits device_limits()
 {
-  DeviceLimits lim{256, kLdsPerCu};
+  constexpr int kMaxDevices = 64;
+  static std::mutex mu;
+  static bool known[kMaxDevices] = {};
+  static DeviceLimits cache[kMaxDevices];
   int dev = 0;
-  if (hipGetDevice(&dev) == hipSuccess)
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices)
   {
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, dev) == hipSuccess)
-    {
-      lim.cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-      int v = 0;
-      if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess &&
-          v > 0)
-      {
-        lim.lds_per_block = static_cast<size_t>(v);
-      }
-    }
+    return DeviceLimits{256, kLdsPerCu};
   }
-  return lim;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!known[dev])
+  {
+    DeviceLimits lim{256, kLdsPerCu};
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+    {
+      lim.cus = v;
+    }
+    v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess &&
+        v > 0)
+    {
+      lim.lds_per_block = static_cast<size_t>(v);
+    }
+    cache[dev] = lim;
+    known[dev] = true;
+  }
+  return cache[dev];
 }
 
 template <int NBL, bool LDS_GRID, bool POW2>
