@@ -45,8 +45,8 @@ namespace ndt2d
 namespace
 {
 
-constexpr int kLaneThreads = 1024;
-constexpr int kLaneWaves = kLaneThreads / kWave;
+constexpr int kLaneThreads = 1024;       // large searches: one block per CU
+constexpr int kLaneThreadsSmall = 256;   // small searches: spread the few work items over more CUs
 constexpr int kPatch = 8;            // patch is kPatch x kPatch candidates = one wave
 constexpr int kUnroll = 8;           // beams per look-up group
 // map coordinates are 8.16 fixed point
@@ -203,8 +203,8 @@ __device__ __forceinline__ void lane_beams(const GridDesc & g, const LaneCtx & c
   }
 }
 
-template <bool POW2, bool LDS_RECORDS>
-__global__ void __launch_bounds__(kLaneThreads) match_lane_kernel(
+template <int THREADS, bool POW2, bool LDS_RECORDS>
+__global__ void __launch_bounds__(THREADS) match_lane_kernel(
   const MatchArgs a, const double4 * __restrict__ outer, const uint8_t * __restrict__ map_image,
   const LaneGeom geo)
 {
@@ -223,7 +223,7 @@ __global__ void __launch_bounds__(kLaneThreads) match_lane_kernel(
     const uint32_t n16 = static_cast<uint32_t>(kMapStride) * geo.map_h / 16;
     const uint4 * src = reinterpret_cast<const uint4 *>(map_image);
     uint4 * dst = reinterpret_cast<uint4 *>(lds_map);
-    for (uint32_t i = threadIdx.x; i < n16; i += kLaneThreads) dst[i] = src[i];
+    for (uint32_t i = threadIdx.x; i < n16; i += THREADS) dst[i] = src[i];
   }
   __syncthreads();
 
@@ -241,6 +241,7 @@ __global__ void __launch_bounds__(kLaneThreads) match_lane_kernel(
   const uint32_t patches_1d = (n_lin + kPatch - 1) / kPatch;
   const uint32_t patches = patches_1d * patches_1d;
   const uint32_t n_items = (a.th_end - a.th_begin) * patches;
+  constexpr uint32_t kLaneWaves = THREADS / kWave;
   const uint32_t n_workers = gridDim.x * kLaneWaves;
   const uint32_t worker = wave * gridDim.x + blockIdx.x;
   const uint64_t per_theta = static_cast<uint64_t>(n_lin) * n_lin;
@@ -430,9 +431,13 @@ hipError_t launch_match_lane(const MatchArgs & args_in, double * outer, double *
 
   const uint32_t p1 = (args.n_lin + kPatch - 1) / kPatch;
   const uint64_t n_items = static_cast<uint64_t>(args.th_end - args.th_begin) * p1 * p1;
-  uint32_t blocks = static_cast<uint32_t>((n_items + kLaneWaves - 1) / kLaneWaves);
+  // Few work items (the plugin's default lattice is 720 of them): 256-thread blocks
+  // put them on four times as many CUs.
+  const bool small = n_items < static_cast<uint64_t>(cus) * (kLaneThreads / kWave);
+  const uint32_t waves_per_block = (small ? kLaneThreadsSmall : kLaneThreads) / kWave;
+  uint32_t blocks = static_cast<uint32_t>((n_items + waves_per_block - 1) / waves_per_block);
   uint32_t max_blocks = static_cast<uint32_t>(cus);
-  if (max_blocks * kLaneWaves > max_workers) max_blocks = max_workers / kLaneWaves;
+  if (max_blocks * waves_per_block > max_workers) max_blocks = max_workers / waves_per_block;
   if (blocks > max_blocks) blocks = max_blocks;
   if (blocks == 0) blocks = 1;
 
@@ -441,7 +446,7 @@ hipError_t launch_match_lane(const MatchArgs & args_in, double * outer, double *
   const size_t lds_bytes =
     map_bytes +
     (lds_records ? static_cast<size_t>(args.grid.ncell + 1) * kCellDoubles * sizeof(double) : 0);
-  auto launch = [&](auto kernel) -> hipError_t {
+  auto launch = [&](auto kernel, int threads) -> hipError_t {
     if (lds_bytes > 48 * 1024)
     {
       hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
@@ -449,20 +454,29 @@ hipError_t launch_match_lane(const MatchArgs & args_in, double * outer, double *
                                           static_cast<int>(lds_bytes));
       if (e2 != hipSuccess) return e2;
     }
-    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kLaneThreads), lds_bytes, stream, args,
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), lds_bytes, stream, args,
                        reinterpret_cast<const double4 *>(outer),
                        static_cast<const uint8_t *>(map_image), geo);
     return hipGetLastError();
   };
-  if (lds_records)
+  const bool pow2 = args.grid.pow2 != 0;
+  if (small)
   {
-    e = args.grid.pow2 ? launch(match_lane_kernel<true, true>) : launch(match_lane_kernel<false, true>);
+    constexpr int T = kLaneThreadsSmall;
+    e = lds_records ? (pow2 ? launch(match_lane_kernel<T, true, true>, T)
+                            : launch(match_lane_kernel<T, false, true>, T))
+                    : (pow2 ? launch(match_lane_kernel<T, true, false>, T)
+                            : launch(match_lane_kernel<T, false, false>, T));
   }
   else
   {
-    e = args.grid.pow2 ? launch(match_lane_kernel<true, false>) : launch(match_lane_kernel<false, false>);
+    constexpr int T = kLaneThreads;
+    e = lds_records ? (pow2 ? launch(match_lane_kernel<T, true, true>, T)
+                            : launch(match_lane_kernel<T, false, true>, T))
+                    : (pow2 ? launch(match_lane_kernel<T, true, false>, T)
+                            : launch(match_lane_kernel<T, false, false>, T));
   }
-  if (n_workers_out != nullptr) *n_workers_out = blocks * kLaneWaves;
+  if (n_workers_out != nullptr) *n_workers_out = blocks * waves_per_block;
   return e;
 }
 
