@@ -227,6 +227,40 @@ def test_ragged_beam_counts(cfg1, n_beams):
     assert np.max(np.abs(gpu.scorePoses(pts, poses) - O.pf_measure(ref, poses, pts))) < TOL_TIGHT
 
 
+@pytest.mark.parametrize("lin,ang", [((0.004, 0.005), (0.001, 0.0025)),    # 2 x 2 x 1 lattice
+                                     ((0.0, 0.005), (0.0, 0.0025)),         # empty lattice
+                                     ((0.011, 0.005), (0.006, 0.0025)),     # 5 x 5 x 5
+                                     ((0.3, 0.07), (0.02, 0.013))])          # 9 x 9 x 4, ragged patches
+def test_tiny_and_ragged_lattices(cfg1, lin, ang):
+    _, _, scans, guess, pts = cfg1
+    params = synth.matcher_params(1, search_linear_size=lin[0], search_linear_resolution=lin[1],
+                                  search_angular_size=ang[0], search_angular_resolution=ang[1])
+    ref = O.ScanMatcherNDT()
+    ref.initialize(**params)
+    ref.addScans(scans)
+    gpu = ScanMatcherNDT(0)
+    gpu.initialize("t", **params)
+    gpu.addScans(scans)
+    exp = ref.matchScan(guess, pts, pose=(9.0, 9.0, 9.0), want_scores=True)
+    for variant in ("lane", "wave"):
+        gpu.set_variant(variant)
+        got = gpu.matchScan(guess, pts, pose=(9.0, 9.0, 9.0), want_scores=True)
+        assert got["n_candidates"] == exp["n_candidates"]
+        if exp["n_candidates"] == 0:
+            # the loops never run: pose untouched, 0/0 covariance, 0.0 returned
+            assert got["score"] == exp["score"] == 0.0
+            assert np.array_equal(got["pose"], [9.0, 9.0, 9.0])
+            assert np.isnan(got["covariance"]).all() and np.isnan(exp["covariance"]).all()
+        else:
+            _check_match(got, exp, 720)
+
+
+def test_single_beam_scan(cfg1):
+    gpu, ref, _, guess, pts = cfg1
+    one = pts[100:101]
+    _check_match(gpu.matchScan(guess, one, want_scores=True), ref.matchScan(guess, one, want_scores=True), 1)
+
+
 def test_cfg2_full_size():
     """BASELINE.json configs[1]: 2,000,000 candidates x 720 beams on one GPU."""
     gpu, ref, _, guess, pts = _pair(2)
