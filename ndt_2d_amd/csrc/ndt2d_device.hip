@@ -26,6 +26,16 @@ struct DeviceBuffer
   size_t cap = 0;  // doubles
 };
 
+// Pinned host staging for small uploads: the copy is truly asynchronous and the
+// caller's buffer is free as soon as the call returns.
+struct PinnedStage
+{
+  double * ptr = nullptr;
+  size_t cap = 0;  // doubles
+  hipEvent_t done = nullptr;
+  bool pending = false;
+};
+
 struct ndt2d_context
 {
   int device = 0;
@@ -46,6 +56,7 @@ struct ndt2d_context
 
   DeviceBuffer beams;
   size_t n_beams = 0;
+  PinnedStage stage_beams, stage_tables;
 
   DeviceBuffer tables;  // dth | cos | sin | dlin
   size_t n_th = 0, n_lin = 0;
@@ -104,6 +115,42 @@ int ensure(ndt2d_context * h, DeviceBuffer & b, size_t doubles)
   NDT2D_HIP(h, hipMalloc(reinterpret_cast<void **>(&b.ptr), cap * sizeof(double)));
   b.cap = cap;
   return NDT2D_OK;
+}
+
+// Make `st` ready to take `doubles` values: wait for the previous copy out of it.
+int stage_acquire(ndt2d_context * h, PinnedStage & st, size_t doubles)
+{
+  if (st.done == nullptr) NDT2D_HIP(h, hipEventCreateWithFlags(&st.done, hipEventDisableTiming));
+  if (st.pending)
+  {
+    NDT2D_HIP(h, hipEventSynchronize(st.done));
+    st.pending = false;
+  }
+  if (doubles > st.cap || st.ptr == nullptr)
+  {
+    if (st.ptr != nullptr) NDT2D_HIP(h, hipHostFree(st.ptr));
+    st.ptr = nullptr;
+    st.cap = 0;
+    const size_t cap = doubles < 4096 ? 4096 : doubles;
+    NDT2D_HIP(h, hipHostMalloc(reinterpret_cast<void **>(&st.ptr), cap * sizeof(double), hipHostMallocDefault));
+    st.cap = cap;
+  }
+  return NDT2D_OK;
+}
+
+int stage_submit(ndt2d_context * h, PinnedStage & st, double * dst, size_t doubles)
+{
+  NDT2D_HIP(h, hipMemcpyAsync(dst, st.ptr, doubles * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  NDT2D_HIP(h, hipEventRecord(st.done, h->stream));
+  st.pending = true;
+  return NDT2D_OK;
+}
+
+void release(PinnedStage & st)
+{
+  if (st.ptr != nullptr) (void)hipHostFree(st.ptr);
+  if (st.done != nullptr) (void)hipEventDestroy(st.done);
+  st = PinnedStage{};
 }
 
 void release(DeviceBuffer & b)
@@ -173,6 +220,8 @@ int ndt2d_destroy(ndt2d_handle h)
   release(h->b_temp);
   release(h->b_seg);
   release(h->beams);
+  release(h->stage_beams);
+  release(h->stage_tables);
   release(h->tables);
   release(h->ws_match);
   release(h->outer);
@@ -438,9 +487,11 @@ int ndt2d_set_beams(ndt2d_handle h, const double * beams_xy, size_t n_beams)
   NDT2D_HIP(h, hipSetDevice(h->device));
   int rc = ensure(h, h->beams, 2 * n_beams + 2);
   if (rc != NDT2D_OK) return rc;
-  NDT2D_HIP(h, hipMemcpyAsync(h->beams.ptr, beams_xy, 2 * n_beams * sizeof(double),
-                              hipMemcpyHostToDevice, h->stream));
-  NDT2D_HIP(h, hipStreamSynchronize(h->stream));
+  rc = stage_acquire(h, h->stage_beams, 2 * n_beams);
+  if (rc != NDT2D_OK) return rc;
+  std::memcpy(h->stage_beams.ptr, beams_xy, 2 * n_beams * sizeof(double));
+  rc = stage_submit(h, h->stage_beams, h->beams.ptr, 2 * n_beams);
+  if (rc != NDT2D_OK) return rc;
   h->n_beams = n_beams;
   h->beam_rmax = 0.0;
   for (size_t i = 0; i < n_beams; ++i)
@@ -464,16 +515,18 @@ int ndt2d_set_search(ndt2d_handle h, double pose_x, double pose_y, const double 
     return fail(h, NDT2D_ERR_INVALID, "ndt2d_set_search: bad argument");
   }
   NDT2D_HIP(h, hipSetDevice(h->device));
-  std::vector<double> t(3 * n_th + n_lin);
-  std::memcpy(&t[0], dth, n_th * sizeof(double));
-  std::memcpy(&t[n_th], cos_th, n_th * sizeof(double));
-  std::memcpy(&t[2 * n_th], sin_th, n_th * sizeof(double));
-  std::memcpy(&t[3 * n_th], dlin, n_lin * sizeof(double));
-  int rc = ensure(h, h->tables, t.size());
+  const size_t n_tab = 3 * n_th + n_lin;
+  int rc = ensure(h, h->tables, n_tab);
   if (rc != NDT2D_OK) return rc;
-  NDT2D_HIP(h, hipMemcpyAsync(h->tables.ptr, t.data(), t.size() * sizeof(double),
-                              hipMemcpyHostToDevice, h->stream));
-  NDT2D_HIP(h, hipStreamSynchronize(h->stream));
+  rc = stage_acquire(h, h->stage_tables, n_tab);
+  if (rc != NDT2D_OK) return rc;
+  double * t = h->stage_tables.ptr;
+  std::memcpy(t, dth, n_th * sizeof(double));
+  std::memcpy(t + n_th, cos_th, n_th * sizeof(double));
+  std::memcpy(t + 2 * n_th, sin_th, n_th * sizeof(double));
+  std::memcpy(t + 3 * n_th, dlin, n_lin * sizeof(double));
+  rc = stage_submit(h, h->stage_tables, h->tables.ptr, n_tab);
+  if (rc != NDT2D_OK) return rc;
   h->n_th = n_th;
   h->n_lin = n_lin;
   h->dlin_absmax = 0.0;
