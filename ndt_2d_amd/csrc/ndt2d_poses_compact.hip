@@ -38,6 +38,7 @@ constexpr uint32_t kCellMask = (1u << kCellBits) - 1;
 // result does not depend on the launch geometry or on how a particle set is
 // sharded.  (It differs from the reference's single running sum by a few ulps.)
 constexpr int kChunks = 8;
+constexpr int kPhaseA = 2;               // beams per dense step
 constexpr size_t kLdsBudget = 160 * 1024;
 
 template <int THREADS>
@@ -133,14 +134,8 @@ __global__ void __launch_bounds__(THREADS) score_poses_compact_kernel(const Pose
       const uint32_t k1 = min(k0 + chunk_len, a.n_beams);
       my_sums[lane] = 0.0;
       uint32_t head = 0, count = 0;
-      for (uint32_t k = k0; k < k1; ++k)
-      {
-        const double2 p = reinterpret_cast<const double2 *>(lds_beams)[k];
-        // p = t * (x, y, 1) (:172-173): translation + (c*x + (-s)*y), (s*x + c*y)
-        const double px = x + (c * p.x - s * p.y);
-        const double py = y + (s * p.x + c * p.y);
-        const uint32_t idx = cell_index<POW2>(g, px, py);
-        const bool occ = ((lds_bits[idx >> 5] >> (idx & 31u)) & 1u) != 0;
+      // one beam's queue step: occupied lanes append, a full queue is drained
+      auto push = [&](double px, double py, uint32_t idx, bool occ) {
         const uint64_t mask = __ballot(occ);
         if (mask != 0)
         {
@@ -161,6 +156,36 @@ __global__ void __launch_bounds__(THREADS) score_poses_compact_kernel(const Pose
             count -= kWave;
           }
         }
+      };
+      // kPhaseA beams per step so that their LDS reads (beam, bitmap word) overlap
+      uint32_t k = k0;
+      for (; k + kPhaseA <= k1; k += kPhaseA)
+      {
+        double px[kPhaseA], py[kPhaseA];
+        uint32_t idx[kPhaseA], word[kPhaseA];
+#pragma unroll
+        for (int u = 0; u < kPhaseA; ++u)
+        {
+          const double2 p = reinterpret_cast<const double2 *>(lds_beams)[k + u];
+          // p = t * (x, y, 1) (:172-173): translation + (c*x + (-s)*y), (s*x + c*y)
+          px[u] = x + (c * p.x - s * p.y);
+          py[u] = y + (s * p.x + c * p.y);
+          idx[u] = cell_index<POW2>(g, px[u], py[u]);
+          word[u] = lds_bits[idx[u] >> 5];
+        }
+#pragma unroll
+        for (int u = 0; u < kPhaseA; ++u)
+        {
+          push(px[u], py[u], idx[u], ((word[u] >> (idx[u] & 31u)) & 1u) != 0);
+        }
+      }
+      for (; k < k1; ++k)
+      {
+        const double2 p = reinterpret_cast<const double2 *>(lds_beams)[k];
+        const double px = x + (c * p.x - s * p.y);
+        const double py = y + (s * p.x + c * p.y);
+        const uint32_t idx = cell_index<POW2>(g, px, py);
+        push(px, py, idx, ((lds_bits[idx >> 5] >> (idx & 31u)) & 1u) != 0);
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       drain(head, count);
