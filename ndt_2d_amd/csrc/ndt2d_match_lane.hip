@@ -60,7 +60,12 @@ constexpr double kTwo52 = 4503599627370496.0;
 struct LaneGeom
 {
   int32_t pad;     // border cells on every side of the window in the map
-  int32_t map_h;   // win_h + 2 * pad rows of kMapStride bytes
+  // The map is kept at 2^sub_log2 sub-cells per cell (as fine as the one-byte
+  // coordinate and LDS allow): "a neighbour is occupied" then means a neighbouring
+  // SUB-cell, so fewer empty cells next to walls take the careful path.
+  int32_t sub_log2;
+  double unit_scale;  // fixed-point units per cell = 2^16 << sub_log2
+  int32_t map_h;   // ((win_h + 2 * pad) << sub_log2) rows of kMapStride bytes
   // Window of grid cells the map covers: every point this search can produce
   // (scan pose +- (longest beam + largest offset)) lies inside it or outside the
   // grid.  For small grids it is the whole grid.
@@ -88,20 +93,22 @@ __global__ void __launch_bounds__(256) outer_table_kernel(const MatchArgs a, dou
     const uint32_t n_map = static_cast<uint32_t>(kMapStride) * geo.map_h;
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_map; i += gridDim.x * 256)
     {
-      // map cell -> grid cell
-      const int32_t cx = static_cast<int32_t>(i & (kMapStride - 1)) - geo.pad + geo.win_x0;
-      const int32_t cy = static_cast<int32_t>(i >> 8) - geo.pad + geo.win_y0;
+      // map sub-cell (mx, my) and its eight neighbours -> parent grid cells
+      const int32_t mx = static_cast<int32_t>(i & (kMapStride - 1));
+      const int32_t my = static_cast<int32_t>(i >> 8);
       uint32_t self = 0, around = 0;
-      for (int32_t ny = cy - 1; ny <= cy + 1; ++ny)
+      for (int32_t b = -1; b <= 1; ++b)
       {
-        for (int32_t nx = cx - 1; nx <= cx + 1; ++nx)
+        for (int32_t c = -1; c <= 1; ++c)
         {
+          const int32_t nx = ((mx + c) >> geo.sub_log2) - geo.pad + geo.win_x0;
+          const int32_t ny = ((my + b) >> geo.sub_log2) - geo.pad + geo.win_y0;
           if (nx >= 0 && nx < sx && ny >= 0 && ny < sy)
           {
             const uint32_t cell = static_cast<uint32_t>(ny * sx + nx);
             const uint32_t o = (g.occ_bits[cell >> 5] >> (cell & 31u)) & 1u;
             around |= o;
-            if (nx == cx && ny == cy) self = o;
+            if (b == 0 && c == 0) self = o;
           }
         }
       }
@@ -122,8 +129,8 @@ __global__ void __launch_bounds__(256) outer_table_kernel(const MatchArgs a, dou
     double4 o;
     o.x = p.x * ct - p.y * st + a.pose_x;
     o.y = p.x * st + p.y * ct + a.pose_y;
-    double kx = ((o.x - a.grid.origin_x) * a.grid.inv_cell_size + (geo.pad - geo.win_x0)) * kFracScale;
-    double ky = ((o.y - a.grid.origin_y) * a.grid.inv_cell_size + (geo.pad - geo.win_y0)) * kFracScale;
+    double kx = ((o.x - a.grid.origin_x) * a.grid.inv_cell_size + (geo.pad - geo.win_x0)) * geo.unit_scale;
+    double ky = ((o.y - a.grid.origin_y) * a.grid.inv_cell_size + (geo.pad - geo.win_y0)) * geo.unit_scale;
     // !(k >= min) also catches NaN
     kx = !(kx >= geo.k_min) ? geo.k_min : (kx > geo.k_max_x ? geo.k_max_x : kx);
     ky = !(ky >= geo.k_min) ? geo.k_min : (ky > geo.k_max_y ? geo.k_max_y : ky);
@@ -137,6 +144,7 @@ struct LaneCtx
 {
   const double * lds_cells;
   const uint8_t * lds_map;
+  int32_t sub_log2;       // map sub-cell -> map cell: shift right
   int32_t off_x, off_y;   // map cell -> grid cell: subtract (pad - win_x0), (pad - win_y0)
   int32_t size_x;
 };
@@ -187,8 +195,8 @@ __device__ __forceinline__ void lane_beams(const GridDesc & g, const LaneCtx & c
           else
           {
             // interior of a cell: the look-up cell is the reference's cell
-            const int32_t cx = static_cast<int32_t>((lo[u] >> 16) & 0xffu) - c.off_x;
-            const int32_t cy = static_cast<int32_t>((hi[u] >> 8) & 0xffu) - c.off_y;
+            const int32_t cx = static_cast<int32_t>(((lo[u] >> 16) & 0xffu) >> c.sub_log2) - c.off_x;
+            const int32_t cy = static_cast<int32_t>(((hi[u] >> 8) & 0xffu) >> c.sub_log2) - c.off_y;
             idx = occ ? static_cast<uint32_t>(cy * c.size_x + cx) : g.ncell;
           }
           const double e = indexed_exponent<LDS_RECORDS>(g, c.lds_cells, idx, px, py);
@@ -230,6 +238,7 @@ __global__ void __launch_bounds__(THREADS) match_lane_kernel(
   LaneCtx c;
   c.lds_cells = lds_cells;
   c.lds_map = lds_map;
+  c.sub_log2 = geo.sub_log2;
   c.off_x = geo.pad - geo.win_x0;
   c.off_y = geo.pad - geo.win_y0;
   c.size_x = static_cast<int32_t>(g.size_x);
@@ -245,7 +254,7 @@ __global__ void __launch_bounds__(THREADS) match_lane_kernel(
   const uint32_t n_workers = gridDim.x * kLaneWaves;
   const uint32_t worker = wave * gridDim.x + blockIdx.x;
   const uint64_t per_theta = static_cast<uint64_t>(n_lin) * n_lin;
-  const double inv_scaled = g.inv_cell_size * kFracScale;
+  const double inv_scaled = g.inv_cell_size * geo.unit_scale;
 
   double best_s = 0.0;       // `double best_score = 0;` (:83)
   double best_i = kNoIndex;
@@ -355,7 +364,7 @@ bool axis_window(double pose, double reach, double origin, double inv_cell, uint
 
 // Map geometry for a search; false if the byte-per-axis cell coordinate cannot
 // hold the padded window.
-bool lane_geometry(const MatchArgs & args, LaneGeom * geo, size_t * map_bytes)
+bool lane_geometry(const MatchArgs & args, size_t lds_per_block, LaneGeom * geo, size_t * map_bytes)
 {
   const double lin_cells = args.dlin_absmax * args.grid.inv_cell_size;
   if (!(lin_cells >= 0.0) || lin_cells > kMaxMapCells) return false;
@@ -374,13 +383,30 @@ bool lane_geometry(const MatchArgs & args, LaneGeom * geo, size_t * map_bytes)
   const uint64_t need_h = static_cast<uint64_t>(geo->win_h) + 2 * pad;
   if (need_w > kMaxMapCells || need_h > kMaxMapCells) return false;
   geo->pad = pad;
-  geo->map_h = static_cast<int32_t>(need_h);
-  // lanes add |d| <= lin_cells * 2^16 (+0.5 rounding); one cell of margin each side
-  const double reach_units = (lin_cells + 1.0) * kFracScale;
+  // finest sub-cell resolution whose coordinates fit one byte and whose map leaves
+  // room in LDS for the cell records whenever the coarsest map would
+  const size_t grid_bytes = static_cast<size_t>(args.grid.ncell + 1) * kCellDoubles * sizeof(double);
+  const bool records_fit = grid_bytes + kMapStride * need_h <= lds_per_block;
+  // (a small search does not repay copying a 16x larger map into every block)
+  const uint64_t p1 = (args.n_lin + kPatch - 1) / kPatch;
+  const bool small_search = static_cast<uint64_t>(args.th_end - args.th_begin) * p1 * p1 < 4096;
+  int sub_log2 = small_search ? 0 : 2;
+  for (; sub_log2 > 0; --sub_log2)
+  {
+    const uint64_t w = need_w << sub_log2, h = need_h << sub_log2;
+    if (w > kMaxMapCells || h > kMaxMapCells) continue;
+    const size_t bytes = static_cast<size_t>(kMapStride) * h + (records_fit ? grid_bytes : 0);
+    if (bytes <= lds_per_block) break;
+  }
+  geo->sub_log2 = sub_log2;
+  geo->unit_scale = kFracScale * static_cast<double>(1 << sub_log2);
+  geo->map_h = static_cast<int32_t>(need_h << sub_log2);
+  // lanes add |d| <= lin_cells * unit_scale (+0.5 rounding); one cell of margin each side
+  const double reach_units = (lin_cells + 1.0) * geo->unit_scale;
   geo->k_min = reach_units;
-  geo->k_max_x = static_cast<double>(need_w - 1) * kFracScale - reach_units;
-  geo->k_max_y = static_cast<double>(need_h - 1) * kFracScale - reach_units;
-  *map_bytes = static_cast<size_t>(kMapStride) * need_h;
+  geo->k_max_x = static_cast<double>(need_w - 1) * geo->unit_scale - reach_units;
+  geo->k_max_y = static_cast<double>(need_h - 1) * geo->unit_scale - reach_units;
+  *map_bytes = static_cast<size_t>(kMapStride) * geo->map_h;
   return true;
 }
 
@@ -403,7 +429,7 @@ bool match_lane_supported(const MatchArgs & args, size_t lds_per_block)
 {
   LaneGeom geo;
   size_t map_bytes = 0;
-  if (args.grid.occ_bits == nullptr || !lane_geometry(args, &geo, &map_bytes)) return false;
+  if (args.grid.occ_bits == nullptr || !lane_geometry(args, lds_per_block, &geo, &map_bytes)) return false;
   const uint64_t p1 = (args.n_lin + kPatch - 1) / kPatch;
   const uint64_t items = static_cast<uint64_t>(args.th_end - args.th_begin) * p1 * p1;
   return map_bytes <= lds_per_block && items < (1ull << 32);
@@ -417,7 +443,7 @@ hipError_t launch_match_lane(const MatchArgs & args_in, double * outer, double *
   args.partials = workspace;
   LaneGeom geo;
   size_t map_bytes = 0;
-  if (!lane_geometry(args, &geo, &map_bytes)) return hipErrorInvalidValue;
+  if (!lane_geometry(args, lds_per_block, &geo, &map_bytes)) return hipErrorInvalidValue;
 
   const uint64_t n_outer = static_cast<uint64_t>(args.th_end - args.th_begin) * args.n_beams;
   uint32_t oblocks = static_cast<uint32_t>((n_outer + 255) / 256);
