@@ -72,6 +72,55 @@ __device__ __forceinline__ double record_likelihood(double mx, double my, double
   return exp(record_exponent(mx, my, h00, h01, h11, px, py));
 }
 
+// exp(x) for the exponents of Cell::score: x is finite or -inf and far below the
+// overflow range (x <= 0 for any positive semi-definite information matrix).
+// Same algorithm and polynomial as the device library's exp (n = rint(x log2 e),
+// r = x - n ln2 in two pieces, degree-11 minimax polynomial, ldexp), minus its
+// range fix-ups: the clamp maps -inf to an exponent whose ldexp underflows to
+// +0.0, and v_ldexp_f64 rounds into the denormal range by itself.  NaN is NOT
+// propagated (max() drops it): callers route NaN exponents to exp().
+//
+// The Horner steps are written as three-address v_fma_f64: left to itself the
+// compiler prefers the two-address v_fmac_f64 and pays a v_mov_b64 per step to
+// copy the polynomial constant into the accumulator (35 instead of 19 VALU
+// instructions per exp in this register-starved kernel).
+__device__ __forceinline__ double fma3(double a, double b, double c)
+{
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+
+__device__ __forceinline__ double exp_of_exponent(double x)
+{
+  x = __builtin_fmax(x, -1000.0);
+  const double n = rint(x * 1.4426950408889634);             // 0x3ff71547652b82fe
+  double r = fma(n, -0.6931471805599453, x);                  // 0xbfe62e42fefa39ef
+  r = fma(n, -2.3190468138462996e-17, r);                     // 0xbc7abc9e3b39803f
+  double p = fma3(r, 0x1.ade156a5dcb37p-26, 0x1.28af3fca7ab0cp-22);
+  p = fma3(r, p, 0x1.71dee623fde64p-19);
+  p = fma3(r, p, 0x1.a01997c89e6b0p-16);
+  p = fma3(r, p, 0x1.a01a014761f6ep-13);
+  p = fma3(r, p, 0x1.6c16c1852b7b0p-10);
+  p = fma3(r, p, 0x1.1111111122322p-7);
+  p = fma3(r, p, 0x1.55555555502a1p-5);
+  p = fma3(r, p, 0x1.5555555555511p-3);
+  p = fma3(r, p, 0x1.000000000000bp-1);
+  p = fma3(r, p, 1.0);
+  p = fma3(r, p, 1.0);
+  return ldexp(p, static_cast<int>(n));
+}
+
+// exp() of a Cell::score exponent for the register-tight kernels (lane mapping,
+// compacted particle scoring; the wave mapping keeps the library exp, whose
+// constants live in SGPRs there): the lean evaluation above, except that a wave
+// holding a NaN exponent (degenerate cell) takes the library path so that the NaN
+// propagates as in the reference.
+__device__ __forceinline__ double exp_score(double e)
+{
+  return __any(e != e) ? exp(e) : exp_of_exponent(e);
+}
+
 // A non-negative term t = exp(e) leaves a running sum s > 0 unchanged,
 // RN(s + t) == s, whenever t < 2^-54 * s (less than half an ulp of s), i.e.
 // e < ln(s) - 37.43.  negligible_below(s) returns a conservative such bound

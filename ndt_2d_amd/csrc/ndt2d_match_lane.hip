@@ -203,7 +203,7 @@ __device__ __forceinline__ void lane_beams(const GridDesc & g, const LaneCtx & c
           // !(e < bound) also keeps NaN exponents (degenerate cells) on the exact path
           if (__any(!(e < skip_below)))
           {
-            sum += exp(e);
+            sum += exp_score(e);
           }
         }
       }

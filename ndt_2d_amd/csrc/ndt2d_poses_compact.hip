@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(THREADS) score_poses_compact_kernel(const Pose
       const double py = q_py[slot];
       const uint32_t meta = q_meta[slot];
       const double e = indexed_exponent<false>(g, nullptr, meta & kCellMask, px, py);
-      atomicAdd(&my_sums[meta >> kCellBits], exp(e));
+      atomicAdd(&my_sums[meta >> kCellBits], exp_score(e));
     }
   };
 
