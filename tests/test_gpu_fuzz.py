@@ -1,0 +1,90 @@
+"""Randomised parity: random maps, scans and search lattices through every kernel
+variant against the oracle (seeded, so failures reproduce)."""
+import math
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from ndt_2d_amd import ScanMatcherNDT
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_case(rng):
+    res = float(rng.choice([0.1, 0.25, 0.3, 0.5, 1.0]))
+    range_max = float(rng.uniform(1.5, 6.0))
+    scans = []
+    for _ in range(int(rng.integers(1, 6))):
+        pose = (rng.uniform(-3, 3), rng.uniform(-3, 3), rng.uniform(-math.pi, math.pi))
+        n = int(rng.integers(0, 400))
+        kind = rng.integers(0, 3)
+        if kind == 0:      # a wall segment with noise
+            t = rng.uniform(-1, 1, n)
+            pts = np.stack([rng.uniform(1, 4) + 0.02 * rng.standard_normal(n), 3 * t], axis=1)
+        elif kind == 1:    # a few tight clusters (degenerate-ish cells)
+            c = rng.uniform(-4, 4, (max(1, n // 40), 2))
+            pts = c[rng.integers(0, len(c), n)] + 0.005 * rng.standard_normal((n, 2))
+        else:              # scattered
+            pts = rng.uniform(-5, 5, (n, 2))
+        scans.append((pose, pts))
+    n_q = int(rng.integers(1, 300))
+    query = np.concatenate([rng.uniform(-5, 5, (n_q // 2 + 1, 2)),
+                            np.stack([rng.uniform(1, 4, n_q // 2 + 1),
+                                      rng.uniform(-3, 3, n_q // 2 + 1)], axis=1)])[:n_q]
+    scan_pose = (rng.uniform(-3, 3), rng.uniform(-3, 3), rng.uniform(-math.pi, math.pi))
+    lin_res = float(rng.choice([0.005, 0.02, 0.05, 0.13]))
+    lin_size = lin_res * float(rng.uniform(0.5, 14))
+    ang_res = float(rng.choice([0.0025, 0.01, 0.05]))
+    ang_size = ang_res * float(rng.uniform(0.5, 5))
+    params = dict(ndt_resolution=res, range_max=range_max,
+                  search_linear_size=lin_size, search_linear_resolution=lin_res,
+                  search_angular_size=ang_size, search_angular_resolution=ang_res,
+                  laser_max_beams=int(rng.choice([1, 7, 64, 100, 1000])))
+    poses = np.stack([rng.uniform(-6, 6, 97), rng.uniform(-6, 6, 97),
+                      rng.uniform(-math.pi, math.pi, 97)], axis=1)
+    return params, scans, scan_pose, query, poses
+
+
+@pytest.mark.parametrize("seed", range(64))
+def test_random_case(seed):
+    rng = np.random.default_rng(1000 + seed)
+    params, scans, scan_pose, query, poses = _random_case(rng)
+    ref = O.ScanMatcherNDT()
+    ref.initialize(**params)
+    ref.addScans(scans)
+    exp = ref.matchScan(scan_pose, query, want_scores=True)
+    w_exp = O.pf_measure(ref, poses, query)
+    gpu = ScanMatcherNDT(0)
+    gpu.initialize("fuzz", **params)
+    for build in ("host", "device"):
+        gpu.set_build_mode(build)
+        gpu.addScans(scans)
+        assert np.array_equal(gpu.grid()[0], ref.ndt.cells6(), equal_nan=True), (seed, build)
+    for variant in ("lane", "wave", "wave-global"):
+        gpu.set_variant(variant)
+        try:
+            got = gpu.matchScan(scan_pose, query, want_scores=True)
+        except Exception as e:
+            # the lane mapping may not apply (map window too large for byte coordinates)
+            assert variant == "lane" and "launch_match" in str(e), (seed, variant, e)
+            continue
+        assert got["n_candidates"] == exp["n_candidates"], (seed, variant)
+        assert np.array_equal(np.isnan(got["scores"]), np.isnan(exp["scores"])), (seed, variant)
+        assert np.allclose(got["scores"], exp["scores"], rtol=0, atol=1e-9, equal_nan=True), (seed, variant)
+        finite = exp["scores"][~np.isnan(exp["scores"])]
+        unique_min = finite.size > 0 and np.sum(finite == finite.min()) == 1 and \
+            (np.sort(finite)[1] - finite.min() > 1e-9 if finite.size > 1 else True)
+        if unique_min:
+            assert got["best_index"] == exp["best_index"], (seed, variant)
+            assert np.array_equal(got["pose"], exp["pose"])
+        assert got["score"] == pytest.approx(exp["score"], abs=1e-9, nan_ok=True)
+        if abs(np.nansum(exp["scores"])) > 1e-6:
+            assert np.allclose(got["covariance"], exp["covariance"], rtol=1e-7, atol=1e-12,
+                               equal_nan=True), (seed, variant)
+    gpu.set_variant("auto")
+    for variant in ("auto", "dense"):
+        gpu.set_variant(variant)
+        w = gpu.scorePoses(query, poses)
+        assert np.array_equal(np.isnan(w), np.isnan(w_exp)), (seed, variant)
+        assert np.allclose(w, w_exp, rtol=0, atol=1e-9, equal_nan=True), (seed, variant)
