@@ -170,6 +170,45 @@ int ndt2d_pf_finalize_launch(ndt2d_handle h, const double * d_poses_xyt, size_t 
 int ndt2d_pf_measure(ndt2d_handle h, const double * h_poses_xyt, size_t n_poses,
                      double * h_weights, double * h_out);
 
+/* ---- particle-filter steps either side of `measure` (particles stay in HBM) ----
+ *
+ * The reference draws three std::normal_distribution<float> values per particle
+ * from an mt19937 seeded by std::random_device (include/ndt_2d/motion_model.hpp:
+ * 63-64, particle_filter.hpp), i.e. not reproducibly.  Every call below takes the
+ * draws either as d_noise = [n][3] float standard normals (device pointer), or
+ * with d_noise == NULL from a counter-based stream: Philox4x32-10 keyed by
+ * `seed`, counter (first_index + i, step) for particle i, Box-Muller.  The stream
+ * depends on (seed, step, global particle index) only, so shards of a particle set
+ * on different GPUs draw what the whole set would.  ndt2d_pf_noise_launch writes
+ * that stream out (the same numbers a fused call uses). */
+int ndt2d_pf_noise_launch(ndt2d_handle h, uint64_t seed, uint64_t step, uint64_t first_index,
+                          size_t n, float * d_noise_out);
+/* MotionModel::sample (src/motion_model.cpp:45-83) applied in place to
+ * d_poses_xyt[n][3]; alphas5 = the model's {a1..a5} (motion_model.cpp:39-43;
+ * a5 is unused by the reference too).  Asynchronous. */
+int ndt2d_pf_motion_launch(ndt2d_handle h, double * d_poses_xyt, size_t n, double dx, double dy,
+                           double dth, const double * alphas5, const float * d_noise,
+                           uint64_t seed, uint64_t step, uint64_t first_index);
+/* ParticleFilter::init sampling loop (src/particle_filter.cpp:53-65): poses
+ * written as (float draw) widened to double, theta through normalize_angle. */
+int ndt2d_pf_init_launch(ndt2d_handle h, double * d_poses_xyt, size_t n, double x, double y,
+                         double theta, double sigma_x, double sigma_y, double sigma_theta,
+                         const float * d_noise, uint64_t seed, uint64_t step,
+                         uint64_t first_index);
+/* The moment sums of updateStatistics (src/particle_filter.cpp:166-200) for given
+ * weights (d_weights == NULL: uniform 1/n, as init assigns at :67): d_stats gets
+ * NDT2D_POSE_STATS_DOUBLES doubles in ndt2d_score_poses_launch's layout, ready for
+ * ndt2d_pf_finalize_launch (after an all-reduce when the set is sharded). */
+int ndt2d_pose_moments_launch(ndt2d_handle h, const double * d_poses_xyt, size_t n,
+                              const double * d_weights, double * d_stats);
+/* Host-pointer convenience = ParticleFilter::update (src/particle_filter.cpp:
+ * 71-76): motion model on h_poses_xyt in place (h_noise [n][3] or NULL = Philox),
+ * then updateStatistics with h_weights (normalised in place) into h_out
+ * (NDT2D_PF_RESULT_DOUBLES, see ndt2d_pf_finalize_launch). */
+int ndt2d_pf_update(ndt2d_handle h, double * h_poses_xyt, size_t n, double dx, double dy,
+                    double dth, const double * alphas5, const float * h_noise, uint64_t seed,
+                    uint64_t step, double * h_weights, double * h_out);
+
 /* Block until everything launched on the context's stream has finished. */
 int ndt2d_synchronize(ndt2d_handle h);
 /* GPU time (HIP events on the launch stream) of the dominant kernel -- the

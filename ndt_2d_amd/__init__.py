@@ -6,8 +6,9 @@ the reference's ScanMatcher plugin interface, the synthetic workload generator
 and the multi-GPU sharding helper.
 """
 from ._capi import LIB_PATH, Ndt2dError  # noqa: F401
+from .particle_filter import MotionModel, ParticleFilter  # noqa: F401
 from .scan_matcher import (DEFAULT_PARAMS, ScanMatcherNDT, host_build_grid,  # noqa: F401
-                           pf_measure, search_offsets)
+                           pf_measure, pf_update, search_offsets)
 
-__all__ = ["ScanMatcherNDT", "pf_measure", "search_offsets", "host_build_grid",
-           "DEFAULT_PARAMS", "Ndt2dError", "LIB_PATH"]
+__all__ = ["ScanMatcherNDT", "ParticleFilter", "MotionModel", "pf_measure", "pf_update",
+           "search_offsets", "host_build_grid", "DEFAULT_PARAMS", "Ndt2dError", "LIB_PATH"]

@@ -19,6 +19,7 @@ ERR_STATE = 5
 NO_INDEX = (1 << 64) - 1
 MATCH_RECORD_DOUBLES = 12
 POSE_STATS_DOUBLES = 8
+PF_RESULT_DOUBLES = 8
 
 _ERR_NAMES = {1: "NDT2D_ERR_INVALID", 2: "NDT2D_ERR_NO_GRID", 3: "NDT2D_ERR_HIP",
               4: "NDT2D_ERR_NO_DEVICE", 5: "NDT2D_ERR_STATE"}
@@ -45,6 +46,7 @@ _dp = C.POINTER(C.c_double)
 _vp = C.c_void_p
 _d = C.c_double
 _sz = C.c_size_t
+_u64 = C.c_uint64
 _u32 = C.c_uint32
 _szp = C.POINTER(C.c_size_t)
 
@@ -71,6 +73,13 @@ SIGNATURES = {
     "ndt2d_score_poses": (C.c_int, [_vp, _dp, _sz, _dp, _dp]),
     "ndt2d_pf_finalize_launch": (C.c_int, [_vp, _vp, _sz, _vp, _vp, _vp]),
     "ndt2d_pf_measure": (C.c_int, [_vp, _dp, _sz, _dp, _dp]),
+    "ndt2d_pf_noise_launch": (C.c_int, [_vp, _u64, _u64, _u64, _sz, _vp]),
+    "ndt2d_pf_motion_launch": (C.c_int, [_vp, _vp, _sz, _d, _d, _d, _dp, _vp, _u64, _u64, _u64]),
+    "ndt2d_pf_init_launch": (C.c_int, [_vp, _vp, _sz, _d, _d, _d, _d, _d, _d, _vp, _u64, _u64,
+                                       _u64]),
+    "ndt2d_pose_moments_launch": (C.c_int, [_vp, _vp, _sz, _vp, _vp]),
+    "ndt2d_pf_update": (C.c_int, [_vp, _dp, _sz, _d, _d, _d, _dp, C.POINTER(C.c_float), _u64,
+                                  _u64, _dp, _dp]),
     "ndt2d_synchronize": (C.c_int, [_vp]),
     "ndt2d_last_launch_ms": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "ndt2d_last_variant": (C.c_char_p, [_vp]),

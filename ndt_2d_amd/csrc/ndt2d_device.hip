@@ -66,7 +66,7 @@ struct ndt2d_context
   bool has_search = false;
 
   DeviceBuffer ws_match, ws_poses, record, stats, outer;
-  DeviceBuffer tmp_scores, tmp_poses;
+  DeviceBuffer tmp_scores, tmp_poses, tmp_noise;
 
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
@@ -160,6 +160,38 @@ void release(DeviceBuffer & b)
   b.cap = 0;
 }
 
+// angles::normalize_angle / shortest_angular_distance (ROS `angles`)
+double normalize_angle(double a)
+{
+  const double r = std::fmod(a + M_PI, 2.0 * M_PI);
+  return r <= 0.0 ? r + M_PI : r - M_PI;
+}
+double angle_diff(double from, double to) { return normalize_angle(to - from); }
+
+// The per-call part of MotionModel::sample (reference src/motion_model.cpp:48-72):
+// decompose the odometry delta and derive the three (mean, sigma) pairs, narrowed
+// to float as std::normal_distribution<float> holds them.
+ndt2d::MotionParams motion_params(double dx, double dy, double dth, const double * a)
+{
+  const double trans = std::hypot(dx, dy);
+  const double rot1 = (trans > 0.01) ? std::atan2(dy, dx) : 0.0;
+  const double rot2 = angle_diff(rot1, dth);
+  const double rot1_ = std::min(std::fabs(angle_diff(rot1, 0.0)), std::fabs(angle_diff(rot1, M_PI)));
+  const double rot2_ = std::min(std::fabs(angle_diff(rot2, 0.0)), std::fabs(angle_diff(rot2, M_PI)));
+  const double sigma_rot1 = std::sqrt(a[0] * rot1_ * rot1_ + a[1] * trans * trans);
+  const double sigma_trans =
+    std::sqrt(a[2] * trans * trans + a[3] * rot1_ * rot1_ + a[3] * rot2_ * rot2_);
+  const double sigma_rot2 = std::sqrt(a[0] * rot2_ * rot2_ + a[1] * trans * trans);
+  ndt2d::MotionParams p;
+  p.rot1 = static_cast<float>(rot1);
+  p.trans = static_cast<float>(trans);
+  p.rot2 = static_cast<float>(rot2);
+  p.sigma_rot1 = static_cast<float>(sigma_rot1);
+  p.sigma_trans = static_cast<float>(sigma_trans);
+  p.sigma_rot2 = static_cast<float>(sigma_rot2);
+  return p;
+}
+
 bool is_pow2(double v)
 {
   if (!(v > 0.0) || !std::isfinite(v)) return false;
@@ -230,6 +262,7 @@ int ndt2d_destroy(ndt2d_handle h)
   release(h->stats);
   release(h->tmp_scores);
   release(h->tmp_poses);
+  release(h->tmp_noise);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -749,6 +782,125 @@ int ndt2d_pf_measure(ndt2d_handle h, const double * h_poses_xyt, size_t n_poses,
   rc = ndt2d_pf_finalize_launch(h, h->tmp_poses.ptr, n_poses, h->tmp_scores.ptr, h->stats.ptr, d_out);
   if (rc != NDT2D_OK) return rc;
   NDT2D_HIP(h, hipMemcpyAsync(h_weights, h->tmp_scores.ptr, n_poses * sizeof(double),
+                              hipMemcpyDeviceToHost, h->stream));
+  NDT2D_HIP(h, hipMemcpyAsync(h_out, d_out, NDT2D_PF_RESULT_DOUBLES * sizeof(double),
+                              hipMemcpyDeviceToHost, h->stream));
+  NDT2D_HIP(h, hipStreamSynchronize(h->stream));
+  return NDT2D_OK;
+}
+
+int ndt2d_pf_noise_launch(ndt2d_handle h, uint64_t seed, uint64_t step, uint64_t first_index,
+                          size_t n, float * d_noise_out)
+{
+  if (h == nullptr) return NDT2D_ERR_INVALID;
+  if (d_noise_out == nullptr || n == 0)
+  {
+    return fail(h, NDT2D_ERR_INVALID, "ndt2d_pf_noise_launch: bad argument");
+  }
+  NDT2D_HIP(h, hipSetDevice(h->device));
+  hipError_t e = ndt2d::launch_pf_noise(d_noise_out, n, seed, first_index, step, h->stream);
+  if (e != hipSuccess) return fail_hip(h, e, "launch_pf_noise");
+  return NDT2D_OK;
+}
+
+int ndt2d_pf_motion_launch(ndt2d_handle h, double * d_poses_xyt, size_t n, double dx, double dy,
+                           double dth, const double * alphas5, const float * d_noise,
+                           uint64_t seed, uint64_t step, uint64_t first_index)
+{
+  if (h == nullptr) return NDT2D_ERR_INVALID;
+  if (d_poses_xyt == nullptr || alphas5 == nullptr || n == 0)
+  {
+    return fail(h, NDT2D_ERR_INVALID, "ndt2d_pf_motion_launch: bad argument");
+  }
+  NDT2D_HIP(h, hipSetDevice(h->device));
+  const ndt2d::MotionParams p = motion_params(dx, dy, dth, alphas5);
+  hipError_t e =
+    ndt2d::launch_pf_motion(d_poses_xyt, n, p, d_noise, seed, first_index, step, h->stream);
+  if (e != hipSuccess) return fail_hip(h, e, "launch_pf_motion");
+  return NDT2D_OK;
+}
+
+int ndt2d_pf_init_launch(ndt2d_handle h, double * d_poses_xyt, size_t n, double x, double y,
+                         double theta, double sigma_x, double sigma_y, double sigma_theta,
+                         const float * d_noise, uint64_t seed, uint64_t step,
+                         uint64_t first_index)
+{
+  if (h == nullptr) return NDT2D_ERR_INVALID;
+  if (d_poses_xyt == nullptr || n == 0)
+  {
+    return fail(h, NDT2D_ERR_INVALID, "ndt2d_pf_init_launch: bad argument");
+  }
+  NDT2D_HIP(h, hipSetDevice(h->device));
+  ndt2d::InitParams p;
+  p.x = static_cast<float>(x);
+  p.y = static_cast<float>(y);
+  p.theta = static_cast<float>(theta);
+  p.sigma_x = static_cast<float>(sigma_x);
+  p.sigma_y = static_cast<float>(sigma_y);
+  p.sigma_theta = static_cast<float>(sigma_theta);
+  hipError_t e =
+    ndt2d::launch_pf_init(d_poses_xyt, n, p, d_noise, seed, first_index, step, h->stream);
+  if (e != hipSuccess) return fail_hip(h, e, "launch_pf_init");
+  return NDT2D_OK;
+}
+
+int ndt2d_pose_moments_launch(ndt2d_handle h, const double * d_poses_xyt, size_t n,
+                              const double * d_weights, double * d_stats)
+{
+  if (h == nullptr) return NDT2D_ERR_INVALID;
+  if (d_poses_xyt == nullptr || d_stats == nullptr || n == 0)
+  {
+    return fail(h, NDT2D_ERR_INVALID, "ndt2d_pose_moments_launch: bad argument");
+  }
+  NDT2D_HIP(h, hipSetDevice(h->device));
+  int rc = ensure(h, h->ws_poses, ndt2d::poses_workspace_doubles(n));
+  if (rc != NDT2D_OK) return rc;
+  hipError_t e =
+    ndt2d::launch_pose_moments(d_poses_xyt, n, d_weights, h->ws_poses.ptr, d_stats, h->stream);
+  if (e != hipSuccess) return fail_hip(h, e, "launch_pose_moments");
+  return NDT2D_OK;
+}
+
+int ndt2d_pf_update(ndt2d_handle h, double * h_poses_xyt, size_t n, double dx, double dy,
+                    double dth, const double * alphas5, const float * h_noise, uint64_t seed,
+                    uint64_t step, double * h_weights, double * h_out)
+{
+  if (h == nullptr) return NDT2D_ERR_INVALID;
+  if (h_poses_xyt == nullptr || alphas5 == nullptr || h_weights == nullptr || h_out == nullptr ||
+      n == 0)
+  {
+    return fail(h, NDT2D_ERR_INVALID, "ndt2d_pf_update: bad argument");
+  }
+  NDT2D_HIP(h, hipSetDevice(h->device));
+  int rc = ensure(h, h->tmp_poses, 3 * n);
+  if (rc != NDT2D_OK) return rc;
+  rc = ensure(h, h->tmp_scores, n);
+  if (rc != NDT2D_OK) return rc;
+  rc = ensure(h, h->stats, NDT2D_POSE_STATS_DOUBLES + NDT2D_PF_RESULT_DOUBLES);
+  if (rc != NDT2D_OK) return rc;
+  const float * d_noise = nullptr;
+  if (h_noise != nullptr)
+  {
+    rc = ensure(h, h->tmp_noise, (3 * n * sizeof(float) + sizeof(double) - 1) / sizeof(double));
+    if (rc != NDT2D_OK) return rc;
+    NDT2D_HIP(h, hipMemcpyAsync(h->tmp_noise.ptr, h_noise, 3 * n * sizeof(float),
+                                hipMemcpyHostToDevice, h->stream));
+    d_noise = reinterpret_cast<const float *>(h->tmp_noise.ptr);
+  }
+  NDT2D_HIP(h, hipMemcpyAsync(h->tmp_poses.ptr, h_poses_xyt, 3 * n * sizeof(double),
+                              hipMemcpyHostToDevice, h->stream));
+  NDT2D_HIP(h, hipMemcpyAsync(h->tmp_scores.ptr, h_weights, n * sizeof(double),
+                              hipMemcpyHostToDevice, h->stream));
+  rc = ndt2d_pf_motion_launch(h, h->tmp_poses.ptr, n, dx, dy, dth, alphas5, d_noise, seed, step, 0);
+  if (rc != NDT2D_OK) return rc;
+  rc = ndt2d_pose_moments_launch(h, h->tmp_poses.ptr, n, h->tmp_scores.ptr, h->stats.ptr);
+  if (rc != NDT2D_OK) return rc;
+  double * d_out = h->stats.ptr + NDT2D_POSE_STATS_DOUBLES;
+  rc = ndt2d_pf_finalize_launch(h, h->tmp_poses.ptr, n, h->tmp_scores.ptr, h->stats.ptr, d_out);
+  if (rc != NDT2D_OK) return rc;
+  NDT2D_HIP(h, hipMemcpyAsync(h_poses_xyt, h->tmp_poses.ptr, 3 * n * sizeof(double),
+                              hipMemcpyDeviceToHost, h->stream));
+  NDT2D_HIP(h, hipMemcpyAsync(h_weights, h->tmp_scores.ptr, n * sizeof(double),
                               hipMemcpyDeviceToHost, h->stream));
   NDT2D_HIP(h, hipMemcpyAsync(h_out, d_out, NDT2D_PF_RESULT_DOUBLES * sizeof(double),
                               hipMemcpyDeviceToHost, h->stream));

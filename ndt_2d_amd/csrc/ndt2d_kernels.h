@@ -116,6 +116,37 @@ hipError_t launch_pf_finalize(const double * poses_xyt, uint64_t n_poses, double
                               const double * stats, double * workspace, double * out,
                               hipStream_t stream);
 
+// Particle-filter steps around `measure` (ndt2d_motion.hip).  The float fields are
+// the parameters std::normal_distribution<float>(mean, sigma) holds
+// (reference src/motion_model.cpp:70-72, src/particle_filter.cpp:56-58).
+struct MotionParams
+{
+  float rot1, trans, rot2;
+  float sigma_rot1, sigma_trans, sigma_rot2;
+};
+struct InitParams
+{
+  float x, y, theta;
+  float sigma_x, sigma_y, sigma_theta;
+};
+// Grid-stride cap of the streaming particle kernels; poses_workspace_doubles()
+// holds 8 doubles for each of these blocks.
+constexpr uint32_t kMaxStreamBlocks = 4096;
+// noise: [n][3] standard normals (float) or null = the Philox4x32-10 stream of
+// (seed, step), particle i using counter first_index + i.
+hipError_t launch_pf_noise(float * noise_out, uint64_t n, uint64_t seed, uint64_t first_index,
+                           uint64_t step, hipStream_t stream);
+hipError_t launch_pf_motion(double * poses_xyt, uint64_t n, const MotionParams & params,
+                            const float * noise, uint64_t seed, uint64_t first_index,
+                            uint64_t step, hipStream_t stream);
+hipError_t launch_pf_init(double * poses_xyt, uint64_t n, const InitParams & params,
+                          const float * noise, uint64_t seed, uint64_t first_index,
+                          uint64_t step, hipStream_t stream);
+// stats_out[8] = sums {w, w x, w y, w cos, w sin, w xx, w xy, w yy}; weights null =
+// uniform 1/n.  workspace: poses_workspace_doubles() doubles.
+hipError_t launch_pose_moments(const double * poses_xyt, uint64_t n, const double * weights,
+                               double * workspace, double * stats_out, hipStream_t stream);
+
 // Lane-per-candidate search (ndt2d_match_lane.hip).  outer: device scratch of
 // match_lane_outer_doubles() doubles for the rotated-beam table; workspace
 // receives one partial record per wave (*n_workers_out of them).

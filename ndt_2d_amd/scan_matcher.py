@@ -252,6 +252,35 @@ class ScanMatcherNDT:
                                                          weights_ptr, stats_ptr, out_ptr),
                         "ndt2d_pf_finalize_launch")
 
+    def pf_noise_launch(self, seed, step, first_index, n, noise_ptr):
+        """Write the Philox standard-normal stream of (seed, step) for particles
+        first_index .. first_index + n into DEVICE float[n][3]."""
+        self._dev_check(self._L.ndt2d_pf_noise_launch(self.device_handle, seed, step, first_index,
+                                                      n, noise_ptr), "ndt2d_pf_noise_launch")
+
+    def pf_motion_launch(self, poses_ptr, n, dx, dy, dth, alphas, noise_ptr=None, seed=0, step=0,
+                         first_index=0):
+        """MotionModel::sample (reference src/motion_model.cpp:45-83) in place on DEVICE
+        poses[n][3]; noise_ptr = DEVICE float[n][3] standard normals or None (Philox)."""
+        a = _f64(alphas, (5,))
+        self._dev_check(self._L.ndt2d_pf_motion_launch(self.device_handle, poses_ptr, n, dx, dy,
+                                                       dth, dptr(a), noise_ptr, seed, step,
+                                                       first_index), "ndt2d_pf_motion_launch")
+
+    def pf_init_launch(self, poses_ptr, n, x, y, theta, sigma_x, sigma_y, sigma_theta,
+                       noise_ptr=None, seed=0, step=0, first_index=0):
+        """ParticleFilter::init sampling loop (reference src/particle_filter.cpp:53-65)."""
+        self._dev_check(self._L.ndt2d_pf_init_launch(self.device_handle, poses_ptr, n, x, y, theta,
+                                                     sigma_x, sigma_y, sigma_theta, noise_ptr,
+                                                     seed, step, first_index),
+                        "ndt2d_pf_init_launch")
+
+    def pose_moments_launch(self, poses_ptr, n, weights_ptr, stats_ptr):
+        """Moment sums of updateStatistics for DEVICE weights (None = uniform 1/n)."""
+        self._dev_check(self._L.ndt2d_pose_moments_launch(self.device_handle, poses_ptr, n,
+                                                          weights_ptr, stats_ptr),
+                        "ndt2d_pose_moments_launch")
+
     def set_stream(self, stream_ptr):
         self._dev_check(self._L.ndt2d_set_stream(self.device_handle, stream_ptr),
                         "ndt2d_set_stream")
@@ -308,3 +337,37 @@ def pf_measure(matcher, particles, points, cov_prev=None):
                                               len(pts), dptr(w), dptr(mean), dptr(cov)),
                    "pf_measure")
     return w, mean, cov.reshape(3, 3)
+
+
+def pf_update(matcher, particles, weights, dx, dy, dth, alphas, noise=None, seed=0, step=0,
+              cov_prev=None):
+    """ParticleFilter::update (reference src/particle_filter.cpp:71-76): the motion model
+    on every particle, then updateStatistics.  noise = float32[n, 3] standard normals, or
+    None for the device's Philox stream of (seed, step).  Returns (particles, normalised
+    weights, mean[3], cov[3, 3])."""
+    L = _capi.lib()
+    pa = _f64(particles, (-1, 3)).copy()
+    w = _f64(weights, (len(pa),)).copy()
+    a = _f64(alphas, (5,))
+    out = np.zeros(_capi.PF_RESULT_DOUBLES)
+    zp = None
+    if noise is not None:
+        z = np.ascontiguousarray(noise, dtype=np.float32).reshape(len(pa), 3)
+        zp = z.ctypes.data_as(C.POINTER(C.c_float))
+    matcher._dev_check(L.ndt2d_pf_update(matcher.device_handle, dptr(pa), len(pa), dx, dy, dth,
+                                         dptr(a), zp, seed, step, dptr(w), dptr(out)),
+                       "ndt2d_pf_update")
+    cov = np.zeros((3, 3)) if cov_prev is None else np.array(cov_prev, dtype=np.float64).reshape(3, 3)
+    return pa, w, out[1:4].copy(), statistics_covariance(out, cov)
+
+
+def statistics_covariance(out, cov_prev):
+    """cov_ after updateStatistics from an NDT2D_PF_RESULT_DOUBLES record: the x/y block
+    is overwritten (:208-211), (2,2) accumulates (:216), the rest is kept."""
+    cov = np.array(cov_prev, dtype=np.float64).reshape(3, 3).copy()
+    cov[0, 0] = out[4]
+    cov[0, 1] = out[5]
+    cov[1, 0] = out[5]
+    cov[1, 1] = out[6]
+    cov[2, 2] += out[7]
+    return cov

@@ -753,3 +753,69 @@ void orc_pf_update_statistics(const double * particles_xyt, double * weights,
     cov_inout[8] += weights[i] * d * d;
   }
 }
+
+/* ------------------------------------------------------------------------- */
+/* MotionModel                                                               */
+/* ------------------------------------------------------------------------- */
+
+/* MotionModel::sample, src/motion_model.cpp:45-83 */
+void orc_motion_sample(double dx, double dy, double dth, const double * alphas5,
+                       double * poses_xyt, size_t n, const float * z, double * params_out)
+{
+  const double a1 = alphas5[0], a2 = alphas5[1], a3 = alphas5[2], a4 = alphas5[3];
+  /* :49-52 */
+  const double trans = hypot(dx, dy);
+  const double rot1 = (trans > 0.01) ? atan2(dy, dx) : 0.0;
+  const double rot2 = orc_shortest_angular_distance(rot1, dth);
+  /* :55-58 */
+  const double rot1_ = fmin(fabs(orc_shortest_angular_distance(rot1, 0.0)),
+                            fabs(orc_shortest_angular_distance(rot1, M_PI)));
+  const double rot2_ = fmin(fabs(orc_shortest_angular_distance(rot2, 0.0)),
+                            fabs(orc_shortest_angular_distance(rot2, M_PI)));
+  /* :61-67 */
+  const double sigma_rot1 = sqrt(a1 * rot1_ * rot1_ + a2 * trans * trans);
+  const double sigma_trans = sqrt(a3 * trans * trans + a4 * rot1_ * rot1_ + a4 * rot2_ * rot2_);
+  const double sigma_rot2 = sqrt(a1 * rot2_ * rot2_ + a2 * trans * trans);
+  if (params_out)
+  {
+    params_out[0] = rot1;
+    params_out[1] = trans;
+    params_out[2] = rot2;
+    params_out[3] = sigma_rot1;
+    params_out[4] = sigma_trans;
+    params_out[5] = sigma_rot2;
+  }
+  /* :70-72 normal_distribution<float>(mean, sigma): parameters held as float */
+  const float m1 = (float)rot1, s1 = (float)sigma_rot1;
+  const float mt = (float)trans, st = (float)sigma_trans;
+  const float m2 = (float)rot2, s2 = (float)sigma_rot2;
+  for (size_t i = 0; i < n; ++i)
+  {
+    /* :76-78 */
+    const float r1 = z[3 * i] * s1 + m1;
+    const float t = z[3 * i + 1] * st + mt;
+    const float r2 = z[3 * i + 2] * s2 + m2;
+    double * pose = poses_xyt + 3 * i;
+    /* :80-82 */
+    pose[0] += t * cos(pose[2] + r1);
+    pose[1] += t * sin(pose[2] + r1);
+    pose[2] = orc_normalize_angle(pose[2] + r1 + r2);
+  }
+}
+
+/* ParticleFilter::init, src/particle_filter.cpp:53-69 (the sampling loop) */
+void orc_pf_init(double x, double y, double theta, double sigma_x, double sigma_y,
+                 double sigma_theta, double * poses_xyt, size_t n, const float * z)
+{
+  /* :56-58 normal_distribution<float>(mean, sigma) */
+  const float mx = (float)x, sx = (float)sigma_x;
+  const float my = (float)y, sy = (float)sigma_y;
+  const float mt = (float)theta, st = (float)sigma_theta;
+  for (size_t i = 0; i < n; ++i)
+  {
+    /* :62-64 float draws widened to double */
+    poses_xyt[3 * i] = z[3 * i] * sx + mx;
+    poses_xyt[3 * i + 1] = z[3 * i + 1] * sy + my;
+    poses_xyt[3 * i + 2] = orc_normalize_angle(z[3 * i + 2] * st + mt);
+  }
+}

@@ -16,6 +16,11 @@
  *     reference holds no test, fixture or golden vector for them, and the
  *     reference cannot be compiled here (Eigen3, rclcpp, pluginlib, tf2,
  *     angles are absent; no network).
+ *   - MotionModel::sample: pinned statistically only -- the reference's
+ *     scenario (test/particle_tests.cpp:74-140, 50 poses, tolerances 0.3/0.5)
+ *     is run in tests/test_particle_host.py; the reference's RNG is seeded by
+ *     std::random_device, so no bit-level vector can exist.  ParticleFilter::
+ *     init: PARITY UNPINNED (no reference test).
  *
  * Third-party arithmetic restated (not under /root/reference):
  *   Eigen3 (unpinned; 3.4.0 on ROS 2 Humble): fixed-size 2x2 inverse,
@@ -140,7 +145,21 @@ void orc_pf_measure_omp(const orc_matcher * m, const double * particles_xyt,
 void orc_pf_update_statistics(const double * particles_xyt, double * weights,
                               size_t n_particles, double * mean_out, double * cov_inout);
 
-/* ROS angles (restated): used by updateStatistics only. */
+/* MotionModel::sample (src/motion_model.cpp:45-83) with the three
+ * std::normal_distribution<float> draws per pose replaced by given standard
+ * normals z[3i..3i+2] (the reference seeds its mt19937 from random_device, so
+ * its draws are not reproducible): r = z * (float)sigma + (float)mean in float,
+ * as libstdc++'s normal_distribution<float> computes it.  params_out (optional)
+ * receives {rot1, trans, rot2, sigma_rot1, sigma_trans, sigma_rot2}. */
+void orc_motion_sample(double dx, double dy, double dth, const double * alphas5,
+                       double * poses_xyt, size_t n, const float * z, double * params_out);
+
+/* ParticleFilter::init sampling loop (src/particle_filter.cpp:53-69), same
+ * treatment of the draws (x, y, theta per particle, in that order). */
+void orc_pf_init(double x, double y, double theta, double sigma_x, double sigma_y,
+                 double sigma_theta, double * poses_xyt, size_t n, const float * z);
+
+/* ROS angles (restated): used by updateStatistics and the motion model. */
 double orc_normalize_angle(double a);
 double orc_shortest_angular_distance(double from, double to);
 

@@ -91,6 +91,8 @@ def lib():
     sig("orc_pf_measure", None, [vp, _dp, sz, _dp, sz, _dp, C.c_int])
     sig("orc_pf_measure_omp", None, [vp, _dp, sz, _dp, sz, _dp, C.c_int])
     sig("orc_pf_update_statistics", None, [_dp, _dp, sz, _dp, _dp])
+    sig("orc_motion_sample", None, [d, d, d, _dp, _dp, sz, C.POINTER(C.c_float), _dp])
+    sig("orc_pf_init", None, [d, d, d, d, d, d, _dp, sz, C.POINTER(C.c_float)])
     sig("orc_normalize_angle", d, [d])
     sig("orc_shortest_angular_distance", d, [d, d])
     _lib = L
@@ -317,3 +319,25 @@ def pf_update_statistics(particles, weights, cov_prev=None):
     lib().orc_pf_update_statistics(pap, w.ctypes.data_as(_dp), len(pa),
                                    mean.ctypes.data_as(_dp), cov.ctypes.data_as(_dp))
     return w, mean, cov.reshape(3, 3)
+
+
+def motion_sample(dx, dy, dth, alphas, poses, z):
+    """MotionModel::sample (reference motion_model.cpp:45-83) with given standard
+    normals z[n, 3] (float32).  Returns (new poses[n, 3], params[6])."""
+    ps = np.array(poses, dtype=np.float64).reshape(-1, 3).copy()
+    zz = np.ascontiguousarray(z, dtype=np.float32).reshape(-1, 3)
+    a, ap = _arr(alphas)
+    params = np.zeros(6)
+    lib().orc_motion_sample(dx, dy, dth, ap, ps.ctypes.data_as(_dp), len(ps),
+                            zz.ctypes.data_as(C.POINTER(C.c_float)), params.ctypes.data_as(_dp))
+    return ps, params
+
+
+def pf_init(x, y, theta, sigma_x, sigma_y, sigma_theta, z):
+    """ParticleFilter::init sampling loop (reference particle_filter.cpp:53-69)
+    with given standard normals z[n, 3] (float32).  Returns poses[n, 3]."""
+    zz = np.ascontiguousarray(z, dtype=np.float32).reshape(-1, 3)
+    ps = np.zeros((len(zz), 3))
+    lib().orc_pf_init(x, y, theta, sigma_x, sigma_y, sigma_theta, ps.ctypes.data_as(_dp),
+                      len(zz), zz.ctypes.data_as(C.POINTER(C.c_float)))
+    return ps
