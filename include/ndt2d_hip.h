@@ -209,6 +209,44 @@ int ndt2d_pf_update(ndt2d_handle h, double * h_poses_xyt, size_t n, double dx, d
                     double dth, const double * alphas5, const float * h_noise, uint64_t seed,
                     uint64_t step, double * h_weights, double * h_out);
 
+/* ---- LaserScan -> Scan conversion on the device ----
+ *
+ * The loop of NdtMapper::laserCallback that turns a sensor_msgs/LaserScan into
+ * the point list of an ndt_2d::Scan (src/ndt_mapper.cpp:385-453).  The message
+ * fields keep their ROS types (float32); motion_* is `translation` (:386-389),
+ * the odometry motion between the start and the end of the sweep; laser_* is
+ * laser_transform_; range_max is the node's range_max_ (NaN and longer ranges are
+ * dropped, :413,436); inverted is laser_inverted_ (descending visiting order,
+ * index 0 never visited, :410). */
+typedef struct ndt2d_laser_scan
+{
+  float angle_min, angle_increment;
+  double range_max;
+  int inverted;
+  double laser_x, laser_y, laser_theta;
+  double motion_x, motion_y, motion_theta;
+} ndt2d_laser_scan;
+/* d_ranges: device float[n_ranges]; d_points_xy_out: device double[n_ranges][2],
+ * filled with the kept points in the reference's order; d_info_out: device
+ * double[2] = {number of points kept, upper bound of max |point|}.  Asynchronous. */
+int ndt2d_convert_scan_launch(ndt2d_handle h, const float * d_ranges, size_t n_ranges,
+                              const ndt2d_laser_scan * scan, double * d_points_xy_out,
+                              double * d_info_out);
+/* Host-pointer convenience: H2D ranges, convert, D2H points (capacity n_ranges). */
+int ndt2d_convert_scan(ndt2d_handle h, const float * h_ranges, size_t n_ranges,
+                       const ndt2d_laser_scan * scan, double * h_points_xy_out,
+                       size_t * n_points_out);
+/* Conversion fused with matchScan's beam subsampling (src/scan_matcher_ndt.cpp:
+ * 95-96,110): the ranges go H2D (4 B/beam), the points and the beams of
+ * ndt2d_set_beams stay on the device.  Blocks for a 24-byte D2H of the counts.
+ * *n_beams_out == 0 (no point kept) leaves the context without beams. */
+int ndt2d_set_beams_from_ranges(ndt2d_handle h, const float * h_ranges, size_t n_ranges,
+                                const ndt2d_laser_scan * scan, size_t laser_max_beams,
+                                size_t * n_points_out, size_t * n_beams_out);
+/* The points of the last ndt2d_set_beams_from_ranges (device pointer, valid until
+ * the next conversion on this context) and their number. */
+const double * ndt2d_scan_points(ndt2d_handle h, size_t * n_points_out);
+
 /* Block until everything launched on the context's stream has finished. */
 int ndt2d_synchronize(ndt2d_handle h);
 /* GPU time (HIP events on the launch stream) of the dominant kernel -- the
@@ -292,6 +330,17 @@ int ndt2d_matcher_score_points(ndt2d_matcher * m, const double * points_xy, size
 /* ScanMatcherNDT::reset (:180-183). */
 int ndt2d_matcher_reset(ndt2d_matcher * m);
 int ndt2d_matcher_has_ndt(ndt2d_matcher * m);
+
+/* laserCallback's LaserScan -> Scan conversion (src/ndt_mapper.cpp:385-453) fused
+ * with matchScan: the raw ranges go to the device, where they are converted,
+ * de-skewed, subsampled and searched; *n_points_out (optional) = points the
+ * conversion kept.  Same outputs and conventions as ndt2d_matcher_match_scan on
+ * the converted points. */
+int ndt2d_matcher_match_laser_scan(ndt2d_matcher * m, const double * scan_pose_xyt,
+                                   const float * ranges, size_t n_ranges,
+                                   const ndt2d_laser_scan * scan, double * pose_inout,
+                                   double * covariance_out, double * score_out,
+                                   size_t * n_points_out);
 
 /* Additive batched interface (not in the reference's ScanMatcher): scores
  * n_poses poses in one launch; scores_out[i] == scorePoints(points, pose_i). */

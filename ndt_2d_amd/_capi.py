@@ -37,6 +37,14 @@ class MatchResult(C.Structure):
                 ("acc", C.c_double * 10), ("n_candidates", C.c_uint64)]
 
 
+class LaserScan(C.Structure):
+    """ndt2d_laser_scan"""
+    _fields_ = [("angle_min", C.c_float), ("angle_increment", C.c_float),
+                ("range_max", C.c_double), ("inverted", C.c_int),
+                ("laser_x", C.c_double), ("laser_y", C.c_double), ("laser_theta", C.c_double),
+                ("motion_x", C.c_double), ("motion_y", C.c_double), ("motion_theta", C.c_double)]
+
+
 class World(C.Structure):
     _fields_ = [("room_half", C.c_double), ("pillar_pitch", C.c_double),
                 ("pillar_half", C.c_double)]
@@ -80,6 +88,12 @@ SIGNATURES = {
     "ndt2d_pose_moments_launch": (C.c_int, [_vp, _vp, _sz, _vp, _vp]),
     "ndt2d_pf_update": (C.c_int, [_vp, _dp, _sz, _d, _d, _d, _dp, C.POINTER(C.c_float), _u64,
                                   _u64, _dp, _dp]),
+    "ndt2d_convert_scan_launch": (C.c_int, [_vp, _vp, _sz, C.POINTER(LaserScan), _vp, _vp]),
+    "ndt2d_convert_scan": (C.c_int, [_vp, C.POINTER(C.c_float), _sz, C.POINTER(LaserScan), _dp,
+                                     _szp]),
+    "ndt2d_set_beams_from_ranges": (C.c_int, [_vp, C.POINTER(C.c_float), _sz,
+                                              C.POINTER(LaserScan), _sz, _szp, _szp]),
+    "ndt2d_scan_points": (_vp, [_vp, _szp]),
     "ndt2d_synchronize": (C.c_int, [_vp]),
     "ndt2d_last_launch_ms": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "ndt2d_last_variant": (C.c_char_p, [_vp]),
@@ -94,6 +108,8 @@ SIGNATURES = {
     "ndt2d_matcher_match_scan": (C.c_int, [_vp, _dp, _dp, _sz, _dp, _dp, _dp]),
     "ndt2d_matcher_match_scan_ex": (C.c_int, [_vp, _dp, _dp, _sz, _dp, _dp, _dp, _dp, _sz,
                                              _szp, C.POINTER(C.c_uint64)]),
+    "ndt2d_matcher_match_laser_scan": (C.c_int, [_vp, _dp, C.POINTER(C.c_float), _sz,
+                                                 C.POINTER(LaserScan), _dp, _dp, _dp, _szp]),
     "ndt2d_matcher_prepare_search": (C.c_int, [_vp, _dp, _dp, _sz, _szp, _szp, _szp]),
     "ndt2d_matcher_finish_match": (C.c_int, [_vp, _dp, _dp, _dp, _dp]),
     "ndt2d_matcher_prepare_beams": (C.c_int, [_vp, _dp, _sz, _szp]),

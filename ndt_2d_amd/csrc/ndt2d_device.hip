@@ -67,6 +67,9 @@ struct ndt2d_context
 
   DeviceBuffer ws_match, ws_poses, record, stats, outer;
   DeviceBuffer tmp_scores, tmp_poses, tmp_noise;
+  // LaserScan conversion: ranges (floats), points, {n, rmax | n, use, rmax}
+  DeviceBuffer scan_ranges, scan_points, scan_info;
+  size_t n_scan_points = 0;
 
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
@@ -263,6 +266,9 @@ int ndt2d_destroy(ndt2d_handle h)
   release(h->tmp_scores);
   release(h->tmp_poses);
   release(h->tmp_noise);
+  release(h->scan_ranges);
+  release(h->scan_points);
+  release(h->scan_info);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -906,6 +912,151 @@ int ndt2d_pf_update(ndt2d_handle h, double * h_poses_xyt, size_t n, double dx, d
                               hipMemcpyDeviceToHost, h->stream));
   NDT2D_HIP(h, hipStreamSynchronize(h->stream));
   return NDT2D_OK;
+}
+
+}  // extern "C"
+
+namespace
+{
+
+ndt2d::ScanDesc scan_desc(const ndt2d_laser_scan & s)
+{
+  ndt2d::ScanDesc d;
+  d.angle_min = s.angle_min;
+  d.angle_increment = s.angle_increment;
+  d.range_max = s.range_max;
+  d.inverted = s.inverted != 0 ? 1 : 0;
+  d.laser_x = s.laser_x;
+  d.laser_y = s.laser_y;
+  // reference src/ndt_mapper.cpp:403-404 ("minor optimization"): host libm
+  d.cos_lt = std::cos(s.laser_theta);
+  d.sin_lt = std::sin(s.laser_theta);
+  d.motion_x = s.motion_x;
+  d.motion_y = s.motion_y;
+  d.motion_theta = s.motion_theta;
+  return d;
+}
+
+// H2D of the ranges into the context's scratch + conversion into scan_points;
+// scan_info[0..1] receives {n, rmax}.
+int upload_and_convert(ndt2d_context * h, const float * h_ranges, size_t n_ranges,
+                       const ndt2d_laser_scan * scan)
+{
+  int rc = ensure(h, h->scan_ranges, (n_ranges * sizeof(float) + sizeof(double) - 1) / sizeof(double));
+  if (rc != NDT2D_OK) return rc;
+  rc = ensure(h, h->scan_points, 2 * n_ranges);
+  if (rc != NDT2D_OK) return rc;
+  rc = ensure(h, h->scan_info, 8);
+  if (rc != NDT2D_OK) return rc;
+  NDT2D_HIP(h, hipMemcpyAsync(h->scan_ranges.ptr, h_ranges, n_ranges * sizeof(float),
+                              hipMemcpyHostToDevice, h->stream));
+  return ndt2d_convert_scan_launch(h, reinterpret_cast<const float *>(h->scan_ranges.ptr), n_ranges,
+                                   scan, h->scan_points.ptr, h->scan_info.ptr);
+}
+
+}  // namespace
+
+extern "C" {
+
+int ndt2d_convert_scan_launch(ndt2d_handle h, const float * d_ranges, size_t n_ranges,
+                              const ndt2d_laser_scan * scan, double * d_points_xy_out,
+                              double * d_info_out)
+{
+  if (h == nullptr) return NDT2D_ERR_INVALID;
+  if (d_ranges == nullptr || scan == nullptr || d_points_xy_out == nullptr ||
+      d_info_out == nullptr || n_ranges == 0 || n_ranges > (1u << 24))
+  {
+    return fail(h, NDT2D_ERR_INVALID, "ndt2d_convert_scan_launch: bad argument");
+  }
+  NDT2D_HIP(h, hipSetDevice(h->device));
+  hipError_t e = ndt2d::launch_convert_scan(d_ranges, static_cast<uint32_t>(n_ranges),
+                                            scan_desc(*scan), d_points_xy_out, d_info_out,
+                                            h->stream);
+  if (e != hipSuccess) return fail_hip(h, e, "launch_convert_scan");
+  return NDT2D_OK;
+}
+
+int ndt2d_convert_scan(ndt2d_handle h, const float * h_ranges, size_t n_ranges,
+                       const ndt2d_laser_scan * scan, double * h_points_xy_out,
+                       size_t * n_points_out)
+{
+  if (h == nullptr) return NDT2D_ERR_INVALID;
+  if (scan == nullptr || n_points_out == nullptr || (n_ranges > 0 && h_ranges == nullptr) ||
+      (n_ranges > 0 && h_points_xy_out == nullptr))
+  {
+    return fail(h, NDT2D_ERR_INVALID, "ndt2d_convert_scan: bad argument");
+  }
+  *n_points_out = 0;
+  if (n_ranges == 0) return NDT2D_OK;  // an empty message holds no points
+  NDT2D_HIP(h, hipSetDevice(h->device));
+  int rc = upload_and_convert(h, h_ranges, n_ranges, scan);
+  if (rc != NDT2D_OK) return rc;
+  double info[2] = {0.0, 0.0};
+  NDT2D_HIP(h, hipMemcpyAsync(info, h->scan_info.ptr, sizeof(info), hipMemcpyDeviceToHost, h->stream));
+  NDT2D_HIP(h, hipStreamSynchronize(h->stream));
+  const size_t n = static_cast<size_t>(info[0]);
+  h->n_scan_points = n;
+  if (n > 0)
+  {
+    NDT2D_HIP(h, hipMemcpyAsync(h_points_xy_out, h->scan_points.ptr, 2 * n * sizeof(double),
+                                hipMemcpyDeviceToHost, h->stream));
+    NDT2D_HIP(h, hipStreamSynchronize(h->stream));
+  }
+  *n_points_out = n;
+  return NDT2D_OK;
+}
+
+int ndt2d_set_beams_from_ranges(ndt2d_handle h, const float * h_ranges, size_t n_ranges,
+                                const ndt2d_laser_scan * scan, size_t laser_max_beams,
+                                size_t * n_points_out, size_t * n_beams_out)
+{
+  if (h == nullptr) return NDT2D_ERR_INVALID;
+  if (scan == nullptr || n_beams_out == nullptr || (n_ranges > 0 && h_ranges == nullptr) ||
+      laser_max_beams > (1u << 20))
+  {
+    return fail(h, NDT2D_ERR_INVALID, "ndt2d_set_beams_from_ranges: bad argument");
+  }
+  *n_beams_out = 0;
+  if (n_points_out != nullptr) *n_points_out = 0;
+  h->n_scan_points = 0;
+  if (n_ranges == 0 || laser_max_beams == 0) return NDT2D_OK;
+  NDT2D_HIP(h, hipSetDevice(h->device));
+  int rc = upload_and_convert(h, h_ranges, n_ranges, scan);
+  if (rc != NDT2D_OK) return rc;
+  const size_t cap = std::min(laser_max_beams, n_ranges);
+  rc = ensure(h, h->beams, 2 * cap + 2);
+  if (rc != NDT2D_OK) return rc;
+  // the beam buffer may still be the target of a pending staged upload
+  if (h->stage_beams.pending)
+  {
+    NDT2D_HIP(h, hipEventSynchronize(h->stage_beams.done));
+    h->stage_beams.pending = false;
+  }
+  hipError_t e = ndt2d::launch_subsample(h->scan_points.ptr, h->scan_info.ptr,
+                                         static_cast<uint32_t>(laser_max_beams), h->beams.ptr,
+                                         h->scan_info.ptr + 2, h->stream);
+  if (e != hipSuccess) return fail_hip(h, e, "launch_subsample");
+  double info[3] = {0.0, 0.0, 0.0};
+  NDT2D_HIP(h, hipMemcpyAsync(info, h->scan_info.ptr + 2, sizeof(info), hipMemcpyDeviceToHost,
+                              h->stream));
+  NDT2D_HIP(h, hipStreamSynchronize(h->stream));
+  h->n_scan_points = static_cast<size_t>(info[0]);
+  if (n_points_out != nullptr) *n_points_out = h->n_scan_points;
+  const size_t use = static_cast<size_t>(info[1]);
+  *n_beams_out = use;
+  if (use > 0)
+  {
+    h->n_beams = use;
+    h->beam_rmax = info[2];
+  }
+  return NDT2D_OK;
+}
+
+const double * ndt2d_scan_points(ndt2d_handle h, size_t * n_points_out)
+{
+  if (h == nullptr) return nullptr;
+  if (n_points_out != nullptr) *n_points_out = h->n_scan_points;
+  return h->scan_points.ptr;
 }
 
 int ndt2d_synchronize(ndt2d_handle h)

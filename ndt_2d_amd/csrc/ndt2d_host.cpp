@@ -266,6 +266,7 @@ struct ndt2d_matcher
   int build_mode = 0;             // 0 auto, 1 host, 2 device
   // state of the last prepare_search (subsampled beams + visited offsets)
   std::vector<double> beams, dth, dlin;
+  size_t n_use = 0;               // beams in use (the N of `best / N`, :148)
   bool search_ready = false;
 };
 
@@ -281,6 +282,33 @@ int mfail(ndt2d_matcher * m, int code, const std::string & msg)
 int dev_fail(ndt2d_matcher * m, int code, const char * what)
 {
   return mfail(m, code, std::string(what) + ": " + ndt2d_last_error(m->dev));
+}
+
+// The visited offsets of the search and the per-theta cos/sin (reference
+// src/scan_matcher_ndt.cpp:103-107,117,119), uploaded once the beams are on the device.
+int prepare_tables(ndt2d_matcher * m, const double * scan_pose_xyt, size_t use, size_t * n_th_out,
+                   size_t * n_lin_out)
+{
+  m->dth = search_offsets(m->angular_size, m->angular_res);
+  m->dlin = search_offsets(m->linear_size, m->linear_res);
+  const size_t n_th = m->dth.size(), n_lin = m->dlin.size();
+  if (n_th_out != nullptr) *n_th_out = n_th;
+  if (n_lin_out != nullptr) *n_lin_out = n_lin;
+  m->search_ready = false;
+  if (use == 0 || n_th == 0 || n_lin == 0 || !m->have_ndt) return NDT2D_OK;  // nothing to upload
+
+  std::vector<double> cos_th(n_th), sin_th(n_th);
+  for (size_t i = 0; i < n_th; ++i)
+  {
+    // reference src/scan_matcher_ndt.cpp:106-107
+    cos_th[i] = std::cos(scan_pose_xyt[2] + m->dth[i]);
+    sin_th[i] = std::sin(scan_pose_xyt[2] + m->dth[i]);
+  }
+  int rc = ndt2d_set_search(m->dev, scan_pose_xyt[0], scan_pose_xyt[1], m->dth.data(), cos_th.data(),
+                            sin_th.data(), n_th, m->dlin.data(), n_lin);
+  if (rc != NDT2D_OK) return dev_fail(m, rc, "ndt2d_set_search");
+  m->search_ready = true;
+  return NDT2D_OK;
 }
 
 }  // namespace
@@ -418,37 +446,23 @@ int ndt2d_matcher_prepare_search(ndt2d_matcher * m, const double * scan_pose_xyt
   if (m == nullptr || scan_pose_xyt == nullptr) return NDT2D_ERR_INVALID;
   if (n_points > 0 && points_xy == nullptr) return mfail(m, NDT2D_ERR_INVALID, "null points");
   m->beams = subsample(points_xy, n_points, m->laser_max_beams);
-  m->dth = search_offsets(m->angular_size, m->angular_res);
-  m->dlin = search_offsets(m->linear_size, m->linear_res);
   const size_t use = m->beams.size() / 2;
-  const size_t n_th = m->dth.size(), n_lin = m->dlin.size();
-  if (n_th_out != nullptr) *n_th_out = n_th;
-  if (n_lin_out != nullptr) *n_lin_out = n_lin;
+  m->n_use = use;
   if (n_beams_out != nullptr) *n_beams_out = use;
   m->search_ready = false;
-  if (use == 0 || n_th == 0 || n_lin == 0 || !m->have_ndt) return NDT2D_OK;  // nothing to upload
-
-  std::vector<double> cos_th(n_th), sin_th(n_th);
-  for (size_t i = 0; i < n_th; ++i)
+  if (use > 0 && m->have_ndt)
   {
-    // reference src/scan_matcher_ndt.cpp:106-107
-    cos_th[i] = std::cos(scan_pose_xyt[2] + m->dth[i]);
-    sin_th[i] = std::sin(scan_pose_xyt[2] + m->dth[i]);
+    int rc = ndt2d_set_beams(m->dev, m->beams.data(), use);
+    if (rc != NDT2D_OK) return dev_fail(m, rc, "ndt2d_set_beams");
   }
-  int rc = ndt2d_set_beams(m->dev, m->beams.data(), use);
-  if (rc != NDT2D_OK) return dev_fail(m, rc, "ndt2d_set_beams");
-  rc = ndt2d_set_search(m->dev, scan_pose_xyt[0], scan_pose_xyt[1], m->dth.data(), cos_th.data(),
-                        sin_th.data(), n_th, m->dlin.data(), n_lin);
-  if (rc != NDT2D_OK) return dev_fail(m, rc, "ndt2d_set_search");
-  m->search_ready = true;
-  return NDT2D_OK;
+  return prepare_tables(m, scan_pose_xyt, use, n_th_out, n_lin_out);
 }
 
 int ndt2d_matcher_finish_match(ndt2d_matcher * m, const double * record, double * pose_inout,
                                double * covariance_out, double * score_out)
 {
   if (m == nullptr || record == nullptr || score_out == nullptr) return NDT2D_ERR_INVALID;
-  const size_t use = m->beams.size() / 2;
+  const size_t use = m->n_use;
   const size_t n_lin = m->dlin.size();
   const double best_score = record[0];
   if (record[1] >= 0.0 && pose_inout != nullptr && n_lin > 0)
@@ -558,6 +572,47 @@ int ndt2d_matcher_match_scan(ndt2d_matcher * m, const double * scan_pose_xyt,
                                      covariance_out, score_out, nullptr, 0, nullptr, nullptr);
 }
 
+int ndt2d_matcher_match_laser_scan(ndt2d_matcher * m, const double * scan_pose_xyt,
+                                   const float * ranges, size_t n_ranges,
+                                   const ndt2d_laser_scan * scan, double * pose_inout,
+                                   double * covariance_out, double * score_out,
+                                   size_t * n_points_out)
+{
+  if (m == nullptr || score_out == nullptr || scan_pose_xyt == nullptr || scan == nullptr)
+  {
+    return NDT2D_ERR_INVALID;
+  }
+  if (n_ranges > 0 && ranges == nullptr) return mfail(m, NDT2D_ERR_INVALID, "null ranges");
+  if (n_points_out != nullptr) *n_points_out = 0;
+  // `if (!ndt_) return 0.0;` (reference src/scan_matcher_ndt.cpp:80): outputs untouched
+  if (!m->have_ndt)
+  {
+    *score_out = 0.0;
+    return NDT2D_OK;
+  }
+  size_t n_points = 0, use = 0;
+  int rc = ndt2d_set_beams_from_ranges(m->dev, ranges, n_ranges, scan, m->laser_max_beams,
+                                       &n_points, &use);
+  if (rc != NDT2D_OK) return dev_fail(m, rc, "ndt2d_set_beams_from_ranges");
+  if (n_points_out != nullptr) *n_points_out = n_points;
+  m->beams.clear();
+  m->n_use = use;
+  size_t n_th = 0, n_lin = 0;
+  rc = prepare_tables(m, scan_pose_xyt, use, &n_th, &n_lin);
+  if (rc != NDT2D_OK) return rc;
+  double record[NDT2D_MATCH_RECORD_DOUBLES] = {0, -1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (m->search_ready)
+  {
+    ndt2d_match_result res;
+    rc = ndt2d_match(m->dev, 0, n_th, nullptr, &res);
+    if (rc != NDT2D_OK) return dev_fail(m, rc, "ndt2d_match");
+    record[0] = res.best_score;
+    record[1] = res.best_index == NDT2D_NO_INDEX ? -1.0 : static_cast<double>(res.best_index);
+    for (int i = 0; i < 10; ++i) record[2 + i] = res.acc[i];
+  }
+  return ndt2d_matcher_finish_match(m, record, pose_inout, covariance_out, score_out);
+}
+
 int ndt2d_matcher_score_poses(ndt2d_matcher * m, const double * points_xy, size_t n_points,
                               const double * poses_xyt, size_t n_poses, double * scores_out)
 {
@@ -595,6 +650,7 @@ int ndt2d_matcher_prepare_beams(ndt2d_matcher * m, const double * points_xy, siz
   if (n_points > 0 && points_xy == nullptr) return mfail(m, NDT2D_ERR_INVALID, "null points");
   m->beams = subsample(points_xy, n_points, m->laser_max_beams);
   const size_t use = m->beams.size() / 2;
+  m->n_use = use;
   if (n_beams_out != nullptr) *n_beams_out = use;
   if (use == 0) return NDT2D_OK;
   int rc = ndt2d_set_beams(m->dev, m->beams.data(), use);

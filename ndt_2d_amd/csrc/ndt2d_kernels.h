@@ -147,6 +147,25 @@ hipError_t launch_pf_init(double * poses_xyt, uint64_t n, const InitParams & par
 hipError_t launch_pose_moments(const double * poses_xyt, uint64_t n, const double * weights,
                                double * workspace, double * stats_out, hipStream_t stream);
 
+// LaserScan -> Scan conversion + beam subsampling (ndt2d_scan.hip).  cos_lt / sin_lt
+// are the host libm values of reference src/ndt_mapper.cpp:403-404.
+struct ScanDesc
+{
+  float angle_min, angle_increment;
+  double range_max;
+  int inverted;
+  double laser_x, laser_y, cos_lt, sin_lt;
+  double motion_x, motion_y, motion_theta;
+};
+// points_xy: [n_ranges][2]; info_out[2] = {points kept, upper bound of max |point|}
+hipError_t launch_convert_scan(const float * ranges, uint32_t n_ranges, const ScanDesc & desc,
+                               double * points_xy, double * info_out, hipStream_t stream);
+// beams_xy: [max_beams][2]; scan_info = launch_convert_scan's record;
+// info_out[3] = {points, beams used, upper bound of max |beam|}
+hipError_t launch_subsample(const double * points_xy, const double * scan_info,
+                            uint32_t max_beams, double * beams_xy, double * info_out,
+                            hipStream_t stream);
+
 // Lane-per-candidate search (ndt2d_match_lane.hip).  outer: device scratch of
 // match_lane_outer_doubles() doubles for the rotated-beam table; workspace
 // receives one partial record per wave (*n_workers_out of them).

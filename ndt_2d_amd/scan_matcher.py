@@ -154,6 +154,43 @@ class ScanMatcherNDT:
                     covariance=cov.reshape(3, 3) if has else None,
                     n_candidates=ncand.value, best_index=best.value, scores=scores)
 
+    @staticmethod
+    def _laser_scan(angle_min, angle_increment, range_max, inverted, laser, motion):
+        return _capi.LaserScan(angle_min, angle_increment, range_max, 1 if inverted else 0,
+                               laser[0], laser[1], laser[2], motion[0], motion[1], motion[2])
+
+    def convertScan(self, ranges, angle_min, angle_increment, range_max, inverted=False,
+                    laser=(0.0, 0.0, 0.0), motion=(0.0, 0.0, 0.0)):
+        """LaserScan -> Scan points on the device (reference src/ndt_mapper.cpp:385-453):
+        ranges float32[n]; laser = laser_transform_; motion = odometry motion over the
+        sweep (`translation`, :386-389).  Returns points[m, 2]."""
+        r = np.ascontiguousarray(ranges, dtype=np.float32)
+        d = self._laser_scan(angle_min, angle_increment, range_max, inverted, laser, motion)
+        out = np.zeros((max(len(r), 1), 2), dtype=np.float64)
+        n = C.c_size_t(0)
+        self._dev_check(self._L.ndt2d_convert_scan(
+            self.device_handle, r.ctypes.data_as(C.POINTER(C.c_float)), len(r), C.byref(d),
+            dptr(out), C.byref(n)), "ndt2d_convert_scan")
+        return out[:n.value].copy()
+
+    def matchLaserScan(self, scan_pose, ranges, angle_min, angle_increment, range_max,
+                       inverted=False, laser=(0.0, 0.0, 0.0), motion=(0.0, 0.0, 0.0), pose=None):
+        """Conversion fused with matchScan: only the raw ranges cross PCIe.  Returns
+        dict(score, pose, covariance, n_points)."""
+        sp = _f64(scan_pose, (3,))
+        r = np.ascontiguousarray(ranges, dtype=np.float32)
+        d = self._laser_scan(angle_min, angle_increment, range_max, inverted, laser, motion)
+        pose_io = np.array([0.0, 0.0, 0.0] if pose is None else pose, dtype=np.float64)
+        cov = np.full(9, np.nan)
+        score = C.c_double(0.0)
+        npts = C.c_size_t(0)
+        self._check(self._L.ndt2d_matcher_match_laser_scan(
+            self._m, dptr(sp), r.ctypes.data_as(C.POINTER(C.c_float)), len(r), C.byref(d),
+            dptr(pose_io), dptr(cov), C.byref(score), C.byref(npts)), "matchLaserScan")
+        has = bool(self._L.ndt2d_matcher_has_ndt(self._m))
+        return dict(score=score.value, pose=pose_io,
+                    covariance=cov.reshape(3, 3) if has else None, n_points=npts.value)
+
     def scoreScan(self, scan_pose, points):
         sp = _f64(scan_pose, (3,))
         pts = _f64(points, (-1, 2))

@@ -819,3 +819,70 @@ void orc_pf_init(double x, double y, double theta, double sigma_x, double sigma_
     poses_xyt[3 * i + 2] = orc_normalize_angle(z[3 * i + 2] * st + mt);
   }
 }
+
+/* ------------------------------------------------------------------------- */
+/* LaserScan -> Scan conversion                                              */
+/* ------------------------------------------------------------------------- */
+
+/* NdtMapper::laserCallback, src/ndt_mapper.cpp:385-453 */
+size_t orc_convert_scan(const float * ranges, size_t n_ranges, const orc_laser_scan * scan,
+                        double * points_xy_out)
+{
+  /* :391-394 */
+  const double per_x = scan->motion_x / n_ranges;
+  const double per_y = scan->motion_y / n_ranges;
+  const double per_th = scan->motion_theta / n_ranges;
+  /* :403-404 */
+  const double cos_lt = cos(scan->laser_theta);
+  const double sin_lt = sin(scan->laser_theta);
+  const double range_max = scan->range_max;
+  size_t n_out = 0;
+  if (scan->inverted)
+  {
+    if (n_ranges == 0) return 0;  /* size() - 1 would wrap in the reference */
+    /* :410 `for (i = size - 1; i > 0; --i)`: index 0 is never visited */
+    for (size_t i = n_ranges - 1; i > 0; --i)
+    {
+      /* :413 */
+      if (isnan(ranges[i]) || ranges[i] > range_max) continue;
+      /* :415 float arithmetic (size_t * float -> float), negated, widened */
+      const float a = -(scan->angle_min + (float)i * scan->angle_increment);
+      const double angle = a;
+      const double lx = cos(angle) * ranges[i];
+      const double ly = sin(angle) * ranges[i];
+      /* :419-420 */
+      const double px = cos_lt * lx - sin_lt * ly + scan->laser_x;
+      const double py = sin_lt * lx + cos_lt * ly + scan->laser_y;
+      /* :422-426 */
+      const double cos_tt = cos(scan->motion_theta - (per_th * i));
+      const double sin_tt = sin(scan->motion_theta - (per_th * i));
+      points_xy_out[2 * n_out] = cos_tt * px - sin_tt * py + (scan->motion_x - (per_x * i));
+      points_xy_out[2 * n_out + 1] = sin_tt * px + cos_tt * py + (scan->motion_y - (per_y * i));
+      ++n_out;
+    }
+  }
+  else
+  {
+    /* :433 */
+    for (size_t i = 0; i < n_ranges; ++i)
+    {
+      /* :436 */
+      if (isnan(ranges[i]) || ranges[i] > range_max) continue;
+      /* :438 */
+      const float a = (scan->angle_min + (float)i * scan->angle_increment);
+      const double angle = a;
+      const double lx = cos(angle) * ranges[i];
+      const double ly = sin(angle) * ranges[i];
+      /* :442-443 */
+      const double px = cos_lt * lx - sin_lt * ly + scan->laser_x;
+      const double py = sin_lt * lx + cos_lt * ly + scan->laser_y;
+      /* :445-448 */
+      const double cos_tt = cos(per_th * i);
+      const double sin_tt = sin(per_th * i);
+      points_xy_out[2 * n_out] = cos_tt * px - sin_tt * py + (per_x * i);
+      points_xy_out[2 * n_out + 1] = sin_tt * px + cos_tt * py + (per_y * i);
+      ++n_out;
+    }
+  }
+  return n_out;
+}

@@ -159,6 +159,25 @@ void orc_motion_sample(double dx, double dy, double dth, const double * alphas5,
 void orc_pf_init(double x, double y, double theta, double sigma_x, double sigma_y,
                  double sigma_theta, double * poses_xyt, size_t n, const float * z);
 
+/* LaserScan -> Scan points, the conversion loop of NdtMapper::laserCallback
+ * (src/ndt_mapper.cpp:385-453).  The message fields keep their ROS types
+ * (sensor_msgs/LaserScan: float32 ranges, angle_min, angle_increment);
+ * motion_* is `translation` (:386-389), the odometry motion between the start
+ * and the end of the sweep; laser_* is laser_transform_.  Writes the kept
+ * points (NaN / beyond range_max dropped, :413,436) in the reference's order
+ * (descending index, index 0 never visited, when inverted: :410) and returns
+ * their number. */
+typedef struct orc_laser_scan
+{
+  float angle_min, angle_increment;
+  double range_max;
+  int inverted;
+  double laser_x, laser_y, laser_theta;
+  double motion_x, motion_y, motion_theta;
+} orc_laser_scan;
+size_t orc_convert_scan(const float * ranges, size_t n_ranges, const orc_laser_scan * scan,
+                        double * points_xy_out);
+
 /* ROS angles (restated): used by updateStatistics and the motion model. */
 double orc_normalize_angle(double a);
 double orc_shortest_angular_distance(double from, double to);

@@ -341,3 +341,24 @@ def pf_init(x, y, theta, sigma_x, sigma_y, sigma_theta, z):
     lib().orc_pf_init(x, y, theta, sigma_x, sigma_y, sigma_theta, ps.ctypes.data_as(_dp),
                       len(zz), zz.ctypes.data_as(C.POINTER(C.c_float)))
     return ps
+
+
+class OrcLaserScan(C.Structure):
+    _fields_ = [("angle_min", C.c_float), ("angle_increment", C.c_float),
+                ("range_max", C.c_double), ("inverted", C.c_int),
+                ("laser_x", C.c_double), ("laser_y", C.c_double), ("laser_theta", C.c_double),
+                ("motion_x", C.c_double), ("motion_y", C.c_double), ("motion_theta", C.c_double)]
+
+
+def convert_scan(ranges, angle_min, angle_increment, range_max, inverted=False,
+                 laser=(0.0, 0.0, 0.0), motion=(0.0, 0.0, 0.0)):
+    """LaserScan -> Scan points (reference ndt_mapper.cpp:385-453).  Returns points[m, 2]."""
+    r = np.ascontiguousarray(ranges, dtype=np.float32)
+    d = OrcLaserScan(angle_min, angle_increment, range_max, 1 if inverted else 0,
+                     laser[0], laser[1], laser[2], motion[0], motion[1], motion[2])
+    out = np.zeros((max(len(r), 1), 2))
+    f = lib().orc_convert_scan
+    f.restype = C.c_size_t
+    f.argtypes = [C.POINTER(C.c_float), C.c_size_t, C.POINTER(OrcLaserScan), _dp]
+    n = f(r.ctypes.data_as(C.POINTER(C.c_float)), len(r), C.byref(d), out.ctypes.data_as(_dp))
+    return out[:n].copy()
