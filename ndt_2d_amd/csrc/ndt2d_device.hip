@@ -1090,6 +1090,7 @@ int ndt2d_set_variant(ndt2d_handle h, const char * name)
   else if (std::strcmp(name, "wave-lds") == 0) h->force_variant = ndt2d::kVariantWave | ndt2d::kVariantLds;
   else if (std::strcmp(name, "wave-global") == 0) h->force_variant = ndt2d::kVariantWave | ndt2d::kVariantGlobal;
   else if (std::strcmp(name, "lane") == 0) h->force_variant = ndt2d::kVariantLane;
+  else if (std::strcmp(name, "lane-noskip") == 0) h->force_variant = ndt2d::kVariantLane | ndt2d::kVariantNoSkip;
   else if (std::strcmp(name, "dense") == 0) h->force_variant = ndt2d::kVariantDense;
   else return fail(h, NDT2D_ERR_INVALID, "ndt2d_set_variant: unknown variant");
   return NDT2D_OK;

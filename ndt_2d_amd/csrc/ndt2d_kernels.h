@@ -171,8 +171,10 @@ hipError_t launch_subsample(const double * points_xy, const double * scan_info,
 // receives one partial record per wave (*n_workers_out of them).
 size_t match_lane_outer_doubles(const MatchArgs & args);
 bool match_lane_supported(const MatchArgs & args, size_t lds_per_block);
+// no_skip: every beam of every candidate takes the exact path (no occupancy / bound
+// / negligible-term skipping) -- the bit-exactness control for the skipping logic.
 hipError_t launch_match_lane(const MatchArgs & args, double * outer, double * workspace,
-                             uint32_t max_workers, int cus, size_t lds_per_block,
+                             uint32_t max_workers, int cus, size_t lds_per_block, bool no_skip,
                              hipStream_t stream, uint32_t * n_workers_out, bool * lds_records_out);
 
 // Particle scoring with per-wave compaction of the occupied (pose, beam) pairs
@@ -183,7 +185,7 @@ hipError_t launch_poses_compact(const PosesArgs & args, int cus, hipStream_t str
 
 // force_variant: grid placement in the low bits, candidate mapping above them
 enum { kVariantAuto = 0, kVariantLds = 1, kVariantGlobal = 2, kVariantGridMask = 3,
-       kVariantWave = 4, kVariantLane = 8, kVariantDense = 16 };
+       kVariantWave = 4, kVariantLane = 8, kVariantDense = 16, kVariantNoSkip = 32 };
 
 }  // namespace ndt2d
 

@@ -459,7 +459,8 @@ hipError_t launch_match(const MatchArgs & args_in, double * workspace, double * 
   if (use_lane)
   {
     e = launch_match_lane(args, outer, workspace, kMaxMatchBlocks * kMatchWaves, lim.cus,
-                          lim.lds_per_block, stream, &n_workers, &lane_lds_records);
+                          lim.lds_per_block, (force_variant & kVariantNoSkip) != 0, stream,
+                          &n_workers, &lane_lds_records);
     if (e != hipSuccess) return e;
   }
   else

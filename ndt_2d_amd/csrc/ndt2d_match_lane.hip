@@ -54,6 +54,9 @@ constexpr double kFracScale = 65536.0;
 constexpr int kMapStride = 256;      // map row stride in bytes = 2^8 cells
 constexpr int kMaxMapCells = 256;    // cell coordinate is one byte
 constexpr uint32_t kNearUnits = 4;   // guard band around cell boundaries, in 2^-16 cells
+// widening of a map sub-cell's box (fraction of a sub-cell) when its exponent bound
+// is taken: 16 x the rounding of the fixed-point coordinate that selects it
+constexpr double kBoxMargin = 1.0 / 1024.0;
 constexpr double kTwo24 = 16777216.0;
 constexpr double kTwo52 = 4503599627370496.0;
 
@@ -71,7 +74,48 @@ struct LaneGeom
   // grid.  For small grids it is the whole grid.
   int32_t win_x0, win_y0, win_w, win_h;
   double k_min, k_max_x, k_max_y;  // clamp of the per-beam fixed-point coordinate
+  int32_t no_skip;  // control mode: every beam takes the exact path
 };
+
+// Upper bound of Cell::score's exponent e(p) = q^T h q, q = p - mean (h = -0.5 *
+// information, packed record rec) over the box [x0, x1] x [y0, y1].  For a
+// negative definite h the form is concave: its maximum over the box is 0 at the
+// mean if the box holds it, else it lies on one of the four edges, where the
+// restriction is a concave parabola whose clamped vertex is found in closed form.
+// Anything else (NaN / degenerate information) returns +inf: no claim.  The slack
+// covers the rounding of this evaluation and of the reference's own.
+__device__ __forceinline__ double exponent_upper_bound(const double * rec, double x0, double x1,
+                                                       double y0, double y1)
+{
+  const double mx = rec[0], my = rec[1], h00 = rec[2], h01 = rec[3], h11 = rec[4];
+  if (!(h00 < 0.0 && h11 < 0.0 && h00 * h11 - h01 * h01 > 0.0)) return HUGE_VAL;
+  const double a0 = x0 - mx, a1 = x1 - mx, b0 = y0 - my, b1 = y1 - my;
+  double best;
+  if (a0 <= 0.0 && a1 >= 0.0 && b0 <= 0.0 && b1 >= 0.0)
+  {
+    best = 0.0;
+  }
+  else
+  {
+    best = -HUGE_VAL;
+    const double qa[2] = {a0, a1}, qb[2] = {b0, b1};
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+    {
+      // edge x = const: maximise over q1 in [b0, b1]
+      double q0 = qa[k];
+      double q1 = fmin(fmax(-h01 * q0 / h11, b0), b1);
+      best = fmax(best, h00 * q0 * q0 + 2.0 * h01 * q0 * q1 + h11 * q1 * q1);
+      // edge y = const: maximise over q0 in [a0, a1]
+      q1 = qb[k];
+      q0 = fmin(fmax(-h01 * q1 / h00, a0), a1);
+      best = fmax(best, h00 * q0 * q0 + 2.0 * h01 * q0 * q1 + h11 * q1 * q1);
+    }
+  }
+  const double am = fmax(fabs(a0), fabs(a1)), bm = fmax(fabs(b0), fabs(b1));
+  const double magnitude = fabs(h00) * am * am + 2.0 * fabs(h01) * am * bm + fabs(h11) * bm * bm;
+  return best + (1e-9 * magnitude + 1e-6);
+}
 
 // points_outer for the slab (reference :106-115) plus the packed fixed-point
 // map coordinate of each rotated beam:
@@ -93,26 +137,50 @@ __global__ void __launch_bounds__(256) outer_table_kernel(const MatchArgs a, dou
     const uint32_t n_map = static_cast<uint32_t>(kMapStride) * geo.map_h;
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_map; i += gridDim.x * 256)
     {
-      // map sub-cell (mx, my) and its eight neighbours -> parent grid cells
+      // map sub-cell (mx, my): its box in the world, widened by kBoxMargin of a
+      // sub-cell so that it holds every point whose rounded fixed-point coordinate
+      // lands in this sub-cell, and the grid cells that widened box overlaps (its
+      // own, plus the neighbours across a cell boundary it touches)
       const int32_t mx = static_cast<int32_t>(i & (kMapStride - 1));
       const int32_t my = static_cast<int32_t>(i >> 8);
-      uint32_t self = 0, around = 0;
-      for (int32_t b = -1; b <= 1; ++b)
+      const int32_t sub = 1 << geo.sub_log2;
+      const double sub_size = g.cell_size / static_cast<double>(sub);
+      const int32_t cx = (mx >> geo.sub_log2) - geo.pad + geo.win_x0;
+      const int32_t cy = (my >> geo.sub_log2) - geo.pad + geo.win_y0;
+      const int32_t lx = mx & (sub - 1), ly = my & (sub - 1);
+      const double x0 = g.origin_x + (static_cast<double>(cx) * sub + lx - kBoxMargin) * sub_size;
+      const double y0 = g.origin_y + (static_cast<double>(cy) * sub + ly - kBoxMargin) * sub_size;
+      const double x1 = x0 + (1.0 + 2.0 * kBoxMargin) * sub_size;
+      const double y1 = y0 + (1.0 + 2.0 * kBoxMargin) * sub_size;
+      uint32_t self = 0;
+      double bound = -HUGE_VAL;
+      for (int32_t b = (ly == 0 ? -1 : 0); b <= (ly == sub - 1 ? 1 : 0); ++b)
       {
-        for (int32_t c = -1; c <= 1; ++c)
+        for (int32_t c = (lx == 0 ? -1 : 0); c <= (lx == sub - 1 ? 1 : 0); ++c)
         {
-          const int32_t nx = ((mx + c) >> geo.sub_log2) - geo.pad + geo.win_x0;
-          const int32_t ny = ((my + b) >> geo.sub_log2) - geo.pad + geo.win_y0;
+          const int32_t nx = cx + c, ny = cy + b;
           if (nx >= 0 && nx < sx && ny >= 0 && ny < sy)
           {
             const uint32_t cell = static_cast<uint32_t>(ny * sx + nx);
             const uint32_t o = (g.occ_bits[cell >> 5] >> (cell & 31u)) & 1u;
-            around |= o;
             if (b == 0 && c == 0) self = o;
+            if (o != 0)
+            {
+              const double e = exponent_upper_bound(g.cells_lds_image + static_cast<size_t>(cell) * kCellDoubles,
+                                                    x0, x1, y0, y1);
+              bound = !(e <= bound) ? e : bound;   // NaN-propagating max
+            }
           }
         }
       }
-      map_out[i] = static_cast<uint8_t>(self | (around << 1));
+      // level 0: no distribution can be hit from here; level l >= 1: every exponent
+      // reachable from this sub-cell is <= l - 63 (level 63: no claim)
+      uint32_t level = 0;
+      if (bound > -HUGE_VAL || bound != bound)
+      {
+        level = !(bound <= 0.0) ? 63u : (bound < -62.0 ? 1u : static_cast<uint32_t>(63 + static_cast<int32_t>(ceil(bound))));
+      }
+      map_out[i] = static_cast<uint8_t>(self | (level != 0 ? 2u : 0u) | (level << 2));
     }
   }
 
@@ -151,15 +219,43 @@ struct LaneCtx
 
 // U consecutive beams of one patch; o[] holds their table rows, dxy the lane's
 // packed fixed-point offset.
+// Per-lane skip state.  Terms whose exponent is below skip_below cannot change
+// the lane's sum (bit-exact skip); skip_level is the same threshold on the map's
+// scale, pre-shifted to the byte's layout: a map byte below it promises an
+// exponent below skip_below.  Both only ever rise with the sum, so they are
+// refreshed after a group of beams that added something, not per beam.
+struct SkipState
+{
+  double skip_below;
+  uint32_t skip_level;
+};
+
+__device__ __forceinline__ SkipState skip_state(double sum, int32_t no_skip)
+{
+  SkipState s;
+  if (no_skip)
+  {
+    s.skip_below = -HUGE_VAL;
+    s.skip_level = 0;
+    return s;
+  }
+  s.skip_below = negligible_below(sum);
+  // level l promises e <= l - 63; l <= ceil(T) + 62 then gives e <= ceil(T) - 1 < T
+  const int32_t l = static_cast<int32_t>(ceil(s.skip_below)) + 63;
+  s.skip_level = static_cast<uint32_t>(min(max(l, 1), 63)) << 2;
+  return s;
+}
+
 template <int U, bool POW2, bool LDS_RECORDS>
 __device__ __forceinline__ void lane_beams(const GridDesc & g, const LaneCtx & c,
                                            const double4 (&o)[U], double dx, double dy,
-                                           double dxy, double & sum)
+                                           double dxy, double & sum, SkipState & skip,
+                                           int32_t no_skip)
 {
-  // terms below this exponent cannot change this lane's sum (bit-exact skip)
-  const double skip_below = negligible_below(sum);
+  const double skip_below = skip.skip_below;
+  const uint32_t skip_level = skip.skip_level;
   uint32_t lo[U], hi[U], m[U];
-  uint32_t any_bits = 0;
+  uint32_t top = 0;
 #pragma unroll
   for (int u = 0; u < U; ++u)
   {
@@ -168,19 +264,20 @@ __device__ __forceinline__ void lane_beams(const GridDesc & g, const LaneCtx & c
     hi[u] = static_cast<uint32_t>(__double2hiint(s));
     // byte 0 <- lo.byte2 (cell x), byte 1 <- hi.byte1 (cell y), bytes 2,3 <- 0
     m[u] = c.lds_map[__builtin_amdgcn_perm(hi[u], lo[u], 0x0c0c0502u)];
-    any_bits |= m[u];
+    top = max(top, m[u]);
   }
-  if (__any(any_bits & 2u))
+  if (__any(top >= skip_level))
   {
+    bool added = false;
 #pragma unroll
     for (int u = 0; u < U; ++u)
     {
-      if (__any(m[u] & 2u))
+      if (__any(m[u] >= skip_level))
       {
         const uint32_t frac_x = lo[u] & 0xffffu;
         const uint32_t frac_y = __builtin_amdgcn_alignbit(hi[u], lo[u], 24) & 0xffffu;
         const bool near = (((frac_x + kNearUnits) & 0xffffu) < 2u * kNearUnits) |
-                          (((frac_y + kNearUnits) & 0xffffu) < 2u * kNearUnits);
+                          (((frac_y + kNearUnits) & 0xffffu) < 2u * kNearUnits) | (no_skip != 0);
         const bool occ = (m[u] & 1u) != 0;
         if (__any(occ | near))
         {
@@ -204,10 +301,12 @@ __device__ __forceinline__ void lane_beams(const GridDesc & g, const LaneCtx & c
           if (__any(!(e < skip_below)))
           {
             sum += exp_score(e);
+            added = true;
           }
         }
       }
     }
+    if (added) skip = skip_state(sum, no_skip);
   }
 }
 
@@ -278,18 +377,19 @@ __global__ void __launch_bounds__(THREADS) match_lane_kernel(
     const double4 * __restrict__ row = outer + static_cast<size_t>(t) * a.n_beams;
 
     double sum = 0.0;
+    SkipState skip = skip_state(0.0, geo.no_skip);
     uint32_t b = 0;
     for (; b + kUnroll <= a.n_beams; b += kUnroll)
     {
       double4 o[kUnroll];
 #pragma unroll
       for (int u = 0; u < kUnroll; ++u) o[u] = row[b + u];
-      lane_beams<kUnroll, POW2, LDS_RECORDS>(g, c, o, dx, dy, dxy, sum);
+      lane_beams<kUnroll, POW2, LDS_RECORDS>(g, c, o, dx, dy, dxy, sum, skip, geo.no_skip);
     }
     for (; b < a.n_beams; ++b)
     {
       const double4 one[1] = {row[b]};
-      lane_beams<1, POW2, LDS_RECORDS>(g, c, one, dx, dy, dxy, sum);
+      lane_beams<1, POW2, LDS_RECORDS>(g, c, one, dx, dy, dxy, sum, skip, geo.no_skip);
     }
 
     if (valid)
@@ -436,7 +536,7 @@ bool match_lane_supported(const MatchArgs & args, size_t lds_per_block)
 }
 
 hipError_t launch_match_lane(const MatchArgs & args_in, double * outer, double * workspace,
-                             uint32_t max_workers, int cus, size_t lds_per_block,
+                             uint32_t max_workers, int cus, size_t lds_per_block, bool no_skip,
                              hipStream_t stream, uint32_t * n_workers_out, bool * lds_records_out)
 {
   MatchArgs args = args_in;
@@ -444,6 +544,7 @@ hipError_t launch_match_lane(const MatchArgs & args_in, double * outer, double *
   LaneGeom geo;
   size_t map_bytes = 0;
   if (!lane_geometry(args, lds_per_block, &geo, &map_bytes)) return hipErrorInvalidValue;
+  geo.no_skip = no_skip ? 1 : 0;
 
   const uint64_t n_outer = static_cast<uint64_t>(args.th_end - args.th_begin) * args.n_beams;
   uint32_t oblocks = static_cast<uint32_t>((n_outer + 255) / 256);

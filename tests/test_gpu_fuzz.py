@@ -61,14 +61,20 @@ def test_random_case(seed):
         gpu.set_build_mode(build)
         gpu.addScans(scans)
         assert np.array_equal(gpu.grid()[0], ref.ndt.cells6(), equal_nan=True), (seed, build)
-    for variant in ("lane", "wave", "wave-global"):
+    lane_scores = None
+    for variant in ("lane", "lane-noskip", "wave", "wave-global"):
         gpu.set_variant(variant)
         try:
             got = gpu.matchScan(scan_pose, query, want_scores=True)
         except Exception as e:
             # the lane mapping may not apply (map window too large for byte coordinates)
-            assert variant == "lane" and "launch_match" in str(e), (seed, variant, e)
+            assert variant.startswith("lane") and "launch_match" in str(e), (seed, variant, e)
             continue
+        if variant == "lane":
+            lane_scores = got["scores"]
+        elif variant == "lane-noskip":
+            # the skipping of the lane mapping never changes a bit
+            assert np.array_equal(got["scores"], lane_scores, equal_nan=True), seed
         assert got["n_candidates"] == exp["n_candidates"], (seed, variant)
         assert np.array_equal(np.isnan(got["scores"]), np.isnan(exp["scores"])), (seed, variant)
         assert np.allclose(got["scores"], exp["scores"], rtol=0, atol=1e-9, equal_nan=True), (seed, variant)

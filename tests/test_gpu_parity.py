@@ -185,6 +185,35 @@ def test_kernel_variants_agree(cfg1):
     assert d_lane.max() < 1e-12
 
 
+@pytest.mark.parametrize("cfg,override", [
+    (1, {}),
+    (1, dict(ndt_resolution=0.1, search_linear_size=0.3, search_angular_size=0.1)),
+    (1, dict(ndt_resolution=1.0, search_linear_size=0.6, search_linear_resolution=0.03)),
+    (2, dict(search_angular_size=0.05)),                                    # 4x4 sub-cell map
+    (3, dict(search_angular_size=0.05, search_linear_size=0.5)),            # records gathered from HBM
+])
+def test_lane_skipping_is_bit_exact(cfg, override):
+    """Every term the lane mapping skips -- empty sub-cells, sub-cells whose exponent
+    bound is below the lane's threshold, exponents below the threshold -- is a term
+    that cannot change the sum: with all skipping disabled ("lane-noskip": every beam
+    of every candidate evaluated exactly) every candidate score is bit-identical."""
+    gpu, ref, _, guess, pts = _pair(cfg, **override)
+    try:
+        gpu.set_variant("lane")
+        fast = gpu.matchScan(guess, pts, want_scores=True)
+        gpu.set_variant("lane-noskip")
+        full = gpu.matchScan(guess, pts, want_scores=True)
+        assert "lane-per-candidate" in gpu.last_variant()
+    finally:
+        gpu.set_variant("auto")
+    assert np.array_equal(fast["scores"], full["scores"])
+    assert fast["best_index"] == full["best_index"] and fast["score"] == full["score"]
+    assert np.array_equal(fast["covariance"], full["covariance"], equal_nan=True)
+    assert (fast["scores"] < 0).sum() > 100          # the search does hit the map
+    exp = ref.matchScan(guess, pts, want_scores=True)
+    _check_match(full, exp, min(720, len(pts)))
+
+
 def test_runs_are_deterministic(cfg1):
     gpu, _, _, guess, pts = cfg1
     a = gpu.matchScan(guess, pts, want_scores=True)
