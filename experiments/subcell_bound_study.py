@@ -69,6 +69,7 @@ def main():
     act = 0
     sig_exact = 0
     keep = {s: 0 for s in bounds}
+    live_lanes, sig_lanes, per_group = [], [], []
     for _ in range(200):
         ith = rng.integers(len(dth))
         ix0 = rng.integers(len(dlin) - 8)
@@ -98,11 +99,23 @@ def main():
             ins = (hx >= 0) & (hx < sx * sub) & (hy >= 0) & (hy < sy * sub)
             ub = np.where(ins, B[np.clip(hy, 0, sy * sub - 1), np.clip(hx, 0, sx * sub - 1)], -np.inf)
             assert np.all(ub >= e - 1e-9)
-            keep[sub] += (ub.max(axis=1) >= THRESH).sum()
+            kept = ub.max(axis=1) >= THRESH
+            keep[sub] += kept.sum()
+            if sub == 4:
+                live_lanes.append((ub[kept] >= THRESH).mean(axis=1))
+                sig_lanes.append((e[kept] >= THRESH).mean(axis=1))
+                k8 = kept[:len(kept) // 8 * 8].reshape(-1, 8).sum(axis=1)
+                per_group.append(k8)
     print("wave-iterations with an occupied lane      : %.4f" % (act / tot))
     print("... with a lane whose exponent >= %.0f (ideal): %.4f" % (THRESH, sig_exact / tot))
     for sub in bounds:
         print("... kept by the %dx%d sub-cell bound           : %.4f" % (sub, sub, keep[sub] / tot))
+    ll = np.concatenate(live_lanes)
+    sl = np.concatenate(sig_lanes)
+    pg = np.concatenate(per_group)
+    print("kept iterations: mean fraction of lanes above the bound %.3f, truly significant %.3f"
+          % (ll.mean(), sl.mean()))
+    print("kept beams per group of 8: histogram", np.bincount(pg, minlength=9) / len(pg))
 
 
 if __name__ == "__main__":

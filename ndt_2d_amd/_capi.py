@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libndt2d_hip.so")
+# NDT2D_HIP_LIB selects another build of the same library (A/B timing of kernels)
+LIB_PATH = os.environ.get("NDT2D_HIP_LIB") or os.path.join(_PKG, "libndt2d_hip.so")
 
 OK = 0
 ERR_INVALID = 1

@@ -48,7 +48,7 @@ namespace
 constexpr int kLaneThreads = 1024;       // large searches: one block per CU
 constexpr int kLaneThreadsSmall = 256;   // small searches: spread the few work items over more CUs
 constexpr int kPatch = 8;            // patch is kPatch x kPatch candidates = one wave
-constexpr int kUnroll = 8;           // beams per look-up group
+constexpr int kUnroll = 8;  // beams per look-up group
 // map coordinates are 8.16 fixed point
 constexpr double kFracScale = 65536.0;
 constexpr int kMapStride = 256;      // map row stride in bytes = 2^8 cells
@@ -59,6 +59,8 @@ constexpr uint32_t kNearUnits = 4;   // guard band around cell boundaries, in 2^
 constexpr double kBoxMargin = 1.0 / 1024.0;
 constexpr double kTwo24 = 16777216.0;
 constexpr double kTwo52 = 4503599627370496.0;
+constexpr double kNearBias = kNearUnits * (kTwo24 + 1.0);  // +kNearUnits on both packed fractions
+static_assert(kNearUnits == 4, "the near test masks bits 3..15 of the biased fractions");
 
 struct LaneGeom
 {
@@ -219,6 +221,16 @@ struct LaneCtx
 
 // U consecutive beams of one patch; o[] holds their table rows, dxy the lane's
 // packed fixed-point offset.
+// The map sits at LDS address 0 (the kernel's only LDS is its dynamic block, whose
+// first bytes are the map; checked at kernel entry), so the packed cell bytes ARE
+// the address: reading through an absolute LDS pointer saves the per-beam
+// v_add_u32 of the array base that indexing a __shared__ array costs.
+__device__ __forceinline__ uint32_t lds_byte_at(uint32_t address)
+{
+  typedef const __attribute__((address_space(3))) uint8_t * lds_byte_ptr;
+  return *reinterpret_cast<lds_byte_ptr>(address);
+}
+
 // Per-lane skip state.  Terms whose exponent is below skip_below cannot change
 // the lane's sum (bit-exact skip); skip_level is the same threshold on the map's
 // scale, pre-shifted to the byte's layout: a map byte below it promises an
@@ -263,7 +275,7 @@ __device__ __forceinline__ void lane_beams(const GridDesc & g, const LaneCtx & c
     lo[u] = static_cast<uint32_t>(__double2loint(s));
     hi[u] = static_cast<uint32_t>(__double2hiint(s));
     // byte 0 <- lo.byte2 (cell x), byte 1 <- hi.byte1 (cell y), bytes 2,3 <- 0
-    m[u] = c.lds_map[__builtin_amdgcn_perm(hi[u], lo[u], 0x0c0c0502u)];
+    m[u] = lds_byte_at(__builtin_amdgcn_perm(hi[u], lo[u], 0x0c0c0502u));
     top = max(top, m[u]);
   }
   if (__any(top >= skip_level))
@@ -272,13 +284,21 @@ __device__ __forceinline__ void lane_beams(const GridDesc & g, const LaneCtx & c
 #pragma unroll
     for (int u = 0; u < U; ++u)
     {
-      if (__any(m[u] >= skip_level))
+      // lanes below their level are negligible whatever cell they are in: they
+      // neither need the exact cell nor keep the wave on this path
+      const bool live = m[u] >= skip_level;
+      if (__any(live))
       {
-        const uint32_t frac_x = lo[u] & 0xffffu;
-        const uint32_t frac_y = __builtin_amdgcn_alignbit(hi[u], lo[u], 24) & 0xffffu;
-        const bool near = (((frac_x + kNearUnits) & 0xffffu) < 2u * kNearUnits) |
-                          (((frac_y + kNearUnits) & 0xffffu) < 2u * kNearUnits) | (no_skip != 0);
-        const bool occ = (m[u] & 1u) != 0;
+        // within kNearUnits of a unit boundary on either axis: one more exact f64 add
+        // biases both 16-bit fractions at once, then (frac + 4) mod 2^16 < 8 is
+        // "bits 3..15 clear"; the y fraction straddles the two words (bytes 3, 4)
+        const double sn = __hiloint2double(static_cast<int>(hi[u]), static_cast<int>(lo[u])) + kNearBias;
+        const uint32_t nlo = static_cast<uint32_t>(__double2loint(sn));
+        const uint32_t nhi = static_cast<uint32_t>(__double2hiint(sn));
+        const uint32_t tx = nlo & 0xfff8u;
+        const uint32_t ty = __builtin_amdgcn_perm(nhi, nlo, 0x0c0c0403u) & 0xfff8u;
+        const bool near = live & ((min(tx, ty) == 0u) | (no_skip != 0));
+        const bool occ = live & ((m[u] & 1u) != 0);
         if (__any(occ | near))
         {
           // points_inner (:121-125) and Cell::score, exact
@@ -322,6 +342,8 @@ __global__ void __launch_bounds__(THREADS) match_lane_kernel(
   extern __shared__ __align__(16) double lds[];
   const GridDesc & g = a.grid;
   uint8_t * lds_map = reinterpret_cast<uint8_t *>(lds);
+  // lds_byte_at() addresses the map absolutely: it must start at LDS offset 0
+  if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();
   double * lds_cells = lds + (static_cast<size_t>(geo.map_h) * kMapStride) / sizeof(double);
 
   if (LDS_RECORDS) stage_grid_to_lds(g, lds_cells);
