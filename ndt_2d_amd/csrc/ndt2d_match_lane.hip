@@ -24,17 +24,20 @@
 //   (cell_y << 8) | cell_x is two bytes of the sum picked by one v_perm_b32.
 //
 // The map is padded by more cells than any offset reaches and beams are
-// pre-clamped, so no per-lane range check exists.  Map byte: bit 0 = the cell
-// holds a distribution, bit 1 = the cell or one of its eight neighbours does.
-// If no lane of the wave sees bit 1 the beam adds exactly +0.0 to all 64 sums
-// and is skipped -- the fixed-point coordinate may sit on the wrong side of a
-// cell boundary (it is rounded), but then the true cell is a neighbour, which
-// bit 1 covers.  Otherwise lanes within 4 fixed-point units (2^-14 cell) of a
-// boundary are "near"; if any lane is occupied or near, the wave runs the exact
+// pre-clamped, so no per-lane range check exists.  The map is kept at up to
+// 4 x 4 sub-cells per cell.  Map byte: bit 0 = the cell holds a distribution;
+// bits 2..7 = a level: 0 if no distribution can be hit from this sub-cell (its
+// box, slightly widened because the fixed-point coordinate is rounded, touches no
+// occupied cell), else an upper bound l - 63 of Cell::score's exponent over that
+// box (63: no claim).  Each lane carries the level below which a term cannot
+// change its sum (RN(s + exp(e)) == s); if every lane's byte is below its level
+// the beam is skipped.  Otherwise lanes within 4 fixed-point units of a boundary
+// are "near"; if any live lane is occupied or near, the wave runs the exact
 // reference arithmetic (points_inner :121-125, NDT::getIndex
 // src/ndt_model.cpp:203-218 for near lanes, Cell::score :105-116).  Every
-// skipped term is an exact zero, so the sums are bit-identical to the unskipped
-// evaluation.
+// skipped term is one that leaves the sum unchanged, so the sums are
+// bit-identical to the unskipped evaluation (variant "lane-noskip" is that
+// evaluation; the tests compare the two bitwise).
 #include <cmath>
 
 #include "ndt2d_device_fn.h"
