@@ -93,7 +93,8 @@ __device__ __forceinline__ double fma3(double a, double b, double c)
 
 __device__ __forceinline__ double exp_of_exponent(double x)
 {
-  x = __builtin_fmax(x, -1000.0);
+  // (one v_max_f64; fmax() would first canonicalise x with a second one)
+  asm("v_max_f64 %0, %1, %2" : "=v"(x) : "v"(x), "s"(-1000.0));
   const double n = rint(x * 1.4426950408889634);             // 0x3ff71547652b82fe
   double r = fma(n, -0.6931471805599453, x);                  // 0xbfe62e42fefa39ef
   r = fma(n, -2.3190468138462996e-17, r);                     // 0xbc7abc9e3b39803f
@@ -111,6 +112,14 @@ __device__ __forceinline__ double exp_of_exponent(double x)
   return ldexp(p, static_cast<int>(n));
 }
 
+// "Some lane of the wave holds p": the lane mask of the compare itself is tested in
+// scalar registers.  (__any() first materialises p as 0 / 1 in a vector register
+// and compares again: two VALU instructions per test in VALU-bound loops.)
+__device__ __forceinline__ bool wave_any(bool p)
+{
+  return __builtin_amdgcn_ballot_w64(p) != 0ull;
+}
+
 // exp() of a Cell::score exponent for the register-tight kernels (lane mapping,
 // compacted particle scoring; the wave mapping keeps the library exp, whose
 // constants live in SGPRs there): the lean evaluation above, except that a wave
@@ -118,7 +127,7 @@ __device__ __forceinline__ double exp_of_exponent(double x)
 // propagates as in the reference.
 __device__ __forceinline__ double exp_score(double e)
 {
-  return __any(e != e) ? exp(e) : exp_of_exponent(e);
+  return wave_any(e != e) ? exp(e) : exp_of_exponent(e);
 }
 
 // A non-negative term t = exp(e) leaves a running sum s > 0 unchanged,

@@ -215,11 +215,12 @@ __global__ void __launch_bounds__(256) outer_table_kernel(const MatchArgs a, dou
 
 struct LaneCtx
 {
-  const double * lds_cells;
-  const uint8_t * lds_map;
-  int32_t sub_log2;       // map sub-cell -> map cell: shift right
-  int32_t off_x, off_y;   // map cell -> grid cell: subtract (pad - win_x0), (pad - win_y0)
-  int32_t size_x;
+  uint32_t lds_cells_address;  // LDS byte address of the packed records (behind the map)
+  uint32_t sub_log2;           // map sub-cell -> map cell: shift right
+  // map cell (col, row) -> grid cell index: row * size_x + col - idx_bias,
+  // idx_bias = (pad - win_y0) * size_x + (pad - win_x0), modulo 2^32
+  uint32_t idx_bias;
+  uint32_t size_x;
 };
 
 // U consecutive beams of one patch; o[] holds their table rows, dxy the lane's
@@ -232,6 +233,17 @@ __device__ __forceinline__ uint32_t lds_byte_at(uint32_t address)
 {
   typedef const __attribute__((address_space(3))) uint8_t * lds_byte_ptr;
   return *reinterpret_cast<lds_byte_ptr>(address);
+}
+
+// Cell::score's exponent against packed record idx of the LDS copy, addressed with
+// 32-bit LDS arithmetic (one v_mad_u32_u24; idx < 2^24 for any grid that fits LDS).
+__device__ __forceinline__ double lds_record_exponent(uint32_t cells_address, uint32_t idx,
+                                                      double px, double py)
+{
+  typedef const __attribute__((address_space(3), aligned(16))) double * lds_double_ptr;
+  const lds_double_ptr rec = reinterpret_cast<lds_double_ptr>(
+    __umul24(idx, static_cast<uint32_t>(kCellDoubles * sizeof(double))) + cells_address);
+  return record_exponent(rec[0], rec[1], rec[2], rec[3], rec[4], px, py);
 }
 
 // Per-lane skip state.  Terms whose exponent is below skip_below cannot change
@@ -281,16 +293,20 @@ __device__ __forceinline__ void lane_beams(const GridDesc & g, const LaneCtx & c
     m[u] = lds_byte_at(__builtin_amdgcn_perm(hi[u], lo[u], 0x0c0c0502u));
     top = max(top, m[u]);
   }
-  if (__any(top >= skip_level))
+  if (wave_any(top >= skip_level))
   {
     bool added = false;
 #pragma unroll
     for (int u = 0; u < U; ++u)
     {
-      // lanes below their level are negligible whatever cell they are in: they
-      // neither need the exact cell nor keep the wave on this path
-      const bool live = m[u] >= skip_level;
-      if (__any(live))
+      // Lanes below their level are negligible whatever cell they are in: they do
+      // not keep the wave on this path.  (If the wave stays for another lane, their
+      // term is still evaluated exactly -- and, being negligible, changes nothing.)
+      // The wave-level tests combine the compares' lane masks as 64-bit integers in
+      // scalar registers; a ballot of a combined bool would round-trip through a
+      // vector register.
+      const uint64_t live_mask = __builtin_amdgcn_ballot_w64(m[u] >= skip_level);
+      if (live_mask != 0ull)
       {
         // within kNearUnits of a unit boundary on either axis: one more exact f64 add
         // biases both 16-bit fractions at once, then (frac + 4) mod 2^16 < 8 is
@@ -300,28 +316,32 @@ __device__ __forceinline__ void lane_beams(const GridDesc & g, const LaneCtx & c
         const uint32_t nhi = static_cast<uint32_t>(__double2hiint(sn));
         const uint32_t tx = nlo & 0xfff8u;
         const uint32_t ty = __builtin_amdgcn_perm(nhi, nlo, 0x0c0c0403u) & 0xfff8u;
-        const bool near = live & ((min(tx, ty) == 0u) | (no_skip != 0));
-        const bool occ = live & ((m[u] & 1u) != 0);
-        if (__any(occ | near))
+        const bool occ = (m[u] & 1u) != 0;
+        const uint64_t near_mask =
+          (__builtin_amdgcn_ballot_w64(min(tx, ty) == 0u) | (no_skip != 0 ? ~0ull : 0ull)) & live_mask;
+        const uint64_t occ_mask = __builtin_amdgcn_ballot_w64(occ) & live_mask;
+        if ((occ_mask | near_mask) != 0ull)
         {
           // points_inner (:121-125) and Cell::score, exact
           const double px = o[u].x + dx;
           const double py = o[u].y + dy;
           uint32_t idx;
-          if (__any(near))
+          if (near_mask != 0ull)
           {
             idx = cell_index<POW2>(g, px, py);
           }
           else
           {
-            // interior of a cell: the look-up cell is the reference's cell
-            const int32_t cx = static_cast<int32_t>(((lo[u] >> 16) & 0xffu) >> c.sub_log2) - c.off_x;
-            const int32_t cy = static_cast<int32_t>(((hi[u] >> 8) & 0xffu) >> c.sub_log2) - c.off_y;
-            idx = occ ? static_cast<uint32_t>(cy * c.size_x + cx) : g.ncell;
+            // interior of a cell: the look-up cell is the reference's cell,
+            // row * size_x + column with the window's offset folded into idx_bias
+            const uint32_t col = ((lo[u] >> 16) & 0xffu) >> c.sub_log2;
+            const uint32_t row = ((hi[u] >> 8) & 0xffu) >> c.sub_log2;
+            idx = occ ? __umul24(row, c.size_x) + (col - c.idx_bias) : g.ncell;
           }
-          const double e = indexed_exponent<LDS_RECORDS>(g, c.lds_cells, idx, px, py);
+          const double e = LDS_RECORDS ? lds_record_exponent(c.lds_cells_address, idx, px, py)
+                                       : indexed_exponent<false>(g, nullptr, idx, px, py);
           // !(e < bound) also keeps NaN exponents (degenerate cells) on the exact path
-          if (__any(!(e < skip_below)))
+          if (wave_any(!(e < skip_below)))
           {
             sum += exp_score(e);
             added = true;
@@ -360,12 +380,11 @@ __global__ void __launch_bounds__(THREADS) match_lane_kernel(
   __syncthreads();
 
   LaneCtx c;
-  c.lds_cells = lds_cells;
-  c.lds_map = lds_map;
-  c.sub_log2 = geo.sub_log2;
-  c.off_x = geo.pad - geo.win_x0;
-  c.off_y = geo.pad - geo.win_y0;
-  c.size_x = static_cast<int32_t>(g.size_x);
+  c.lds_cells_address = static_cast<uint32_t>(geo.map_h) * kMapStride;
+  c.sub_log2 = static_cast<uint32_t>(geo.sub_log2);
+  c.idx_bias = static_cast<uint32_t>(geo.pad - geo.win_y0) * g.size_x +
+               static_cast<uint32_t>(geo.pad - geo.win_x0);
+  c.size_x = g.size_x;
 
   const uint32_t lane = threadIdx.x & (kWave - 1);
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -557,7 +576,9 @@ bool match_lane_supported(const MatchArgs & args, size_t lds_per_block)
   if (args.grid.occ_bits == nullptr || !lane_geometry(args, lds_per_block, &geo, &map_bytes)) return false;
   const uint64_t p1 = (args.n_lin + kPatch - 1) / kPatch;
   const uint64_t items = static_cast<uint64_t>(args.th_end - args.th_begin) * p1 * p1;
-  return map_bytes <= lds_per_block && items < (1ull << 32);
+  // (24-bit multiplies index the grid rows and the LDS records)
+  return map_bytes <= lds_per_block && items < (1ull << 32) && args.grid.size_x < (1u << 24) &&
+         args.grid.ncell < (1u << 24);
 }
 
 hipError_t launch_match_lane(const MatchArgs & args_in, double * outer, double * workspace,
