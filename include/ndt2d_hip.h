@@ -247,6 +247,36 @@ int ndt2d_set_beams_from_ranges(ndt2d_handle h, const float * h_ranges, size_t n
  * the next conversion on this context) and their number. */
 const double * ndt2d_scan_points(ndt2d_handle h, size_t * n_points_out);
 
+/* ---- OccupancyGrid rendering on the device ----
+ *
+ * OccupancyGrid::getMsg (src/occupancy_grid.cpp:47-152) with its updateBounds
+ * (:154-185): every beam of every scan is ray-traced from its scan pose through
+ * the reference's simplified Bresenham line, cells are counted as hit / empty and
+ * published as -1 (unknown) / 0 (free) / 100 (occupied, hit ratio > occ_thresh).
+ * Scans are given as for ndt2d_build_grid.
+ *
+ * bounds_inout = {min_x_, max_x_, min_y_, max_y_} of the generator (all 0 when it
+ * is new, :37-40) and n_scans_bounded = its num_scans_: as in the reference the
+ * bounds are extended by the scans [n_scans_bounded, n_scans) only, and only when
+ * the two counts differ (:51-54), then rounded to the resolution (:181-184).
+ * info_out receives the message's meta data (:60-65).  With data_out == NULL the
+ * call stops there (use it to size the buffer); otherwise data_out[width*height]
+ * (row-major, y * width + x) receives the map.  A ray cell outside the grid is
+ * skipped (the reference would write out of bounds: its bounds cover the scans'
+ * points, not their poses).  Counts are integers, so the result is bit-identical
+ * to the sequential loop. */
+typedef struct ndt2d_occupancy_info
+{
+  double resolution;
+  uint32_t width, height;
+  double origin_x, origin_y;
+} ndt2d_occupancy_info;
+int ndt2d_occupancy_grid(ndt2d_handle h, double resolution, double occ_thresh,
+                         const double * poses_xyt, const double * points_xy,
+                         const size_t * offsets, size_t n_scans, size_t n_scans_bounded,
+                         double * bounds_inout, ndt2d_occupancy_info * info_out,
+                         signed char * data_out, size_t data_capacity);
+
 /* Block until everything launched on the context's stream has finished. */
 int ndt2d_synchronize(ndt2d_handle h);
 /* GPU time (HIP events on the launch stream) of the dominant kernel -- the

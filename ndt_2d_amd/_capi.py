@@ -46,6 +46,12 @@ class LaserScan(C.Structure):
                 ("motion_x", C.c_double), ("motion_y", C.c_double), ("motion_theta", C.c_double)]
 
 
+class OccupancyInfo(C.Structure):
+    """ndt2d_occupancy_info"""
+    _fields_ = [("resolution", C.c_double), ("width", C.c_uint32), ("height", C.c_uint32),
+                ("origin_x", C.c_double), ("origin_y", C.c_double)]
+
+
 class World(C.Structure):
     _fields_ = [("room_half", C.c_double), ("pillar_pitch", C.c_double),
                 ("pillar_half", C.c_double)]
@@ -95,6 +101,8 @@ SIGNATURES = {
     "ndt2d_set_beams_from_ranges": (C.c_int, [_vp, C.POINTER(C.c_float), _sz,
                                               C.POINTER(LaserScan), _sz, _szp, _szp]),
     "ndt2d_scan_points": (_vp, [_vp, _szp]),
+    "ndt2d_occupancy_grid": (C.c_int, [_vp, _d, _d, _dp, _dp, _szp, _sz, _sz, _dp,
+                                       C.POINTER(OccupancyInfo), _vp, _sz]),
     "ndt2d_synchronize": (C.c_int, [_vp]),
     "ndt2d_last_launch_ms": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "ndt2d_last_variant": (C.c_char_p, [_vp]),

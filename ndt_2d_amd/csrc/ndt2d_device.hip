@@ -1059,6 +1059,127 @@ const double * ndt2d_scan_points(ndt2d_handle h, size_t * n_points_out)
   return h->scan_points.ptr;
 }
 
+int ndt2d_occupancy_grid(ndt2d_handle h, double resolution, double occ_thresh,
+                         const double * poses_xyt, const double * points_xy,
+                         const size_t * offsets, size_t n_scans, size_t n_scans_bounded,
+                         double * bounds_inout, ndt2d_occupancy_info * info_out,
+                         signed char * data_out, size_t data_capacity)
+{
+  if (h == nullptr) return NDT2D_ERR_INVALID;
+  if (!(resolution > 0.0) || bounds_inout == nullptr || info_out == nullptr ||
+      n_scans_bounded > n_scans || n_scans > (1u << 30) ||
+      (n_scans > 0 && (poses_xyt == nullptr || offsets == nullptr)))
+  {
+    return fail(h, NDT2D_ERR_INVALID, "ndt2d_occupancy_grid: bad argument");
+  }
+  const size_t n_points = n_scans > 0 ? offsets[n_scans] : 0;
+  if (n_points >= (1ull << 31) || (n_points > 0 && points_xy == nullptr))
+  {
+    return fail(h, NDT2D_ERR_INVALID, "ndt2d_occupancy_grid: bad points");
+  }
+  NDT2D_HIP(h, hipSetDevice(h->device));
+
+  // scans and points to the device (the NDT build's buffers and staging are reused)
+  NDT2D_HIP(h, hipStreamSynchronize(h->stream));
+  h->stage_scans.resize(4 * n_scans + 4);
+  h->stage_offsets.resize(((n_scans + 1) + 1) & ~size_t(1));
+  for (size_t k = 0; k < n_scans; ++k)
+  {
+    h->stage_scans[4 * k] = poses_xyt[3 * k];
+    h->stage_scans[4 * k + 1] = poses_xyt[3 * k + 1];
+    h->stage_scans[4 * k + 2] = std::cos(poses_xyt[3 * k + 2]);  // :78-79,163-164, host libm
+    h->stage_scans[4 * k + 3] = std::sin(poses_xyt[3 * k + 2]);
+    h->stage_offsets[k] = static_cast<uint32_t>(offsets[k]);
+  }
+  h->stage_offsets[n_scans] = static_cast<uint32_t>(n_points);
+  int rc;
+  if ((rc = ensure(h, h->b_points, 2 * n_points + 2)) != NDT2D_OK) return rc;
+  if ((rc = ensure(h, h->b_scans, 4 * n_scans + 4)) != NDT2D_OK) return rc;
+  if ((rc = ensure(h, h->b_offsets, h->stage_offsets.size() / 2 + 1)) != NDT2D_OK) return rc;
+  if ((rc = ensure(h, h->ws_poses, ndt2d::poses_workspace_doubles(n_points))) != NDT2D_OK) return rc;
+  if ((rc = ensure(h, h->stats, NDT2D_POSE_STATS_DOUBLES + NDT2D_PF_RESULT_DOUBLES)) != NDT2D_OK) return rc;
+  if (n_points > 0)
+  {
+    NDT2D_HIP(h, hipMemcpyAsync(h->b_points.ptr, points_xy, 2 * n_points * sizeof(double),
+                                hipMemcpyHostToDevice, h->stream));
+  }
+  if (n_scans > 0)
+  {
+    NDT2D_HIP(h, hipMemcpyAsync(h->b_scans.ptr, h->stage_scans.data(), 4 * n_scans * sizeof(double),
+                                hipMemcpyHostToDevice, h->stream));
+  }
+  NDT2D_HIP(h, hipMemcpyAsync(h->b_offsets.ptr, h->stage_offsets.data(),
+                              (n_scans + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+
+  ndt2d::OccupancyArgs args{};
+  args.points_xy = h->b_points.ptr;
+  args.n_points = static_cast<uint32_t>(n_points);
+  args.scans = h->b_scans.ptr;
+  args.offsets = reinterpret_cast<const uint32_t *>(h->b_offsets.ptr);
+  args.n_scans = static_cast<uint32_t>(n_scans);
+  args.resolution = resolution;
+
+  // updateBounds (:154-185), only when the scan count changed (:51-54)
+  if (n_scans != n_scans_bounded)
+  {
+    double found[4] = {HUGE_VAL, -HUGE_VAL, HUGE_VAL, -HUGE_VAL};
+    const size_t first_point = offsets[n_scans_bounded];
+    if (n_points > first_point)
+    {
+      hipError_t e = ndt2d::launch_occupancy_bounds(args, static_cast<uint32_t>(first_point),
+                                                    h->ws_poses.ptr, h->stats.ptr, h->stream);
+      if (e != hipSuccess) return fail_hip(h, e, "launch_occupancy_bounds");
+      NDT2D_HIP(h, hipMemcpyAsync(found, h->stats.ptr, sizeof(found), hipMemcpyDeviceToHost, h->stream));
+      NDT2D_HIP(h, hipStreamSynchronize(h->stream));
+    }
+    const double min_x = std::min(found[0], bounds_inout[0]);
+    const double max_x = std::max(found[1], bounds_inout[1]);
+    const double min_y = std::min(found[2], bounds_inout[2]);
+    const double max_y = std::max(found[3], bounds_inout[3]);
+    // :181-184
+    bounds_inout[0] = std::floor(min_x / resolution) * resolution;
+    bounds_inout[1] = std::ceil(max_x / resolution) * resolution;
+    bounds_inout[2] = std::floor(min_y / resolution) * resolution;
+    bounds_inout[3] = std::ceil(max_y / resolution) * resolution;
+  }
+
+  // :57-65 (info.width / height are uint32: the quotient is truncated)
+  const double pad = 5 * resolution;
+  const double fw = (bounds_inout[1] - bounds_inout[0] + 2 * pad) / resolution;
+  const double fh = (bounds_inout[3] - bounds_inout[2] + 2 * pad) / resolution;
+  if (!(fw >= 0.0) || !(fh >= 0.0) || fw >= 2147483648.0 || fh >= 2147483648.0 ||
+      fw * fh >= 2147483648.0)
+  {
+    return fail(h, NDT2D_ERR_INVALID, "ndt2d_occupancy_grid: degenerate map extent");
+  }
+  args.width = static_cast<uint32_t>(fw);
+  args.height = static_cast<uint32_t>(fh);
+  args.origin_x = bounds_inout[0] - pad;
+  args.origin_y = bounds_inout[2] - pad;
+  info_out->resolution = resolution;
+  info_out->width = args.width;
+  info_out->height = args.height;
+  info_out->origin_x = args.origin_x;
+  info_out->origin_y = args.origin_y;
+  if (data_out == nullptr)
+  {
+    NDT2D_HIP(h, hipStreamSynchronize(h->stream));  // the staged uploads are done with
+    return NDT2D_OK;
+  }
+  const size_t n_cells = static_cast<size_t>(args.width) * args.height;
+  if (data_capacity < n_cells) return fail(h, NDT2D_ERR_INVALID, "ndt2d_occupancy_grid: data_out too small");
+  if (n_cells == 0) return NDT2D_OK;
+  // counters (8 B per cell) and the int8 map behind them
+  if ((rc = ensure(h, h->b_world, n_cells + (n_cells + 7) / 8 + 2)) != NDT2D_OK) return rc;
+  unsigned long long * counts = reinterpret_cast<unsigned long long *>(h->b_world.ptr);
+  signed char * d_data = reinterpret_cast<signed char *>(h->b_world.ptr + n_cells);
+  hipError_t e = ndt2d::launch_occupancy_render(args, occ_thresh, counts, d_data, h->stream);
+  if (e != hipSuccess) return fail_hip(h, e, "launch_occupancy_render");
+  NDT2D_HIP(h, hipMemcpyAsync(data_out, d_data, n_cells, hipMemcpyDeviceToHost, h->stream));
+  NDT2D_HIP(h, hipStreamSynchronize(h->stream));
+  return NDT2D_OK;
+}
+
 int ndt2d_synchronize(ndt2d_handle h)
 {
   if (h == nullptr) return NDT2D_ERR_INVALID;

@@ -166,6 +166,26 @@ hipError_t launch_subsample(const double * points_xy, const double * scan_info,
                             uint32_t max_beams, double * beams_xy, double * info_out,
                             hipStream_t stream);
 
+// OccupancyGrid rendering (ndt2d_occupancy.hip).  Scans as in BuildArgs.
+struct OccupancyArgs
+{
+  const double * points_xy;   // [n_points][2] robot frame, scans concatenated
+  uint32_t n_points;
+  const double * scans;       // [n_scans][4] {pose_x, pose_y, cos(theta), sin(theta)}
+  const uint32_t * offsets;   // [n_scans + 1]
+  uint32_t n_scans;
+  double resolution, origin_x, origin_y;
+  uint32_t width, height;
+};
+// bounds_out[4] = {min_x, max_x, min_y, max_y} of the map-frame points
+// [first_point, n_points) (+inf / -inf if none); workspace: poses_workspace_doubles().
+hipError_t launch_occupancy_bounds(const OccupancyArgs & args, uint32_t first_point,
+                                   double * workspace, double * bounds_out, hipStream_t stream);
+// counts: [width * height] scratch; data: [width * height] out, -1 / 0 / 100.
+hipError_t launch_occupancy_render(const OccupancyArgs & args, double occ_thresh,
+                                   unsigned long long * counts, signed char * data,
+                                   hipStream_t stream);
+
 // Lane-per-candidate search (ndt2d_match_lane.hip).  outer: device scratch of
 // match_lane_outer_doubles() doubles for the rotated-beam table; workspace
 // receives one partial record per wave (*n_workers_out of them).

@@ -886,3 +886,129 @@ size_t orc_convert_scan(const float * ranges, size_t n_ranges, const orc_laser_s
   }
   return n_out;
 }
+
+/* ------------------------------------------------------------------------- */
+/* OccupancyGrid                                                             */
+/* ------------------------------------------------------------------------- */
+
+/* OccupancyGrid::updateBounds, src/occupancy_grid.cpp:154-185 */
+void orc_occupancy_update_bounds(double * bounds, double resolution, const double * poses_xyt,
+                                 const double * points_xy, const size_t * offsets,
+                                 size_t first_scan, size_t n_scans)
+{
+  double min_x = bounds[0], max_x = bounds[1], min_y = bounds[2], max_y = bounds[3];
+  for (size_t i = first_scan; i < n_scans; ++i)
+  {
+    const double x = poses_xyt[3 * i], y = poses_xyt[3 * i + 1];
+    const double cos_th = cos(poses_xyt[3 * i + 2]);
+    const double sin_th = sin(poses_xyt[3 * i + 2]);
+    for (size_t k = offsets[i]; k < offsets[i + 1]; ++k)
+    {
+      const double qx = points_xy[2 * k], qy = points_xy[2 * k + 1];
+      /* :171-173 */
+      double px = x, py = y;
+      px += qx * cos_th - qy * sin_th;
+      py += qx * sin_th + qy * cos_th;
+      /* :174-177 std::min(p, m) = (m < p) ? m : p;  std::max(p, m) = (p < m) ? m : p */
+      min_x = (min_x < px) ? min_x : px;
+      max_x = (px < max_x) ? max_x : px;
+      min_y = (min_y < py) ? min_y : py;
+      max_y = (py < max_y) ? max_y : py;
+    }
+  }
+  /* :181-184 */
+  bounds[0] = floor(min_x / resolution) * resolution;
+  bounds[1] = ceil(max_x / resolution) * resolution;
+  bounds[2] = floor(min_y / resolution) * resolution;
+  bounds[3] = ceil(max_y / resolution) * resolution;
+}
+
+/* OccupancyGrid::getMsg after the bounds update, src/occupancy_grid.cpp:56-151 */
+void orc_occupancy_render(const double * bounds, double resolution, double occ_thresh,
+                          const double * poses_xyt, const double * points_xy,
+                          const size_t * offsets, size_t n_scans, uint32_t * info_wh,
+                          double * origin_xy, signed char * data)
+{
+  /* :57-65 (info.width / height are uint32: the quotient is truncated) */
+  const double pad = 5 * resolution;
+  const uint32_t width = (uint32_t)((bounds[1] - bounds[0] + 2 * pad) / resolution);
+  const uint32_t height = (uint32_t)((bounds[3] - bounds[2] + 2 * pad) / resolution);
+  const double origin_x = bounds[0] - pad;
+  const double origin_y = bounds[2] - pad;
+  info_wh[0] = width;
+  info_wh[1] = height;
+  origin_xy[0] = origin_x;
+  origin_xy[1] = origin_y;
+  if (data == NULL) return;
+  const size_t n_cells = (size_t)width * height;
+  int * hit = (int *)calloc(n_cells ? n_cells : 1, sizeof(int));
+  int * empty = (int *)calloc(n_cells ? n_cells : 1, sizeof(int));
+  for (size_t i = 0; i < n_scans; ++i)
+  {
+    const double pose_x = poses_xyt[3 * i], pose_y = poses_xyt[3 * i + 1];
+    const double cos_th = cos(poses_xyt[3 * i + 2]);
+    const double sin_th = sin(poses_xyt[3 * i + 2]);
+    /* :82-83 */
+    const int start_x = (int)((pose_x - origin_x) / resolution);
+    const int start_y = (int)((pose_y - origin_y) / resolution);
+    for (size_t k = offsets[i]; k < offsets[i + 1]; ++k)
+    {
+      const double qx = points_xy[2 * k], qy = points_xy[2 * k + 1];
+      /* :87-91 */
+      const double point_x = qx * cos_th - qy * sin_th + pose_x;
+      const double point_y = qx * sin_th + qy * cos_th + pose_y;
+      const int end_x = (int)((point_x - origin_x) / resolution);
+      const int end_y = (int)((point_y - origin_y) / resolution);
+      /* :93-98 simplified Bresenham */
+      int dx = abs(end_x - start_x);
+      int sx = (start_x < end_x) ? 1 : -1;
+      int dy = -abs(end_y - start_y);
+      int sy = (start_y < end_y) ? 1 : -1;
+      int error = dx + dy;
+      int x = start_x, y = start_y;
+      while (1)
+      {
+        const int inside = x >= 0 && y >= 0 && (uint32_t)x < width && (uint32_t)y < height;
+        const size_t index = inside ? (size_t)x + (size_t)y * width : 0;
+        if (x == end_x && y == end_y)
+        {
+          if (inside) ++hit[index];
+          break;
+        }
+        if (inside) ++empty[index];
+        if (2 * error >= dy)
+        {
+          if (x == end_x)
+          {
+            if (inside) ++hit[index];
+            break;
+          }
+          error = error + dy;
+          x += sx;
+        }
+        if (2 * error <= dx)
+        {
+          if (y == end_y)
+          {
+            if (inside) ++hit[index];
+            break;
+          }
+          error = error + dx;
+          y += sy;
+        }
+      }
+    }
+  }
+  /* :134-150 */
+  for (size_t i = 0; i < n_cells; ++i)
+  {
+    const double touches = hit[i] + empty[i];
+    data[i] = -1;
+    if (touches > 0.5)
+    {
+      data[i] = ((double)hit[i] / touches > occ_thresh) ? 100 : 0;
+    }
+  }
+  free(hit);
+  free(empty);
+}

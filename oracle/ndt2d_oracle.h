@@ -21,6 +21,9 @@
  *     is run in tests/test_particle_host.py; the reference's RNG is seeded by
  *     std::random_device, so no bit-level vector can exist.  ParticleFilter::
  *     init: PARITY UNPINNED (no reference test).
+ *   - LaserScan conversion (NdtMapper::laserCallback) and OccupancyGrid:
+ *     PARITY UNPINNED (no reference test); each is cross-checked against an
+ *     independent numpy / Python statement of the same lines in tests/.
  *
  * Third-party arithmetic restated (not under /root/reference):
  *   Eigen3 (unpinned; 3.4.0 on ROS 2 Humble): fixed-size 2x2 inverse,
@@ -177,6 +180,24 @@ typedef struct orc_laser_scan
 } orc_laser_scan;
 size_t orc_convert_scan(const float * ranges, size_t n_ranges, const orc_laser_scan * scan,
                         double * points_xy_out);
+
+/* OccupancyGrid (src/occupancy_grid.cpp).  Scans are given as for
+ * orc_matcher_add_scans.  bounds = {min_x_, max_x_, min_y_, max_y_}, all 0 in a
+ * fresh generator (:37-40).
+ * orc_occupancy_update_bounds = updateBounds (:154-185) over scans
+ * [first_scan, n_scans), including the final floor/ceil to the resolution.
+ * orc_occupancy_render = the rest of getMsg (:56-151): info = {width, height} and
+ * origin = {origin_x, origin_y} (:61-65), data[width*height] = -1 / 0 / 100.
+ * With data == NULL only info and origin are produced.  A ray cell outside the
+ * grid (the reference would write out of bounds: the bounds cover the scans'
+ * points, not their poses) is skipped. */
+void orc_occupancy_update_bounds(double * bounds, double resolution, const double * poses_xyt,
+                                 const double * points_xy, const size_t * offsets,
+                                 size_t first_scan, size_t n_scans);
+void orc_occupancy_render(const double * bounds, double resolution, double occ_thresh,
+                          const double * poses_xyt, const double * points_xy,
+                          const size_t * offsets, size_t n_scans, uint32_t * info_wh,
+                          double * origin_xy, signed char * data);
 
 /* ROS angles (restated): used by updateStatistics and the motion model. */
 double orc_normalize_angle(double a);

@@ -362,3 +362,52 @@ def convert_scan(ranges, angle_min, angle_increment, range_max, inverted=False,
     f.argtypes = [C.POINTER(C.c_float), C.c_size_t, C.POINTER(OrcLaserScan), _dp]
     n = f(r.ctypes.data_as(C.POINTER(C.c_float)), len(r), C.byref(d), out.ctypes.data_as(_dp))
     return out[:n].copy()
+
+
+def _pack_scans(scans):
+    poses = np.ascontiguousarray([s[0] for s in scans], dtype=np.float64).reshape(-1, 3)
+    pts = [np.ascontiguousarray(s[1], dtype=np.float64).reshape(-1, 2) for s in scans]
+    offsets = np.zeros(len(scans) + 1, dtype=np.uint64)
+    if scans:
+        offsets[1:] = np.cumsum([len(p) for p in pts])
+    allpts = np.ascontiguousarray(np.concatenate(pts) if pts else np.zeros((0, 2)))
+    return poses, allpts, offsets
+
+
+class OccupancyGrid:
+    """Mirror of ndt_2d::OccupancyGrid (reference include/ndt_2d/occupancy_grid.hpp:44-74)."""
+
+    def __init__(self, resolution, occ_thresh):
+        self.resolution = resolution
+        self.occ_thresh = occ_thresh
+        self.bounds = np.zeros(4)        # min_x_, max_x_, min_y_, max_y_ (:37-40)
+        self.num_scans = 0
+
+    def getMsg(self, scans):
+        """Returns dict(resolution, width, height, origin_x, origin_y, data[height, width])."""
+        L = lib()
+        scans = list(scans)
+        poses, allpts, offsets = _pack_scans(scans)
+        szp = C.POINTER(C.c_size_t)
+        L.orc_occupancy_update_bounds.restype = None
+        L.orc_occupancy_update_bounds.argtypes = [_dp, C.c_double, _dp, _dp, szp, C.c_size_t,
+                                                  C.c_size_t]
+        L.orc_occupancy_render.restype = None
+        L.orc_occupancy_render.argtypes = [_dp, C.c_double, C.c_double, _dp, _dp, szp, C.c_size_t,
+                                           C.POINTER(C.c_uint32), _dp, C.c_void_p]
+        off_p = offsets.ctypes.data_as(szp)
+        if len(scans) != self.num_scans:                       # :51-54
+            L.orc_occupancy_update_bounds(self.bounds.ctypes.data_as(_dp), self.resolution,
+                                          poses.ctypes.data_as(_dp), allpts.ctypes.data_as(_dp),
+                                          off_p, self.num_scans, len(scans))
+            self.num_scans = len(scans)
+        wh = (C.c_uint32 * 2)()
+        origin = np.zeros(2)
+        args = (self.bounds.ctypes.data_as(_dp), self.resolution, self.occ_thresh,
+                poses.ctypes.data_as(_dp), allpts.ctypes.data_as(_dp), off_p, len(scans), wh,
+                origin.ctypes.data_as(_dp))
+        L.orc_occupancy_render(*args, None)
+        data = np.zeros((wh[1], wh[0]), dtype=np.int8)
+        L.orc_occupancy_render(*args, data.ctypes.data_as(C.c_void_p))
+        return dict(resolution=self.resolution, width=int(wh[0]), height=int(wh[1]),
+                    origin_x=origin[0], origin_y=origin[1], data=data)
