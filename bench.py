@@ -215,13 +215,14 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    kernel_ms = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        kernel_ms.append(m.last_launch_ms()[0])  # HIP events around the search kernel
     fence()
     elapsed = time.perf_counter() - t0
+    # HIP events the library recorded around the search kernel of each of those
+    # launches, on the launch stream (it keeps the last 256 pairs)
+    kernel_ms = m.launch_history_ms(min(args.steps, 256))
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         all_reduce(t, dist.ReduceOp.MAX)

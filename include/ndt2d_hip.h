@@ -284,11 +284,19 @@ int ndt2d_synchronize(ndt2d_handle h);
  * most recent ndt2d_match_launch / ndt2d_score_poses_launch.  Synchronises.
  * *n_kernels (optional) = kernels launched by that call. */
 int ndt2d_last_launch_ms(ndt2d_handle h, float * ms, int * n_kernels);
+/* The same figure for the last launches, oldest first (the context keeps the
+ * event pairs of its last NDT2D_TIMING_HISTORY launches): lets a caller queue
+ * launches back to back and read the kernel durations afterwards.  Writes at
+ * most `capacity` values, *n_out = how many; blocks until the newest finished. */
+#define NDT2D_TIMING_HISTORY 256
+int ndt2d_launch_history_ms(ndt2d_handle h, float * ms_out, size_t capacity, size_t * n_out);
 /* Tuning / introspection: name of the kernel variant the last launch used. */
 const char * ndt2d_last_variant(ndt2d_handle h);
 /* Force a kernel variant (testing / A-B measurement): "auto", "lds", "global"
  * (grid placement), "wave", "wave-lds", "wave-global", "lane" (candidate mapping
- * of the match search). */
+ * of the match search), "lane-noskip" (the lane mapping with every term
+ * evaluated: the bit-exactness control of its skipping), "dense" (particle
+ * scoring without compaction). */
 int ndt2d_set_variant(ndt2d_handle h, const char * name);
 
 /* ------------------------------------------------------------------------ */

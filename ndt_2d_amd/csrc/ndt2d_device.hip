@@ -71,7 +71,11 @@ struct ndt2d_context
   DeviceBuffer scan_ranges, scan_points, scan_info;
   size_t n_scan_points = 0;
 
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // HIP events around the dominant kernel of each launch: a ring, so that a caller
+  // can queue launches back to back and read their durations afterwards
+  hipEvent_t ring0[NDT2D_TIMING_HISTORY] = {}, ring1[NDT2D_TIMING_HISTORY] = {};
+  uint64_t n_timed_launches = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;  // the current launch's pair
   bool timed = false;
   int last_kernels = 0;
   const char * last_variant = "";
@@ -195,6 +199,18 @@ ndt2d::MotionParams motion_params(double dx, double dy, double dth, const double
   return p;
 }
 
+// Take the next pair of timing events (created on first use) as h->ev0 / h->ev1.
+int next_timing_slot(ndt2d_context * h)
+{
+  const size_t slot = static_cast<size_t>(h->n_timed_launches % NDT2D_TIMING_HISTORY);
+  if (h->ring0[slot] == nullptr) NDT2D_HIP(h, hipEventCreate(&h->ring0[slot]));
+  if (h->ring1[slot] == nullptr) NDT2D_HIP(h, hipEventCreate(&h->ring1[slot]));
+  h->ev0 = h->ring0[slot];
+  h->ev1 = h->ring1[slot];
+  ++h->n_timed_launches;
+  return NDT2D_OK;
+}
+
 bool is_pow2(double v)
 {
   if (!(v > 0.0) || !std::isfinite(v)) return false;
@@ -225,8 +241,7 @@ int ndt2d_create(ndt2d_handle * out, int device_id)
   if (h == nullptr) return NDT2D_ERR_INVALID;
   h->device = device_id;
   if (hipSetDevice(device_id) != hipSuccess ||
-      hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess)
+      hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess)
   {
     (void)hipGetLastError();
     delete h;
@@ -269,8 +284,11 @@ int ndt2d_destroy(ndt2d_handle h)
   release(h->scan_ranges);
   release(h->scan_points);
   release(h->scan_info);
-  if (h->ev0) (void)hipEventDestroy(h->ev0);
-  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  for (int i = 0; i < NDT2D_TIMING_HISTORY; ++i)
+  {
+    if (h->ring0[i]) (void)hipEventDestroy(h->ring0[i]);
+    if (h->ring1[i]) (void)hipEventDestroy(h->ring1[i]);
+  }
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
   return NDT2D_OK;
@@ -469,6 +487,7 @@ int ndt2d_build_grid(ndt2d_handle h, double ndt_resolution, double range_max,
   a.cells_lds_image = h->cells_lds_image.ptr;
   a.cells_global = h->cells_global.ptr;
   a.occ_bits = reinterpret_cast<uint32_t *>(h->occ_bits.ptr);
+  if (int trc = next_timing_slot(h); trc != NDT2D_OK) return trc;
   NDT2D_HIP(h, hipEventRecord(h->ev0, h->stream));
   hipError_t e = ndt2d::launch_build_grid(a, h->stream);
   if (e != hipSuccess) return fail_hip(h, e, "launch_build_grid");
@@ -626,6 +645,7 @@ int ndt2d_match_launch(ndt2d_handle h, size_t th_begin, size_t th_end, double * 
   }
 
   ndt2d::LaunchInfo info{"", 0};
+  if (int trc = next_timing_slot(h); trc != NDT2D_OK) return trc;
   NDT2D_HIP(h, hipEventRecord(h->ev0, h->stream));
   hipError_t e = ndt2d::launch_match(a, h->ws_match.ptr, outer, h->record.ptr, d_record,
                                      h->force_variant, h->stream, h->ev1, &info);
@@ -704,6 +724,7 @@ int ndt2d_score_poses_launch(ndt2d_handle h, const double * d_poses_xyt, size_t 
   a.scores = d_scores;
 
   ndt2d::LaunchInfo info{"", 0};
+  if (int trc = next_timing_slot(h); trc != NDT2D_OK) return trc;
   NDT2D_HIP(h, hipEventRecord(h->ev0, h->stream));
   hipError_t e = ndt2d::launch_score_poses(a, h->ws_poses.ptr, d_stats, h->force_variant,
                                            h->stream, h->ev1, &info);
@@ -1196,6 +1217,24 @@ int ndt2d_last_launch_ms(ndt2d_handle h, float * ms, int * n_kernels)
   NDT2D_HIP(h, hipEventSynchronize(h->ev1));
   NDT2D_HIP(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
   if (n_kernels != nullptr) *n_kernels = h->last_kernels;
+  return NDT2D_OK;
+}
+
+int ndt2d_launch_history_ms(ndt2d_handle h, float * ms_out, size_t capacity, size_t * n_out)
+{
+  if (h == nullptr || n_out == nullptr || (capacity > 0 && ms_out == nullptr)) return NDT2D_ERR_INVALID;
+  *n_out = 0;
+  NDT2D_HIP(h, hipSetDevice(h->device));
+  size_t n = static_cast<size_t>(std::min<uint64_t>(h->n_timed_launches, NDT2D_TIMING_HISTORY));
+  if (n > capacity) n = capacity;
+  if (n == 0) return NDT2D_OK;
+  NDT2D_HIP(h, hipEventSynchronize(h->ev1));  // the newest; the stream is in order
+  for (size_t k = 0; k < n; ++k)
+  {
+    const size_t slot = static_cast<size_t>((h->n_timed_launches - n + k) % NDT2D_TIMING_HISTORY);
+    NDT2D_HIP(h, hipEventElapsedTime(&ms_out[k], h->ring0[slot], h->ring1[slot]));
+  }
+  *n_out = n;
   return NDT2D_OK;
 }
 

@@ -350,6 +350,15 @@ class ScanMatcherNDT:
             raise Ndt2dError(rc, "ndt2d_last_launch_ms")
         return ms.value, nk.value
 
+    def launch_history_ms(self, n=256):
+        """Kernel durations (ms) of the last up-to-n launches, oldest first; blocks until
+        the newest has finished."""
+        buf = (C.c_float * n)()
+        got = C.c_size_t(0)
+        self._dev_check(self._L.ndt2d_launch_history_ms(self.device_handle, buf, n, C.byref(got)),
+                        "ndt2d_launch_history_ms")
+        return [buf[i] for i in range(got.value)]
+
     def last_variant(self):
         v = self._L.ndt2d_last_variant(self.device_handle)
         return v.decode() if v else ""

@@ -214,6 +214,20 @@ def test_lane_skipping_is_bit_exact(cfg, override):
     _check_match(full, exp, min(720, len(pts)))
 
 
+def test_launch_timing_history(cfg1):
+    """ndt2d_launch_history_ms: durations of back-to-back launches, read afterwards."""
+    gpu, _, _, guess, pts = cfg1
+    n_th, _, _ = gpu.prepare_search(guess, pts)
+    for _ in range(5):
+        gpu.match_launch(0, n_th)
+    hist = gpu.launch_history_ms(5)
+    last, n_kernels = gpu.last_launch_ms()
+    assert len(hist) == 5 and all(0.0 < t < 50.0 for t in hist)
+    assert hist[-1] == last and n_kernels >= 2
+    assert len(gpu.launch_history_ms(3)) == 3
+    gpu.match_fetch()
+
+
 def test_runs_are_deterministic(cfg1):
     gpu, _, _, guess, pts = cfg1
     a = gpu.matchScan(guess, pts, want_scores=True)
