@@ -722,6 +722,7 @@ int ndt2d_score_poses_launch(ndt2d_handle h, const double * d_poses_xyt, size_t 
   a.poses_xyt = d_poses_xyt;
   a.n_poses = n_poses;
   a.scores = d_scores;
+  a.beam_rmax = h->beam_rmax;
 
   ndt2d::LaunchInfo info{"", 0};
   if (int trc = next_timing_slot(h); trc != NDT2D_OK) return trc;
@@ -1252,6 +1253,7 @@ int ndt2d_set_variant(ndt2d_handle h, const char * name)
   else if (std::strcmp(name, "lane") == 0) h->force_variant = ndt2d::kVariantLane;
   else if (std::strcmp(name, "lane-noskip") == 0) h->force_variant = ndt2d::kVariantLane | ndt2d::kVariantNoSkip;
   else if (std::strcmp(name, "dense") == 0) h->force_variant = ndt2d::kVariantDense;
+  else if (std::strcmp(name, "compact-exact") == 0) h->force_variant = ndt2d::kVariantNoSkip;
   else return fail(h, NDT2D_ERR_INVALID, "ndt2d_set_variant: unknown variant");
   return NDT2D_OK;
 }

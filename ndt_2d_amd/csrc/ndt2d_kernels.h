@@ -62,6 +62,8 @@ struct PosesArgs
   uint64_t n_poses;
   double * scores;           // [n_poses]
   double * partials;         // [n_blocks][8]  (may be null)
+  double beam_rmax;          // max |beam| (host side copy of the scan's reach)
+  float screen_guard;        // set by launch_poses_compact: FP32 screening error bound, cells
 };
 
 // NDT build on the device (ndt2d_build.hip).  `grid` carries the geometry only.
@@ -200,7 +202,9 @@ hipError_t launch_match_lane(const MatchArgs & args, double * outer, double * wo
 // Particle scoring with per-wave compaction of the occupied (pose, beam) pairs
 // (ndt2d_poses_compact.hip).
 bool poses_compact_supported(const PosesArgs & args, size_t lds_per_block);
-hipError_t launch_poses_compact(const PosesArgs & args, int cus, hipStream_t stream,
+// screen: phase A decides in FP32 which pairs can contribute (exact FP64 follows for
+// those); false = the exact phase A ("compact-exact", the control).
+hipError_t launch_poses_compact(const PosesArgs & args, int cus, bool screen, hipStream_t stream,
                                 uint32_t * blocks_out);
 
 // force_variant: grid placement in the low bits, candidate mapping above them

@@ -665,11 +665,11 @@ hipError_t launch_score_poses(const PosesArgs & args_in, double * workspace, dou
   // Default: per-wave compaction of the occupied (pose, beam) pairs; the dense
   // kernels remain for grids whose occupancy bitmap does not fit in LDS and for
   // A/B measurement ("dense", "lds", "global").
-  const bool use_compact = force_variant == kVariantAuto &&
+  const bool use_compact = (force_variant == kVariantAuto || force_variant == kVariantNoSkip) &&
                            poses_compact_supported(args, lim.lds_per_block);
   if (use_compact)
   {
-    e = launch_poses_compact(args, lim.cus, stream, &blocks);
+    e = launch_poses_compact(args, lim.cus, force_variant == kVariantAuto, stream, &blocks);
   }
   else if (use_lds)
 

@@ -21,6 +21,18 @@
 // The queue is FIFO in beam order and a (pose, beam) pair appears at most once, so
 // each owner's terms arrive in the reference's beam order; only exact zeros are
 // left out of the sums.
+//
+// SCREEN (default): phase A does not need the exact point, only a conservative answer
+// to "can this pair hit a cell with a distribution?".  It evaluates the cell
+// coordinate in FP32 -- u = U0 + (c/cell) bx - (s/cell) by with per-lane FP32
+// constants, four v_fma_f32 instead of eight FP64 operations -- takes the cell by
+// floor, and queues the pair {beam | lane} if that cell is occupied OR the
+// coordinate lies within `guard` (a bound of the FP32 error, see screen_guard())
+// of a cell boundary or of the grid's edge.  Phase B then redoes the transform and
+// NDT::getIndex exactly in FP64 for the few queued pairs.  Every pair that can
+// contribute is queued, in the same order, and a queued pair that turns out to be
+// empty adds exactly +0.0, so the scores are those of the unscreened kernel bit for
+// bit (variant "compact-exact" is that kernel; the tests compare the two).
 #include "ndt2d_device_fn.h"
 
 namespace ndt2d
@@ -46,15 +58,28 @@ struct CompactLayout
 {
   static constexpr int kWaves = THREADS / kWave;
   // doubles: [stats kWaves*8][sums THREADS][q_px kWaves*cap][q_py kWaves*cap]
-  //          [q_meta (u32) kWaves*cap/2]; then beams, occupancy bitmap and, when
-  //          several waves share a group, the chunk sums [groups][kChunks][64]
+  //          [q_meta (u32) kWaves*cap/2]; then beams (f64), beams (f32, SCREEN only),
+  //          occupancy bitmap and, when several waves share a group, the chunk sums
+  //          [groups][kChunks][64].  (SCREEN leaves q_px / q_py unused.)
   static constexpr size_t kFixedDoubles =
     static_cast<size_t>(kWaves) * 8 + THREADS + 2 * static_cast<size_t>(kWaves) * kQueueCap +
     static_cast<size_t>(kWaves) * kQueueCap / 2;
 };
 
+constexpr uint32_t kBeamBits = 26;       // SCREEN queue word = beam index | lane << 26
+
+// Bound (in cells) of |u_f32 - u| for the screening coordinate of a pose whose own
+// cell coordinate is within `reach` cells of the grid: the four fused operations and
+// the rounding of their FP32 inputs each contribute at most 2^-24 of the largest
+// magnitude involved; 16x that, and never less than 2^-12 cell.
+__host__ __device__ inline float screen_guard(float magnitude)
+{
+  const float g = magnitude * (16.0f / 16777216.0f);
+  return g > (1.0f / 4096.0f) ? g : (1.0f / 4096.0f);
+}
+
 // SPLIT waves share the 64 poses of a group; each takes kChunks / SPLIT chunks.
-template <int THREADS, bool POW2>
+template <int THREADS, bool POW2, bool SCREEN>
 __global__ void __launch_bounds__(THREADS) score_poses_compact_kernel(const PosesArgs a,
                                                                       const uint32_t split)
 {
@@ -66,10 +91,17 @@ __global__ void __launch_bounds__(THREADS) score_poses_compact_kernel(const Pose
   double * q_py_all = q_px_all + L::kWaves * kQueueCap;
   uint32_t * q_meta_all = reinterpret_cast<uint32_t *>(q_py_all + L::kWaves * kQueueCap);
   double * lds_beams = reinterpret_cast<double *>(q_meta_all + L::kWaves * kQueueCap);
-  uint32_t * lds_bits = reinterpret_cast<uint32_t *>(lds_beams + 2 * ((a.n_beams + 1) & ~1u));
+  float * lds_beams_f = reinterpret_cast<float *>(lds_beams + 2 * ((a.n_beams + 1) & ~1u));
+  uint32_t * lds_bits =
+    reinterpret_cast<uint32_t *>(lds_beams_f + (SCREEN ? 2 * ((a.n_beams + 1) & ~1u) : 0));
 
   const GridDesc & g = a.grid;
-  for (uint32_t i = threadIdx.x; i < 2 * a.n_beams; i += THREADS) lds_beams[i] = a.beams_xy[i];
+  for (uint32_t i = threadIdx.x; i < 2 * a.n_beams; i += THREADS)
+  {
+    const double v = a.beams_xy[i];
+    lds_beams[i] = v;
+    if (SCREEN) lds_beams_f[i] = static_cast<float>(v);
+  }
   const uint32_t n_words = (g.ncell + 1 + 31) / 32;
   // chunk sums [group][chunk][lane], only used (and allocated) when split > 1
   double * sh_chunk = reinterpret_cast<double *>(lds_bits + ((n_words + 3) & ~3u));
@@ -94,9 +126,33 @@ __global__ void __launch_bounds__(THREADS) score_poses_compact_kernel(const Pose
 #pragma unroll
   for (int k = 0; k < 8; ++k) st[k] = 0.0;
 
+  // SCREEN: what a pose needs for the exact transform in phase B, read from its owner
+  // lane with wave shuffles
+  double pose_x = 0.0, pose_y = 0.0, pose_c = 0.0, pose_s = 0.0;
+
   // Phase B: lanes [0, n) each evaluate one queued item
   auto drain = [&](uint32_t head, uint32_t n) {
-    if (lane < n)
+    if (SCREEN)
+    {
+      const uint32_t slot = (head + lane) & (kQueueCap - 1);
+      const uint32_t meta = lane < n ? q_meta[slot] : 0u;
+      const int owner = static_cast<int>(meta >> kBeamBits);
+      // (all lanes take part in the shuffles)
+      const double ox = __shfl(pose_x, owner, kWave);
+      const double oy = __shfl(pose_y, owner, kWave);
+      const double oc = __shfl(pose_c, owner, kWave);
+      const double os = __shfl(pose_s, owner, kWave);
+      if (lane < n)
+      {
+        const double2 p = reinterpret_cast<const double2 *>(lds_beams)[meta & ((1u << kBeamBits) - 1u)];
+        // p = t * (x, y, 1) (:172-173), exactly as the unscreened phase A has it
+        const double px = ox + (oc * p.x - os * p.y);
+        const double py = oy + (os * p.x + oc * p.y);
+        const double e = indexed_exponent<false>(g, nullptr, cell_index<POW2>(g, px, py), px, py);
+        atomicAdd(&my_sums[owner], exp_score(e));
+      }
+    }
+    else if (lane < n)
     {
       const uint32_t slot = (head + lane) & (kQueueCap - 1);
       const double px = q_px[slot];
@@ -125,6 +181,27 @@ __global__ void __launch_bounds__(THREADS) score_poses_compact_kernel(const Pose
     // toEigen(pose): AngleAxisd(theta, Z) -> [[c,-s],[s,c]] (conversions.hpp:64-68)
     double s, c;
     sincos(th, &s, &c);
+
+    // SCREEN: FP32 cell coordinate of a beam end, u = u0 + ci * bx - si * by,
+    // v = v0 + si * bx + ci * by.  A pose further from the grid than any beam reaches
+    // (or not finite) cannot hit it: its coordinate is parked far outside.
+    float u0 = 0.0f, v0 = 0.0f, ci = 0.0f, si = 0.0f;
+    if (SCREEN)
+    {
+      pose_x = x;
+      pose_y = y;
+      pose_c = c;
+      pose_s = s;
+      const double inv = 1.0 / g.cell_size;
+      const double du = (x - g.origin_x) * inv, dv = (y - g.origin_y) * inv;
+      const double reach = a.beam_rmax * inv + 2.0;
+      const bool in_band = du > -reach && du < static_cast<double>(g.size_x) + reach &&
+                           dv > -reach && dv < static_cast<double>(g.size_y) + reach;
+      u0 = in_band ? static_cast<float>(du) : -1.0e30f;
+      v0 = in_band ? static_cast<float>(dv) : -1.0e30f;
+      ci = in_band ? static_cast<float>(c * inv) : 0.0f;
+      si = in_band ? static_cast<float>(s * inv) : 0.0f;
+    }
 
     double total = 0.0;
     for (uint32_t cj = 0; cj < chunks_per_part; ++cj)
@@ -157,8 +234,79 @@ __global__ void __launch_bounds__(THREADS) score_poses_compact_kernel(const Pose
           }
         }
       };
+      // SCREEN: can this pair contribute?  Yes if the FP32 cell is occupied, or if the
+      // coordinate is so close to a cell boundary (or to the grid's edge) that the
+      // exact point may lie in the neighbouring cell; no if the cell is empty or the
+      // point is more than a cell outside the grid.
+      // Written branch-free (bitwise & / |, an unconditional bitmap read of the
+      // never-set bit `ncell` for points outside) and in two halves, so that the LDS
+      // reads of the kPhaseA beams of a step are in flight together.
+      struct Screen
+      {
+        uint32_t idx;   // bitmap bit to test
+        bool near;
+      };
+      auto screen_address = [&](float2 bf) -> Screen {
+        const float u = fmaf(ci, bf.x, fmaf(-si, bf.y, u0));
+        const float v = fmaf(si, bf.x, fmaf(ci, bf.y, v0));
+        const float flu = floorf(u), flv = floorf(v);
+        const int iu = static_cast<int>(flu), iv = static_cast<int>(flv);
+        const bool inside = (static_cast<uint32_t>(iu) < g.size_x) & (static_cast<uint32_t>(iv) < g.size_y);
+        const bool around = (static_cast<uint32_t>(iu + 1) <= g.size_x + 1u) &
+                            (static_cast<uint32_t>(iv + 1) <= g.size_y + 1u);
+        Screen r;
+        r.idx = inside ? static_cast<uint32_t>(iv) * g.size_x + static_cast<uint32_t>(iu) : g.ncell;
+        r.near = around &
+                 (fmaxf(fabsf((u - flu) - 0.5f), fabsf((v - flv) - 0.5f)) > 0.5f - a.screen_guard);
+        return r;
+      };
+      auto push_screened = [&](uint32_t beam, bool candidate) {
+        const uint64_t mask = __ballot(candidate);
+        if (mask != 0)
+        {
+          if (candidate)
+          {
+            const uint32_t slot =
+              (head + count + static_cast<uint32_t>(__popcll(mask & lanes_below))) & (kQueueCap - 1);
+            q_meta[slot] = beam | (lane << kBeamBits);
+          }
+          count += static_cast<uint32_t>(__popcll(mask));
+          if (count >= kWave)
+          {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            drain(head, kWave);
+            head = (head + kWave) & (kQueueCap - 1);
+            count -= kWave;
+          }
+        }
+      };
       // kPhaseA beams per step so that their LDS reads (beam, bitmap word) overlap
       uint32_t k = k0;
+      if (SCREEN)
+      {
+        constexpr int kScreenStep = 4;
+        for (; k + kScreenStep <= k1; k += kScreenStep)
+        {
+          Screen sc[kScreenStep];
+          uint32_t word[kScreenStep];
+#pragma unroll
+          for (int u = 0; u < kScreenStep; ++u)
+          {
+            sc[u] = screen_address(reinterpret_cast<const float2 *>(lds_beams_f)[k + u]);
+            word[u] = lds_bits[sc[u].idx >> 5];
+          }
+#pragma unroll
+          for (int u = 0; u < kScreenStep; ++u)
+          {
+            push_screened(k + u, (((word[u] >> (sc[u].idx & 31u)) & 1u) != 0) | sc[u].near);
+          }
+        }
+        for (; k < k1; ++k)
+        {
+          const Screen sc = screen_address(reinterpret_cast<const float2 *>(lds_beams_f)[k]);
+          push_screened(k, (((lds_bits[sc.idx >> 5] >> (sc.idx & 31u)) & 1u) != 0) | sc.near);
+        }
+      }
       for (; k + kPhaseA <= k1; k += kPhaseA)
       {
         double px[kPhaseA], py[kPhaseA];
@@ -254,7 +402,8 @@ size_t compact_lds_bytes(const PosesArgs & args, int threads, uint32_t split)
 {
   const size_t fixed = threads == 1024 ? CompactLayout<1024>::kFixedDoubles
                                        : CompactLayout<256>::kFixedDoubles;
-  const size_t beams = static_cast<size_t>(2) * ((args.n_beams + 1) & ~1u);
+  // f64 beams + (screening) their f32 copy, 1.5 doubles per coordinate
+  const size_t beams = static_cast<size_t>(3) * ((args.n_beams + 1) & ~1u);
   const size_t words = (static_cast<size_t>(args.grid.ncell) + 1 + 31) / 32;
   const size_t chunk_sums =
     split > 1 ? static_cast<size_t>(threads / kWave / split) * kChunks * kWave : 0;
@@ -278,7 +427,7 @@ uint32_t choose_split(const PosesArgs & args, int cus, uint32_t waves_per_block)
 
 template <int THREADS>
 hipError_t launch_compact(const PosesArgs & args, uint32_t blocks, uint32_t split,
-                          size_t lds_bytes, hipStream_t stream)
+                          size_t lds_bytes, bool screen, hipStream_t stream)
 {
   auto launch = [&](auto kernel) -> hipError_t {
     if (lds_bytes > 48 * 1024)
@@ -291,8 +440,13 @@ hipError_t launch_compact(const PosesArgs & args, uint32_t blocks, uint32_t spli
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(THREADS), lds_bytes, stream, args, split);
     return hipGetLastError();
   };
-  return args.grid.pow2 ? launch(score_poses_compact_kernel<THREADS, true>)
-                        : launch(score_poses_compact_kernel<THREADS, false>);
+  if (screen)
+  {
+    return args.grid.pow2 ? launch(score_poses_compact_kernel<THREADS, true, true>)
+                          : launch(score_poses_compact_kernel<THREADS, false, true>);
+  }
+  return args.grid.pow2 ? launch(score_poses_compact_kernel<THREADS, true, false>)
+                        : launch(score_poses_compact_kernel<THREADS, false, false>);
 }
 
 }  // namespace
@@ -303,9 +457,18 @@ bool poses_compact_supported(const PosesArgs & args, size_t lds_per_block)
          compact_lds_bytes(args, 1024, 1) <= lds_per_block;
 }
 
-hipError_t launch_poses_compact(const PosesArgs & args, int cus, hipStream_t stream,
-                                uint32_t * blocks_out)
+hipError_t launch_poses_compact(const PosesArgs & args_in, int cus, bool screen,
+                                hipStream_t stream, uint32_t * blocks_out)
 {
+  PosesArgs args = args_in;
+  // screening needs a finite bound of the beams' reach, and a grid the FP32 cell
+  // coordinate resolves to well under a cell
+  const double reach_cells = args.beam_rmax / args.grid.cell_size;
+  const double magnitude =
+    static_cast<double>(args.grid.size_x > args.grid.size_y ? args.grid.size_x : args.grid.size_y) +
+    2.0 * reach_cells + 4.0;
+  if (!(magnitude < 65536.0)) screen = false;   // also catches NaN / inf reach
+  args.screen_guard = screen ? screen_guard(static_cast<float>(magnitude)) : 0.0f;
   // Small LDS image: 256-thread blocks, several per CU.  Large occupancy bitmap:
   // one 1024-thread block per CU shares it.
   uint32_t split = choose_split(args, cus, 4);
@@ -330,8 +493,8 @@ hipError_t launch_poses_compact(const PosesArgs & args, int cus, hipStream_t str
   const uint64_t cap = use_small ? 4096 : static_cast<uint64_t>(cus);
   const uint32_t blocks = static_cast<uint32_t>(need < cap ? need : cap);
   if (blocks_out != nullptr) *blocks_out = blocks;
-  return use_small ? launch_compact<256>(args, blocks, split, lds_bytes, stream)
-                   : launch_compact<1024>(args, blocks, split, lds_bytes, stream);
+  return use_small ? launch_compact<256>(args, blocks, split, lds_bytes, screen, stream)
+                   : launch_compact<1024>(args, blocks, split, lds_bytes, screen, stream);
 }
 
 }  // namespace ndt2d

@@ -89,8 +89,12 @@ def test_random_case(seed):
             assert np.allclose(got["covariance"], exp["covariance"], rtol=1e-7, atol=1e-12,
                                equal_nan=True), (seed, variant)
     gpu.set_variant("auto")
-    for variant in ("auto", "dense"):
+    w_by = {}
+    for variant in ("auto", "compact-exact", "dense"):
         gpu.set_variant(variant)
-        w = gpu.scorePoses(query, poses)
+        w = w_by[variant] = gpu.scorePoses(query, poses)
         assert np.array_equal(np.isnan(w), np.isnan(w_exp)), (seed, variant)
         assert np.allclose(w, w_exp, rtol=0, atol=1e-9, equal_nan=True), (seed, variant)
+    # the FP32 screening of the particle kernel never changes a bit
+    assert np.array_equal(w_by["auto"], w_by["compact-exact"], equal_nan=True), seed
+    gpu.set_variant("auto")

@@ -586,6 +586,46 @@ def test_cfg5_sized_particle_set():
     assert np.array_equal(halves, w)
     small = np.concatenate([gpu.scorePoses(pts, parts[i:i + 7777]) for i in range(0, 70000, 7777)])
     assert np.array_equal(small, w[:len(small)])
+    # the FP32 screening of phase A leaves every weight bit-identical
+    try:
+        gpu.set_variant("compact-exact")
+        assert np.array_equal(gpu.scorePoses(pts, parts), w)
+    finally:
+        gpu.set_variant("auto")
+
+
+@pytest.mark.parametrize("cfg", [1, 3])
+def test_particle_screening_is_bit_exact(cfg):
+    """Poses inside, on the rim of and far outside the grid, beams ending on cell
+    boundaries: the screened kernel ("auto") and the exact phase A ("compact-exact")
+    give the same bits, and both match the oracle."""
+    gpu, ref, _, _, pts = _pair(cfg, laser_max_beams=2000)
+    _, sx, sy, cell, ox, oy = gpu.grid()
+    rng = np.random.default_rng(cfg)
+    n = 20000
+    parts = np.stack([rng.uniform(ox, ox + sx * cell, n), rng.uniform(oy, oy + sy * cell, n),
+                      rng.uniform(-np.pi, np.pi, n)], axis=1)
+    # a quarter of the poses around / beyond the edge of the grid
+    edge = rng.integers(0, n, n // 4)
+    parts[edge, 0] = ox + rng.choice([-1.0, 0.0, 1.0], len(edge)) * sx * cell * rng.uniform(0.9, 1.6, len(edge))
+    parts[edge[: len(edge) // 2], 1] = oy + sy * cell * rng.uniform(-0.5, 1.5, len(edge) // 2)
+    parts[rng.integers(0, n, 50)] = [1e9, -1e9, 0.3]
+    # beams that end exactly on cell boundaries for axis-aligned poses on the lattice
+    parts[:64, 0] = ox + cell * rng.integers(1, sx - 1, 64)
+    parts[:64, 1] = oy + cell * rng.integers(1, sy - 1, 64)
+    parts[:64, 2] = rng.choice([0.0, np.pi / 2, np.pi, -np.pi / 2], 64)
+    beams = np.concatenate([pts, cell * rng.integers(-12, 12, size=(80, 2)).astype(np.float64)])
+    want = O.pf_measure(ref, parts, beams, omp_threads=os.cpu_count())
+    try:
+        got = gpu.scorePoses(beams, parts)
+        assert "compact" in gpu.last_variant()
+        gpu.set_variant("compact-exact")
+        exact = gpu.scorePoses(beams, parts)
+    finally:
+        gpu.set_variant("auto")
+    assert np.array_equal(got, exact)
+    assert np.max(np.abs(got - want)) < TOL_TIGHT
+    assert (got < 0).sum() > n // 2
 
 
 def test_no_ndt_returns_zero_and_leaves_outputs():
