@@ -197,8 +197,9 @@ __global__ void __launch_bounds__(THREADS) score_poses_compact_kernel(const Pose
       const double reach = a.beam_rmax * inv + 2.0;
       const bool in_band = du > -reach && du < static_cast<double>(g.size_x) + reach &&
                            dv > -reach && dv < static_cast<double>(g.size_y) + reach;
-      u0 = in_band ? static_cast<float>(du) : -1.0e30f;
-      v0 = in_band ? static_cast<float>(dv) : -1.0e30f;
+      // (parked at the centre of cell (-2, -2): outside, and not near any boundary)
+      u0 = in_band ? static_cast<float>(du) : -1.5f;
+      v0 = in_band ? static_cast<float>(dv) : -1.5f;
       ci = in_band ? static_cast<float>(c * inv) : 0.0f;
       si = in_band ? static_cast<float>(s * inv) : 0.0f;
     }
@@ -244,21 +245,29 @@ __global__ void __launch_bounds__(THREADS) score_poses_compact_kernel(const Pose
       struct Screen
       {
         uint32_t idx;   // bitmap bit to test
-        bool near;
+        float edge;     // max over the axes of |fraction - 0.5|: near a boundary if > 0.5 - guard
       };
       auto screen_address = [&](float2 bf) -> Screen {
         const float u = fmaf(ci, bf.x, fmaf(-si, bf.y, u0));
         const float v = fmaf(si, bf.x, fmaf(ci, bf.y, v0));
-        const float flu = floorf(u), flv = floorf(v);
-        const int iu = static_cast<int>(flu), iv = static_cast<int>(flv);
+        int iu, iv;  // floor, one instruction each
+        asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(iu) : "v"(u));
+        asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(iv) : "v"(v));
         const bool inside = (static_cast<uint32_t>(iu) < g.size_x) & (static_cast<uint32_t>(iv) < g.size_y);
-        const bool around = (static_cast<uint32_t>(iu + 1) <= g.size_x + 1u) &
-                            (static_cast<uint32_t>(iv + 1) <= g.size_y + 1u);
         Screen r;
-        r.idx = inside ? static_cast<uint32_t>(iv) * g.size_x + static_cast<uint32_t>(iu) : g.ncell;
-        r.near = around &
-                 (fmaxf(fabsf((u - flu) - 0.5f), fabsf((v - flv) - 0.5f)) > 0.5f - a.screen_guard);
+        r.idx = inside ? __umul24(static_cast<uint32_t>(iv), g.size_x) + static_cast<uint32_t>(iu) : g.ncell;
+        // fractional part within `guard` of 0 or 1 on either axis.  (Far outside the
+        // grid this also fires now and then: a harmless false candidate.)
+        const float fu = __builtin_amdgcn_fractf(u) - 0.5f, fv = __builtin_amdgcn_fractf(v) - 0.5f;
+        r.edge = fmaxf(fabsf(fu), fabsf(fv));
         return r;
+      };
+      // mask = 2 * mask + (edge > limit): compare into vcc, add-with-carry shifts it in
+      auto shift_in_near = [](uint32_t & mask, float edge, float limit) {
+        asm("v_cmp_gt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+            : "+v"(mask)
+            : "v"(edge), "v"(limit)
+            : "vcc");
       };
       auto push_screened = [&](uint32_t beam, bool candidate) {
         const uint64_t mask = __ballot(candidate);
@@ -284,28 +293,61 @@ __global__ void __launch_bounds__(THREADS) score_poses_compact_kernel(const Pose
       uint32_t k = k0;
       if (SCREEN)
       {
+        // Nearly every beam has a candidate in SOME lane, so a queue step per beam would
+        // run every time.  Instead each lane collects the candidates of kScreenBlock beams
+        // as bits of one register, and the block is queued in rounds: round r appends
+        // every lane's r-th candidate.  A lane's pairs still enter the queue in beam
+        // order, which is all its running sum depends on; the rounds are as many as
+        // the busiest lane has candidates (a few), not kScreenBlock.
         constexpr int kScreenStep = 4;
-        for (; k + kScreenStep <= k1; k += kScreenStep)
+        constexpr int kScreenBlock = 32;
+        const float near_limit = 0.5f - a.screen_guard;
+        for (; k < k1; k += kScreenBlock)
         {
-          Screen sc[kScreenStep];
-          uint32_t word[kScreenStep];
-#pragma unroll
-          for (int u = 0; u < kScreenStep; ++u)
+          uint32_t cmask = 0;
+          if (k + kScreenBlock <= k1)
           {
-            sc[u] = screen_address(reinterpret_cast<const float2 *>(lds_beams_f)[k + u]);
-            word[u] = lds_bits[sc[u].idx >> 5];
+            // occupancy bits are OR-ed in place (v_bfe + v_lshl_or); the "near" bits are
+            // shifted in first-beam-first and bit-reversed at the end of the block
+            uint32_t near_rev = 0;
+#pragma unroll
+            for (int b0 = 0; b0 < kScreenBlock; b0 += kScreenStep)
+            {
+              Screen sc[kScreenStep];
+              uint32_t word[kScreenStep];
+#pragma unroll
+              for (int u = 0; u < kScreenStep; ++u)
+              {
+                sc[u] = screen_address(reinterpret_cast<const float2 *>(lds_beams_f)[k + b0 + u]);
+                word[u] = lds_bits[sc[u].idx >> 5];
+              }
+#pragma unroll
+              for (int u = 0; u < kScreenStep; ++u)
+              {
+                cmask |= ((word[u] >> (sc[u].idx & 31u)) & 1u) << (b0 + u);
+                shift_in_near(near_rev, sc[u].edge, near_limit);
+              }
+            }
+            cmask |= __builtin_bitreverse32(near_rev);
           }
-#pragma unroll
-          for (int u = 0; u < kScreenStep; ++u)
+          else
           {
-            push_screened(k + u, (((word[u] >> (sc[u].idx & 31u)) & 1u) != 0) | sc[u].near);
+            for (uint32_t b = 0; k + b < k1; ++b)
+            {
+              const Screen sc = screen_address(reinterpret_cast<const float2 *>(lds_beams_f)[k + b]);
+              const bool candidate =
+                (((lds_bits[sc.idx >> 5] >> (sc.idx & 31u)) & 1u) != 0) | (sc.edge > near_limit);
+              cmask |= candidate ? (1u << b) : 0u;
+            }
+          }
+          while (__builtin_amdgcn_ballot_w64(cmask != 0u) != 0ull)
+          {
+            const uint32_t lowest = static_cast<uint32_t>(__ffs(static_cast<int>(cmask))) - 1u;
+            push_screened(k + lowest, cmask != 0u);
+            cmask &= cmask - 1u;
           }
         }
-        for (; k < k1; ++k)
-        {
-          const Screen sc = screen_address(reinterpret_cast<const float2 *>(lds_beams_f)[k]);
-          push_screened(k, (((lds_bits[sc.idx >> 5] >> (sc.idx & 31u)) & 1u) != 0) | sc.near);
-        }
+        k = k1;
       }
       for (; k + kPhaseA <= k1; k += kPhaseA)
       {
@@ -468,6 +510,7 @@ hipError_t launch_poses_compact(const PosesArgs & args_in, int cus, bool screen,
     static_cast<double>(args.grid.size_x > args.grid.size_y ? args.grid.size_x : args.grid.size_y) +
     2.0 * reach_cells + 4.0;
   if (!(magnitude < 65536.0)) screen = false;   // also catches NaN / inf reach
+  if (args.grid.size_x >= (1u << 24)) screen = false;  // 24-bit multiply of the bitmap index
   args.screen_guard = screen ? screen_guard(static_cast<float>(magnitude)) : 0.0f;
   // Small LDS image: 256-thread blocks, several per CU.  Large occupancy bitmap:
   // one 1024-thread block per CU shares it.
