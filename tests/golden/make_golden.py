@@ -107,11 +107,50 @@ def cfg3_poses(n=256):
         weights_raw=w_raw, weights=w, mean=mean, cov=cov)
 
 
+def next_rows():
+    """The steps either side of the hot path: LaserScan
+    conversion, motion model / filter init, occupancy grid -- oracle outputs."""
+    out = {}
+    # N2: the cfg-1 query scan as a LaserScan (ranges float32), with drop-outs
+    _, pts, _ = synth.query_scan(1)
+    rng = np.random.default_rng(11)
+    ranges = np.hypot(pts[:, 0], pts[:, 1]).astype(np.float32)
+    ranges[rng.random(len(ranges)) < 0.04] = np.nan
+    ranges[rng.random(len(ranges)) < 0.02] = 1e6
+    conv = dict(angle_min=-np.pi, angle_increment=2.0 * np.pi / len(ranges), range_max=4.75,
+                laser=(0.05, -0.02, 0.01), motion=(0.02, -0.01, 0.015))
+    out.update(scan_ranges=ranges, scan_params_json=json.dumps(conv),
+               scan_points=O.convert_scan(ranges, inverted=False, **conv),
+               scan_points_inverted=O.convert_scan(ranges, inverted=True, **conv))
+    # N3: MotionModel::sample and ParticleFilter::init on given standard normals
+    poses = np.stack([rng.uniform(-3, 3, 256), rng.uniform(-3, 3, 256),
+                      rng.uniform(-np.pi, np.pi, 256)], axis=1)
+    z = rng.standard_normal((256, 3)).astype(np.float32)
+    alphas = [0.2, 0.05, 0.15, 0.02, 0.0]
+    moved, mparams = O.motion_sample(0.3, -0.1, 0.4, alphas, poses, z)
+    out.update(pf_poses=poses, pf_noise=z, pf_alphas=np.array(alphas), pf_motion=np.array([0.3, -0.1, 0.4]),
+               pf_moved=moved, pf_motion_params=mparams,
+               pf_init_args=np.array([1.25, -3.5, 3.0, 0.3, 0.2, 0.5]),
+               pf_init=O.pf_init(1.25, -3.5, 3.0, 0.3, 0.2, 0.5, z))
+    # N4: the cfg-1 map rendered at 5 cm, hit ratio 0.25
+    m = O.OccupancyGrid(0.05, 0.25).getMsg(synth.map_scans(1))
+    out.update(occ_info=np.array([m["resolution"], m["width"], m["height"], m["origin_x"], m["origin_y"]]),
+               occ_data=m["data"])
+    return out
+
+
+FIXTURES = {"cfg1_match.npz": cfg1_match, "cfg3_poses256.npz": cfg3_poses, "next_rows.npz": next_rows}
+
+
 def main():
-    with open(os.path.join(HERE, "reference_ndt_model_tests.json"), "w") as f:
-        json.dump(reference_vectors(), f, indent=1, sort_keys=True)
-    np.savez_compressed(os.path.join(HERE, "cfg1_match.npz"), **cfg1_match())
-    np.savez_compressed(os.path.join(HERE, "cfg3_poses256.npz"), **cfg3_poses())
+    """python make_golden.py [fixture.npz ...]   (default: all)"""
+    names = sys.argv[1:] or ["reference_ndt_model_tests.json"] + sorted(FIXTURES)
+    for name in names:
+        if name == "reference_ndt_model_tests.json":
+            with open(os.path.join(HERE, name), "w") as f:
+                json.dump(reference_vectors(), f, indent=1, sort_keys=True)
+        else:
+            np.savez_compressed(os.path.join(HERE, name), **FIXTURES[name]())
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))
 
