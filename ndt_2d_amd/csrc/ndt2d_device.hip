@@ -427,8 +427,7 @@ int ndt2d_build_grid(ndt2d_handle h, double ndt_resolution, double range_max,
   {
     h->stage_scans[4 * k] = poses_xyt[3 * k];
     h->stage_scans[4 * k + 1] = poses_xyt[3 * k + 1];
-    h->stage_scans[4 * k + 2] = std::cos(poses_xyt[3 * k + 2]);  // :135-136, host libm
-    h->stage_scans[4 * k + 3] = std::sin(poses_xyt[3 * k + 2]);
+    ndt2d_cos_sin(poses_xyt[3 * k + 2], &h->stage_scans[4 * k + 2], &h->stage_scans[4 * k + 3]);  // :135-136, host libm
     h->stage_offsets[k] = static_cast<uint32_t>(offsets[k]);
   }
   h->stage_offsets[n_scans] = static_cast<uint32_t>(n_points);
@@ -951,8 +950,7 @@ ndt2d::ScanDesc scan_desc(const ndt2d_laser_scan & s)
   d.laser_x = s.laser_x;
   d.laser_y = s.laser_y;
   // reference src/ndt_mapper.cpp:403-404 ("minor optimization"): host libm
-  d.cos_lt = std::cos(s.laser_theta);
-  d.sin_lt = std::sin(s.laser_theta);
+  ndt2d_cos_sin(s.laser_theta, &d.cos_lt, &d.sin_lt);
   d.motion_x = s.motion_x;
   d.motion_y = s.motion_y;
   d.motion_theta = s.motion_theta;
@@ -1109,8 +1107,7 @@ int ndt2d_occupancy_grid(ndt2d_handle h, double resolution, double occ_thresh,
   {
     h->stage_scans[4 * k] = poses_xyt[3 * k];
     h->stage_scans[4 * k + 1] = poses_xyt[3 * k + 1];
-    h->stage_scans[4 * k + 2] = std::cos(poses_xyt[3 * k + 2]);  // :78-79,163-164, host libm
-    h->stage_scans[4 * k + 3] = std::sin(poses_xyt[3 * k + 2]);
+    ndt2d_cos_sin(poses_xyt[3 * k + 2], &h->stage_scans[4 * k + 2], &h->stage_scans[4 * k + 3]);  // :78-79,163-164, host libm
     h->stage_offsets[k] = static_cast<uint32_t>(offsets[k]);
   }
   h->stage_offsets[n_scans] = static_cast<uint32_t>(n_points);

@@ -22,6 +22,15 @@
 namespace
 {
 
+// cos(t) and sin(t) of one argument, as a GCC-built reference gets them: wherever
+// the reference writes the pair, GCC merges the two calls into one glibc sincos(),
+// whose sine can differ from sin()'s in the last ulp (t = 0.4710119964311561).
+// (Same helper as in ndt2d_kernels.h; this file stays free of HIP headers.)
+inline void ndt2d_cos_sin(double t, double * c, double * s)
+{
+  sincos(t, s, c);
+}
+
 // ---------------------------------------------------------------------------
 // Host NDT build
 // ---------------------------------------------------------------------------
@@ -136,8 +145,8 @@ public:
   // NDT::addScan, reference src/ndt_model.cpp:132-152
   void add_scan(double pose_x, double pose_y, double pose_theta, const double * pts, size_t n)
   {
-    const double cos_th = std::cos(pose_theta);
-    const double sin_th = std::sin(pose_theta);
+    double cos_th, sin_th;
+    ndt2d_cos_sin(pose_theta, &cos_th, &sin_th);  // :135-136
     for (size_t k = 0; k < n; ++k)
     {
       const double px = pts[2 * k], py = pts[2 * k + 1];
@@ -301,8 +310,7 @@ int prepare_tables(ndt2d_matcher * m, const double * scan_pose_xyt, size_t use, 
   for (size_t i = 0; i < n_th; ++i)
   {
     // reference src/scan_matcher_ndt.cpp:106-107
-    cos_th[i] = std::cos(scan_pose_xyt[2] + m->dth[i]);
-    sin_th[i] = std::sin(scan_pose_xyt[2] + m->dth[i]);
+    ndt2d_cos_sin(scan_pose_xyt[2] + m->dth[i], &cos_th[i], &sin_th[i]);
   }
   int rc = ndt2d_set_search(m->dev, scan_pose_xyt[0], scan_pose_xyt[1], m->dth.data(), cos_th.data(),
                             sin_th.data(), n_th, m->dlin.data(), n_lin);
@@ -719,8 +727,10 @@ int ndt2d_matcher_pf_measure(ndt2d_matcher * m, const double * particles_xyt,
     stats[0] += w;
     stats[1] += w * p[0];
     stats[2] += w * p[1];
-    stats[3] += w * std::cos(p[2]);
-    stats[4] += w * std::sin(p[2]);
+    double cos_p, sin_p;
+    ndt2d_cos_sin(p[2], &cos_p, &sin_p);
+    stats[3] += w * cos_p;
+    stats[4] += w * sin_p;
     stats[5] += w * p[0] * p[0];
     stats[6] += w * p[0] * p[1];
     stats[7] += w * p[1] * p[1];

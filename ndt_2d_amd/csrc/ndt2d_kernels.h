@@ -5,8 +5,19 @@
 #define NDT2D_KERNELS_H_
 
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stddef.h>
 #include <stdint.h>
+
+// cos(t) and sin(t) of one argument on the HOST, as a GCC-built reference gets them:
+// wherever the reference writes the pair (`cos(pose.theta)`, `sin(pose.theta)`, ...)
+// GCC merges the two calls into one glibc sincos(), whose sine can differ from sin()'s
+// in the last ulp (t = 0.4710119964311561).  Host code of this library therefore asks
+// for the pair explicitly instead of leaving it to the compiler that builds it.
+inline void ndt2d_cos_sin(double t, double * c, double * s)
+{
+  sincos(t, s, c);
+}
 
 namespace ndt2d
 {

@@ -7,6 +7,7 @@
  * with no FMA contraction (build with -ffp-contract=off; the reference's
  * default x86-64 Release build has no FMA instructions to contract into).
  */
+#define _GNU_SOURCE /* sincos() */
 #include "ndt2d_oracle.h"
 
 #include <float.h>
@@ -17,6 +18,19 @@
 #ifdef _OPENMP
 #include <omp.h>
 #endif
+
+/* cos(t) and sin(t) of the same argument, as the reference evaluates them.
+ * Wherever the reference writes the pair -- `cos(pose.theta)` / `sin(pose.theta)`
+ * and the like -- GCC (the ROS 2 toolchain; -O1 and up, no fast-math needed)
+ * merges the two calls into ONE call of glibc's sincos().  That matters at the
+ * last bit: glibc's sincos() and sin() are different code paths and can disagree
+ * by one ulp (t = 0.4710119964311561: sin() ends ...722, sincos() ...721), which
+ * then shows in every point transformed with it.  The pair is therefore spelled
+ * out as sincos() here instead of being left to whatever compiler builds this file. */
+static inline void cos_sin(double t, double * c, double * s)
+{
+  sincos(t, s, c);
+}
 
 /* ------------------------------------------------------------------------- */
 /* Cell                                                                      */
@@ -218,8 +232,8 @@ int orc_ndt_get_index(const orc_ndt * ndt, double x, double y)
 void orc_ndt_add_scan(orc_ndt * ndt, double pose_x, double pose_y, double pose_theta,
                       const double * points_xy, size_t n_points)
 {
-  const double cos_th = cos(pose_theta);
-  const double sin_th = sin(pose_theta);
+  double cos_th, sin_th;
+  cos_sin(pose_theta, &cos_th, &sin_th);
   for (size_t k = 0; k < n_points; ++k)
   {
     const double px = points_xy[2 * k], py = points_xy[2 * k + 1];
@@ -284,7 +298,8 @@ double orc_ndt_likelihood_scan(const orc_ndt * ndt, double pose_x, double pose_y
                                double pose_theta, const double * points_xy,
                                size_t n_points)
 {
-  const double c = cos(pose_theta), s = sin(pose_theta);
+  double c, s;
+  cos_sin(pose_theta, &c, &s);
   double score = 0.0;
   for (size_t k = 0; k < n_points; ++k)
   {
@@ -437,8 +452,8 @@ static void match_theta_slab(const orc_matcher * m, const double * scan_pose,
 {
   (void)n_points;
   /* :106-115 */
-  const double costh = cos(scan_pose[2] + dth);
-  const double sinth = sin(scan_pose[2] + dth);
+  double costh, sinth;
+  cos_sin(scan_pose[2] + dth, &costh, &sinth);
   for (size_t i = 0; i < scan_points_to_use; ++i)
   {
     size_t scan_idx = (size_t)(i * scan_step);
@@ -618,7 +633,8 @@ double orc_matcher_score_points(const orc_matcher * m, const double * points_xy,
   /* :159 */
   if (!m->ndt) return 0.0;
   /* :162, conversions.hpp:64-68 */
-  const double c = cos(pose_xyt[2]), s = sin(pose_xyt[2]);
+  double c, s;
+  cos_sin(pose_xyt[2], &c, &s);
   /* :165-166 */
   size_t scan_points_to_use = m->laser_max_beams < n_points ? m->laser_max_beams : n_points;
   double scan_step = (double)n_points / (double)scan_points_to_use;
@@ -720,8 +736,10 @@ void orc_pf_update_statistics(const double * particles_xyt, double * weights,
     mean[0] += w * p[0];
     mean[1] += w * p[1];
     mean[2] += w * p[2];
-    sum_cos_th += w * cos(p[2]);
-    sum_sin_th += w * sin(p[2]);
+    double cos_p, sin_p;
+    cos_sin(p[2], &cos_p, &sin_p);
+    sum_cos_th += w * cos_p;
+    sum_sin_th += w * sin_p;
     for (int j = 0; j < 2; ++j)
     {
       for (int k = j; k < 2; ++k)
@@ -797,8 +815,10 @@ void orc_motion_sample(double dx, double dy, double dth, const double * alphas5,
     const float r2 = z[3 * i + 2] * s2 + m2;
     double * pose = poses_xyt + 3 * i;
     /* :80-82 */
-    pose[0] += t * cos(pose[2] + r1);
-    pose[1] += t * sin(pose[2] + r1);
+    double cos_h, sin_h;
+    cos_sin(pose[2] + r1, &cos_h, &sin_h);
+    pose[0] += t * cos_h;
+    pose[1] += t * sin_h;
     pose[2] = orc_normalize_angle(pose[2] + r1 + r2);
   }
 }
@@ -833,8 +853,8 @@ size_t orc_convert_scan(const float * ranges, size_t n_ranges, const orc_laser_s
   const double per_y = scan->motion_y / n_ranges;
   const double per_th = scan->motion_theta / n_ranges;
   /* :403-404 */
-  const double cos_lt = cos(scan->laser_theta);
-  const double sin_lt = sin(scan->laser_theta);
+  double cos_lt, sin_lt;
+  cos_sin(scan->laser_theta, &cos_lt, &sin_lt);
   const double range_max = scan->range_max;
   size_t n_out = 0;
   if (scan->inverted)
@@ -848,14 +868,16 @@ size_t orc_convert_scan(const float * ranges, size_t n_ranges, const orc_laser_s
       /* :415 float arithmetic (size_t * float -> float), negated, widened */
       const float a = -(scan->angle_min + (float)i * scan->angle_increment);
       const double angle = a;
-      const double lx = cos(angle) * ranges[i];
-      const double ly = sin(angle) * ranges[i];
+      double cos_a, sin_a;
+      cos_sin(angle, &cos_a, &sin_a);
+      const double lx = cos_a * ranges[i];
+      const double ly = sin_a * ranges[i];
       /* :419-420 */
       const double px = cos_lt * lx - sin_lt * ly + scan->laser_x;
       const double py = sin_lt * lx + cos_lt * ly + scan->laser_y;
       /* :422-426 */
-      const double cos_tt = cos(scan->motion_theta - (per_th * i));
-      const double sin_tt = sin(scan->motion_theta - (per_th * i));
+      double cos_tt, sin_tt;
+      cos_sin(scan->motion_theta - (per_th * i), &cos_tt, &sin_tt);
       points_xy_out[2 * n_out] = cos_tt * px - sin_tt * py + (scan->motion_x - (per_x * i));
       points_xy_out[2 * n_out + 1] = sin_tt * px + cos_tt * py + (scan->motion_y - (per_y * i));
       ++n_out;
@@ -871,14 +893,16 @@ size_t orc_convert_scan(const float * ranges, size_t n_ranges, const orc_laser_s
       /* :438 */
       const float a = (scan->angle_min + (float)i * scan->angle_increment);
       const double angle = a;
-      const double lx = cos(angle) * ranges[i];
-      const double ly = sin(angle) * ranges[i];
+      double cos_a, sin_a;
+      cos_sin(angle, &cos_a, &sin_a);
+      const double lx = cos_a * ranges[i];
+      const double ly = sin_a * ranges[i];
       /* :442-443 */
       const double px = cos_lt * lx - sin_lt * ly + scan->laser_x;
       const double py = sin_lt * lx + cos_lt * ly + scan->laser_y;
       /* :445-448 */
-      const double cos_tt = cos(per_th * i);
-      const double sin_tt = sin(per_th * i);
+      double cos_tt, sin_tt;
+      cos_sin(per_th * i, &cos_tt, &sin_tt);
       points_xy_out[2 * n_out] = cos_tt * px - sin_tt * py + (per_x * i);
       points_xy_out[2 * n_out + 1] = sin_tt * px + cos_tt * py + (per_y * i);
       ++n_out;
@@ -900,8 +924,8 @@ void orc_occupancy_update_bounds(double * bounds, double resolution, const doubl
   for (size_t i = first_scan; i < n_scans; ++i)
   {
     const double x = poses_xyt[3 * i], y = poses_xyt[3 * i + 1];
-    const double cos_th = cos(poses_xyt[3 * i + 2]);
-    const double sin_th = sin(poses_xyt[3 * i + 2]);
+    double cos_th, sin_th;
+    cos_sin(poses_xyt[3 * i + 2], &cos_th, &sin_th);
     for (size_t k = offsets[i]; k < offsets[i + 1]; ++k)
     {
       const double qx = points_xy[2 * k], qy = points_xy[2 * k + 1];
@@ -946,8 +970,8 @@ void orc_occupancy_render(const double * bounds, double resolution, double occ_t
   for (size_t i = 0; i < n_scans; ++i)
   {
     const double pose_x = poses_xyt[3 * i], pose_y = poses_xyt[3 * i + 1];
-    const double cos_th = cos(poses_xyt[3 * i + 2]);
-    const double sin_th = sin(poses_xyt[3 * i + 2]);
+    double cos_th, sin_th;
+    cos_sin(poses_xyt[3 * i + 2], &cos_th, &sin_th);
     /* :82-83 */
     const int start_x = (int)((pose_x - origin_x) / resolution);
     const int start_y = (int)((pose_y - origin_y) / resolution);
