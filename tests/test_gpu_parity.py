@@ -226,6 +226,13 @@ def test_launch_timing_history(cfg1):
     assert hist[-1] == last and n_kernels >= 2
     assert len(gpu.launch_history_ms(3)) == 3
     gpu.match_fetch()
+    # the ring keeps the last 256 launches
+    for _ in range(300):
+        gpu.match_launch(0, 1)
+    hist = gpu.launch_history_ms(1000)
+    assert len(hist) == 256 and all(0.0 < t < 50.0 for t in hist)
+    assert hist[-1] == gpu.last_launch_ms()[0]
+    gpu.match_fetch()
 
 
 def test_runs_are_deterministic(cfg1):
