@@ -170,6 +170,30 @@ def test_match_scan_agrees(cfg1):
     assert np.allclose(cov, exp["covariance"], rtol=1e-6, atol=1e-12)
 
 
+def test_update_statistics_agrees():
+    """ParticleFilter::updateStatistics (src/particle_filter.cpp:163-218), vectorised."""
+    rng = np.random.default_rng(5)
+    n = 5000
+    parts = np.stack([rng.normal(2.0, 0.4, n), rng.normal(-1.0, 0.7, n), rng.normal(3.0, 0.5, n)], axis=1)
+    parts[:, 2] = (parts[:, 2] + np.pi) % (2 * np.pi) - np.pi
+    w_raw = -rng.uniform(0.01, 1.0, n)              # scores are negative (:86)
+    cov_prev = np.zeros((3, 3))
+    cov_prev[2, 2] = 0.0625
+    w, mean, cov = O.pf_update_statistics(parts, w_raw, cov_prev)
+    wn = w_raw / w_raw.sum()                        # :166-174
+    assert np.allclose(w, wn, rtol=1e-13, atol=0) and np.all(wn > 0)
+    mx, my = (wn * parts[:, 0]).sum(), (wn * parts[:, 1]).sum()
+    mth = math.atan2((wn * np.sin(parts[:, 2])).sum(), (wn * np.cos(parts[:, 2])).sum())   # :205
+    assert np.allclose(mean, [mx, my, mth], rtol=1e-11, atol=1e-13)
+    want = np.zeros((3, 3))
+    want[0, 0] = (wn * parts[:, 0] ** 2).sum() - mx * mx                                   # :208-215
+    want[0, 1] = want[1, 0] = (wn * parts[:, 0] * parts[:, 1]).sum() - mx * my
+    want[1, 1] = (wn * parts[:, 1] ** 2).sum() - my * my
+    d = (mth - parts[:, 2] + np.pi) % (2 * np.pi) - np.pi                                   # shortest_angular_distance
+    want[2, 2] = cov_prev[2, 2] + (wn * d * d).sum()                                        # :216, never zeroed
+    assert np.allclose(cov, want, rtol=1e-9, atol=1e-12)
+
+
 def test_score_points_agrees(cfg1):
     ndt, ref, p = cfg1
     _, pts, _ = synth.query_scan(1)
