@@ -1,0 +1,83 @@
+"""One localisation + mapping step through every device entry point in sequence, the
+oracle walking the same steps on the CPU: LaserScan conversion -> matchScan against the
+map -> particle filter update / measure -> the scan joins the map (NDT rebuilt) ->
+occupancy grid.  Each stage has its own parity tests; this one checks that they
+compose (state left on the device by one stage is what the next one needs)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from ndt_2d_amd import MotionModel, ParticleFilter, ScanMatcherNDT, synth
+from ndt_2d_amd.occupancy_grid import OccupancyGrid
+
+pytestmark = pytest.mark.gpu
+
+
+def test_one_slam_step_composes():
+    import torch
+    cfg = 1
+    scans = synth.map_scans(cfg)
+    params = synth.matcher_params(cfg)
+    gpu = ScanMatcherNDT(0)
+    gpu.initialize("pipeline", **params)
+    gpu.set_build_mode("device")
+    gpu.addScans(scans)
+    ref = O.ScanMatcherNDT()
+    ref.initialize(**params)
+    ref.addScans(scans)
+    assert np.array_equal(gpu.grid()[0], ref.ndt.cells6(), equal_nan=True)
+
+    # 1. the sensor message: ranges of the cfg-1 query scan, with drop-outs, taken while moving
+    guess, pts, _ = synth.query_scan(cfg)
+    n = len(pts)
+    ranges = np.hypot(pts[:, 0], pts[:, 1]).astype(np.float32)
+    ranges[::37] = np.nan
+    conv = dict(angle_min=-np.pi, angle_increment=2.0 * np.pi / n, range_max=params["range_max"],
+                laser=(0.03, 0.0, 0.0), motion=(0.01, 0.0, 0.005))
+    points_ref = O.convert_scan(ranges, **conv)
+    points_gpu = gpu.convertScan(ranges, **conv)
+    assert points_gpu.shape == points_ref.shape and np.max(np.abs(points_gpu - points_ref)) < 1e-12
+
+    # 2. match it against the map, from the raw ranges
+    exp = ref.matchScan(guess, points_ref, pose=[0.0, 0.0, 0.0])
+    got = gpu.matchLaserScan(guess, ranges, pose=[0.0, 0.0, 0.0], **conv)
+    assert np.array_equal(got["pose"], exp["pose"]) and abs(got["score"] - exp["score"]) < 1e-9
+    corrected = np.array(guess) + got["pose"]          # reference src/ndt_mapper.cpp:521-524
+
+    # 3. particle filter: init around the corrected pose, odometry update, measurement
+    seed, n_p = 7, 2000
+    pf = ParticleFilter(n_p, 4000, MotionModel(0.1, 0.1, 0.1, 0.1, 0.0), gpu, seed=seed)
+    pf.init(corrected[0], corrected[1], corrected[2], 0.1, 0.1, 0.05)
+    pf.update(0.02, 0.0, 0.01)
+    pf.measure(gpu, points_gpu)
+
+    def noise(step):
+        z = torch.empty((n_p, 3), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        gpu.pf_noise_launch(seed, step, 0, n_p, z.data_ptr())
+        gpu.synchronize()
+        return z.cpu().numpy()
+
+    p = O.pf_init(corrected[0], corrected[1], corrected[2], 0.1, 0.1, 0.05, noise(1))
+    cov = np.zeros((3, 3))
+    w, _, cov = O.pf_update_statistics(p, np.full(n_p, 1.0 / n_p), cov)
+    p, _ = O.motion_sample(0.02, 0.0, 0.01, [0.1, 0.1, 0.1, 0.1, 0.0], p, noise(2))
+    w, _, cov = O.pf_update_statistics(p, w, cov)
+    w, mean, cov = O.pf_update_statistics(p, O.pf_measure(ref, p, points_ref), cov)
+    assert np.allclose(pf.getMean(), mean, rtol=1e-9, atol=1e-11)
+    assert np.allclose(pf.getCovariance(), cov, rtol=1e-7, atol=1e-10)
+    assert np.linalg.norm(pf.getMean()[:2] - corrected[:2]) < 0.2
+
+    # 4. the scan joins the map: NDT rebuilt on the device, bit-identical to the oracle's
+    new_scans = scans + [(tuple(corrected), points_ref)]
+    gpu.reset()
+    gpu.addScans(new_scans)
+    ref.reset()
+    ref.addScans(new_scans)
+    assert np.array_equal(gpu.grid()[0], ref.ndt.cells6(), equal_nan=True)
+
+    # 5. the published map
+    want = O.OccupancyGrid(0.05, 0.25).getMsg(new_scans)
+    have = OccupancyGrid(0.05, 0.25, gpu).getMsg(new_scans)
+    assert (have["width"], have["height"]) == (want["width"], want["height"])
+    assert np.array_equal(have["data"], want["data"])
