@@ -296,7 +296,8 @@ const char * ndt2d_last_variant(ndt2d_handle h);
  * (grid placement), "wave", "wave-lds", "wave-global", "lane" (candidate mapping
  * of the match search), "lane-noskip" (the lane mapping with every term
  * evaluated: the bit-exactness control of its skipping), "dense" (particle
- * scoring without compaction). */
+ * scoring without compaction), "compact-exact" (particle scoring with the exact
+ * FP64 phase A: the bit-exactness control of the FP32 screen). */
 int ndt2d_set_variant(ndt2d_handle h, const char * name);
 
 /* ------------------------------------------------------------------------ */
