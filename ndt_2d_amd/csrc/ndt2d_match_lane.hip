@@ -69,8 +69,8 @@ struct LaneGeom
 {
   int32_t pad;     // border cells on every side of the window in the map
   // The map is kept at 2^sub_log2 sub-cells per cell (as fine as the one-byte
-  // coordinate and LDS allow): "a neighbour is occupied" then means a neighbouring
-  // SUB-cell, so fewer empty cells next to walls take the careful path.
+  // coordinate and LDS allow): the finer the sub-cell, the tighter its bound on the
+  // exponent, so fewer beams next to walls take the exact path.
   int32_t sub_log2;
   double unit_scale;  // fixed-point units per cell = 2^16 << sub_log2
   int32_t map_h;   // ((win_h + 2 * pad) << sub_log2) rows of kMapStride bytes
