@@ -67,6 +67,7 @@ struct CompactLayout
 };
 
 constexpr uint32_t kBeamBits = 26;       // SCREEN queue word = beam index | lane << 26
+constexpr uint32_t kScreenPadFloats = 64; // f32 beam array: one screening block (32 beams) of slack
 
 // Bound (in cells) of |u_f32 - u| for the screening coordinate of a pose whose own
 // cell coordinate is within `reach` cells of the grid: the four fused operations and
@@ -93,7 +94,7 @@ __global__ void __launch_bounds__(THREADS) score_poses_compact_kernel(const Pose
   double * lds_beams = reinterpret_cast<double *>(q_meta_all + L::kWaves * kQueueCap);
   float * lds_beams_f = reinterpret_cast<float *>(lds_beams + 2 * ((a.n_beams + 1) & ~1u));
   uint32_t * lds_bits =
-    reinterpret_cast<uint32_t *>(lds_beams_f + (SCREEN ? 2 * ((a.n_beams + 1) & ~1u) : 0));
+    reinterpret_cast<uint32_t *>(lds_beams_f + (SCREEN ? 2 * ((a.n_beams + 1) & ~1u) + kScreenPadFloats : 0));
 
   const GridDesc & g = a.grid;
   for (uint32_t i = threadIdx.x; i < 2 * a.n_beams; i += THREADS)
@@ -304,42 +305,31 @@ __global__ void __launch_bounds__(THREADS) score_poses_compact_kernel(const Pose
         const float near_limit = 0.5f - a.screen_guard;
         for (; k < k1; k += kScreenBlock)
         {
-          uint32_t cmask = 0;
-          if (k + kScreenBlock <= k1)
+          // occupancy bits are OR-ed in place (v_bfe + v_lshl_or); the "near" bits are
+          // shifted in first-beam-first and bit-reversed at the end of the block.  A block
+          // that runs past the chunk's end screens whatever follows in LDS (the f32 beam
+          // array is padded by a block) and drops those bits.
+          uint32_t cmask = 0, near_rev = 0;
+#pragma unroll
+          for (int b0 = 0; b0 < kScreenBlock; b0 += kScreenStep)
           {
-            // occupancy bits are OR-ed in place (v_bfe + v_lshl_or); the "near" bits are
-            // shifted in first-beam-first and bit-reversed at the end of the block
-            uint32_t near_rev = 0;
+            Screen sc[kScreenStep];
+            uint32_t word[kScreenStep];
 #pragma unroll
-            for (int b0 = 0; b0 < kScreenBlock; b0 += kScreenStep)
+            for (int u = 0; u < kScreenStep; ++u)
             {
-              Screen sc[kScreenStep];
-              uint32_t word[kScreenStep];
-#pragma unroll
-              for (int u = 0; u < kScreenStep; ++u)
-              {
-                sc[u] = screen_address(reinterpret_cast<const float2 *>(lds_beams_f)[k + b0 + u]);
-                word[u] = lds_bits[sc[u].idx >> 5];
-              }
-#pragma unroll
-              for (int u = 0; u < kScreenStep; ++u)
-              {
-                cmask |= ((word[u] >> (sc[u].idx & 31u)) & 1u) << (b0 + u);
-                shift_in_near(near_rev, sc[u].edge, near_limit);
-              }
+              sc[u] = screen_address(reinterpret_cast<const float2 *>(lds_beams_f)[k + b0 + u]);
+              word[u] = lds_bits[sc[u].idx >> 5];
             }
-            cmask |= __builtin_bitreverse32(near_rev);
-          }
-          else
-          {
-            for (uint32_t b = 0; k + b < k1; ++b)
+#pragma unroll
+            for (int u = 0; u < kScreenStep; ++u)
             {
-              const Screen sc = screen_address(reinterpret_cast<const float2 *>(lds_beams_f)[k + b]);
-              const bool candidate =
-                (((lds_bits[sc.idx >> 5] >> (sc.idx & 31u)) & 1u) != 0) | (sc.edge > near_limit);
-              cmask |= candidate ? (1u << b) : 0u;
+              cmask |= ((word[u] >> (sc[u].idx & 31u)) & 1u) << (b0 + u);
+              shift_in_near(near_rev, sc[u].edge, near_limit);
             }
           }
+          cmask |= __builtin_bitreverse32(near_rev);
+          if (k1 - k < static_cast<uint32_t>(kScreenBlock)) cmask &= (1u << (k1 - k)) - 1u;
           while (__builtin_amdgcn_ballot_w64(cmask != 0u) != 0ull)
           {
             const uint32_t lowest = static_cast<uint32_t>(__ffs(static_cast<int>(cmask))) - 1u;
@@ -445,7 +435,7 @@ size_t compact_lds_bytes(const PosesArgs & args, int threads, uint32_t split)
   const size_t fixed = threads == 1024 ? CompactLayout<1024>::kFixedDoubles
                                        : CompactLayout<256>::kFixedDoubles;
   // f64 beams + (screening) their f32 copy, 1.5 doubles per coordinate
-  const size_t beams = static_cast<size_t>(3) * ((args.n_beams + 1) & ~1u);
+  const size_t beams = static_cast<size_t>(3) * ((args.n_beams + 1) & ~1u) + kScreenPadFloats / 2;
   const size_t words = (static_cast<size_t>(args.grid.ncell) + 1 + 31) / 32;
   const size_t chunk_sums =
     split > 1 ? static_cast<size_t>(threads / kWave / split) * kChunks * kWave : 0;
