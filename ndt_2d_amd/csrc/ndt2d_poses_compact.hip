@@ -270,9 +270,8 @@ __global__ void __launch_bounds__(THREADS) score_poses_compact_kernel(const Pose
             : "v"(edge), "v"(limit)
             : "vcc");
       };
-      auto push_screened = [&](uint32_t beam, bool candidate) {
-        const uint64_t mask = __ballot(candidate);
-        if (mask != 0)
+      // (mask = the wave's ballot of `candidate`, taken by the caller from the compare itself)
+      auto push_screened = [&](uint32_t beam, bool candidate, uint64_t mask) {
         {
           if (candidate)
           {
@@ -330,10 +329,11 @@ __global__ void __launch_bounds__(THREADS) score_poses_compact_kernel(const Pose
           }
           cmask |= __builtin_bitreverse32(near_rev);
           if (k1 - k < static_cast<uint32_t>(kScreenBlock)) cmask &= (1u << (k1 - k)) - 1u;
-          while (__builtin_amdgcn_ballot_w64(cmask != 0u) != 0ull)
+          for (uint64_t pending = __builtin_amdgcn_ballot_w64(cmask != 0u); pending != 0ull;
+               pending = __builtin_amdgcn_ballot_w64(cmask != 0u))
           {
             const uint32_t lowest = static_cast<uint32_t>(__ffs(static_cast<int>(cmask))) - 1u;
-            push_screened(k + lowest, cmask != 0u);
+            push_screened(k + lowest, cmask != 0u, pending);
             cmask &= cmask - 1u;
           }
         }
