@@ -277,6 +277,17 @@ int ndt2d_occupancy_grid(ndt2d_handle h, double resolution, double occ_thresh,
                          double * bounds_inout, ndt2d_occupancy_info * info_out,
                          signed char * data_out, size_t data_capacity);
 
+/* ---- device memory for hosts without a GPU runtime of their own ----
+ *
+ * The *_launch entry points take device pointers.  A host that already manages
+ * device memory (PyTorch, a HIP application) passes its own; the C++ mirrors in
+ * ndt_2d_amd/plugin/ (particle_filter_hip.hpp) use these four.  Copies are
+ * ordered on the context's stream and return when the data has arrived. */
+int ndt2d_device_alloc(ndt2d_handle h, size_t bytes, void ** d_out);
+int ndt2d_device_free(ndt2d_handle h, void * d_ptr);
+int ndt2d_copy_to_device(ndt2d_handle h, void * d_dst, const void * h_src, size_t bytes);
+int ndt2d_copy_to_host(ndt2d_handle h, void * h_dst, const void * d_src, size_t bytes);
+
 /* Block until everything launched on the context's stream has finished. */
 int ndt2d_synchronize(ndt2d_handle h);
 /* GPU time (HIP events on the launch stream) of the dominant kernel -- the

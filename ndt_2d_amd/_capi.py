@@ -103,6 +103,10 @@ SIGNATURES = {
     "ndt2d_scan_points": (_vp, [_vp, _szp]),
     "ndt2d_occupancy_grid": (C.c_int, [_vp, _d, _d, _dp, _dp, _szp, _sz, _sz, _dp,
                                        C.POINTER(OccupancyInfo), _vp, _sz]),
+    "ndt2d_device_alloc": (C.c_int, [_vp, _sz, C.POINTER(_vp)]),
+    "ndt2d_device_free": (C.c_int, [_vp, _vp]),
+    "ndt2d_copy_to_device": (C.c_int, [_vp, _vp, _vp, _sz]),
+    "ndt2d_copy_to_host": (C.c_int, [_vp, _vp, _vp, _sz]),
     "ndt2d_launch_history_ms": (C.c_int, [_vp, C.POINTER(C.c_float), _sz, _szp]),
     "ndt2d_synchronize": (C.c_int, [_vp]),
     "ndt2d_last_launch_ms": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]),

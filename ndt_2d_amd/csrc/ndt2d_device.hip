@@ -1199,6 +1199,48 @@ int ndt2d_occupancy_grid(ndt2d_handle h, double resolution, double occ_thresh,
   return NDT2D_OK;
 }
 
+int ndt2d_device_alloc(ndt2d_handle h, size_t bytes, void ** d_out)
+{
+  if (h == nullptr || d_out == nullptr) return NDT2D_ERR_INVALID;
+  *d_out = nullptr;
+  if (bytes == 0) return fail(h, NDT2D_ERR_INVALID, "ndt2d_device_alloc: zero size");
+  NDT2D_HIP(h, hipSetDevice(h->device));
+  NDT2D_HIP(h, hipMalloc(d_out, bytes));
+  return NDT2D_OK;
+}
+
+int ndt2d_device_free(ndt2d_handle h, void * d_ptr)
+{
+  if (h == nullptr) return NDT2D_ERR_INVALID;
+  if (d_ptr == nullptr) return NDT2D_OK;
+  NDT2D_HIP(h, hipSetDevice(h->device));
+  NDT2D_HIP(h, hipStreamSynchronize(h->stream));  // nothing in flight may still use it
+  NDT2D_HIP(h, hipFree(d_ptr));
+  return NDT2D_OK;
+}
+
+int ndt2d_copy_to_device(ndt2d_handle h, void * d_dst, const void * h_src, size_t bytes)
+{
+  if (h == nullptr) return NDT2D_ERR_INVALID;
+  if (bytes == 0) return NDT2D_OK;
+  if (d_dst == nullptr || h_src == nullptr) return fail(h, NDT2D_ERR_INVALID, "ndt2d_copy_to_device: null pointer");
+  NDT2D_HIP(h, hipSetDevice(h->device));
+  NDT2D_HIP(h, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, h->stream));
+  NDT2D_HIP(h, hipStreamSynchronize(h->stream));
+  return NDT2D_OK;
+}
+
+int ndt2d_copy_to_host(ndt2d_handle h, void * h_dst, const void * d_src, size_t bytes)
+{
+  if (h == nullptr) return NDT2D_ERR_INVALID;
+  if (bytes == 0) return NDT2D_OK;
+  if (h_dst == nullptr || d_src == nullptr) return fail(h, NDT2D_ERR_INVALID, "ndt2d_copy_to_host: null pointer");
+  NDT2D_HIP(h, hipSetDevice(h->device));
+  NDT2D_HIP(h, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, h->stream));
+  NDT2D_HIP(h, hipStreamSynchronize(h->stream));
+  return NDT2D_OK;
+}
+
 int ndt2d_synchronize(ndt2d_handle h)
 {
   if (h == nullptr) return NDT2D_ERR_INVALID;
