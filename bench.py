@@ -158,7 +158,11 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     local_rank = dev_index
-    if world > 1:
+    # NDT2D_BENCH_FORCE_COLLECTIVE=1: take the multi-rank code path (process group,
+    # all-reduce, barrier) with a single rank too -- the only way to exercise the
+    # RCCL path on a 1-GPU box
+    collective = world > 1 or os.environ.get("NDT2D_BENCH_FORCE_COLLECTIVE") == "1"
+    if collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -201,14 +205,14 @@ def main():
     table = torch.zeros((world, shard.MATCH_RECORD), dtype=torch.float64, device=dev)
 
     def step():
-        if world > 1:
+        if collective:
             table.zero_()
         m.match_launch(th_begin, th_end, record_ptr=table[rank].data_ptr())
-        if world > 1:
+        if collective:
             all_reduce(table, dist.ReduceOp.SUM)
 
     def fence():
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -224,7 +228,7 @@ def main():
     # launches, on the launch stream (it keeps the last 256 pairs)
     kernel_ms = m.launch_history_ms(min(args.steps, 256))
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if collective:
         all_reduce(t, dist.ReduceOp.MAX)
     elapsed = float(t[0])
     ms_per_step = elapsed / args.steps * 1e3
@@ -291,7 +295,7 @@ def main():
 
     m.set_stream(None)
     m.close()
-    if world > 1:
+    if collective:
         dist.barrier()
         dist.destroy_process_group()
 
