@@ -57,14 +57,24 @@ template <int THREADS>
 struct CompactLayout
 {
   static constexpr int kWaves = THREADS / kWave;
-  // doubles: [stats kWaves*8][sums THREADS][q_px kWaves*cap][q_py kWaves*cap]
-  //          [q_meta (u32) kWaves*cap/2]; then beams (f64), beams (f32, SCREEN only),
-  //          occupancy bitmap and, when several waves share a group, the chunk sums
-  //          [groups][kChunks][64].  (SCREEN leaves q_px / q_py unused.)
+  // occupancy bitmap (at LDS offset 0), then doubles: [stats kWaves*8][sums THREADS]
+  //          [q_px kWaves*cap][q_py kWaves*cap][q_meta (u32) kWaves*cap/2]; then beams
+  //          (f64), beams (f32, SCREEN only) and, when several waves share a group, the
+  //          chunk sums [groups][kChunks][64].  (SCREEN leaves q_px / q_py unused.)
   static constexpr size_t kFixedDoubles =
     static_cast<size_t>(kWaves) * 8 + THREADS + 2 * static_cast<size_t>(kWaves) * kQueueCap +
     static_cast<size_t>(kWaves) * kQueueCap / 2;
 };
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// The occupancy bitmap starts at LDS offset 0 (checked at kernel entry), so a word's
+// byte offset is its LDS address: no per-look-up add of an array base.
+__device__ __forceinline__ uint32_t lds_word_at(uint32_t address)
+{
+  typedef const __attribute__((address_space(3))) uint32_t * lds_word_ptr;
+  return *reinterpret_cast<lds_word_ptr>(address);
+}
 
 constexpr uint32_t kBeamBits = 26;       // SCREEN queue word = beam index | lane << 26
 constexpr uint32_t kScreenPadFloats = 64; // f32 beam array: one screening block (32 beams) of slack
@@ -81,31 +91,37 @@ __host__ __device__ inline float screen_guard(float magnitude)
 
 // SPLIT waves share the 64 poses of a group; each takes kChunks / SPLIT chunks.
 template <int THREADS, bool POW2, bool SCREEN>
-__global__ void __launch_bounds__(THREADS) score_poses_compact_kernel(const PosesArgs a,
-                                                                      const uint32_t split)
+// (4 waves per SIMD = at most 128 VGPRs, also for the 256-thread geometry: the
+// accumulators that no longer fit are spilled on the once-per-pose path, and a CU
+// holds four blocks instead of three)
+__global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4)))
+score_poses_compact_kernel(const PosesArgs a, const uint32_t split)
 {
   using L = CompactLayout<THREADS>;
   extern __shared__ __align__(16) double lds[];
-  double * sh_stats = lds;
+  const GridDesc & g = a.grid;
+  // The occupancy bitmap comes first: lds_word_at() addresses it absolutely, so it
+  // must start at LDS offset 0.
+  if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();
+  uint32_t * lds_bits = reinterpret_cast<uint32_t *>(lds);
+  const uint32_t n_words = (g.ncell + 1 + 31) / 32;
+  double * sh_stats = lds + ((n_words + 3) & ~3u) / 2;
   double * sh_sum = sh_stats + L::kWaves * 8;
   double * q_px_all = sh_sum + THREADS;
   double * q_py_all = q_px_all + L::kWaves * kQueueCap;
   uint32_t * q_meta_all = reinterpret_cast<uint32_t *>(q_py_all + L::kWaves * kQueueCap);
   double * lds_beams = reinterpret_cast<double *>(q_meta_all + L::kWaves * kQueueCap);
   float * lds_beams_f = reinterpret_cast<float *>(lds_beams + 2 * ((a.n_beams + 1) & ~1u));
-  uint32_t * lds_bits =
-    reinterpret_cast<uint32_t *>(lds_beams_f + (SCREEN ? 2 * ((a.n_beams + 1) & ~1u) + kScreenPadFloats : 0));
+  // chunk sums [group][chunk][lane], only used (and allocated) when split > 1
+  double * sh_chunk =
+    reinterpret_cast<double *>(lds_beams_f + (SCREEN ? 2 * ((a.n_beams + 1) & ~1u) + kScreenPadFloats : 0));
 
-  const GridDesc & g = a.grid;
   for (uint32_t i = threadIdx.x; i < 2 * a.n_beams; i += THREADS)
   {
     const double v = a.beams_xy[i];
     lds_beams[i] = v;
     if (SCREEN) lds_beams_f[i] = static_cast<float>(v);
   }
-  const uint32_t n_words = (g.ncell + 1 + 31) / 32;
-  // chunk sums [group][chunk][lane], only used (and allocated) when split > 1
-  double * sh_chunk = reinterpret_cast<double *>(lds_bits + ((n_words + 3) & ~3u));
   for (uint32_t i = threadIdx.x; i < n_words; i += THREADS) lds_bits[i] = g.occ_bits[i];
   __syncthreads();
 
@@ -186,7 +202,7 @@ __global__ void __launch_bounds__(THREADS) score_poses_compact_kernel(const Pose
     // SCREEN: FP32 cell coordinate of a beam end, u = u0 + ci * bx - si * by,
     // v = v0 + si * bx + ci * by.  A pose further from the grid than any beam reaches
     // (or not finite) cannot hit it: its coordinate is parked far outside.
-    float u0 = 0.0f, v0 = 0.0f, ci = 0.0f, si = 0.0f;
+    f32x2 uv0 = {0.0f, 0.0f}, rot_x = {0.0f, 0.0f}, rot_y = {0.0f, 0.0f};
     if (SCREEN)
     {
       pose_x = x;
@@ -199,10 +215,13 @@ __global__ void __launch_bounds__(THREADS) score_poses_compact_kernel(const Pose
       const bool in_band = du > -reach && du < static_cast<double>(g.size_x) + reach &&
                            dv > -reach && dv < static_cast<double>(g.size_y) + reach;
       // (parked at the centre of cell (-2, -2): outside, and not near any boundary)
-      u0 = in_band ? static_cast<float>(du) : -1.5f;
-      v0 = in_band ? static_cast<float>(dv) : -1.5f;
-      ci = in_band ? static_cast<float>(c * inv) : 0.0f;
-      si = in_band ? static_cast<float>(s * inv) : 0.0f;
+      const double guard = static_cast<double>(a.screen_guard);
+      const float ci = in_band ? static_cast<float>(c * inv) : 0.0f;
+      const float si = in_band ? static_cast<float>(s * inv) : 0.0f;
+      uv0 = f32x2{in_band ? static_cast<float>(du + guard) : -1.5f,
+                  in_band ? static_cast<float>(dv + guard) : -1.5f};
+      rot_x = f32x2{ci, si};
+      rot_y = f32x2{-si, ci};
     }
 
     double total = 0.0;
@@ -246,26 +265,27 @@ __global__ void __launch_bounds__(THREADS) score_poses_compact_kernel(const Pose
       struct Screen
       {
         uint32_t idx;   // bitmap bit to test
-        float edge;     // max over the axes of |fraction - 0.5|: near a boundary if > 0.5 - guard
+        float edge;     // min over the axes of fract(coordinate + guard): near a boundary if < 2 guard
       };
       auto screen_address = [&](float2 bf) -> Screen {
-        const float u = fmaf(ci, bf.x, fmaf(-si, bf.y, u0));
-        const float v = fmaf(si, bf.x, fmaf(ci, bf.y, v0));
+        // (u, v) + guard: one packed FMA per beam coordinate
+        const f32x2 uv = __builtin_elementwise_fma(
+          rot_x, f32x2{bf.x, bf.x}, __builtin_elementwise_fma(rot_y, f32x2{bf.y, bf.y}, uv0));
         int iu, iv;  // floor, one instruction each
-        asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(iu) : "v"(u));
-        asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(iv) : "v"(v));
+        asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(iu) : "v"(uv.x));
+        asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(iv) : "v"(uv.y));
         const bool inside = (static_cast<uint32_t>(iu) < g.size_x) & (static_cast<uint32_t>(iv) < g.size_y);
         Screen r;
         r.idx = inside ? __umul24(static_cast<uint32_t>(iv), g.size_x) + static_cast<uint32_t>(iu) : g.ncell;
-        // fractional part within `guard` of 0 or 1 on either axis.  (Far outside the
-        // grid this also fires now and then: a harmless false candidate.)
-        const float fu = __builtin_amdgcn_fractf(u) - 0.5f, fv = __builtin_amdgcn_fractf(v) - 0.5f;
-        r.edge = fmaxf(fabsf(fu), fabsf(fv));
+        // The coordinate carries +guard, so "within guard of a cell boundary" reads
+        // fract < 2 guard, and where that is false floor() is the exact point's cell.
+        // (Far outside the grid it also fires now and then: a harmless false candidate.)
+        r.edge = fminf(__builtin_amdgcn_fractf(uv.x), __builtin_amdgcn_fractf(uv.y));
         return r;
       };
-      // mask = 2 * mask + (edge > limit): compare into vcc, add-with-carry shifts it in
+      // mask = 2 * mask + (edge < limit): compare into vcc, add-with-carry shifts it in
       auto shift_in_near = [](uint32_t & mask, float edge, float limit) {
-        asm("v_cmp_gt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+        asm("v_cmp_lt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
             : "+v"(mask)
             : "v"(edge), "v"(limit)
             : "vcc");
@@ -301,11 +321,11 @@ __global__ void __launch_bounds__(THREADS) score_poses_compact_kernel(const Pose
         // the busiest lane has candidates (a few), not kScreenBlock.
         constexpr int kScreenStep = 4;
         constexpr int kScreenBlock = 32;
-        const float near_limit = 0.5f - a.screen_guard;
+        const float near_limit = 2.0f * a.screen_guard;
         for (; k < k1; k += kScreenBlock)
         {
-          // occupancy bits are OR-ed in place (v_bfe + v_lshl_or); the "near" bits are
-          // shifted in first-beam-first and bit-reversed at the end of the block.  A block
+          // occupancy bits are funnel-shifted in from the top (v_lshrrev + v_alignbit); the
+          // "near" bits are shifted in first-beam-first and bit-reversed at the end of the block.  A block
           // that runs past the chunk's end screens whatever follows in LDS (the f32 beam
           // array is padded by a block) and drops those bits.
           uint32_t cmask = 0, near_rev = 0;
@@ -318,12 +338,13 @@ __global__ void __launch_bounds__(THREADS) score_poses_compact_kernel(const Pose
             for (int u = 0; u < kScreenStep; ++u)
             {
               sc[u] = screen_address(reinterpret_cast<const float2 *>(lds_beams_f)[k + b0 + u]);
-              word[u] = lds_bits[sc[u].idx >> 5];
+              word[u] = lds_word_at((sc[u].idx >> 3) & ~3u);
             }
 #pragma unroll
             for (int u = 0; u < kScreenStep; ++u)
             {
-              cmask |= ((word[u] >> (sc[u].idx & 31u)) & 1u) << (b0 + u);
+              // bit (idx & 31) of the word enters at the top; after 32 beams beam j is bit j
+              cmask = __builtin_amdgcn_alignbit(word[u] >> (sc[u].idx & 31u), cmask, 1u);
               shift_in_near(near_rev, sc[u].edge, near_limit);
             }
           }
