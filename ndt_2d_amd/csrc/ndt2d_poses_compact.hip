@@ -25,10 +25,11 @@
 // SCREEN (default): phase A does not need the exact point, only a conservative answer
 // to "can this pair hit a cell with a distribution?".  It evaluates the cell
 // coordinate in FP32 -- u = U0 + (c/cell) bx - (s/cell) by with per-lane FP32
-// constants, four v_fma_f32 instead of eight FP64 operations -- takes the cell by
-// floor, and queues the pair {beam | lane} if that cell is occupied OR the
-// coordinate lies within `guard` (a bound of the FP32 error, see screen_guard())
-// of a cell boundary or of the grid's edge.  Phase B then redoes the transform and
+// constants, u and v as the two halves of v_pk_fma_f32: two instructions instead
+// of eight FP64 operations -- takes the cell by floor, and queues the pair
+// {beam | lane} if that cell is occupied OR the coordinate lies within `guard` (a
+// bound of the FP32 error, see screen_guard()) of a cell boundary or of the grid's
+// edge.  Phase B then redoes the transform and
 // NDT::getIndex exactly in FP64 for the few queued pairs.  Every pair that can
 // contribute is queued, in the same order, and a queued pair that turns out to be
 // empty adds exactly +0.0, so the scores are those of the unscreened kernel bit for
