@@ -12,6 +12,12 @@ for p in (_HERE, _ROOT):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu)")
+    # A fresh checkout has no built library (it is git-ignored): build it once, as
+    # __graft_entry__.build() does.  hipcc cross-compiles for gfx950 without a GPU.
+    from ndt_2d_amd import _capi
+    if not os.path.exists(_capi.LIB_PATH):
+        from ndt_2d_amd import build as _build
+        _build.build_all()
 
 
 def _gpu_available():
