@@ -411,6 +411,21 @@ int ndt2d_matcher_grid_cells6(ndt2d_matcher * m, double * cells6_out, size_t cap
 /* The search lattice the matcher visits (the reference's FP-accumulated
  * loops): writes up to cap values, returns the count through *n_out. */
 int ndt2d_search_offsets(double size, double res, double * out, size_t cap, size_t * n_out);
+/* The draw-and-stop loop of ParticleFilter::resample (src/particle_filter.cpp:
+ * 94-134), host code: KLD sampling is a sequential stopping rule and stays on the
+ * CPU.  Draw i picks the particle whose cumulative weight
+ * first exceeds uniforms[i] * sum(weights) (what std::discrete_distribution does
+ * with its own generator, :94,110; the caller supplies the uniforms in [0, 1), so
+ * any generator can drive it), inserts its KD-tree key
+ * static_cast<int>(value / leaf_size3[d]) (kd_tree.hpp:95-98; the leaf count is the
+ * number of distinct keys) and recomputes Mx (:117-126); the loop ends when the
+ * count reaches max(min_particles, Mx) or max_particles (:107,129-132).
+ * indices_out[max_particles] receives the chosen particle of every draw kept,
+ * *n_out their number.  n_uniforms must be at least max_particles. */
+int ndt2d_kld_resample(const double * particles_xyt, const double * weights, size_t n,
+                       size_t min_particles, size_t max_particles, double kld_err, double kld_z,
+                       const double * leaf_size3, const double * uniforms, size_t n_uniforms,
+                       uint32_t * indices_out, size_t * n_out);
 /* Host-only (no GPU needed) NDT build: the arithmetic of addScans without the
  * upload, for hosts that only want the packed grid. */
 int ndt2d_host_build_grid(double ndt_resolution, double range_max, const double * poses_xyt,

@@ -136,6 +136,8 @@ SIGNATURES = {
     "ndt2d_matcher_grid_info": (C.c_int, [_vp, C.POINTER(_u32), C.POINTER(_u32), _dp, _dp, _dp]),
     "ndt2d_matcher_grid_cells6": (C.c_int, [_vp, _dp, _sz]),
     "ndt2d_search_offsets": (C.c_int, [_d, _d, _dp, _sz, _szp]),
+    "ndt2d_kld_resample": (C.c_int, [_dp, _dp, _sz, _sz, _sz, _d, _d, _dp, _dp, _sz,
+                                     C.POINTER(_u32), _szp]),
     "ndt2d_host_build_grid": (C.c_int, [_d, _d, _dp, _dp, _szp, _sz, _dp, _sz,
                                        C.POINTER(_u32), C.POINTER(_u32), _dp, _dp]),
     "ndt2d_synth_scan": (C.c_int, [C.POINTER(World), _dp, _sz, _d, C.c_uint64, _dp]),

@@ -7,6 +7,7 @@
 //   * the batched particle path (ParticleFilter::measure),
 //   * the synthetic workload generator.
 // No scoring arithmetic happens here: every likelihood is evaluated on the GPU.
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
 #include <cstdint>
@@ -15,6 +16,7 @@
 #include <memory>
 #include <new>
 #include <string>
+#include <unordered_set>
 #include <vector>
 
 #include "ndt2d_hip.h"
@@ -786,6 +788,83 @@ int ndt2d_search_offsets(double size, double res, double * out, size_t cap, size
   {
     for (size_t i = 0; i < v.size() && i < cap; ++i) out[i] = v[i];
   }
+  return NDT2D_OK;
+}
+
+int ndt2d_kld_resample(const double * particles_xyt, const double * weights, size_t n,
+                       size_t min_particles, size_t max_particles, double kld_err, double kld_z,
+                       const double * leaf_size3, const double * uniforms, size_t n_uniforms,
+                       uint32_t * indices_out, size_t * n_out)
+{
+  if (n_out == nullptr) return NDT2D_ERR_INVALID;
+  *n_out = 0;
+  if (max_particles == 0) return NDT2D_OK;
+  if (n == 0 || n > 0xffffffffull || particles_xyt == nullptr || weights == nullptr ||
+      leaf_size3 == nullptr || uniforms == nullptr || indices_out == nullptr ||
+      n_uniforms < max_particles)
+  {
+    return NDT2D_ERR_INVALID;
+  }
+  // cumulative weights; a draw u picks the first particle with cdf > u * total
+  std::vector<double> cdf(n);
+  double total = 0.0;
+  for (size_t i = 0; i < n; ++i)
+  {
+    total += weights[i];
+    cdf[i] = total;
+  }
+  // KDTree::insert's key (kd_tree.hpp:95-98); one leaf per distinct key
+  struct Key
+  {
+    int32_t k[3];
+    bool operator==(const Key & o) const { return k[0] == o.k[0] && k[1] == o.k[1] && k[2] == o.k[2]; }
+  };
+  struct KeyHash
+  {
+    size_t operator()(const Key & key) const
+    {
+      uint64_t h = 0x9e3779b97f4a7c15ull;
+      for (int d = 0; d < 3; ++d)
+      {
+        h ^= static_cast<uint32_t>(key.k[d]);
+        h *= 0xff51afd7ed558ccdull;
+        h ^= h >> 32;
+      }
+      return static_cast<size_t>(h);
+    }
+  };
+  std::unordered_set<Key, KeyHash> leaves;   // kd_tree_.clear() (:97)
+  leaves.reserve(1024);
+  size_t Mx = max_particles;                 // (:105)
+  size_t count = 0;
+  while (count < std::max(min_particles, Mx))
+  {
+    const double u = uniforms[count] * total;
+    size_t p = static_cast<size_t>(std::upper_bound(cdf.begin(), cdf.end(), u) - cdf.begin());
+    if (p >= n) p = n - 1;   // u rounded up to the total (or a NaN weight): the last particle
+    Key key;
+    for (int d = 0; d < 3; ++d)
+    {
+      const double q = particles_xyt[3 * p + d] / leaf_size3[d];
+      // static_cast<int> of the reference; out-of-range values are pinned to the ends
+      key.k[d] = q >= 2147483647.0 ? 2147483647
+                 : (q <= -2147483648.0 ? (-2147483647 - 1) : (q == q ? static_cast<int32_t>(q) : 0));
+    }
+    leaves.insert(key);
+    indices_out[count++] = static_cast<uint32_t>(p);
+    const size_t k = leaves.size();
+    if (k > 1)
+    {
+      const double a = (k - 1) / (2.0 * kld_err);
+      const double b = 2.0 / (9.0 * (k - 1));
+      const double c = 1.0 - b + std::sqrt(b) * kld_z;
+      const double mx = a * c * c * c;       // size_t Mx = double (:125)
+      Mx = mx >= 1.8446744073709552e19 ? ~static_cast<size_t>(0)
+                                        : (mx > 0.0 ? static_cast<size_t>(mx) : 0);
+    }
+    if (count >= max_particles) break;       // (:129-132)
+  }
+  *n_out = count;
   return NDT2D_OK;
 }
 

@@ -69,6 +69,28 @@ def kld_resample_indices(draws, keys, min_particles, max_particles, kld_err, kld
     return draws[:n_keep]
 
 
+def kld_resample_native(particles, weights, min_particles, max_particles, kld_err, kld_z, uniforms,
+                        leaf=KD_LEAF):
+    """ParticleFilter::resample's loop (reference particle_filter.cpp:94-134) through the
+    library's host entry point ndt2d_kld_resample: returns the indices of the draws kept.
+    `uniforms` (at least max_particles values in [0, 1)) stand for the generator."""
+    import ctypes as C
+    L = _capi.lib()
+    pa = np.ascontiguousarray(particles, dtype=np.float64).reshape(-1, 3)
+    w = np.ascontiguousarray(weights, dtype=np.float64)
+    u = np.ascontiguousarray(uniforms, dtype=np.float64)
+    lf = np.array(leaf, dtype=np.float64)
+    out = np.empty(max(int(max_particles), 1), dtype=np.uint32)
+    n_out = C.c_size_t(0)
+    rc = L.ndt2d_kld_resample(_capi.dptr(pa), _capi.dptr(w), len(w), int(min_particles),
+                              int(max_particles), float(kld_err), float(kld_z), _capi.dptr(lf),
+                              _capi.dptr(u), len(u), out.ctypes.data_as(C.POINTER(C.c_uint32)),
+                              C.byref(n_out))
+    if rc != _capi.OK:
+        raise _capi.Ndt2dError(rc, "ndt2d_kld_resample")
+    return out[:n_out.value].copy()
+
+
 class ParticleFilter:
     """ndt_2d::ParticleFilter over the MI355X kernels.  `matcher` supplies the device
     context (an ndt_2d_amd.ScanMatcherNDT); `seed` keys the Philox noise stream
@@ -136,15 +158,11 @@ class ParticleFilter:
         self._stream.synchronize()
         pa = self.particles.cpu().numpy()
         w = self.weights.cpu().numpy()
-        # std::discrete_distribution: P(i) = w_i / sum w, drawn by inverting the CDF
-        cdf = np.cumsum(w / w.sum())
-        cdf[-1] = 1.0
-        u = self._host_rng.random(self.max_particles)
-        draws = np.searchsorted(cdf, u, side="right")
-        keep = kld_resample_indices(draws, kld_leaf_keys(pa), self.min_particles,
-                                    self.max_particles, kld_err, kld_z)
+        # the draw-and-stop loop itself is native host code shared with the C++ mirror
+        keep = kld_resample_native(pa, w, self.min_particles, self.max_particles, kld_err, kld_z,
+                                   self._host_rng.random(self.max_particles))
         with torch.cuda.stream(self._stream):
-            idx = torch.from_numpy(np.ascontiguousarray(keep)).to(self.device)
+            idx = torch.from_numpy(keep.astype(np.int64)).to(self.device)
             self.particles = self.particles.index_select(0, idx).contiguous()
             self.weights = self.weights.index_select(0, idx).contiguous()
         self._update_statistics(have_moments=False)

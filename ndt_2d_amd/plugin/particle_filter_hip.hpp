@@ -14,8 +14,8 @@
 //    runs are reproducible.  resample() keeps an mt19937 (std::discrete_distribution
 //    over the weights, :94), seeded from the same `seed`.
 //  * The KD-tree of the reference (kd_tree.hpp) is only asked for its leaf count
-//    (:118); a std::set of the discrete keys (kd_tree.hpp:95-98) gives the same
-//    number.
+//    (:118); the library's ndt2d_kld_resample counts the distinct discrete keys
+//    (kd_tree.hpp:95-98), which is the same number.
 //  * No Eigen in this header: getMean / getCovariance fill plain arrays (row-major
 //    3 x 3), so that it builds without ROS; scan_matcher_ndt_hip.cpp style adaptors
 //    to Eigen::Vector3d / Matrix3d are two lines.
@@ -26,12 +26,10 @@
 #define NDT_2D_HIP__PARTICLE_FILTER_HIP_HPP_
 
 #include <algorithm>
-#include <array>
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
 #include <random>
-#include <set>
 #include <string>
 #include <vector>
 
@@ -115,29 +113,27 @@ public:
     check(ndt2d_copy_to_host(dev_, particles.data(), d_particles_, particles.size() * sizeof(double)));
     check(ndt2d_copy_to_host(dev_, weights.data(), d_weights_, weights.size() * sizeof(double)));
     if (!ok_) return;
-    std::discrete_distribution<std::size_t> d(weights.begin(), weights.end());
-    std::set<std::array<int, 3>> leaves;   // kd_tree_.clear()
+    // the draws of std::discrete_distribution (:94,110) as uniforms from the same
+    // mt19937; the draw-and-stop loop (:107-133) is the library's host code
+    std::vector<double> uniforms(max_particles_);
+    std::uniform_real_distribution<double> unit(0.0, 1.0);
+    for (double & u : uniforms) u = unit(gen_);
+    // KD-tree leaf size 0.5 x 0.5 x 0.2671 (particle_filter.cpp:44)
+    const double leaf[3] = {0.5, 0.5, 0.2671};
+    std::vector<std::uint32_t> chosen(std::max<std::size_t>(max_particles_, 1));
+    std::size_t n_kept = 0;
+    check(ndt2d_kld_resample(particles.data(), weights.data(), n_, min_particles_, max_particles_,
+                             kld_err, kld_z, leaf, uniforms.data(), uniforms.size(), chosen.data(),
+                             &n_kept));
+    if (!ok_) return;
     std::vector<double> resampled, resampled_weights;
-    resampled.reserve(3 * max_particles_);
-    resampled_weights.reserve(max_particles_);
-    std::size_t Mx = max_particles_;
-    while (resampled_weights.size() < std::max(min_particles_, Mx))
+    resampled.reserve(3 * n_kept);
+    resampled_weights.reserve(n_kept);
+    for (std::size_t i = 0; i < n_kept; ++i)
     {
-      const std::size_t p = d(gen_);
-      // KDTree::insert's key (kd_tree.hpp:95-98), leaf size 0.5 x 0.5 x 0.2671 (particle_filter.cpp:44)
-      leaves.insert({static_cast<int>(particles[3 * p] / 0.5), static_cast<int>(particles[3 * p + 1] / 0.5),
-                     static_cast<int>(particles[3 * p + 2] / 0.2671)});
+      const std::size_t p = chosen[i];
       resampled.insert(resampled.end(), particles.begin() + 3 * p, particles.begin() + 3 * p + 3);
       resampled_weights.push_back(weights[p]);
-      const std::size_t k = leaves.size();
-      if (k > 1)
-      {
-        const double a = (k - 1) / (2.0 * kld_err);
-        const double b = 2.0 / (9.0 * (k - 1));
-        const double c = 1.0 - b + std::sqrt(b) * kld_z;
-        Mx = static_cast<std::size_t>(a * c * c * c);
-      }
-      if (resampled_weights.size() >= max_particles_) break;
     }
     resize(resampled_weights.size());
     check(ndt2d_copy_to_device(dev_, d_particles_, resampled.data(), resampled.size() * sizeof(double)));

@@ -137,3 +137,51 @@ def test_kld_resample_rule_matches_sequential_loop(seed):
     want = _resample_loop(draws, keys, min_p, max_p, kld_err, kld_z)
     assert np.array_equal(got, want)
     assert min(min_p, max_p) <= len(got) <= max_p
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_native_kld_resample_matches_sequential_loop(seed):
+    """ndt2d_kld_resample (host code of the library, no GPU needed) against the loop above.
+    Its draws invert the cumulative weights: draw i = first particle whose running
+    weight sum exceeds u_i * total (sequential sums, as the C code forms them)."""
+    from ndt_2d_amd.particle_filter import kld_resample_native
+    rng = np.random.default_rng(100 + seed)
+    n = int(rng.integers(10, 400))
+    spread = rng.choice([0.05, 0.5, 3.0])
+    particles = rng.normal(0.0, spread, size=(n, 3))
+    weights = rng.random(n) ** 3
+    if seed % 3 == 0:
+        weights[rng.integers(0, n, size=n // 2)] = 0.0      # particles that can never be drawn
+    min_p = int(rng.integers(1, 60))
+    max_p = int(rng.integers(min_p, 3000))
+    kld_err, kld_z = float(rng.choice([0.01, 0.05])), float(rng.choice([0.99, 2.33]))
+    u = rng.random(max_p)
+    got = kld_resample_native(particles, weights, min_p, max_p, kld_err, kld_z, u)
+    cdf = np.zeros(n)
+    total = 0.0
+    for i in range(n):
+        total += weights[i]
+        cdf[i] = total
+    draws = np.minimum(np.searchsorted(cdf, u * total, side="right"), n - 1)
+    want = _resample_loop(draws, kld_leaf_keys(particles), min_p, max_p, kld_err, kld_z)
+    assert np.array_equal(got.astype(np.int64), want)
+    assert np.all(weights[got] > 0.0)
+
+
+def test_native_kld_resample_edge_cases():
+    from ndt_2d_amd import _capi
+    from ndt_2d_amd.particle_filter import kld_resample_native
+    p = np.zeros((5, 3))
+    w = np.full(5, 0.2)
+    # one leaf only: Mx stays max_particles, so max_particles draws are kept (:105-107)
+    assert len(kld_resample_native(p, w, 3, 40, 0.01, 0.99, np.linspace(0, 0.999, 40))) == 40
+    assert len(kld_resample_native(p, w, 3, 0, 0.01, 0.99, np.zeros(0))) == 0
+    # two far-apart leaves: the bound drops to a handful and min_particles takes over
+    p2 = np.array([[0.0, 0.0, 0.0], [10.0, 10.0, 1.0]])
+    got = kld_resample_native(p2, [0.5, 0.5], 7, 1000, 0.05, 0.99, np.tile([0.1, 0.9], 500))
+    assert list(got[:4]) == [0, 1, 0, 1] and 7 <= len(got) < 100
+    # u == 1 - ulp and a cumulative sum that rounds: never past the last particle
+    got = kld_resample_native(p2, [0.1, 0.2], 1, 4, 0.05, 0.99, [np.nextafter(1.0, 0.0)] * 4)
+    assert set(got) == {1}
+    with pytest.raises(_capi.Ndt2dError):
+        kld_resample_native(p2, [0.5, 0.5], 1, 10, 0.05, 0.99, np.zeros(3))   # too few uniforms
