@@ -221,6 +221,8 @@ hipError_t launch_poses_compact(const PosesArgs & args, int cus, bool screen, hi
 // force_variant: grid placement in the low bits, candidate mapping above them
 enum { kVariantAuto = 0, kVariantLds = 1, kVariantGlobal = 2, kVariantGridMask = 3,
        kVariantWave = 4, kVariantLane = 8, kVariantDense = 16, kVariantNoSkip = 32 };
+// launch_match: lattices with fewer candidates than this take the wave-per-candidate mapping
+constexpr uint64_t kWaveMappingBelow = 160000;
 
 }  // namespace ndt2d
 

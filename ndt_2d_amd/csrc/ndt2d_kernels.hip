@@ -451,6 +451,15 @@ hipError_t launch_match(const MatchArgs & args_in, double * workspace, double * 
   bool use_lane = outer != nullptr && force_grid != kVariantGlobal &&
                   match_lane_supported(args, lim.lds_per_block);
   if (force_variant & kVariantWave) use_lane = false;
+  // A small lattice gives the lane mapping fewer work items (theta x 8x8 patches) than
+  // the chip has SIMDs, and each of them walks all the beams one after the other: its
+  // time is then n_beams x ~0.36 us whatever the lattice.  The wave mapping spreads the
+  // beams over the lanes and takes candidates x beams / 5e11 s, which is less below
+  // ~180 k candidates (experiments/small_search_sweep.py: the plugin's default search,
+  // 35,280 candidates x 100 beams, 21 us instead of 51 us).
+  const uint64_t candidates =
+    static_cast<uint64_t>(args.th_end - args.th_begin) * args.n_lin * args.n_lin;
+  if (!(force_variant & kVariantLane) && candidates < kWaveMappingBelow) use_lane = false;
   if ((force_variant & kVariantLane) && !use_lane) return hipErrorInvalidValue;
 
   hipError_t e;

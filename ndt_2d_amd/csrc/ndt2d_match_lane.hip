@@ -605,8 +605,10 @@ hipError_t launch_match_lane(const MatchArgs & args_in, double * outer, double *
   const uint32_t p1 = (args.n_lin + kPatch - 1) / kPatch;
   const uint64_t n_items = static_cast<uint64_t>(args.th_end - args.th_begin) * p1 * p1;
   // Few work items (the plugin's default lattice is 720 of them): 256-thread blocks
-  // put them on four times as many CUs.
-  const bool small = n_items < static_cast<uint64_t>(cus) * (kLaneThreads / kWave);
+  // put them on four times as many CUs -- as long as every wave still gets at most
+  // one item; the LDS image allows one block per CU, so beyond that the larger block
+  // is what puts more waves on a CU.
+  const bool small = n_items <= static_cast<uint64_t>(cus) * (kLaneThreadsSmall / kWave);
   const uint32_t waves_per_block = (small ? kLaneThreadsSmall : kLaneThreads) / kWave;
   uint32_t blocks = static_cast<uint32_t>((n_items + waves_per_block - 1) / waves_per_block);
   uint32_t max_blocks = static_cast<uint32_t>(cus);

@@ -401,24 +401,44 @@ def test_match_scan_on_a_large_map_uses_the_windowed_lane_kernel():
     gpu, ref, _, guess, pts = _pair(3, search_linear_size=0.5, search_linear_resolution=0.05,
                                     search_angular_size=0.1, search_angular_resolution=0.01)
     wrong = guess + np.array([0.21, -0.13, 0.04])          # start off the true pose
-    got = gpu.matchScan(wrong, pts, want_scores=True)
-    assert "lane-per-candidate/lds-map+global-records" in gpu.last_variant(), gpu.last_variant()
     exp = ref.matchScan(wrong, pts, want_scores=True)
-    _check_match(got, exp, 720)
-    assert np.all(np.abs(wrong + got["pose"] - guess) <= [0.05, 0.05, 0.01])
-    # same search through the wave-per-candidate kernel (records gathered from HBM)
-    gpu.set_variant("wave")
+    # (8,820 candidates: left to itself the library takes the wave mapping here, below)
+    gpu.set_variant("lane")
     try:
-        alt = gpu.matchScan(wrong, pts, want_scores=True)
-        assert "wave-per-candidate/global-grid" in gpu.last_variant()
+        got = gpu.matchScan(wrong, pts, want_scores=True)
+        assert "lane-per-candidate/lds-map+global-records" in gpu.last_variant(), gpu.last_variant()
+        _check_match(got, exp, 720)
+        assert np.all(np.abs(wrong + got["pose"] - guess) <= [0.05, 0.05, 0.01])
+        # a scan pose near the map edge and one outside the map
+        for pose in [(-24.0, 20.0, 0.5), (60.0, 60.0, 0.0)]:
+            a = gpu.matchScan(pose, pts, want_scores=True)
+            b = ref.matchScan(pose, pts, want_scores=True)
+            _check_match(a, b, 720)
     finally:
         gpu.set_variant("auto")
+    # same search through the wave-per-candidate kernel (records gathered from HBM),
+    # which is what a lattice this small gets by default
+    alt = gpu.matchScan(wrong, pts, want_scores=True)
+    assert "wave-per-candidate/global-grid" in gpu.last_variant()
     _check_match(alt, exp, 720)
-    # a scan pose near the map edge and one outside the map
     for pose in [(-24.0, 20.0, 0.5), (60.0, 60.0, 0.0)]:
-        a = gpu.matchScan(pose, pts, want_scores=True)
-        b = ref.matchScan(pose, pts, want_scores=True)
-        _check_match(a, b, 720)
+        _check_match(gpu.matchScan(pose, pts, want_scores=True),
+                     ref.matchScan(pose, pts, want_scores=True), 720)
+
+
+def test_mapping_follows_the_lattice_size(cfg1):
+    """Small lattices (the plugin's defaults, cfg-1) take the wave-per-candidate mapping,
+    large ones the lane-per-candidate mapping; both give the oracle's result."""
+    gpu, ref, _, guess, pts = _pair(1)
+    got = gpu.matchScan(guess, pts, want_scores=True)
+    assert "wave-per-candidate" in gpu.last_variant(), gpu.last_variant()
+    exp = ref.matchScan(guess, pts, want_scores=True)
+    _check_match(got, exp, 720)
+    big, ref_big, _, _, _ = _pair(1, search_linear_size=0.25, search_linear_resolution=0.01,
+                                  search_angular_size=0.1, search_angular_resolution=0.002)
+    got = big.matchScan(guess, pts, want_scores=True)      # 50 x 50 x 100 candidates
+    assert "lane-per-candidate" in big.last_variant(), big.last_variant()
+    _check_match(got, ref_big.matchScan(guess, pts, want_scores=True), 720)
 
 
 @pytest.mark.parametrize("cfg", [1, 3, 5])
