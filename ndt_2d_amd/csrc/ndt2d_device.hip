@@ -611,9 +611,7 @@ int ndt2d_match_launch(ndt2d_handle h, size_t th_begin, size_t th_end, double * 
     return fail(h, NDT2D_ERR_INVALID, "ndt2d_match_launch: bad theta range");
   }
   NDT2D_HIP(h, hipSetDevice(h->device));
-  int rc = ensure(h, h->ws_match, ndt2d::match_workspace_doubles());
-  if (rc != NDT2D_OK) return rc;
-  rc = ensure(h, h->record, NDT2D_MATCH_RECORD_DOUBLES);
+  int rc = ensure(h, h->record, NDT2D_MATCH_RECORD_DOUBLES);
   if (rc != NDT2D_OK) return rc;
 
   ndt2d::MatchArgs a{};
@@ -633,6 +631,8 @@ int ndt2d_match_launch(ndt2d_handle h, size_t th_begin, size_t th_end, double * 
   a.pose_x = h->pose_x;
   a.pose_y = h->pose_y;
   a.scores = d_scores;
+  rc = ensure(h, h->ws_match, ndt2d::match_workspace_doubles(a));
+  if (rc != NDT2D_OK) return rc;
 
   // scratch for the rotated-beam table of the lane-per-candidate mapping
   double * outer = nullptr;

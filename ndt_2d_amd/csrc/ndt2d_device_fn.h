@@ -204,12 +204,69 @@ __device__ __forceinline__ double wave_sum(double v)
   return v;
 }
 
+// Wave-wide reductions over the DPP lane network (no LDS traffic, fixed tree): the
+// result is complete in lane 63.  Steps: the two quad permutes, row_half_mirror,
+// row_mirror (a row = 16 lanes), then row_bcast15 into rows 1 and 3 and
+// row_bcast31 into rows 2 and 3.
+constexpr int kDppQuadXor1 = 0xb1;      // quad_perm:[1,0,3,2]
+constexpr int kDppQuadXor2 = 0x4e;      // quad_perm:[2,3,0,1]
+constexpr int kDppRowHalfMirror = 0x141;
+constexpr int kDppRowMirror = 0x140;
+constexpr int kDppRowBcast15 = 0x142;
+constexpr int kDppRowBcast31 = 0x143;
+
+// the other lane's value; lanes of rows outside ROW_MASK get `fallback`
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v, double fallback)
+{
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(fallback), __double2loint(v), CTRL,
+                                             ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(fallback), __double2hiint(v), CTRL,
+                                             ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_sum_to_last_lane(double v)
+{
+  v += dpp_f64<kDppQuadXor1, 0xf>(v, 0.0);
+  v += dpp_f64<kDppQuadXor2, 0xf>(v, 0.0);
+  v += dpp_f64<kDppRowHalfMirror, 0xf>(v, 0.0);
+  v += dpp_f64<kDppRowMirror, 0xf>(v, 0.0);
+  v += dpp_f64<kDppRowBcast15, 0xa>(v, 0.0);
+  v += dpp_f64<kDppRowBcast31, 0xc>(v, 0.0);
+  return v;
+}
+
 // (score, index) ordering of the reference's `if (score < best_score)` scan in
 // loop order (src/scan_matcher_ndt.cpp:128): lower score wins, ties go to the
 // lower flat index.
 __device__ __forceinline__ bool better(double s_a, double i_a, double s_b, double i_b)
 {
   return (s_a < s_b) | ((s_a == s_b) & (i_a < i_b));
+}
+
+// (score, index) minimum of the wave in lane 63, same network.  A lane outside a
+// step's row mask meets its own pair, which changes nothing.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void best_step(double & s, double & i)
+{
+  const double os = dpp_f64<CTRL, ROW_MASK>(s, s);
+  const double oi = dpp_f64<CTRL, ROW_MASK>(i, i);
+  if (better(os, oi, s, i))
+  {
+    s = os;
+    i = oi;
+  }
+}
+
+__device__ __forceinline__ void wave_best_to_last_lane(double & s, double & i)
+{
+  best_step<kDppQuadXor1, 0xf>(s, i);
+  best_step<kDppQuadXor2, 0xf>(s, i);
+  best_step<kDppRowHalfMirror, 0xf>(s, i);
+  best_step<kDppRowMirror, 0xf>(s, i);
+  best_step<kDppRowBcast15, 0xa>(s, i);
+  best_step<kDppRowBcast31, 0xc>(s, i);
 }
 
 }  // namespace ndt2d

@@ -61,6 +61,7 @@ struct MatchArgs
   double pose_x, pose_y;
   double * scores;          // optional, slab-local flat order
   double * partials;        // [n_workers][NDT2D_MATCH_RECORD_DOUBLES]
+  uint32_t * next_item;     // work-item counter of the lane-per-candidate search
   uint32_t chunk;           // candidates per work item
 };
 
@@ -108,7 +109,7 @@ struct LaunchInfo
 // Launch the match search + its final reduction.  record_out: device,
 // 12 doubles.  workspace: device scratch for per-wave partials, at least
 // match_workspace_doubles() doubles.
-size_t match_workspace_doubles();
+size_t match_workspace_doubles(const MatchArgs & args);
 // ev_main_done (optional) is recorded right after the search kernel, before the
 // tiny final reduction, so the caller can time the dominant kernel alone.
 // outer (optional): scratch of match_lane_outer_doubles() doubles; without it the
@@ -221,6 +222,9 @@ hipError_t launch_poses_compact(const PosesArgs & args, int cus, bool screen, hi
 // force_variant: grid placement in the low bits, candidate mapping above them
 enum { kVariantAuto = 0, kVariantLds = 1, kVariantGlobal = 2, kVariantGridMask = 3,
        kVariantWave = 4, kVariantLane = 8, kVariantDense = 16, kVariantNoSkip = 32 };
+// The lane-per-candidate search leaves one record per work item (theta x 8x8 patch);
+// lattices with more items than this (1.5 GB of records) take the wave mapping.
+constexpr uint64_t kMaxLaneItems = 1ull << 24;
 // launch_match: lattices with fewer candidates than this take the wave-per-candidate mapping
 constexpr uint64_t kWaveMappingBelow = 160000;
 

@@ -178,20 +178,26 @@ __global__ void __launch_bounds__(kMatchThreads) match_kernel(const MatchArgs a)
   }
 }
 
-// Final reduction of the per-wave partial records, fixed order (deterministic).
+// Reduction of partial records, fixed order (deterministic).
 // record = {best_score, best_index (exact double, -1 if none), acc[10]}.
-__global__ void __launch_bounds__(256) match_reduce_kernel(const double * partials,
-                                                           uint32_t n_workers, double * record,
-                                                           double * record2)
+// Block b reduces records [b * per_block, min(n, (b + 1) * per_block)) to one.  As the
+// last stage (one block, `final`), it also applies "no candidate scored below 0 ->
+// no index" and writes the result record(s); as a first stage it writes record b of
+// `out`.
+__global__ void __launch_bounds__(256) match_reduce_kernel(const double * partials, uint32_t n,
+                                                           uint32_t per_block, double * out,
+                                                           double * out2, int final)
 {
   __shared__ double sh[256 * kRecord];
   const int t = threadIdx.x;
+  const uint32_t begin = blockIdx.x * per_block;
+  const uint32_t end = min(n, begin + per_block);
   double v[kRecord];
   v[0] = 0.0;
   v[1] = kNoIndex;
 #pragma unroll
   for (int k = 2; k < kRecord; ++k) v[k] = 0.0;
-  for (uint32_t w = t; w < n_workers; w += 256)
+  for (uint32_t w = begin + t; w < end; w += 256)
   {
     const double * p = partials + static_cast<size_t>(w) * kRecord;
     if (better(p[0], p[1], v[0], v[1]))
@@ -224,9 +230,16 @@ __global__ void __launch_bounds__(256) match_reduce_kernel(const double * partia
   if (t < kRecord)
   {
     double val = sh[t];
-    if (t == 1 && !(sh[0] < 0.0)) val = -1.0;
-    record[t] = val;
-    if (record2 != nullptr) record2[t] = val;
+    if (final)
+    {
+      if (t == 1 && !(sh[0] < 0.0)) val = -1.0;
+      out[t] = val;
+      if (out2 != nullptr) out2[t] = val;
+    }
+    else
+    {
+      out[static_cast<size_t>(blockIdx.x) * kRecord + t] = val;
+    }
   }
 }
 
@@ -426,9 +439,18 @@ hipError_t dispatch_match_nbl(const MatchArgs & args, uint32_t blocks, size_t ld
 
 }  // namespace
 
-size_t match_workspace_doubles()
+// Workspace layout: [work-item counter, 8 doubles][256 records of the first reduction
+// stage][partial records: one per wave (wave mapping) or per work item (lane mapping)]
+constexpr size_t kWorkspaceHead = 8 + 256 * static_cast<size_t>(kRecord);
+
+size_t match_workspace_doubles(const MatchArgs & args)
 {
-  return static_cast<size_t>(kMaxMatchBlocks) * kMatchWaves * kRecord;
+  const uint64_t p1 = (args.n_lin + 7) / 8;
+  uint64_t records = static_cast<uint64_t>(args.th_end - args.th_begin) * p1 * p1;
+  if (records > kMaxLaneItems) records = 0;   // the wave mapping will run
+  const uint64_t waves = static_cast<uint64_t>(kMaxMatchBlocks) * kMatchWaves;
+  if (records < waves) records = waves;
+  return kWorkspaceHead + static_cast<size_t>(records) * kRecord;
 }
 
 hipError_t launch_match(const MatchArgs & args_in, double * workspace, double * outer,
@@ -437,6 +459,9 @@ hipError_t launch_match(const MatchArgs & args_in, double * workspace, double * 
 {
   MatchArgs args = args_in;
   if (args.n_beams == 0) return hipErrorInvalidValue;
+  args.next_item = reinterpret_cast<uint32_t *>(workspace);
+  double * const staged = workspace + 8;
+  workspace += kWorkspaceHead;
   const DeviceLimits lim = device_limits();
   const int force_grid = force_variant & kVariantGridMask;
   const bool pow2 = args.grid.pow2 != 0;
@@ -512,8 +537,22 @@ hipError_t launch_match(const MatchArgs & args_in, double * workspace, double * 
     if (e != hipSuccess) return e;
   }
 
-  hipLaunchKernelGGL(match_reduce_kernel, dim3(1), dim3(256), 0, stream, workspace, n_workers,
-                     record_out, record_out2);
+  // Up to 8,192 records: one block.  More (the lane mapping leaves one per work item):
+  // 256 blocks first, each over a contiguous share.
+  const double * records = workspace;
+  if (n_workers > kMaxMatchBlocks * kMatchWaves)
+  {
+    const uint32_t per_block = (n_workers + 255) / 256;
+    const uint32_t stage_blocks = (n_workers + per_block - 1) / per_block;
+    hipLaunchKernelGGL(match_reduce_kernel, dim3(stage_blocks), dim3(256), 0, stream, records,
+                       n_workers, per_block, staged, static_cast<double *>(nullptr), 0);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    records = staged;
+    n_workers = stage_blocks;
+  }
+  hipLaunchKernelGGL(match_reduce_kernel, dim3(1), dim3(256), 0, stream, records, n_workers,
+                     n_workers, record_out, record_out2, 1);
   e = hipGetLastError();
   if (info != nullptr)
   {

@@ -189,6 +189,8 @@ __global__ void __launch_bounds__(256) outer_table_kernel(const MatchArgs a, dou
     }
   }
 
+  // the work-item counter of the search kernel that follows on this stream
+  if (blockIdx.x == 0 && threadIdx.x == 0) *a.next_item = 0u;
   const uint64_t n = static_cast<uint64_t>(a.th_end - a.th_begin) * a.n_beams;
   for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x; i < n;
        i += static_cast<uint64_t>(gridDim.x) * 256)
@@ -399,14 +401,17 @@ __global__ void __launch_bounds__(THREADS) match_lane_kernel(
   const uint64_t per_theta = static_cast<uint64_t>(n_lin) * n_lin;
   const double inv_scaled = g.inv_cell_size * geo.unit_scale;
 
-  double best_s = 0.0;       // `double best_score = 0;` (:83)
-  double best_i = kNoIndex;
-  double acc[10];
-#pragma unroll
-  for (int k = 0; k < 10; ++k) acc[k] = 0.0;
-
-  for (uint32_t item = worker; item < n_items; item += n_workers)
+  // One record per ITEM (not per wave): a wave takes its first item by its index and
+  // every further one from an atomic counter, so which wave ran an item leaves no
+  // trace in the records or in anything reduced from them.
+  for (uint32_t item = worker; item < n_items;)
   {
+    double best_s = 0.0;       // `double best_score = 0;` (:83)
+    double best_i = kNoIndex;
+    double acc[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) acc[k] = 0.0;
+
     const uint32_t t = item / patches;
     const uint32_t p = item - t * patches;
     const uint32_t pxi = p / patches_1d;
@@ -460,30 +465,24 @@ __global__ void __launch_bounds__(THREADS) match_lane_kernel(
       acc[9] += score;
       if (a.scores != nullptr) a.scores[local] = score;
     }
-  }
 
-  // wave-level reduction of the per-lane records
+    // wave-level reduction of the item's per-lane records: complete in lane 63, which
+    // writes the item's record and fetches the wave's next item
+    wave_best_to_last_lane(best_s, best_i);
 #pragma unroll
-  for (int off = kWave / 2; off > 0; off >>= 1)
-  {
-    const double os = __shfl_xor(best_s, off, kWave);
-    const double oi = __shfl_xor(best_i, off, kWave);
-    if (better(os, oi, best_s, best_i))
+    for (int k = 0; k < 10; ++k) acc[k] = wave_sum_to_last_lane(acc[k]);
+
+    uint32_t fetched = 0;
+    if (lane == kWave - 1)
     {
-      best_s = os;
-      best_i = oi;
+      fetched = atomicAdd(a.next_item, 1u);
+      double * out = a.partials + static_cast<size_t>(item) * kRecord;
+      out[0] = best_s;
+      out[1] = best_i;
+#pragma unroll
+      for (int k = 0; k < 10; ++k) out[2 + k] = acc[k];
     }
-  }
-#pragma unroll
-  for (int k = 0; k < 10; ++k) acc[k] = wave_sum(acc[k]);
-
-  if (lane == 0)
-  {
-    double * out = a.partials + static_cast<size_t>(worker) * kRecord;
-    out[0] = best_s;
-    out[1] = best_i;
-#pragma unroll
-    for (int k = 0; k < 10; ++k) out[2 + k] = acc[k];
+    item = n_workers + static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(fetched), kWave - 1));
   }
 }
 
@@ -577,7 +576,7 @@ bool match_lane_supported(const MatchArgs & args, size_t lds_per_block)
   const uint64_t p1 = (args.n_lin + kPatch - 1) / kPatch;
   const uint64_t items = static_cast<uint64_t>(args.th_end - args.th_begin) * p1 * p1;
   // (24-bit multiplies index the grid rows and the LDS records)
-  return map_bytes <= lds_per_block && items < (1ull << 32) && args.grid.size_x < (1u << 24) &&
+  return map_bytes <= lds_per_block && items <= kMaxLaneItems && args.grid.size_x < (1u << 24) &&
          args.grid.ncell < (1u << 24);
 }
 
@@ -591,6 +590,8 @@ hipError_t launch_match_lane(const MatchArgs & args_in, double * outer, double *
   size_t map_bytes = 0;
   if (!lane_geometry(args, lds_per_block, &geo, &map_bytes)) return hipErrorInvalidValue;
   geo.no_skip = no_skip ? 1 : 0;
+  const uint32_t p1 = (args.n_lin + kPatch - 1) / kPatch;
+  const uint64_t n_items = static_cast<uint64_t>(args.th_end - args.th_begin) * p1 * p1;
 
   const uint64_t n_outer = static_cast<uint64_t>(args.th_end - args.th_begin) * args.n_beams;
   uint32_t oblocks = static_cast<uint32_t>((n_outer + 255) / 256);
@@ -602,8 +603,6 @@ hipError_t launch_match_lane(const MatchArgs & args_in, double * outer, double *
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
 
-  const uint32_t p1 = (args.n_lin + kPatch - 1) / kPatch;
-  const uint64_t n_items = static_cast<uint64_t>(args.th_end - args.th_begin) * p1 * p1;
   // Few work items (the plugin's default lattice is 720 of them): 256-thread blocks
   // put them on four times as many CUs -- as long as every wave still gets at most
   // one item; the LDS image allows one block per CU, so beyond that the larger block
@@ -651,7 +650,7 @@ hipError_t launch_match_lane(const MatchArgs & args_in, double * outer, double *
                     : (pow2 ? launch(match_lane_kernel<T, true, false>, T)
                             : launch(match_lane_kernel<T, false, false>, T));
   }
-  if (n_workers_out != nullptr) *n_workers_out = blocks * waves_per_block;
+  if (n_workers_out != nullptr) *n_workers_out = static_cast<uint32_t>(n_items);  // one record per item
   return e;
 }
 
