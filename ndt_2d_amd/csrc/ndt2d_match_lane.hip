@@ -399,6 +399,7 @@ __global__ void __launch_bounds__(THREADS) match_lane_kernel(
   const uint32_t n_workers = gridDim.x * kLaneWaves;
   const uint32_t worker = wave * gridDim.x + blockIdx.x;
   const uint64_t per_theta = static_cast<uint64_t>(n_lin) * n_lin;
+  const uint32_t th_mid = (a.th_end - a.th_begin - 1u) / 2u;
   const double inv_scaled = g.inv_cell_size * geo.unit_scale;
 
   // One record per ITEM (not per wave): a wave takes its first item by its index and
@@ -412,8 +413,12 @@ __global__ void __launch_bounds__(THREADS) match_lane_kernel(
 #pragma unroll
     for (int k = 0; k < 10; ++k) acc[k] = 0.0;
 
-    const uint32_t t = item / patches;
-    const uint32_t p = item - t * patches;
+    // theta steps are visited from the middle of the range outwards: the steps around
+    // the scan's own heading are the expensive ones when the guess is any good, and
+    // the last items a launch hands out should be cheap ones
+    const uint32_t rank = item / patches;
+    const uint32_t p = item - rank * patches;
+    const uint32_t t = (rank & 1u) ? th_mid + (rank + 1u) / 2u : th_mid - rank / 2u;
     const uint32_t pxi = p / patches_1d;
     const uint32_t pyi = p - pxi * patches_1d;
     const uint32_t ix = pxi * kPatch + lx;
