@@ -61,7 +61,7 @@ struct MatchArgs
   double pose_x, pose_y;
   double * scores;          // optional, slab-local flat order
   double * partials;        // [n_workers][NDT2D_MATCH_RECORD_DOUBLES]
-  uint32_t * next_item;     // work-item counter of the lane-per-candidate search
+  uint32_t * next_item;     // work-item counters of the lane-per-candidate search (kItemShards, kItemShardStride apart)
   uint32_t chunk;           // candidates per work item
 };
 
@@ -222,6 +222,11 @@ hipError_t launch_poses_compact(const PosesArgs & args, int cus, bool screen, hi
 // force_variant: grid placement in the low bits, candidate mapping above them
 enum { kVariantAuto = 0, kVariantLds = 1, kVariantGlobal = 2, kVariantGridMask = 3,
        kVariantWave = 4, kVariantLane = 8, kVariantDense = 16, kVariantNoSkip = 32 };
+// Work items of the lane-per-candidate search are handed out by kItemShards counters
+// (one address takes ~88 atomics/us; a launch issues up to tens of thousands), each in
+// a cache line of its own.
+constexpr uint32_t kItemShards = 8;
+constexpr uint32_t kItemShardStride = 64;   // in uint32: 256 bytes
 // The lane-per-candidate search leaves one record per work item (theta x 8x8 patch);
 // lattices with more items than this (1.5 GB of records) take the wave mapping.
 constexpr uint64_t kMaxLaneItems = 1ull << 24;

@@ -439,9 +439,10 @@ hipError_t dispatch_match_nbl(const MatchArgs & args, uint32_t blocks, size_t ld
 
 }  // namespace
 
-// Workspace layout: [work-item counter, 8 doubles][256 records of the first reduction
+// Workspace layout: [work-item counters, 2 KB][256 records of the first reduction
 // stage][partial records: one per wave (wave mapping) or per work item (lane mapping)]
-constexpr size_t kWorkspaceHead = 8 + 256 * static_cast<size_t>(kRecord);
+constexpr size_t kCounterDoubles = static_cast<size_t>(kItemShards) * kItemShardStride * sizeof(uint32_t) / sizeof(double);
+constexpr size_t kWorkspaceHead = kCounterDoubles + 256 * static_cast<size_t>(kRecord);
 
 size_t match_workspace_doubles(const MatchArgs & args)
 {
@@ -460,7 +461,7 @@ hipError_t launch_match(const MatchArgs & args_in, double * workspace, double * 
   MatchArgs args = args_in;
   if (args.n_beams == 0) return hipErrorInvalidValue;
   args.next_item = reinterpret_cast<uint32_t *>(workspace);
-  double * const staged = workspace + 8;
+  double * const staged = workspace + kCounterDoubles;
   workspace += kWorkspaceHead;
   const DeviceLimits lim = device_limits();
   const int force_grid = force_variant & kVariantGridMask;

@@ -40,6 +40,8 @@
 // evaluation; the tests compare the two bitwise).
 #include <cmath>
 
+#include <type_traits>
+
 #include "ndt2d_device_fn.h"
 
 namespace ndt2d
@@ -48,6 +50,7 @@ namespace ndt2d
 namespace
 {
 
+constexpr uint32_t kDynamicItemsFromBeams = 256;
 constexpr int kLaneThreads = 1024;       // large searches: one block per CU
 constexpr int kLaneThreadsSmall = 256;   // small searches: spread the few work items over more CUs
 constexpr int kPatch = 8;            // patch is kPatch x kPatch candidates = one wave
@@ -190,7 +193,7 @@ __global__ void __launch_bounds__(256) outer_table_kernel(const MatchArgs a, dou
   }
 
   // the work-item counter of the search kernel that follows on this stream
-  if (blockIdx.x == 0 && threadIdx.x == 0) *a.next_item = 0u;
+  if (blockIdx.x == 0 && threadIdx.x < kItemShards) a.next_item[threadIdx.x * kItemShardStride] = 0u;
   const uint64_t n = static_cast<uint64_t>(a.th_end - a.th_begin) * a.n_beams;
   for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x; i < n;
        i += static_cast<uint64_t>(gridDim.x) * 256)
@@ -355,7 +358,7 @@ __device__ __forceinline__ void lane_beams(const GridDesc & g, const LaneCtx & c
   }
 }
 
-template <int THREADS, bool POW2, bool LDS_RECORDS>
+template <int THREADS, bool POW2, bool LDS_RECORDS, bool DYNAMIC_ITEMS>
 __global__ void __launch_bounds__(THREADS) match_lane_kernel(
   const MatchArgs a, const double4 * __restrict__ outer, const uint8_t * __restrict__ map_image,
   const LaneGeom geo)
@@ -400,18 +403,19 @@ __global__ void __launch_bounds__(THREADS) match_lane_kernel(
   const uint32_t worker = wave * gridDim.x + blockIdx.x;
   const uint64_t per_theta = static_cast<uint64_t>(n_lin) * n_lin;
   const uint32_t th_mid = (a.th_end - a.th_begin - 1u) / 2u;
+  const uint32_t home_shard = blockIdx.x % kItemShards;
   const double inv_scaled = g.inv_cell_size * geo.unit_scale;
 
   // One record per ITEM (not per wave): a wave takes its first item by its index and
   // every further one from an atomic counter, so which wave ran an item leaves no
   // trace in the records or in anything reduced from them.
+  double best_s = 0.0;       // `double best_score = 0;` (:83)
+  double best_i = kNoIndex;
+  double acc[10];
+#pragma unroll
+  for (int k = 0; k < 10; ++k) acc[k] = 0.0;
   for (uint32_t item = worker; item < n_items;)
   {
-    double best_s = 0.0;       // `double best_score = 0;` (:83)
-    double best_i = kNoIndex;
-    double acc[10];
-#pragma unroll
-    for (int k = 0; k < 10; ++k) acc[k] = 0.0;
 
     // theta steps are visited from the middle of the range outwards: the steps around
     // the scan's own heading are the expensive ones when the guess is any good, and
@@ -471,23 +475,55 @@ __global__ void __launch_bounds__(THREADS) match_lane_kernel(
       if (a.scores != nullptr) a.scores[local] = score;
     }
 
+    if (!DYNAMIC_ITEMS)
+    {
+      item += n_workers;
+      continue;
+    }
     // wave-level reduction of the item's per-lane records: complete in lane 63, which
     // writes the item's record and fetches the wave's next item
     wave_best_to_last_lane(best_s, best_i);
 #pragma unroll
     for (int k = 0; k < 10; ++k) acc[k] = wave_sum_to_last_lane(acc[k]);
 
-    uint32_t fetched = 0;
+    uint32_t next = n_items;
     if (lane == kWave - 1)
     {
-      fetched = atomicAdd(a.next_item, 1u);
       double * out = a.partials + static_cast<size_t>(item) * kRecord;
       out[0] = best_s;
       out[1] = best_i;
 #pragma unroll
       for (int k = 0; k < 10; ++k) out[2 + k] = acc[k];
+      // Items beyond the first n_workers are dealt to kItemShards counters by
+      // index; a wave draws from the shard of its block (blocks b, b + 8, ... are
+      // observed to share an XCD) and, once that is empty, from the others.
+      for (uint32_t tried = 0; tried < kItemShards && next >= n_items; ++tried)
+      {
+        const uint32_t shard = (home_shard + tried) % kItemShards;
+        const uint32_t k = atomicAdd(a.next_item + shard * kItemShardStride, 1u);
+        const uint64_t candidate = static_cast<uint64_t>(n_workers) + static_cast<uint64_t>(k) * kItemShards + shard;
+        if (candidate < n_items) next = static_cast<uint32_t>(candidate);
+      }
     }
-    item = n_workers + static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(fetched), kWave - 1));
+    item = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(next), kWave - 1));
+    best_s = 0.0;
+    best_i = kNoIndex;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) acc[k] = 0.0;
+  }
+  if (!DYNAMIC_ITEMS)
+  {
+    wave_best_to_last_lane(best_s, best_i);
+#pragma unroll
+    for (int k = 0; k < 10; ++k) acc[k] = wave_sum_to_last_lane(acc[k]);
+    if (lane == kWave - 1)
+    {
+      double * out = a.partials + static_cast<size_t>(worker) * kRecord;
+      out[0] = best_s;
+      out[1] = best_i;
+#pragma unroll
+      for (int k = 0; k < 10; ++k) out[2 + k] = acc[k];
+    }
   }
 }
 
@@ -595,6 +631,10 @@ hipError_t launch_match_lane(const MatchArgs & args_in, double * outer, double *
   size_t map_bytes = 0;
   if (!lane_geometry(args, lds_per_block, &geo, &map_bytes)) return hipErrorInvalidValue;
   geo.no_skip = no_skip ? 1 : 0;
+  // Items of few beams are too short to repay a reduction, a record and an atomic
+  // each (100 beams: static assignment is ~15 % faster; 720 beams: dynamic is 17 %
+  // faster, experiments/small_search_sweep.py).
+  const bool dynamic_items = args.n_beams >= kDynamicItemsFromBeams;
   const uint32_t p1 = (args.n_lin + kPatch - 1) / kPatch;
   const uint64_t n_items = static_cast<uint64_t>(args.th_end - args.th_begin) * p1 * p1;
 
@@ -639,23 +679,23 @@ hipError_t launch_match_lane(const MatchArgs & args_in, double * outer, double *
     return hipGetLastError();
   };
   const bool pow2 = args.grid.pow2 != 0;
-  if (small)
+  auto pick = [&](auto threads_tag) -> hipError_t {
+    constexpr int T = decltype(threads_tag)::value;
+    auto with_items = [&](auto dyn_tag) -> hipError_t {
+      constexpr bool D = decltype(dyn_tag)::value;
+      return lds_records ? (pow2 ? launch(match_lane_kernel<T, true, true, D>, T)
+                                 : launch(match_lane_kernel<T, false, true, D>, T))
+                         : (pow2 ? launch(match_lane_kernel<T, true, false, D>, T)
+                                 : launch(match_lane_kernel<T, false, false, D>, T));
+    };
+    return dynamic_items ? with_items(std::true_type{}) : with_items(std::false_type{});
+  };
+  e = small ? pick(std::integral_constant<int, kLaneThreadsSmall>{})
+            : pick(std::integral_constant<int, kLaneThreads>{});
+  if (n_workers_out != nullptr)
   {
-    constexpr int T = kLaneThreadsSmall;
-    e = lds_records ? (pow2 ? launch(match_lane_kernel<T, true, true>, T)
-                            : launch(match_lane_kernel<T, false, true>, T))
-                    : (pow2 ? launch(match_lane_kernel<T, true, false>, T)
-                            : launch(match_lane_kernel<T, false, false>, T));
+    *n_workers_out = dynamic_items ? static_cast<uint32_t>(n_items) : blocks * waves_per_block;
   }
-  else
-  {
-    constexpr int T = kLaneThreads;
-    e = lds_records ? (pow2 ? launch(match_lane_kernel<T, true, true>, T)
-                            : launch(match_lane_kernel<T, false, true>, T))
-                    : (pow2 ? launch(match_lane_kernel<T, true, false>, T)
-                            : launch(match_lane_kernel<T, false, false>, T));
-  }
-  if (n_workers_out != nullptr) *n_workers_out = static_cast<uint32_t>(n_items);  // one record per item
   return e;
 }
 
