@@ -35,6 +35,22 @@ def match_case(cfg, variants, **override):
         m.set_variant(v)
         ms = time_match(m, n_th)
         out[v] = {"kernel_ms": ms, "units_per_s": units / (ms * 1e-3), "variant": m.last_variant()}
+    if cfg == 4:
+        # most cfg-4 units fall off the 41 x 41 grid (an exact 0 without a
+        # cell look-up, in the reference as well): the share that lands inside it, from
+        # 4e6 sampled (candidate, beam) pairs
+        p = synth.matcher_params(cfg, **override)
+        _, gsx, gsy, gcell, gox, goy = m.grid()
+        rng = np.random.default_rng(4)
+        k = 4_000_000
+        th = guess[2] + rng.uniform(-p["search_angular_size"], p["search_angular_size"], k)
+        b = pts[rng.integers(0, len(pts), k)]
+        lin = p["search_linear_size"]
+        x = guess[0] + rng.uniform(-lin, lin, k) + np.cos(th) * b[:, 0] - np.sin(th) * b[:, 1]
+        y = guess[1] + rng.uniform(-lin, lin, k) + np.sin(th) * b[:, 0] + np.cos(th) * b[:, 1]
+        inside = (x >= gox) & (y >= goy) & (x < gox + gsx * gcell) & (y < goy + gsy * gcell)
+        out["in_grid_fraction_sampled"] = float(inside.mean())
+        out["in_grid_units_per_s"] = out["auto"]["units_per_s"] * float(inside.mean())
     m.close()
     return out
 
@@ -90,6 +106,22 @@ def particles_case(cfg, variants):
                 ms.append(t)
         ms = float(np.median(ms))
         out[v] = {"kernel_ms": ms, "units_per_s": units / (ms * 1e-3), "variant": m.last_variant()}
+    if cfg == 4:
+        # most cfg-4 units fall off the 41 x 41 grid (an exact 0 without a
+        # cell look-up, in the reference as well): the share that lands inside it, from
+        # 4e6 sampled (candidate, beam) pairs
+        p = synth.matcher_params(cfg, **override)
+        _, gsx, gsy, gcell, gox, goy = m.grid()
+        rng = np.random.default_rng(4)
+        k = 4_000_000
+        th = guess[2] + rng.uniform(-p["search_angular_size"], p["search_angular_size"], k)
+        b = pts[rng.integers(0, len(pts), k)]
+        lin = p["search_linear_size"]
+        x = guess[0] + rng.uniform(-lin, lin, k) + np.cos(th) * b[:, 0] - np.sin(th) * b[:, 1]
+        y = guess[1] + rng.uniform(-lin, lin, k) + np.sin(th) * b[:, 0] + np.cos(th) * b[:, 1]
+        inside = (x >= gox) & (y >= goy) & (x < gox + gsx * gcell) & (y < goy + gsy * gcell)
+        out["in_grid_fraction_sampled"] = float(inside.mean())
+        out["in_grid_units_per_s"] = out["auto"]["units_per_s"] * float(inside.mean())
     m.close()
     return out
 
