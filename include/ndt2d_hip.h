@@ -132,6 +132,14 @@ typedef struct ndt2d_match_result
  * (for a device-side all-reduce); the context always keeps its own copy. */
 int ndt2d_match_launch(ndt2d_handle h, size_t th_begin, size_t th_end, double * d_scores,
                        double * d_record);
+/* The same for the theta steps th_first, th_first + th_stride, ... (th_count of
+ * them): one rank's share of a lattice whose theta axis is dealt out round-robin
+ * (the cost of a step varies across the angular range, so contiguous slabs leave
+ * the ranks unevenly loaded).  best_index is the flat index in the WHOLE lattice
+ * ((i_theta * n_lin + i_x) * n_lin + i_y, the reference's visiting order
+ * src/scan_matcher_ndt.cpp:103-119), d_scores is local: step k of this call first. */
+int ndt2d_match_launch_strided(ndt2d_handle h, size_t th_first, size_t th_stride,
+                               size_t th_count, double * d_scores, double * d_record);
 /* Wait for the last ndt2d_match_launch and copy its result to the host. */
 int ndt2d_match_fetch(ndt2d_handle h, ndt2d_match_result * out);
 /* launch + fetch; h_scores (host pointer, optional) receives the slab scores. */

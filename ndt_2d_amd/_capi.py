@@ -82,6 +82,7 @@ SIGNATURES = {
     "ndt2d_set_beams": (C.c_int, [_vp, _dp, _sz]),
     "ndt2d_set_search": (C.c_int, [_vp, _d, _d, _dp, _dp, _dp, _sz, _dp, _sz]),
     "ndt2d_match_launch": (C.c_int, [_vp, _sz, _sz, _vp, _vp]),
+    "ndt2d_match_launch_strided": (C.c_int, [_vp, _sz, _sz, _sz, _vp, _vp]),
     "ndt2d_match_fetch": (C.c_int, [_vp, C.POINTER(MatchResult)]),
     "ndt2d_match": (C.c_int, [_vp, _sz, _sz, _dp, C.POINTER(MatchResult)]),
     "ndt2d_score_poses_launch": (C.c_int, [_vp, _vp, _sz, _vp, _vp]),

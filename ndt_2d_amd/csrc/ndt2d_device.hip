@@ -601,15 +601,25 @@ int ndt2d_match_launch(ndt2d_handle h, size_t th_begin, size_t th_end, double * 
                        double * d_record)
 {
   if (h == nullptr) return NDT2D_ERR_INVALID;
+  if (th_begin >= th_end) return fail(h, NDT2D_ERR_INVALID, "ndt2d_match_launch: bad theta range");
+  return ndt2d_match_launch_strided(h, th_begin, 1, th_end - th_begin, d_scores, d_record);
+}
+
+int ndt2d_match_launch_strided(ndt2d_handle h, size_t th_first, size_t th_stride, size_t th_count,
+                               double * d_scores, double * d_record)
+{
+  if (h == nullptr) return NDT2D_ERR_INVALID;
   if (!h->has_grid) return fail(h, NDT2D_ERR_NO_GRID, "ndt2d_match_launch: no grid");
   if (!h->has_search || h->n_beams == 0)
   {
     return fail(h, NDT2D_ERR_STATE, "ndt2d_match_launch: set_beams/set_search first");
   }
-  if (th_begin >= th_end || th_end > h->n_th)
+  if (th_count == 0 || th_stride == 0 || th_first >= h->n_th ||
+      (th_count - 1) > (h->n_th - 1 - th_first) / th_stride)
   {
     return fail(h, NDT2D_ERR_INVALID, "ndt2d_match_launch: bad theta range");
   }
+  const size_t th_begin = th_first, th_end = th_first + th_count;
   NDT2D_HIP(h, hipSetDevice(h->device));
   int rc = ensure(h, h->record, NDT2D_MATCH_RECORD_DOUBLES);
   if (rc != NDT2D_OK) return rc;
@@ -628,6 +638,7 @@ int ndt2d_match_launch(ndt2d_handle h, size_t th_begin, size_t th_end, double * 
   a.n_lin = static_cast<uint32_t>(h->n_lin);
   a.th_begin = static_cast<uint32_t>(th_begin);
   a.th_end = static_cast<uint32_t>(th_end);
+  a.th_stride = static_cast<uint32_t>(th_stride);
   a.pose_x = h->pose_x;
   a.pose_y = h->pose_y;
   a.scores = d_scores;

@@ -57,7 +57,10 @@ struct MatchArgs
   double dlin_absmax;       // max |dlin[i]| (host side copy of the search extent)
   double beam_rmax;         // max |beam| (host side copy of the scan's reach)
   uint32_t n_th, n_lin;
+  // theta steps th_begin + k * th_stride, k in [0, th_end - th_begin): a contiguous slab
+  // (stride 1) or one rank's share of an interleaved sharding
   uint32_t th_begin, th_end;
+  uint32_t th_stride;
   double pose_x, pose_y;
   double * scores;          // optional, slab-local flat order
   double * partials;        // [n_workers][NDT2D_MATCH_RECORD_DOUBLES]

@@ -81,7 +81,8 @@ __global__ void __launch_bounds__(kMatchThreads) match_kernel(const MatchArgs a)
 
   for (uint64_t item = worker; item < n_items; item += n_workers)
   {
-    const uint32_t ith = a.th_begin + static_cast<uint32_t>(item / cps);
+    const uint32_t t_local = static_cast<uint32_t>(item / cps);
+    const uint32_t ith = a.th_begin + t_local * a.th_stride;
     const uint32_t c = static_cast<uint32_t>(item % cps);
     const double ct = a.cos_th[ith];
     const double st = a.sin_th[ith];
@@ -155,7 +156,7 @@ __global__ void __launch_bounds__(kMatchThreads) match_kernel(const MatchArgs a)
 
       if (a.scores != nullptr && lane == 0)
       {
-        a.scores[static_cast<uint64_t>(ith - a.th_begin) * m + f] = score;
+        a.scores[static_cast<uint64_t>(t_local) * m + f] = score;
       }
 
       if (++iy == n_lin)

@@ -200,7 +200,7 @@ __global__ void __launch_bounds__(256) outer_table_kernel(const MatchArgs a, dou
   {
     const uint32_t t = static_cast<uint32_t>(i / a.n_beams);
     const uint32_t b = static_cast<uint32_t>(i - static_cast<uint64_t>(t) * a.n_beams);
-    const uint32_t ith = a.th_begin + t;
+    const uint32_t ith = a.th_begin + t * a.th_stride;
     const double ct = a.cos_th[ith];
     const double st = a.sin_th[ith];
     const double2 p = reinterpret_cast<const double2 *>(a.beams_xy)[b];
@@ -454,14 +454,15 @@ __global__ void __launch_bounds__(THREADS) match_lane_kernel(
     {
       const double score = -sum;  // (:127)
       const uint64_t local = static_cast<uint64_t>(t) * per_theta + static_cast<uint64_t>(ix) * n_lin + iy;
-      const double flat = static_cast<double>(static_cast<uint64_t>(a.th_begin) * per_theta + local);
+      const double flat = static_cast<double>(
+        static_cast<uint64_t>(a.th_begin + t * a.th_stride) * per_theta + static_cast<uint64_t>(ix) * n_lin + iy);
       if (score < best_s)
       {
         best_s = score;
         best_i = flat;
       }
       // k += x x^T score, u += x score, s += score (:137-140)
-      const double dt = a.dth[a.th_begin + t];
+      const double dt = a.dth[a.th_begin + t * a.th_stride];
       acc[0] += (dx * dx) * score;
       acc[1] += (dx * dy) * score;
       acc[2] += (dx * dt) * score;

@@ -1,14 +1,19 @@
 """Multi-GPU sharding of the hot path: one process per GPU, torch.distributed
 (backend "nccl" = RCCL over xGMI on MI355X; "gloo" in the CPU tests).
 
-matchScan: the candidate lattice is split into contiguous theta slabs (theta is
-the outer loop of the reference, src/scan_matcher_ndt.cpp:103, so lower rank =
-earlier in the reference's visiting order, which is what breaks score ties).
-Every rank reduces its slab on its own GPU to one 12-double record
-{best_score, best_index, k00,k01,k02,k11,k12,k22, u0,u1,u2, s}; the records are
-exchanged by ONE all-reduce(sum) of a [world, 12] buffer in which each rank
-fills only its own row (x + 0 is exact, so the exchange is bit-deterministic),
-then combined in rank order with the reference's strict `<`.
+matchScan: the theta axis of the candidate lattice (the outer loop of the
+reference, src/scan_matcher_ndt.cpp:103) is dealt out round-robin: rank r takes
+the steps r, r + world, r + 2 world, ...  (Contiguous slabs are supported too,
+but the cost of a step varies across the angular range -- the steps around the
+scan's own heading hit the map far more often -- and at 8 ranks the busiest
+contiguous slab takes 1.19x the mean, experiments/slab_balance.py.)
+Every rank reduces its share on its own GPU to one 12-double record
+{best_score, best_index, k00,k01,k02,k11,k12,k22, u0,u1,u2, s}, best_index being
+the flat index in the WHOLE lattice; the records are exchanged by ONE
+all-reduce(sum) of a [world, 12] buffer in which each rank fills only its own
+row (x + 0 is exact, so the exchange is bit-deterministic), then combined with
+the reference's first-wins rule: the lower score, and between equal scores the
+lower flat index = the candidate the reference's loops visit first.
 
 ParticleFilter::measure: particles are split into contiguous ranges; each rank
 scores its range and reduces {sum w, sum w*x, ...} (8 doubles); one
@@ -30,18 +35,26 @@ def shard_range(n, rank, world):
     return begin, begin + base + (1 if rank < rem else 0)
 
 
+def shard_strided(n, rank, world):
+    """Round-robin share of n items for `rank`: (first, stride, count)."""
+    return rank, world, (n - rank + world - 1) // world if rank < n else 0
+
+
 def combine_match_records(records):
     """records[world][12] in rank order -> (best_score, best_index or None, acc[10]).
 
-    Strict `<` in rank order reproduces the reference's first-wins rule
-    (src/scan_matcher_ndt.cpp:128): a later slab only wins with a lower score.
-    The accumulators are summed in rank order."""
+    The reference's first-wins rule (src/scan_matcher_ndt.cpp:128, strict `<` in
+    visiting order): the lower score wins, and between equal scores the lower flat
+    index -- for contiguous slabs that is the lower rank, for interleaved shares it
+    is whoever holds the earlier candidate.  The accumulators are summed in rank order."""
     records = np.asarray(records, dtype=np.float64).reshape(-1, MATCH_RECORD)
     best_score, best_index = 0.0, None
     acc = np.zeros(10, dtype=np.float64)
     for rec in records:
-        if rec[1] >= 0.0 and rec[0] < best_score:
-            best_score, best_index = float(rec[0]), int(rec[1])
+        if rec[1] >= 0.0 and rec[0] < 0.0:
+            if best_index is None or rec[0] < best_score or \
+                    (rec[0] == best_score and int(rec[1]) < best_index):
+                best_score, best_index = float(rec[0]), int(rec[1])
         acc += rec[2:]
     return best_score, best_index, acc
 

@@ -255,6 +255,13 @@ class ScanMatcherNDT:
         self._dev_check(self._L.ndt2d_match_launch(self.device_handle, th_begin, th_end,
                                                    scores_ptr, record_ptr), "ndt2d_match_launch")
 
+    def match_launch_strided(self, th_first, th_stride, th_count, record_ptr=None, scores_ptr=None):
+        """Asynchronous search of the theta steps th_first, th_first + th_stride, ...: one
+        rank's share of an interleaved sharding (ndt_2d_amd.dist.shard_strided)."""
+        self._dev_check(self._L.ndt2d_match_launch_strided(
+            self.device_handle, th_first, th_stride, th_count, scores_ptr, record_ptr),
+            "ndt2d_match_launch_strided")
+
     def match_fetch(self):
         res = _capi.MatchResult()
         self._dev_check(self._L.ndt2d_match_fetch(self.device_handle, C.byref(res)),

@@ -24,19 +24,21 @@ def _free_port():
     return port
 
 
-def _slab_record(scores, dth, dlin, th_begin, th_end):
-    """What one GPU's reduction produces for its theta slab."""
+def _share_record(scores, dth, dlin, th_first, th_stride, th_count):
+    """What one GPU's reduction produces for its share of the theta steps
+    (th_first, th_first + th_stride, ...): best_index is the flat index in the WHOLE lattice."""
     n_lin = len(dlin)
     per = n_lin * n_lin
-    sl = scores[th_begin * per:th_end * per]
+    steps = th_first + th_stride * np.arange(th_count)
+    sl = scores.reshape(len(dth), per)[steps].reshape(-1)
     rec = np.zeros(12)
     rec[1] = -1.0
     if len(sl) and sl.min() < 0:
         i = int(np.argmin(sl))  # first occurrence of the minimum
-        rec[0], rec[1] = sl[i], th_begin * per + i
-    th = np.repeat(dth[th_begin:th_end], per)
-    dx = np.tile(np.repeat(dlin, n_lin), th_end - th_begin)
-    dy = np.tile(dlin, (th_end - th_begin) * n_lin)
+        rec[0], rec[1] = sl[i], steps[i // per] * per + i % per
+    th = np.repeat(dth[steps], per)
+    dx = np.tile(np.repeat(dlin, n_lin), th_count)
+    dy = np.tile(dlin, th_count * n_lin)
     x = np.stack([dx, dy, th])
     terms = [x[0] * x[0], x[0] * x[1], x[0] * x[2], x[1] * x[1], x[1] * x[2], x[2] * x[2],
              x[0], x[1], x[2], np.ones_like(dx)]
@@ -62,8 +64,8 @@ def _worker(rank, world, port, out_dir):
     p = json.loads(str(g["params_json"]))
     dth = O.search_offsets(p["search_angular_size"], p["search_angular_resolution"])
     dlin = O.search_offsets(p["search_linear_size"], p["search_linear_resolution"])
-    b, e = shard.shard_range(len(dth), rank, world)
-    row = torch.from_numpy(_slab_record(g["scores"], dth, dlin, b, e))
+    row = torch.from_numpy(_share_record(g["scores"], dth, dlin,
+                                         *shard.shard_strided(len(dth), rank, world)))
     table = shard.allreduce_rows(row, rank, world, dist).numpy()
     best_score, best_index, acc = shard.combine_match_records(table)
     cov = shard.covariance_from_acc(acc)

@@ -153,6 +153,28 @@ def test_device_layer_direct_and_theta_sharding(cfg1):
             assert (s, i) == (full[0], int(full[1]))
             assert np.allclose(acc, full[2:], rtol=1e-12, atol=0)
             assert np.allclose(shard.covariance_from_acc(acc), g["covariance"], rtol=1e-9, atol=0)
+        # interleaved shares (rank r takes theta steps r, r + world, ...): the same
+        # per-candidate scores, the same winner by flat index in the whole lattice
+        def run_strided(first, stride, count):
+            n = count * per
+            assert L.ndt2d_match_launch_strided(h, first, stride, count, None, None) == _capi.OK
+            res = _capi.MatchResult()
+            assert L.ndt2d_match_fetch(h, C.byref(res)) == _capi.OK
+            rec = np.zeros(12)
+            rec[0] = res.best_score
+            rec[1] = -1.0 if res.best_index == _capi.NO_INDEX else float(res.best_index)
+            rec[2:] = res.acc[:]
+            assert res.n_candidates == n
+            return rec
+
+        for world in (2, 3, 8):
+            recs = [run_strided(*shard.shard_strided(len(dth), r, world)) for r in range(world)]
+            s, i, acc = shard.combine_match_records(recs)
+            assert (s, i) == (full[0], int(full[1]))
+            assert np.allclose(acc, full[2:], rtol=1e-12, atol=0)
+        assert L.ndt2d_match_launch_strided(h, 0, 0, 1, None, None) == _capi.ERR_INVALID
+        assert L.ndt2d_match_launch_strided(h, 1, 2, len(dth), None, None) == _capi.ERR_INVALID
+        assert L.ndt2d_match_launch_strided(h, len(dth), 1, 1, None, None) == _capi.ERR_INVALID
         # bad ranges are rejected
         res = _capi.MatchResult()
         assert L.ndt2d_match(h, 5, 5, None, C.byref(res)) == _capi.ERR_INVALID

@@ -102,4 +102,19 @@ def test_combine_match_records_first_wins_on_ties():
     assert (s, i) == (-3.0, 10) and np.all(acc == 3.0)
     s, i, acc = shard.combine_match_records([none, none])
     assert s == 0.0 and i is None
+    # interleaved shares: the tie goes to the lower flat index whatever the rank
+    s, i, acc = shard.combine_match_records([b, none, a])
+    assert (s, i) == (-3.0, 10)
+    better = b.copy(); better[0] = -3.5
+    assert shard.combine_match_records([a, better])[:2] == (-3.5, 500)
+
+
+def test_shard_strided_partitions():
+    for n in (1, 7, 40, 201, 1257):
+        for world in (1, 2, 3, 8):
+            seen = []
+            for r in range(world):
+                first, stride, count = shard.shard_strided(n, r, world)
+                seen += [first + stride * k for k in range(count)]
+            assert sorted(seen) == list(range(n))
     assert shard.decode_index(1065647, 100) == (106, 56, 47)
