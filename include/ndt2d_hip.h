@@ -311,7 +311,11 @@ int ndt2d_last_launch_ms(ndt2d_handle h, float * ms, int * n_kernels);
 int ndt2d_launch_history_ms(ndt2d_handle h, float * ms_out, size_t capacity, size_t * n_out);
 /* Tuning / introspection: name of the kernel variant the last launch used. */
 const char * ndt2d_last_variant(ndt2d_handle h);
-/* Force a kernel variant (testing / A-B measurement): "auto", "lds", "global"
+/* "auto" (the default) picks the candidate mapping of the match search by the size
+ * of the lattice: wave-per-candidate below 160,000 candidates (the plugin's
+ * default search), lane-per-candidate above.  Both give the oracle's result; they
+ * differ from each other in the last bits of a score (summation order).
+ * Force a kernel variant (testing / A-B measurement): "auto", "lds", "global"
  * (grid placement), "wave", "wave-lds", "wave-global", "lane" (candidate mapping
  * of the match search), "lane-noskip" (the lane mapping with every term
  * evaluated: the bit-exactness control of its skipping), "dense" (particle
