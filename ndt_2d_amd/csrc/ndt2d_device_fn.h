@@ -127,7 +127,10 @@ __device__ __forceinline__ bool wave_any(bool p)
 // propagates as in the reference.
 __device__ __forceinline__ double exp_score(double e)
 {
-  return wave_any(e != e) ? exp(e) : exp_of_exponent(e);
+  // (unlikely: otherwise the NaN path is laid out in line and the common one is reached
+  // and left through a far trampoline, two taken branches per exp())
+  if (__builtin_expect(wave_any(e != e), 0)) return exp(e);
+  return exp_of_exponent(e);
 }
 
 // A non-negative term t = exp(e) leaves a running sum s > 0 unchanged,
