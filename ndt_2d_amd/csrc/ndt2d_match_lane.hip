@@ -301,6 +301,10 @@ __device__ __forceinline__ void lane_beams(const GridDesc & g, const LaneCtx & c
   if (wave_any(top >= skip_level))
   {
     bool added = false;
+    // have the beams' end points on their way before the first exact evaluation needs
+    // them (left to itself the compiler loads each pair inside its own branch)
+#pragma unroll
+    for (int u = 0; u < U; ++u) asm volatile("" : : "s"(o[u].x), "s"(o[u].y));
 #pragma unroll
     for (int u = 0; u < U; ++u)
     {
