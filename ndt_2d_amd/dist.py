@@ -59,6 +59,47 @@ def combine_match_records(records):
     return best_score, best_index, acc
 
 
+def match_scan_sharded(matcher, scan_pose, points, rank, world, dist, pose=None):
+    """ScanMatcherNDT::matchScan (reference src/scan_matcher_ndt.cpp:76-149) with the
+    lattice dealt to `world` ranks: every rank calls this with its own matcher (one per
+    GPU, same map, same scan) and gets the same result as a single-GPU matchScan would
+    give -- dict(score, pose, covariance, best_index, n_candidates).
+
+    `dist` is torch.distributed with an initialised process group (nccl = RCCL, or
+    gloo); the one collective is the all-reduce of the [world, 12] record table."""
+    import torch
+    n_th, n_lin, _ = matcher.prepare_search(scan_pose, points)
+    first, stride, count = shard_strided(n_th, rank, world)
+    device = torch.device("cuda", matcher._L.ndt2d_device_id(matcher.device_handle))
+    on_gpu = world == 1 or dist.get_backend() != "gloo"
+    stream = torch.cuda.Stream(device=device)
+    matcher.set_stream(stream.cuda_stream)
+    try:
+        with torch.cuda.stream(stream):
+            table = torch.zeros((world, MATCH_RECORD), dtype=torch.float64, device=device)
+            table[rank, 1] = -1.0   # "no candidate" until the search says otherwise
+            if count:
+                matcher.match_launch_strided(first, stride, count,
+                                             record_ptr=table[rank].data_ptr())
+            if world > 1:
+                if on_gpu:
+                    dist.all_reduce(table, op=dist.ReduceOp.SUM)
+                else:
+                    host = table.cpu()
+                    dist.all_reduce(host, op=dist.ReduceOp.SUM)
+                    table = host
+            records = table.cpu().numpy()
+        stream.synchronize()
+    finally:
+        matcher.set_stream(None)
+    best_score, best_index, acc = combine_match_records(records)
+    rec = np.concatenate([[best_score, -1.0 if best_index is None else float(best_index)], acc])
+    out = matcher.finish_match(rec, pose=pose)
+    out["best_index"] = best_index
+    out["n_candidates"] = n_th * n_lin * n_lin
+    return out
+
+
 def covariance_from_acc(acc):
     """covariance = (1/s) k + (1/(s*s)) u u^T (reference src/scan_matcher_ndt.cpp:146)."""
     k = np.array([[acc[0], acc[1], acc[2]], [acc[1], acc[3], acc[4]], [acc[2], acc[4], acc[5]]])

@@ -172,6 +172,18 @@ def test_device_layer_direct_and_theta_sharding(cfg1):
             s, i, acc = shard.combine_match_records(recs)
             assert (s, i) == (full[0], int(full[1]))
             assert np.allclose(acc, full[2:], rtol=1e-12, atol=0)
+        # ... and through the lane-per-candidate kernel (this lattice is small enough to
+        # get the wave mapping by default)
+        assert L.ndt2d_set_variant(h, b"lane") == _capi.OK
+        try:
+            whole = run_strided(0, 1, len(dth))
+            assert int(whole[1]) == int(full[1]) and abs(whole[0] - full[0]) < TOL_TIGHT
+            recs = [run_strided(*shard.shard_strided(len(dth), r, 3)) for r in range(3)]
+            s, i, acc = shard.combine_match_records(recs)
+            assert (s, i) == (whole[0], int(whole[1]))
+            assert np.allclose(acc, whole[2:], rtol=1e-12, atol=0)
+        finally:
+            assert L.ndt2d_set_variant(h, b"auto") == _capi.OK
         assert L.ndt2d_match_launch_strided(h, 0, 0, 1, None, None) == _capi.ERR_INVALID
         assert L.ndt2d_match_launch_strided(h, 1, 2, len(dth), None, None) == _capi.ERR_INVALID
         assert L.ndt2d_match_launch_strided(h, len(dth), 1, 1, None, None) == _capi.ERR_INVALID
