@@ -28,7 +28,8 @@ def _random_case(rng):
         else:              # scattered
             pts = rng.uniform(-5, 5, (n, 2))
         scans.append((pose, pts))
-    n_q = int(rng.integers(1, 300))
+    # (from 256 beams up the lane kernel hands out its work items dynamically)
+    n_q = int(rng.integers(1, 300)) if rng.random() < 0.65 else int(rng.integers(300, 900))
     query = np.concatenate([rng.uniform(-5, 5, (n_q // 2 + 1, 2)),
                             np.stack([rng.uniform(1, 4, n_q // 2 + 1),
                                       rng.uniform(-3, 3, n_q // 2 + 1)], axis=1)])[:n_q]
