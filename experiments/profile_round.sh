@@ -3,7 +3,7 @@
 # SQ counters of the particle kernel.  Run from the repository root through gpurun.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/prof11
+O=$R/gpurun_out/prof12
 mkdir -p $O
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/kt.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAIT_ANY --output-format csv -d $O/sq -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/sq.log 2>&1
