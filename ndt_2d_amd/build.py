@@ -31,28 +31,44 @@ def hipcc():
     return "hipcc"
 
 
-def _stale():
-    if not os.path.exists(LIB_PATH):
-        return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(_CSRC, s) for s in SOURCES] + HEADERS + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps)
+def _obj(src):
+    return os.path.join(_CSRC, os.path.splitext(src)[0] + ".o")
 
 
-def build_all(force=False, verbose=False):
-    if not force and not _stale():
-        return LIB_PATH
-    objs = []
+def _stale_sources(force):
+    """Sources whose object is missing or older than the source, a header or this file."""
+    common = HEADERS + [os.path.abspath(__file__)]
+    t_common = max(os.path.getmtime(d) for d in common)
+    out = []
     for src in SOURCES:
-        obj = os.path.join(_CSRC, os.path.splitext(src)[0] + ".o")
+        obj = _obj(src)
+        if force or not os.path.exists(obj) or \
+                os.path.getmtime(obj) < max(t_common, os.path.getmtime(os.path.join(_CSRC, src))):
+            out.append(src)
+    return out
+
+
+def build_all(force=False, verbose=False, jobs=4):
+    stale = _stale_sources(force)
+    if not stale and os.path.exists(LIB_PATH) and \
+            os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(_obj(s)) for s in SOURCES):
+        return LIB_PATH
+
+    def compile_one(src):
         cmd = [hipcc(), "--offload-arch=" + ARCH] + FLAGS + [
             "-I", os.path.join(_ROOT, "include"), "-I", _CSRC, "-c",
-            os.path.join(_CSRC, src), "-o", obj]
+            os.path.join(_CSRC, src), "-o", _obj(src)]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
-        objs.append(obj)
-    cmd = [hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC"] + objs + ["-o", LIB_PATH]
+
+    if stale:
+        # a few translation units at a time (each hipcc is itself two compiler passes)
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=max(1, min(jobs, len(stale)))) as pool:
+            list(pool.map(compile_one, stale))
+    cmd = [hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC"] + [_obj(s) for s in SOURCES] + \
+        ["-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

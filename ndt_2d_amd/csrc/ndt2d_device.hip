@@ -324,6 +324,9 @@ int ndt2d_set_grid(ndt2d_handle h, const double * cells6, uint32_t size_x, uint3
   if (ncell64 >= (1ull << 31)) return fail(h, NDT2D_ERR_INVALID, "ndt2d_set_grid: grid too large");
   const uint32_t ncell = static_cast<uint32_t>(ncell64);
   NDT2D_HIP(h, hipSetDevice(h->device));
+  // The old grid is gone from here on (ensure() may free its buffers): a failure
+  // below leaves the context without a grid, never with dangling pointers.
+  h->has_grid = false;
 
   // Pack: h = -0.5 * information (exact); cells with n < 5 cannot score
   // (reference src/ndt_model.cpp:107) and get the sentinel record.
@@ -418,6 +421,8 @@ int ndt2d_build_grid(ndt2d_handle h, double ndt_resolution, double range_max,
   const uint32_t size_y = static_cast<uint32_t>(static_cast<size_t>(fsy));
   const uint32_t ncell = size_x * size_y;
   NDT2D_HIP(h, hipSetDevice(h->device));
+  // as in ndt2d_set_grid: no grid until the new one is complete
+  h->has_grid = false;
 
   // staging that must stay alive until the copies are done: kept in the context
   NDT2D_HIP(h, hipStreamSynchronize(h->stream));
@@ -550,6 +555,9 @@ int ndt2d_set_beams(ndt2d_handle h, const double * beams_xy, size_t n_beams)
   rc = stage_submit(h, h->stage_beams, h->beams.ptr, 2 * n_beams);
   if (rc != NDT2D_OK) return rc;
   h->n_beams = n_beams;
+  // a search prepared for other beams must be set up again (ndt2d_set_search) before
+  // ndt2d_match_launch: its caller pairs the tables with THESE beams
+  h->has_search = false;
   h->beam_rmax = 0.0;
   for (size_t i = 0; i < n_beams; ++i)
   {
@@ -1075,6 +1083,7 @@ int ndt2d_set_beams_from_ranges(ndt2d_handle h, const float * h_ranges, size_t n
   if (n_points_out != nullptr) *n_points_out = h->n_scan_points;
   const size_t use = static_cast<size_t>(info[1]);
   *n_beams_out = use;
+  h->has_search = false;  // see ndt2d_set_beams
   if (use > 0)
   {
     h->n_beams = use;

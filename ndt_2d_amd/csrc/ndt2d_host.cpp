@@ -423,6 +423,7 @@ int ndt2d_matcher_add_scans(ndt2d_matcher * m, const double * poses_xyt,
   if (rc != NDT2D_OK)
   {
     m->ndt.reset();
+    ndt2d_clear_grid(m->dev);
     return dev_fail(m, rc, "ndt2d_set_grid");
   }
   m->have_ndt = true;
@@ -472,6 +473,8 @@ int ndt2d_matcher_finish_match(ndt2d_matcher * m, const double * record, double 
                                double * covariance_out, double * score_out)
 {
   if (m == nullptr || record == nullptr || score_out == nullptr) return NDT2D_ERR_INVALID;
+  // n_use is the N of the search prepared last (prepare_search / match_laser_scan);
+  // scoring calls in between replace the device beams but leave it alone
   const size_t use = m->n_use;
   const size_t n_lin = m->dlin.size();
   const double best_score = record[0];
@@ -646,6 +649,7 @@ int ndt2d_matcher_score_poses(ndt2d_matcher * m, const double * points_xy, size_
     for (size_t i = 0; i < n_poses; ++i) scores_out[i] = std::numeric_limits<double>::quiet_NaN();
     return NDT2D_OK;
   }
+  m->search_ready = false;  // the device beams are replaced: a prepared search is void
   int rc = ndt2d_set_beams(m->dev, beams.data(), use);
   if (rc != NDT2D_OK) return dev_fail(m, rc, "ndt2d_set_beams");
   rc = ndt2d_score_poses(m->dev, poses_xyt, n_poses, scores_out, nullptr);
@@ -660,9 +664,9 @@ int ndt2d_matcher_prepare_beams(ndt2d_matcher * m, const double * points_xy, siz
   if (n_points > 0 && points_xy == nullptr) return mfail(m, NDT2D_ERR_INVALID, "null points");
   m->beams = subsample(points_xy, n_points, m->laser_max_beams);
   const size_t use = m->beams.size() / 2;
-  m->n_use = use;
   if (n_beams_out != nullptr) *n_beams_out = use;
   if (use == 0) return NDT2D_OK;
+  m->search_ready = false;  // the device beams are replaced: a prepared search is void
   int rc = ndt2d_set_beams(m->dev, m->beams.data(), use);
   if (rc != NDT2D_OK) return dev_fail(m, rc, "ndt2d_set_beams");
   return NDT2D_OK;
@@ -697,6 +701,7 @@ int ndt2d_matcher_pf_measure(ndt2d_matcher * m, const double * particles_xyt,
     // updateStatistics (:163-218), all on the device
     if (points_xy == nullptr) return mfail(m, NDT2D_ERR_INVALID, "null points");
     const std::vector<double> beams = subsample(points_xy, n_points, m->laser_max_beams);
+    m->search_ready = false;  // the device beams are replaced: a prepared search is void
     int rc = ndt2d_set_beams(m->dev, beams.data(), beams.size() / 2);
     if (rc != NDT2D_OK) return dev_fail(m, rc, "ndt2d_set_beams");
     double out[NDT2D_PF_RESULT_DOUBLES];

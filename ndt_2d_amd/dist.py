@@ -18,7 +18,9 @@ lower flat index = the candidate the reference's loops visit first.
 ParticleFilter::measure: particles are split into contiguous ranges; each rank
 scores its range and reduces {sum w, sum w*x, ...} (8 doubles); one
 all-reduce(sum) of a [world, 8] buffer gives every rank the total particle
-weight (reference src/particle_filter.cpp:166-174) and the moment sums.
+weight (reference src/particle_filter.cpp:166-174) and the moment sums; the theta
+variance is the reference's second pass (:213-217, it needs the circular mean the
+first pass produces) and costs a second, 1-double all-reduce.
 """
 import math
 
@@ -73,6 +75,9 @@ def match_scan_sharded(matcher, scan_pose, points, rank, world, dist, pose=None)
     device = torch.device("cuda", matcher._L.ndt2d_device_id(matcher.device_handle))
     on_gpu = world == 1 or dist.get_backend() != "gloo"
     stream = torch.cuda.Stream(device=device)
+    # the stream the caller had bound (e.g. a ParticleFilter sharing this matcher binds its
+    # own for good) comes back afterwards; the context's own stream reads as None
+    previous = matcher.get_stream()
     matcher.set_stream(stream.cuda_stream)
     try:
         with torch.cuda.stream(stream):
@@ -91,7 +96,7 @@ def match_scan_sharded(matcher, scan_pose, points, rank, world, dist, pose=None)
             records = table.cpu().numpy()
         stream.synchronize()
     finally:
-        matcher.set_stream(None)
+        matcher.set_stream(previous)
     best_score, best_index, acc = combine_match_records(records)
     rec = np.concatenate([[best_score, -1.0 if best_index is None else float(best_index)], acc])
     out = matcher.finish_match(rec, pose=pose)
@@ -133,12 +138,14 @@ def allreduce_rows(row, rank, world, dist, device=None):
 
 
 def finish_particle_statistics(stats_table, weights_local, particles_local, cov22_prev=0.0,
-                               dist=None):
+                               dist=None, device=None):
     """updateStatistics (reference src/particle_filter.cpp:163-218) from the
     all-reduced moment sums.  stats_table[world][8] un-normalised sums per rank.
-    Returns (normalised local weights, mean[3], cov[3,3]).  The theta variance
-    (second pass, :218-222) is summed over ranks with a second tiny all-reduce
-    when `dist` is given."""
+    Returns (normalised local weights, mean[3], cov[3,3]).  The theta variance is the
+    reference's SECOND pass over the particles (:213-217: it needs the circular mean,
+    which needs the first pass's sums), so a sharded filter needs a second, 1-double
+    all-reduce for it -- done here when `dist` is given.  With the nccl (RCCL) backend
+    the tensor lives on `device` (default: the current GPU); gloo takes a host tensor."""
     st = np.asarray(stats_table, dtype=np.float64).reshape(-1, POSE_STATS).sum(axis=0)
     sum_w = st[0]
     with np.errstate(divide="ignore", invalid="ignore"):
@@ -156,8 +163,12 @@ def finish_particle_statistics(stats_table, weights_local, particles_local, cov2
     local = float(np.sum(w * d * d))
     if dist is not None:
         import torch
-        t = torch.tensor([local], dtype=torch.float64)
+        if dist.get_backend() == "gloo":
+            t = torch.tensor([local], dtype=torch.float64)
+        else:
+            dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+            t = torch.tensor([local], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        local = float(t[0])
+        local = float(t.cpu()[0])
     cov[2, 2] = cov22_prev + local
     return w, np.array([mean_x, mean_y, mean_th]), cov

@@ -328,6 +328,13 @@ class ScanMatcherNDT:
     def set_stream(self, stream_ptr):
         self._dev_check(self._L.ndt2d_set_stream(self.device_handle, stream_ptr),
                         "ndt2d_set_stream")
+        self._bound_stream = bool(stream_ptr)
+
+    def get_stream(self):
+        """The caller-owned stream bound with set_stream, or None while the context
+        launches on its own stream."""
+        cur = self._L.ndt2d_get_stream(self.device_handle)
+        return cur if getattr(self, "_bound_stream", None) else None
 
     def synchronize(self):
         self._dev_check(self._L.ndt2d_synchronize(self.device_handle), "ndt2d_synchronize")

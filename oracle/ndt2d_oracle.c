@@ -569,11 +569,55 @@ double orc_matcher_match_scan(const orc_matcher * m, const double * scan_pose_xy
   return acc.best_score / scan_points_to_use;
 }
 
-double orc_matcher_match_scan_omp(const orc_matcher * m, const double * scan_pose_xyt,
-                                  const double * points_xy, size_t n_points,
-                                  double * pose_inout, double * covariance_out,
-                                  int n_threads)
+/* One (theta, dx) strip of the search: the dy loop of src/scan_matcher_ndt.cpp:119-142 for a
+ * given rotated scan `outer`.  Work unit of the OpenMP variant below. */
+static void match_strip(const orc_matcher * m, size_t scan_points_to_use, double dth, double dx,
+                        uint64_t flat_base, const double * outer, double * inner, match_acc * acc)
 {
+  uint64_t flat = flat_base;
+  for (double dy = -m->linear_size; dy < m->linear_size; dy += m->linear_res)
+  {
+    for (size_t i = 0; i < scan_points_to_use; ++i)
+    {
+      inner[2 * i] = outer[2 * i] + dx;
+      inner[2 * i + 1] = outer[2 * i + 1] + dy;
+    }
+    double score = -orc_ndt_likelihood_points(m->ndt, inner, scan_points_to_use);
+    if (score < acc->best_score)
+    {
+      acc->best_score = score;
+      acc->best_pose[0] = dx;
+      acc->best_pose[1] = dy;
+      acc->best_pose[2] = dth;
+      acc->have_best = 1;
+      acc->best_index = flat;
+    }
+    const double x[3] = {dx, dy, dth};
+    for (int r = 0; r < 3; ++r)
+    {
+      for (int c = 0; c < 3; ++c) acc->k[r * 3 + c] += (x[r] * x[c]) * score;
+      acc->u[r] += x[r] * score;
+    }
+    acc->s += score;
+    ++flat;
+    if (!(m->linear_res > 0.0)) break;
+  }
+}
+
+/* matchScan with the (theta, dx) strips of the lattice dealt to OpenMP threads: the CPU
+ * baseline on all host cores and the generator of full-lattice winners.  Every strip keeps
+ * the reference's candidate order and strict `<`; strips are combined in lattice order, so
+ * the winner (score, pose, flat index) is the sequential loop's.  The covariance
+ * accumulators are per-strip partial sums added in lattice order (the sequential loop
+ * keeps one running sum: equal to rounding). */
+double orc_matcher_match_scan_omp_ex(const orc_matcher * m, const double * scan_pose_xyt,
+                                     const double * points_xy, size_t n_points,
+                                     double * pose_inout, double * covariance_out,
+                                     int n_threads, uint64_t * best_index_out,
+                                     int * threads_used_out)
+{
+  if (best_index_out) *best_index_out = UINT64_MAX;
+  if (threads_used_out) *threads_used_out = 0;
   if (!m->ndt) return 0.0;
   size_t scan_points_to_use = m->laser_max_beams < n_points ? m->laser_max_beams : n_points;
   double scan_step = (double)n_points / (double)scan_points_to_use;
@@ -581,8 +625,12 @@ double orc_matcher_match_scan_omp(const orc_matcher * m, const double * scan_pos
   const size_t n_th = orc_search_offsets(m->angular_size, m->angular_res, NULL, 0);
   const size_t n_lin = orc_search_offsets(m->linear_size, m->linear_res, NULL, 0);
   double * dths = (double *)malloc(sizeof(double) * (n_th + 1));
+  double * dlin = (double *)malloc(sizeof(double) * (n_lin + 1));
   orc_search_offsets(m->angular_size, m->angular_res, dths, n_th);
-  match_acc * accs = (match_acc *)calloc(n_th + 1, sizeof(match_acc));
+  orc_search_offsets(m->linear_size, m->linear_res, dlin, n_lin);
+  const long long n_strips = (long long)n_th * (long long)n_lin;
+  match_acc * accs = (match_acc *)calloc((size_t)n_strips + 1, sizeof(match_acc));
+  int threads_used = 1;
 
 #ifdef _OPENMP
   if (n_threads > 0) omp_set_num_threads(n_threads);
@@ -593,12 +641,34 @@ double orc_matcher_match_scan_omp(const orc_matcher * m, const double * scan_pos
   {
     double * outer = (double *)malloc(sizeof(double) * 2 * (scan_points_to_use + 1));
     double * inner = (double *)malloc(sizeof(double) * 2 * (scan_points_to_use + 1));
-#pragma omp for schedule(dynamic, 1)
-    for (long long t = 0; t < (long long)n_th; ++t)
+    long long outer_t = -1;
+#ifdef _OPENMP
+#pragma omp single
+    threads_used = omp_get_num_threads();
+#endif
+#pragma omp for schedule(dynamic, 4)
+    for (long long w = 0; w < n_strips; ++w)
     {
-      accs[t].best_index = UINT64_MAX;
-      match_theta_slab(m, scan_pose_xyt, points_xy, n_points, scan_points_to_use, scan_step,
-                       dths[t], (uint64_t)t * n_lin * n_lin, outer, inner, &accs[t], NULL, 0);
+      const long long t = w / (long long)n_lin;
+      const long long ix = w - t * (long long)n_lin;
+      if (t != outer_t)
+      {
+        /* :106-115 */
+        double costh, sinth;
+        cos_sin(scan_pose_xyt[2] + dths[t], &costh, &sinth);
+        for (size_t i = 0; i < scan_points_to_use; ++i)
+        {
+          size_t scan_idx = (size_t)(i * scan_step);
+          outer[2 * i] = points_xy[2 * scan_idx] * costh - points_xy[2 * scan_idx + 1] * sinth +
+                         scan_pose_xyt[0];
+          outer[2 * i + 1] = points_xy[2 * scan_idx] * sinth + points_xy[2 * scan_idx + 1] * costh +
+                             scan_pose_xyt[1];
+        }
+        outer_t = t;
+      }
+      accs[w].best_index = UINT64_MAX;
+      match_strip(m, scan_points_to_use, dths[t], dlin[ix],
+                  ((uint64_t)t * n_lin + (uint64_t)ix) * n_lin, outer, inner, &accs[w]);
     }
     free(outer);
     free(inner);
@@ -607,23 +677,35 @@ double orc_matcher_match_scan_omp(const orc_matcher * m, const double * scan_pos
   match_acc acc;
   memset(&acc, 0, sizeof(acc));
   acc.best_index = UINT64_MAX;
-  for (size_t t = 0; t < n_th; ++t)
+  for (long long w = 0; w < n_strips; ++w)
   {
-    if (accs[t].have_best && accs[t].best_score < acc.best_score)
+    if (accs[w].have_best && accs[w].best_score < acc.best_score)
     {
-      acc.best_score = accs[t].best_score;
-      memcpy(acc.best_pose, accs[t].best_pose, sizeof(acc.best_pose));
+      acc.best_score = accs[w].best_score;
+      memcpy(acc.best_pose, accs[w].best_pose, sizeof(acc.best_pose));
       acc.have_best = 1;
-      acc.best_index = accs[t].best_index;
+      acc.best_index = accs[w].best_index;
     }
-    for (int i = 0; i < 9; ++i) acc.k[i] += accs[t].k[i];
-    for (int i = 0; i < 3; ++i) acc.u[i] += accs[t].u[i];
-    acc.s += accs[t].s;
+    for (int i = 0; i < 9; ++i) acc.k[i] += accs[w].k[i];
+    for (int i = 0; i < 3; ++i) acc.u[i] += accs[w].u[i];
+    acc.s += accs[w].s;
   }
   free(accs);
   free(dths);
+  free(dlin);
   match_finish(&acc, pose_inout, covariance_out);
+  if (best_index_out) *best_index_out = acc.best_index;
+  if (threads_used_out) *threads_used_out = threads_used;
   return acc.best_score / scan_points_to_use;
+}
+
+double orc_matcher_match_scan_omp(const orc_matcher * m, const double * scan_pose_xyt,
+                                  const double * points_xy, size_t n_points,
+                                  double * pose_inout, double * covariance_out,
+                                  int n_threads)
+{
+  return orc_matcher_match_scan_omp_ex(m, scan_pose_xyt, points_xy, n_points, pose_inout,
+                                       covariance_out, n_threads, NULL, NULL);
 }
 
 /* ScanMatcherNDT::scorePoints, src/scan_matcher_ndt.cpp:156-178 */

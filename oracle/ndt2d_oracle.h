@@ -117,8 +117,16 @@ double orc_matcher_match_scan(const orc_matcher * m, const double * scan_pose_xy
                               double * pose_inout, double * covariance_out,
                               double * all_scores, size_t all_scores_cap,
                               size_t * n_candidates_out, uint64_t * best_index_out);
-/* Same arithmetic per candidate, OpenMP over theta slabs (CPU baseline only;
- * accumulators are combined per theta in theta order). */
+/* Same arithmetic per candidate, the (theta, dx) strips of the lattice dealt to OpenMP
+ * threads (CPU baseline on all host cores; full-lattice winners for the golden
+ * fixtures).  Strips are combined in lattice order: the winner (score, pose, flat
+ * index) is the sequential loop's; the covariance accumulators are per-strip partial
+ * sums added in lattice order.  *threads_used_out (optional) = threads of the team. */
+double orc_matcher_match_scan_omp_ex(const orc_matcher * m, const double * scan_pose_xyt,
+                                     const double * points_xy, size_t n_points,
+                                     double * pose_inout, double * covariance_out,
+                                     int n_threads, uint64_t * best_index_out,
+                                     int * threads_used_out);
 double orc_matcher_match_scan_omp(const orc_matcher * m, const double * scan_pose_xyt,
                                   const double * points_xy, size_t n_points,
                                   double * pose_inout, double * covariance_out,

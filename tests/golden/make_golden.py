@@ -139,16 +139,42 @@ def next_rows():
     return out
 
 
+def big_winners():
+    """Winners of the full cfg-2 and cfg-4 lattices (BASELINE.json configs[1] and [3]):
+    the oracle over all 2,000,000 / 315,508,257 candidates (about 4 minutes on 8 cores
+    for cfg-4).  The cfg-4 search spans +-pi over a 4-fold symmetric room; range noise
+    makes one of the four basins the oracle's definite winner, and the GPU must pick it."""
+    out = {"source": "oracle/ndt2d_oracle.c orc_matcher_match_scan_omp_ex over the whole lattice"}
+    for cfg in (2, 4):
+        params = synth.matcher_params(cfg)
+        guess, pts, _ = synth.query_scan(cfg)
+        m = O.ScanMatcherNDT()
+        m.initialize(**params)
+        m.addScans(synth.map_scans(cfg))
+        r = m.matchScan(guess, pts, omp_threads=os.cpu_count())
+        n_th = len(O.search_offsets(params["search_angular_size"], params["search_angular_resolution"]))
+        n_lin = len(O.search_offsets(params["search_linear_size"], params["search_linear_resolution"]))
+        out["cfg%d" % cfg] = {
+            "n_theta": n_th, "n_linear": n_lin, "n_candidates": n_th * n_lin * n_lin,
+            "best_index": int(r["best_index"]), "score": float(r["score"]),
+            "score_hex": float(r["score"]).hex(),
+            "pose": [float(v) for v in r["pose"]], "pose_hex": [float(v).hex() for v in r["pose"]],
+            "covariance": [[float(v) for v in row] for row in r["covariance"]],
+        }
+    return out
+
+
 FIXTURES = {"cfg1_match.npz": cfg1_match, "cfg3_poses256.npz": cfg3_poses, "next_rows.npz": next_rows}
+JSON_FIXTURES = {"reference_ndt_model_tests.json": reference_vectors, "big_winners.json": big_winners}
 
 
 def main():
     """python make_golden.py [fixture.npz ...]   (default: all)"""
-    names = sys.argv[1:] or ["reference_ndt_model_tests.json"] + sorted(FIXTURES)
+    names = sys.argv[1:] or sorted(JSON_FIXTURES) + sorted(FIXTURES)
     for name in names:
-        if name == "reference_ndt_model_tests.json":
+        if name in JSON_FIXTURES:
             with open(os.path.join(HERE, name), "w") as f:
-                json.dump(reference_vectors(), f, indent=1, sort_keys=True)
+                json.dump(JSON_FIXTURES[name](), f, indent=1, sort_keys=True)
         else:
             np.savez_compressed(os.path.join(HERE, name), **FIXTURES[name]())
     for f in sorted(os.listdir(HERE)):

@@ -83,6 +83,8 @@ def lib():
     sig("orc_matcher_match_scan", d,
         [vp, _dp, _dp, sz, _dp, _dp, _dp, sz, C.POINTER(sz), C.POINTER(C.c_uint64)])
     sig("orc_matcher_match_scan_omp", d, [vp, _dp, _dp, sz, _dp, _dp, C.c_int])
+    sig("orc_matcher_match_scan_omp_ex", d,
+        [vp, _dp, _dp, sz, _dp, _dp, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_int)])
     sig("orc_matcher_score_points", d, [vp, _dp, sz, _dp])
     sig("orc_matcher_score_scan", d, [vp, _dp, _dp, sz])
     sig("orc_matcher_reset", None, [vp])
@@ -263,10 +265,13 @@ class ScanMatcherNDT:
         pose_io = np.array([0.0, 0.0, 0.0] if pose is None else pose, dtype=np.float64)
         cov = np.zeros(9, dtype=np.float64)
         if omp_threads is not None:
-            score = lib().orc_matcher_match_scan_omp(
+            best = C.c_uint64(0)
+            used = C.c_int(0)
+            score = lib().orc_matcher_match_scan_omp_ex(
                 self.m, spp, pp, len(pts), pose_io.ctypes.data_as(_dp),
-                cov.ctypes.data_as(_dp), int(omp_threads))
-            return dict(score=score, pose=pose_io, covariance=cov.reshape(3, 3))
+                cov.ctypes.data_as(_dp), int(omp_threads), C.byref(best), C.byref(used))
+            return dict(score=score, pose=pose_io, covariance=cov.reshape(3, 3),
+                        best_index=best.value, threads_used=used.value)
         ncand = C.c_size_t(0)
         best = C.c_uint64(0)
         scores = None

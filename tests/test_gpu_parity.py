@@ -351,6 +351,10 @@ def test_cfg2_full_size():
     got = gpu.matchScan(guess, pts, want_scores=True)
     assert got["n_candidates"] == 2000000
     exp = ref.matchScan(guess, pts, omp_threads=os.cpu_count())
+    want = _big_winner(2)
+    assert got["best_index"] == exp["best_index"] == want["best_index"]
+    assert [float(v).hex() for v in got["pose"]] == want["pose_hex"]
+    assert abs(got["score"] - want["score"]) < TOL_TIGHT
     assert np.array_equal(got["pose"], exp["pose"])
     assert abs(got["score"] - exp["score"]) < TOL_TIGHT
     assert np.allclose(got["covariance"], exp["covariance"], rtol=1e-9, atol=0)
@@ -380,15 +384,25 @@ def test_cfg2_full_size():
     assert got["covariance"][2, 2] == pytest.approx(k22 / s_sum + (u2 / s_sum) ** 2, rel=1e-9)
 
 
+def _big_winner(cfg):
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "big_winners.json")) as f:
+        return json.load(f)["cfg%d" % cfg]
+
+
 def test_cfg4_sized_lattice_properties():
-    """BASELINE.json configs[3] lattice (501 x 501 x 1257 = 315.5M candidates) on one GPU
-    through size-independent properties: slab sharding invariance, in-slab sampled
-    parity, and consistency with the cfg-2 search it contains."""
+    """BASELINE.json configs[3] lattice (501 x 501 x 1257 = 315.5M candidates) on one GPU:
+    the oracle's winner over the WHOLE lattice (tests/golden/big_winners.json, 3.5 min on
+    8 cores) from the full launch, from 8 contiguous slabs and from 8 round-robin shares;
+    in-slab sampled parity; consistency with the cfg-2 search it contains."""
     gpu, ref, _, guess, pts = _pair(4)
+    want = _big_winner(4)
     n_th, n_lin, n_beams = gpu.prepare_search(guess, pts)
-    assert (n_th, n_lin, n_beams) == (1257, 501, 720)
+    assert (n_th, n_lin, n_beams) == (1257, 501, 720) == (want["n_theta"], want["n_linear"], 720)
     gpu.match_launch(0, n_th)
     full = gpu.match_fetch()
+    # "select the same best pose" (north_star; src/scan_matcher_ndt.cpp:128-134): the room
+    # is 4-fold symmetric but the noisy scan makes ONE basin the oracle's winner
+    assert int(full[1]) == want["best_index"] == 80443810
     recs = []
     for r in range(8):
         gpu.match_launch(*shard.shard_range(n_th, r, 8))
@@ -396,11 +410,19 @@ def test_cfg4_sized_lattice_properties():
     s, i, acc = shard.combine_match_records(recs)
     assert (s, i) == (full[0], int(full[1]))
     assert np.allclose(acc, full[2:], rtol=1e-11, atol=0)
+    recs = []
+    for r in range(8):
+        gpu.match_launch_strided(*shard.shard_strided(n_th, r, 8))
+        recs.append(gpu.match_fetch())
+    s8, i8, acc8 = shard.combine_match_records(recs)
+    assert (s8, i8) == (full[0], int(full[1]))
+    assert np.allclose(acc8, full[2:], rtol=1e-11, atol=0)
     out = gpu.finish_match(full)
-    # The synthetic room is 4-fold symmetric, so over +-pi the winner may sit in any
-    # of the four rotated basins (noise decides); it must be one of them.
+    assert [float(v).hex() for v in out["pose"]] == want["pose_hex"]
+    assert abs(out["score"] - want["score"]) < TOL_TIGHT
+    assert np.allclose(out["covariance"], want["covariance"], rtol=1e-9, atol=0)
     k = round((out["pose"][2] - 0.031) / (math.pi / 2))
-    assert abs(out["pose"][2] - (0.031 + k * math.pi / 2)) <= 0.005 + 1e-9
+    assert k == -1 and abs(out["pose"][2] - (0.031 + k * math.pi / 2)) <= 0.005 + 1e-9
     assert np.hypot(out["pose"][0], out["pose"][1]) < 0.3
     # the winner's score against the oracle's likelihood of that candidate
     p = gpu.params

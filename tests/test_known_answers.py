@@ -1,0 +1,122 @@
+"""The outer loops of the hot path against known answers derived WITHOUT the oracle.
+
+tests/golden/known_answers.json is written by tests/golden/make_known_answers.py from
+the mathematics of the reference's lines in 60-digit arithmetic (no code shared with
+oracle/ or the kernels): a 2-cell (+ one 4-point cell) map built by addScans from two
+scans, a six-beam scan at a rotated pose, the 3 x 3 x 3 lattice.  It pins what the
+reference's own tests do not: addScans' extent (src/scan_matcher_ndt.cpp:52-66), the
+candidate order / strict-< argmin / returned best/N of matchScan (:103-134,148), its
+accumulators and covariance formula (:137-146) and scorePoints' transform (:156-178).
+Tolerance 1e-12: the two sides differ by IEEE rounding only.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+TOL = 1e-12
+
+
+@pytest.fixture(scope="module")
+def ka():
+    with open(os.path.join(HERE, "golden", "known_answers.json")) as f:
+        return json.load(f)
+
+
+def _scans(ka):
+    return [(np.array(s["pose"]), np.array(s["points"])) for s in ka["map_scans"]]
+
+
+def _check_grid(ka, cells6, size_x, size_y, origin):
+    g = ka["grid"]
+    assert (size_x, size_y) == (g["size_x"], g["size_y"])
+    assert tuple(origin) == tuple(g["origin"])
+    occupied = {c["index"]: c for c in g["cells"]}
+    for idx in range(size_x * size_y):
+        rec = cells6[idx]
+        if idx in occupied:
+            c = occupied[idx]
+            assert rec[5] == c["n"]
+            assert np.allclose(rec[0:2], c["mean"], rtol=0, atol=TOL)
+            assert np.allclose(rec[2:5], c["information"], rtol=1e-12, atol=0)
+        else:
+            assert rec[5] == 0
+
+
+def _check_match(ka, got, n_beams):
+    m = ka["match"]
+    assert got["n_candidates"] == m["n_candidates"] == 27
+    assert np.max(np.abs(got["scores"] - np.array(m["scores"]))) < TOL
+    assert got["best_index"] == m["best_index"]
+    assert tuple(got["pose"]) == tuple(m["pose"])          # the accumulated offsets, exact
+    assert abs(got["score"] - m["score"]) < TOL
+    assert got["score"] * n_beams == pytest.approx(min(m["scores"]), abs=TOL)
+    assert np.allclose(got["covariance"], m["covariance"], rtol=1e-11, atol=0)
+
+
+def test_the_lattice_is_the_binary_exact_one(ka):
+    p = ka["params"]
+    assert list(O.search_offsets(p["search_linear_size"], p["search_linear_resolution"])) == ka["offsets"]
+    assert list(O.search_offsets(p["search_angular_size"], p["search_angular_resolution"])) == ka["offsets"]
+
+
+def test_oracle_reproduces_the_known_answers(ka):
+    ref = O.ScanMatcherNDT()
+    ref.initialize(**ka["params"])
+    ref.addScans(_scans(ka))
+    ndt = ref.ndt
+    _check_grid(ka, ndt.cells6(), ndt.size_x, ndt.size_y, ndt.origin)
+    beams = np.array(ka["beams"])
+    got = ref.matchScan(ka["scan_pose"], beams, want_scores=True)
+    _check_match(ka, got, len(beams))
+    # the all-core variant used for baselines and full-lattice winners: same winner
+    par = ref.matchScan(ka["scan_pose"], beams, omp_threads=2)
+    assert par["best_index"] == ka["match"]["best_index"]
+    assert tuple(par["pose"]) == tuple(ka["match"]["pose"])
+    assert np.allclose(par["covariance"], ka["match"]["covariance"], rtol=1e-11, atol=0)
+    for sp in ka["score_points"]:
+        assert abs(ref.scorePoints(beams, sp["pose"]) - sp["score"]) < TOL
+    assert abs(ref.scoreScan(ka["score_points"][1]["pose"], beams) - ka["score_points"][1]["score"]) < TOL
+
+
+def test_host_ndt_build_reproduces_the_known_cells(ka):
+    """addScans' host build of the product library (no GPU needed)."""
+    from ndt_2d_amd.scan_matcher import host_build_grid
+    p = ka["params"]
+    cells, sx, sy, ox, oy = host_build_grid(p["ndt_resolution"], p["range_max"], _scans(ka))
+    _check_grid(ka, cells, sx, sy, (ox, oy))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["auto", "wave", "lane", "lane-noskip"])
+def test_gpu_reproduces_the_known_answers(ka, variant):
+    from ndt_2d_amd import ScanMatcherNDT
+    gpu = ScanMatcherNDT(0)
+    gpu.initialize("known_answers", **ka["params"])
+    gpu.addScans(_scans(ka))
+    cells, sx, sy, _, ox, oy = gpu.grid()
+    _check_grid(ka, cells, sx, sy, (ox, oy))
+    beams = np.array(ka["beams"])
+    gpu.set_variant(variant)
+    got = gpu.matchScan(ka["scan_pose"], beams, want_scores=True)
+    _check_match(ka, got, len(beams))
+    # the raw accumulators k, u, s of src/scan_matcher_ndt.cpp:137-140
+    gpu.prepare_search(ka["scan_pose"], beams)
+    gpu.match_launch(0, 3)
+    rec = gpu.match_fetch()
+    m = ka["match"]
+    k = np.array(m["k"])
+    assert np.allclose(rec[2:8], [k[0, 0], k[0, 1], k[0, 2], k[1, 1], k[1, 2], k[2, 2]], rtol=1e-11, atol=1e-15)
+    assert np.allclose(rec[8:11], m["u"], rtol=1e-11, atol=1e-15)
+    assert rec[11] == pytest.approx(m["s"], rel=1e-12)
+    gpu.set_variant("auto")
+    for sp in ka["score_points"]:
+        assert abs(gpu.scorePoints(beams, sp["pose"]) - sp["score"]) < TOL
+    assert abs(gpu.scoreScan(ka["score_points"][1]["pose"], beams) - ka["score_points"][1]["score"]) < TOL
+    poses = np.array([sp["pose"] for sp in ka["score_points"]])
+    assert np.max(np.abs(gpu.scorePoses(beams, poses) - [sp["score"] for sp in ka["score_points"]])) < TOL
+    gpu.close()
