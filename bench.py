@@ -1,26 +1,36 @@
 #!/usr/bin/env python3
 """Headline benchmark: pose-candidates x beams scored per second (BASELINE.json).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload auto|cfg2|cfg4]
 
-N = 1 runs BASELINE.json configs[1] ("cfg-2"): one 720-beam scan against the
-41x41 NDT @0.25 m, exhaustive search +-1.0 m / 0.02 m x +-0.5 rad / 0.005 rad =
-100 x 100 x 200 candidate poses = 1.44e9 candidate-beam units per step, inputs
-resident in HBM when the timed region starts.  For N > 1 (launched by
-torch.distributed.run, one rank per GPU, RCCL) the angular resolution is refined
-to 0.005/N rad and the theta steps are dealt round-robin, so every rank owns a cfg-2
-sized share with the same mix of cheap and expensive headings (weak scaling) and
-each step ends with the single all-reduce of the [N, 12] result table; that
-all-reduce runs on RCCL's stream while the next step's search runs (two tables),
-and all of them have completed when the timed region ends.
+A "step" is one pass of the hot path -- ScanMatcherNDT::matchScan's search (reference
+src/scan_matcher_ndt.cpp:103-143) -- over one lattice, inputs resident in HBM.
 
-A "step" is one pass of the hot path (ScanMatcherNDT::matchScan's search,
-reference src/scan_matcher_ndt.cpp:103-143) over that lattice.  Rank 0 prints
-one JSON line.
+N = 1 (workload "auto" -> cfg-2, BASELINE.json configs[1]): one 720-beam scan against
+the 41x41 NDT @0.25 m, +-1.0 m / 0.02 m x +-0.5 rad / 0.005 rad = 100 x 100 x 200
+candidates = 1.44e9 candidate-beam units per step.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL; workload "auto" ->
+cfg-4, BASELINE.json configs[3]): the global loop-closure search +-5 m / 0.02 m x
++-pi / 0.005 rad = 501 x 501 x 1257 = 315,508,257 candidates = 2.27e11 units per step,
+STRONG scaling: the theta steps are dealt round-robin to the ranks, every rank reduces
+its share on its GPU to one 12-double record and the step ends with the single
+all-reduce of the [N, 12] record table (it runs on RCCL's stream while the next step's
+search runs; all of them have completed when the timed region ends).  The same line
+carries `particle_filter` = BASELINE.json configs[4] (cfg-5): 1,000,000 particles x 720
+beams on the 801x801 NDT, particles sharded contiguously, one all-reduce of the [N, 8]
+moment sums (the total particle weight of ParticleFilter::updateStatistics), then the
+statistics on the device and the 1-double all-reduce of the theta variance (the
+reference's second pass, src/particle_filter.cpp:213-217).
+
+Rank 0 prints one JSON line.  `roofline` is the resource that binds the dominant kernel
+-- VALU issue -- as a fraction <= 1; `roofline_hbm` holds the measured HBM-side traffic
+against the 8 TB/s peak and, separately, the declared algorithmic 64 B/unit figure.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -29,66 +39,164 @@ sys.path.insert(0, _ROOT)
 
 BYTES_PER_UNIT = 64.0        # 16 B beam endpoint + 48 B cell record
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MAX_CLOCK_HZ = 2.4e9         # MI355X_MICROARCH.md chip table
+VALU_CYCLES_PER_INST = 4.0   # FP64 and VOP3 wave64 instructions issue in 4 cycles (experiments/ubench_f64.hip)
+FP64_PEAK_TFLOPS = 78.6      # vector FP64
+PMC_FILE = os.path.join(_ROOT, "profiles", "r02_pmc.json")
+CPU_BASELINE_FILE = os.path.join(_ROOT, "profiles", "r02_cpu_baselines.json")
 
 
-def cpu_baseline(params, scans, guess, pts, seconds_hint=20.0):
-    """The oracle (CPU restatement of the reference) on a bounded sample of the
-    same workload: the cfg-2 lattice with every 4th theta (angular resolution
-    0.02 rad -> 50 x 100 x 100 candidates x 720 beams = 3.6e8 units).  Checker
-    code used as the reported CPU baseline only -- never on the product path."""
+# --------------------------------------------------------------------------------------
+# CPU baseline (the oracle = CPU restatement of the reference; checker code, used here as
+# the reported baseline only -- never on the product path)
+# --------------------------------------------------------------------------------------
+
+def cpu_baseline(params, scans, guess, pts):
+    """SURVEY.md 8(d) "CPU path timing" on this box's host cores: the oracle's matchScan
+    on the cfg-2 lattice.  All cores: the FULL lattice (1.44e9 units), 1 warm-up + median
+    of 5, the (theta, dx) strips dealt to OpenMP threads.  Single thread (the reference's
+    own execution model): every 4th theta of the same lattice (3.6e8 units), 1 warm-up +
+    median of 3 -- the full-lattice single-thread medians (8 s per run) are in the
+    committed profiles/r02_cpu_baselines.json, quoted under `committed`."""
     sys.path.insert(0, os.path.join(_ROOT, "tests"))
     import oracle_lib as O
 
-    p = dict(params)
-    p["search_angular_resolution"] = 0.02
-    ref = O.ScanMatcherNDT()
-    ref.initialize(**p)
-    ref.addScans(scans)
-    n_th = len(O.search_offsets(p["search_angular_size"], p["search_angular_resolution"]))
-    n_lin = len(O.search_offsets(p["search_linear_size"], p["search_linear_resolution"]))
-    units = n_th * n_lin * n_lin * min(p["laser_max_beams"], len(pts))
+    def matcher(p):
+        ref = O.ScanMatcherNDT()
+        ref.initialize(**p)
+        ref.addScans(scans)
+        return ref
+
+    def units(p):
+        n_th = len(O.search_offsets(p["search_angular_size"], p["search_angular_resolution"]))
+        n_lin = len(O.search_offsets(p["search_linear_size"], p["search_linear_resolution"]))
+        return n_th * n_lin * n_lin * min(p["laser_max_beams"], len(pts)), (n_th, n_lin)
+
     cores = os.cpu_count() or 1
-    t0 = time.perf_counter()
-    ref.matchScan(guess, pts, omp_threads=cores)
-    t_all = time.perf_counter() - t0
-    # single thread, the reference's own execution model, on a quarter of the sample
-    p1 = dict(p)
-    p1["search_angular_resolution"] = 0.08
-    ref1 = O.ScanMatcherNDT()
-    ref1.initialize(**p1)
-    ref1.addScans(scans)
-    n_th1 = len(O.search_offsets(p1["search_angular_size"], p1["search_angular_resolution"]))
-    units1 = n_th1 * n_lin * n_lin * min(p["laser_max_beams"], len(pts))
-    t0 = time.perf_counter()
-    ref1.matchScan(guess, pts)
-    t_one = time.perf_counter() - t0
-    return {
-        "value": units / t_all, "unit": "candidate-beams/s", "cores": cores, "kind": "port",
-        "sample": "cfg-2 lattice at angular resolution 0.02 rad: %dx%dx%d candidates x %d beams"
-                  " = %.3g units, oracle matchScan, OpenMP over theta on %d threads"
-                  % (n_th, n_lin, n_lin, min(p["laser_max_beams"], len(pts)), units, cores),
-        "single_thread_value": units1 / t_one,
-        "single_thread_sample": "%dx%dx%d candidates (angular resolution 0.08 rad), 1 thread,"
-                                " the reference's own execution model" % (n_th1, n_lin, n_lin),
+    ref = matcher(params)
+    u_all, (n_th, n_lin) = units(params)
+    times, used = [], 0
+    for i in range(6):
+        t0 = time.perf_counter()
+        r = ref.matchScan(guess, pts, omp_threads=cores)
+        if i > 0:
+            times.append(time.perf_counter() - t0)
+        used = r["threads_used"]
+    t_all = statistics.median(times)
+
+    p1 = dict(params)
+    p1["search_angular_resolution"] = params["search_angular_resolution"] * 4
+    ref1 = matcher(p1)
+    u_one, (n_th1, _) = units(p1)
+    times1 = []
+    for i in range(4):
+        t0 = time.perf_counter()
+        ref1.matchScan(guess, pts)
+        if i > 0:
+            times1.append(time.perf_counter() - t0)
+    t_one = statistics.median(times1)
+    out = {
+        "value": u_all / t_all, "unit": "candidate-beams/s", "cores": used, "kind": "port",
+        "sample": "full cfg-2 lattice %dx%dx%d x %d beams = %.3g units, oracle matchScan, "
+                  "(theta, dx) strips over %d OpenMP threads, 1 warm-up + median of 5 (%.3f s)"
+                  % (n_th, n_lin, n_lin, min(params["laser_max_beams"], len(pts)), u_all, used, t_all),
+        "single_thread_value": u_one / t_one,
+        "single_thread_sample": "%dx%dx%d candidates (every 4th theta), 1 thread -- the reference's own "
+                                "execution model -- 1 warm-up + median of 3 (%.3f s)"
+                                % (n_th1, n_lin, n_lin, t_one),
+        "host_logical_cpus": cores,
     }
-
-
-def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC
-    passes (profiles/r01_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in
-    separate --pmc runs of this same command, corrected as MI355X_MICROARCH.md
-    prescribes).  None if the file is absent."""
-    path = os.path.join(_ROOT, "profiles", "r01_pmc_traffic.json")
     try:
-        with open(path) as f:
-            return json.load(f)["match"]
+        with open(CPU_BASELINE_FILE) as f:
+            out["committed"] = {"file": "profiles/r02_cpu_baselines.json", "cfg2": json.load(f)["cfg2"]}
     except (OSError, KeyError, ValueError):
+        pass
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# Roofline from the committed PMC passes + the live kernel time
+# --------------------------------------------------------------------------------------
+
+def load_pmc():
+    try:
+        with open(PMC_FILE) as f:
+            return json.load(f)
+    except (OSError, ValueError):
         return None
 
 
-def particle_bench(matcher_cls, synth, torch, device_index, reps=5):
-    """Secondary figure (not the headline): ParticleFilter::measure's scoring on
-    BASELINE.json configs[2] ("cfg-3"): 100k particles x 720 beams, 201x201 NDT."""
+def roofline(kernel, kernel_ms, units, n_cu, pmc, expected_dispatch_note):
+    """(roofline, roofline_hbm) for `kernel`.
+
+    VALU issue: achieved = VALU wave-instructions per launch (SQ_INSTS_VALU, committed PMC
+    pass of this same workload; the count is a property of the workload, not of the run)
+    / the kernel's average duration measured live with HIP events on the launch stream;
+    peak = SIMDs x clock / 4 cycles per FP64 / VOP3 wave-instruction, at the clock the
+    chip sustained under this kernel in the PMC pass (SQ_BUSY_CU_CYCLES / CUs / duration;
+    it clocks to its power budget, MI355X_MICROARCH.md "DVFS").  frac_pmc is the same
+    fraction from the counters alone: SQ_INSTS_VALU x 4 / (4 x SQ_BUSY_CU_CYCLES)."""
+    t = kernel_ms * 1e-3
+    alg_bytes = units * BYTES_PER_UNIT
+    hbm = {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s", "achieved": None, "frac": None,
+           "traffic": None,
+           "algorithmic_bytes_per_launch": alg_bytes,
+           "algorithmic_GBps": alg_bytes / t / 1e9,
+           "algorithmic_over_peak": alg_bytes / t / 1e9 / HBM_PEAK_GBPS,
+           "note": "achieved / frac = MEASURED HBM-side bytes (PMC) per launch / live kernel time; the "
+                   "declared algorithmic 64 B/unit (SURVEY.md 8d) exceeds the HBM peak because beams "
+                   "and grid are SGPR / LDS resident and empty cells are skipped -- not a roofline"}
+    roof = {"bound": "valu_issue", "achieved": None, "peak": None, "unit": "G wave-instr/s",
+            "frac": None, "traffic": None, "kernel": kernel, "kernel_ms_avg": kernel_ms}
+    k = (pmc or {}).get("kernels", {}).get(kernel)
+    if not k or "SQ_INSTS_VALU" not in k:
+        roof["note"] = "profiles/r02_pmc.json has no counters for this kernel"
+        return roof, hbm
+    n_simd = 4 * n_cu
+    busy_cycles = k["SQ_BUSY_CU_CYCLES"] / n_cu            # per-CU busy cycles of one launch
+    dur_pmc = k.get("avg_duration_ns", {}).get("sq1")
+    clock = busy_cycles / (dur_pmc * 1e-9) if dur_pmc else MAX_CLOCK_HZ
+    clock = min(clock, MAX_CLOCK_HZ)
+    achieved = k["SQ_INSTS_VALU"] / t / 1e9
+    peak = n_simd * clock / VALU_CYCLES_PER_INST / 1e9
+    roof.update(
+        achieved=achieved, peak=peak, frac=achieved / peak,
+        frac_pmc=k["SQ_INSTS_VALU"] * VALU_CYCLES_PER_INST / (4.0 * k["SQ_BUSY_CU_CYCLES"]),
+        frac_at_max_clock=achieved / (n_simd * MAX_CLOCK_HZ / VALU_CYCLES_PER_INST / 1e9),
+        sustained_clock_GHz=clock / 1e9,
+        valu_insts_per_launch=k["SQ_INSTS_VALU"],
+        valu_insts_per_unit=k["SQ_INSTS_VALU"] * 64.0 / units,
+        source="profiles/r02_pmc.json (experiments/profile_r02.sh) + live HIP-event kernel time; "
+               + expected_dispatch_note)
+    if "SQ_ACTIVE_INST_VALU" in k and "SQ_BUSY_CYCLES" in k:
+        # SQ_ACTIVE_INST_VALU counts quad-cycles a SIMD spends issuing VALU work
+        roof["valu_busy_pmc"] = k["SQ_ACTIVE_INST_VALU"] * 4.0 / (4.0 * k["SQ_BUSY_CU_CYCLES"])
+    f64 = [k.get("SQ_INSTS_VALU_ADD_F64"), k.get("SQ_INSTS_VALU_MUL_F64"),
+           k.get("SQ_INSTS_VALU_FMA_F64"), k.get("SQ_INSTS_VALU_TRANS_F64")]
+    if None not in f64:
+        flops = (f64[0] + f64[1] + 2.0 * f64[2] + f64[3]) * 64.0
+        roof["fp64_flops_per_launch"] = flops
+        roof["fp64_flops_frac"] = flops / t / 1e12 / FP64_PEAK_TFLOPS
+        roof["fp64_share_of_valu_insts"] = sum(f64) / k["SQ_INSTS_VALU"]
+    if "SQ_THREAD_CYCLES_VALU" in k and "SQ_ACTIVE_INST_VALU" in k and k["SQ_ACTIVE_INST_VALU"] > 0:
+        roof["avg_active_lanes"] = k["SQ_THREAD_CYCLES_VALU"] / k["SQ_ACTIVE_INST_VALU"] / 4.0
+    if "FETCH_SIZE" in k and "WRITE_SIZE" in k:
+        # FETCH_SIZE doubled: gfx950 tallies 128-B requests at 64 B (MI355X_MICROARCH.md, HBM)
+        traffic = (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
+        roof["traffic"] = traffic
+        hbm.update(traffic=traffic, achieved=traffic / t / 1e9, frac=traffic / t / 1e9 / HBM_PEAK_GBPS,
+                   traffic_bytes_per_unit=traffic / units,
+                   traffic_source="(2*FETCH_SIZE + WRITE_SIZE) KiB, separate --pmc passes, profiles/r02_pmc.json")
+    return roof, hbm
+
+
+# --------------------------------------------------------------------------------------
+# Secondary legs
+# --------------------------------------------------------------------------------------
+
+def particle_bench_1gpu(matcher_cls, synth, torch, device_index, pmc, n_cu, reps=10):
+    """ParticleFilter::measure's scoring on BASELINE.json configs[2] ("cfg-3"): 100k
+    particles x 720 beams, 201x201 NDT, one GPU."""
     m = matcher_cls(device_index)
     m.initialize("global_scan_matcher", **synth.matcher_params(3))
     m.addScans(synth.map_scans(3))
@@ -99,43 +207,141 @@ def particle_bench(matcher_cls, synth, torch, device_index, reps=5):
     d_parts = torch.from_numpy(parts).to(dev)
     d_scores = torch.zeros(len(parts), dtype=torch.float64, device=dev)
     d_stats = torch.zeros(8, dtype=torch.float64, device=dev)
-    # an explicit (non-null) torch stream shared with the library: torch ops and
-    # the kernels are ordered on it
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.synchronize(dev)
     m.set_stream(stream.cuda_stream)
     ms = []
-    for i in range(reps + 1):
-        m.score_poses_launch(d_parts.data_ptr(), len(parts), d_scores.data_ptr(),
-                             d_stats.data_ptr())
+    for i in range(reps + 2):
+        m.score_poses_launch(d_parts.data_ptr(), len(parts), d_scores.data_ptr(), d_stats.data_ptr())
         t, _ = m.last_launch_ms()
-        if i > 0:
+        if i > 1:
             ms.append(t)
     units = len(parts) * n_beams
     avg = sum(ms) / len(ms)
     m.set_stream(None)
-    # PCIe-inclusive: host particles in, host weights out (ndt2d_matcher_score_poses)
-    e2e = []
-    for _ in range(3):
-        t0 = time.perf_counter()
-        m.scorePoses(pts, parts)
-        e2e.append(time.perf_counter() - t0)
-    out = {"workload": "cfg-3: 100000 particles x 720 beams, 201x201 NDT @0.25 m",
-           "host_call_ms": min(e2e) * 1e3, "host_call_value": units / min(e2e),
+    out = {"workload": "cfg-3 (BASELINE.json configs[2]): 100000 particles x 720 beams, 201x201 NDT @0.25 m",
            "units_per_launch": units, "kernel_ms": avg, "value": units / (avg * 1e-3),
-           "unit": "candidate-beams/s", "variant": m.last_variant(),
-           "achieved_GBps": units * BYTES_PER_UNIT / (avg * 1e-3) / 1e9}
+           "unit": "candidate-beams/s", "variant": m.last_variant()}
+    roof, hbm = roofline("score_poses_compact_kernel", avg, units, n_cu, pmc,
+                         "counters of the cfg-3 launch of the same bench command")
+    out["roofline"], out["roofline_hbm"] = roof, hbm
+    # PCIe-inclusive: the whole ParticleFilter::measure call, host particles in, host
+    # weights out.  Pageable host memory (what a std::vector holds) and pinned host
+    # memory (ndt2d_host_alloc; what the C++ mirror's particle store uses).
+    w = None
+    for label, pinned in (("pageable", False), ("pinned", True)):
+        buf_p = m.host_alloc((len(parts), 3)) if pinned and hasattr(m, "host_alloc") else None
+        if pinned and buf_p is None:
+            continue
+        src = parts
+        dst = None
+        if pinned:
+            buf_p[:] = parts
+            src = buf_p
+            dst = m.host_alloc((len(parts),))
+        calls = []
+        for _ in range(12):
+            t0 = time.perf_counter()
+            w = m.scorePoses(pts, src, out=dst) if dst is not None else m.scorePoses(pts, src)
+            calls.append(time.perf_counter() - t0)
+        calls = sorted(calls[2:])
+        out["host_call_%s_ms" % label] = calls[len(calls) // 2] * 1e3
+    out["host_call_ms"] = out.get("host_call_pinned_ms", out["host_call_pageable_ms"])
+    out["host_call_over_kernel"] = out["host_call_ms"] / avg
+    out["host_call_value"] = units / (out["host_call_ms"] * 1e-3)
+    del w
     m.close()
     return out
 
 
+def default_search_bench(matcher_cls, synth, device_index, reps=300):
+    """The node's actual default workload (reference src/scan_matcher_ndt.cpp:37-44): 100 of
+    720 beams, 21 x 21 x 80 = 35,280 candidates, per accepted scan the mapper runs
+    reset + addScans + scoreScan + matchScan (src/ndt_mapper.cpp:508-515).  Host-call
+    latencies (host buffers in, results out), medians."""
+    scans = synth.map_scans(1)
+    params = synth.matcher_params(1, search_linear_size=0.05, search_linear_resolution=0.005,
+                                  search_angular_size=0.1, search_angular_resolution=0.0025,
+                                  laser_max_beams=100)
+    guess, pts, _ = synth.query_scan(1)
+    m = matcher_cls(device_index)
+    m.initialize("local_scan_matcher", **params)
+    m.addScans(scans)
+
+    def med(fn, n=reps):
+        ts = []
+        for i in range(n + 20):
+            t0 = time.perf_counter()
+            fn()
+            if i >= 20:
+                ts.append(time.perf_counter() - t0)
+        ts.sort()
+        return ts[len(ts) // 2] * 1e3, ts[int(len(ts) * 0.99)] * 1e3
+
+    match_ms, match_p99 = med(lambda: m.matchScan(guess, pts))
+    kernel_ms, n_kernels = m.last_launch_ms()
+    variant = m.last_variant()
+    score_ms, _ = med(lambda: m.scoreScan(guess, pts))
+    points_ms, _ = med(lambda: m.scorePoints(pts, guess))
+    add_ms, _ = med(lambda: (m.reset(), m.addScans(scans)), n=100)
+
+    def cycle():
+        m.reset()
+        m.addScans(scans)
+        m.scoreScan(guess, pts)
+        m.matchScan(guess, pts)
+    cycle_ms, cycle_p99 = med(cycle, n=100)
+    # ParticleFilter::measure through the UNCHANGED per-particle loop (reference
+    # src/particle_filter.cpp:81-87): 500 scorePoints calls with the same points
+    poses = synth.particles(3, 500) * [4.0 / 23.0, 4.0 / 23.0, 1.0]
+
+    def loop():
+        for p in poses:
+            m.scorePoints(pts, p)
+    loop_ms, _ = med(loop, n=10)
+    batch_ms, _ = med(lambda: m.scorePoses(pts, poses), n=100)
+    units = 35280 * 100
+    m.close()
+    return {"workload": "plugin defaults: 100 of 720 beams, 21x21x80 = 35,280 candidates, 41x41 NDT from 9 scans",
+            "match_scan_ms": match_ms, "match_scan_p99_ms": match_p99,
+            "match_scan_kernel_ms": kernel_ms, "kernels_per_call": n_kernels, "kernel_variant": variant,
+            "match_scan_value": units / (match_ms * 1e-3),
+            "score_scan_ms": score_ms, "score_points_call_us": points_ms * 1e3,
+            "add_scans_ms": add_ms, "mapper_cycle_ms": cycle_ms, "mapper_cycle_p99_ms": cycle_p99,
+            "measure_500_particles_unchanged_loop_ms": loop_ms,
+            "measure_500_particles_batched_ms": batch_ms,
+            "note": "Python ctypes call overhead (~3-5 us per call) included"}
+
+
+def in_grid_share(np, synth, params, guess, pts, grid, samples=2000000):
+    """Share of the (candidate, beam) pairs of a lattice whose point lies inside the NDT
+    grid (the others are exact zeros in the reference too, src/ndt_model.cpp:165-169)."""
+    from ndt_2d_amd.scan_matcher import search_offsets
+    dth = search_offsets(params["search_angular_size"], params["search_angular_resolution"])
+    dlin = search_offsets(params["search_linear_size"], params["search_linear_resolution"])
+    rng = np.random.default_rng(4)
+    t = dth[rng.integers(0, len(dth), samples)] + guess[2]
+    dx = dlin[rng.integers(0, len(dlin), samples)]
+    dy = dlin[rng.integers(0, len(dlin), samples)]
+    b = pts[rng.integers(0, len(pts), samples)]
+    x = b[:, 0] * np.cos(t) - b[:, 1] * np.sin(t) + guess[0] + dx
+    y = b[:, 0] * np.sin(t) + b[:, 1] * np.cos(t) + guess[1] + dy
+    _, sx, sy, cs, ox, oy = grid
+    inside = (x >= ox) & (y >= oy) & ((x - ox) / cs < sx) & ((y - oy) / cs < sy)
+    return float(inside.mean())
+
+
+# --------------------------------------------------------------------------------------
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", choices=["auto", "cfg2", "cfg4"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-particles", action="store_true")
+    ap.add_argument("--no-default-search", action="store_true")
     args = ap.parse_args()
 
     # Native libraries write to stdout as well (RCCL flushes a version banner at
@@ -152,6 +358,11 @@ def main():
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run "
                              "--nproc-per-node %d" % (args.gpus, args.gpus))
         args.gpus = world
+    cfg = {"auto": 2 if world == 1 else 4, "cfg2": 2, "cfg4": 4}[args.workload]
+    if args.steps is None:
+        args.steps = 200 if cfg == 2 else 20
+    if args.warmup is None:
+        args.warmup = 10 if cfg == 2 else 3
 
     import numpy as np
     import torch
@@ -159,17 +370,17 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
-    # NDT2D_BENCH_BACKEND=gloo is a debugging aid only (several ranks sharing one
-    # GPU on a 1-GPU box, records exchanged through host memory); the driver's
-    # runs use the default: one GPU per rank, RCCL.
+    # NDT2D_BENCH_BACKEND=gloo is a debugging / test aid only (several ranks sharing one
+    # GPU on a 1-GPU box, records exchanged through host memory); the driver's runs use
+    # the default: one GPU per rank, RCCL.
     backend = os.environ.get("NDT2D_BENCH_BACKEND", "nccl")
     dev_index = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    local_rank = dev_index
+    n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
     # NDT2D_BENCH_FORCE_COLLECTIVE=1: take the multi-rank code path (process group,
-    # all-reduce, barrier) with a single rank too -- the only way to exercise the
-    # RCCL path on a 1-GPU box
+    # all-reduces, barrier) with a single rank too -- the only way to exercise the RCCL
+    # path on a 1-GPU box
     collective = world > 1 or os.environ.get("NDT2D_BENCH_FORCE_COLLECTIVE") == "1"
     if collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -180,24 +391,28 @@ def main():
         else:
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
 
-    def all_reduce(tensor, op):
+    def all_reduce(tensor, op, async_op=False):
         if backend == "gloo":
             host = tensor.cpu()
             dist.all_reduce(host, op=op)
             tensor.copy_(host)
-        else:
-            dist.all_reduce(tensor, op=op)
+            return None
+        return dist.all_reduce(tensor, op=op, async_op=async_op)
+
+    def fence():
+        if collective:
+            dist.barrier()
+        torch.cuda.synchronize()
 
     from ndt_2d_amd import ScanMatcherNDT, synth
     from ndt_2d_amd import dist as shard
 
-    # ---- workload: cfg-2, theta axis refined N-fold for weak scaling ----
-    params = synth.matcher_params(2)
-    params["search_angular_resolution"] = params["search_angular_resolution"] / world
-    scans = synth.map_scans(2)
-    guess, pts, _ = synth.query_scan(2)
+    # ---- headline: the matchScan search, theta steps dealt round-robin to the ranks ----
+    params = synth.matcher_params(cfg)
+    scans = synth.map_scans(cfg)
+    guess, pts, _ = synth.query_scan(cfg)
 
-    m = ScanMatcherNDT(local_rank)
+    m = ScanMatcherNDT(dev_index)
     m.initialize("global_scan_matcher", **params)
     m.addScans(scans)
     n_th, n_lin, n_beams = m.prepare_search(guess, pts)
@@ -232,26 +447,22 @@ def main():
             table.zero_()
         m.match_launch_strided(th_first, th_stride, th_count, record_ptr=table[rank].data_ptr())
         if collective:
-            if backend == "gloo":
-                all_reduce(table, dist.ReduceOp.SUM)
-            else:
-                pending[slot] = dist.all_reduce(table, op=dist.ReduceOp.SUM, async_op=True)
+            pending[slot] = all_reduce(table, dist.ReduceOp.SUM, async_op=True)
 
-    def fence():
+    def drain():
         for slot in (0, 1):
             if pending[slot] is not None:
                 pending[slot].wait()
                 pending[slot] = None
-        if collective:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
+    drain()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()
     fence()
     elapsed = time.perf_counter() - t0
     # HIP events the library recorded around the search kernel of each of those
@@ -263,64 +474,95 @@ def main():
     elapsed = float(t[0])
     ms_per_step = elapsed / args.steps * 1e3
 
-    # the result the search produced (sanity: finite, a winner was found)
+    # the result the search produced
     rec = tables[(n_steps_run[0] - 1) & 1].cpu().numpy()
     best_score, best_index, acc = shard.combine_match_records(rec)
     result = m.finish_match(np.concatenate([[best_score, -1.0 if best_index is None else best_index], acc]))
     variant = m.last_variant()
 
+    # ---- N > 1: the same whole lattice on ONE GPU, measured by rank 0 in this job ----
+    single = None
+    if world > 1 and rank == 0:
+        ms1 = []
+        for i in range(4):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            m.match_launch(0, n_th)
+            torch.cuda.synchronize()
+            if i > 0:
+                ms1.append((time.perf_counter() - t0) * 1e3)
+        single = {"ms_per_step": min(ms1), "value": total_units / (min(ms1) * 1e-3),
+                  "what": "the whole lattice searched by rank 0's GPU alone, same job (untimed region), "
+                          "best of 3: the 1-GPU figure for THIS workload"}
+    if collective:
+        dist.barrier()
+
+    # ---- cfg-5: sharded ParticleFilter::measure (N > 1 or forced collective) ----
+    pf5 = None
+    if collective and not args.no_particles:
+        pf5 = particle_bench_sharded(ScanMatcherNDT, synth, shard, torch, dist, dev, dev_index, rank,
+                                     world, backend, all_reduce, fence)
+
     if rank == 0:
         avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
-        achieved = my_units * BYTES_PER_UNIT / (avg_kernel_ms * 1e-3) / 1e9
+        pmc = load_pmc()
+        lane = "lane" in variant
+        kname = "match_lane_kernel" if lane else "match_kernel"
+        roof, hbm = roofline(kname, avg_kernel_ms, my_units, n_cu, pmc if cfg == 2 and world == 1 else None,
+                             "counters of the cfg-2 launch of the same bench command")
+        grid = m.grid()
         line = {
             "metric": "pose-candidates x beams scored per second",
             "value": total_units / (ms_per_step * 1e-3),
             "unit": "candidate-beams/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "strong" if cfg == 4 else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {
-                "workload": "cfg-2 (BASELINE.json configs[1]): one 720-beam scan vs 41x41 NDT "
-                            "@0.25 m, exhaustive search +-1.0 m/0.02 m x +-0.5 rad/%g rad"
-                            % params["search_angular_resolution"],
+                "workload": ("cfg-2 (BASELINE.json configs[1]): one 720-beam scan vs 41x41 NDT @0.25 m, "
+                             "exhaustive search +-1.0 m/0.02 m x +-0.5 rad/0.005 rad") if cfg == 2 else
+                            ("cfg-4 (BASELINE.json configs[3]): global loop-closure search, one 720-beam scan "
+                             "vs 41x41 NDT @0.25 m, +-5 m/0.02 m x +-pi/0.005 rad, pose grid sharded over "
+                             "%d GPU(s) + argmin/covariance all-reduce" % world),
                 "candidates": n_th * n_lin * n_lin, "n_theta": n_th, "n_linear": n_lin,
                 "beams": n_beams, "units_per_step": total_units,
-                "sharding": "theta steps dealt round-robin to the ranks, one all-reduce of the [N,12] record table per search, overlapped with the next search",
+                "sharding": "theta steps dealt round-robin to the ranks (total work fixed), one all-reduce "
+                            "of the [N,12] record table per search, overlapped with the next search",
                 "kernel_variant": variant,
             },
-            "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                "kernel": "match_lane_kernel (+ its 7 us rotated-beam table pre-pass)"
-                          if "lane" in variant else "match_kernel",
-                "kernel_ms_avg": avg_kernel_ms,
-                "algorithmic_bytes_per_launch": my_units * BYTES_PER_UNIT,
-                "note": "algorithmic 64 B/unit; compulsory HBM traffic is ~0.02 B/unit "
-                        "(grid + beams are LDS/register resident) -- see DESIGN.md",
-            },
+            "roofline": roof,
+            "roofline_hbm": hbm,
             "match_result": {"score": result["score"], "pose": [float(v) for v in result["pose"]],
                              "best_index": best_index},
         }
-        traffic = pmc_traffic()
-        if traffic is not None:
-            line["roofline"]["traffic"] = traffic["bytes_per_launch"]
-            line["roofline"]["traffic_source"] = traffic["source"]
-        if world == 1:
+        if cfg == 4:
+            share = in_grid_share(np, synth, params, guess, pts, grid)
+            line["config"]["in_grid_share_of_units"] = share
+            line["value_in_grid_units"] = line["value"] * share
+            if single is not None:
+                line["single_gpu_same_workload"] = single
+        if world == 1 and cfg == 2:
             # PCIe-inclusive figure (never `value`): the whole matchScan call with host
             # buffers in and out (subsample, tables, H2D, search, D2H of the 12-double record)
             m.set_stream(None)
             e2e = []
-            for _ in range(3):
+            for _ in range(5):
                 t0 = time.perf_counter()
                 m.matchScan(guess, pts)
                 e2e.append(time.perf_counter() - t0)
             line["host_call"] = {"ms": min(e2e) * 1e3, "value": total_units / min(e2e),
                                  "what": "ndt2d_matcher_match_scan, host buffers in/out"}
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(synth.matcher_params(2), scans, guess, pts)
+            line["cpu_baseline"] = cpu_baseline(synth.matcher_params(2), synth.map_scans(2),
+                                                *synth.query_scan(2)[:2])
         if world == 1 and not args.no_particles:
             m.set_stream(None)
-            line["particle_filter"] = particle_bench(ScanMatcherNDT, synth, torch, local_rank)
+            line["particle_filter"] = particle_bench_1gpu(ScanMatcherNDT, synth, torch, dev_index, pmc, n_cu)
+        if pf5 is not None:
+            line["particle_filter_cfg5" if world == 1 else "particle_filter"] = pf5
+        if world == 1 and not args.no_default_search:
+            line["default_search"] = default_search_bench(ScanMatcherNDT, synth, dev_index)
         os.write(json_fd, (json.dumps(line) + "\n").encode())
 
     m.set_stream(None)
@@ -328,6 +570,74 @@ def main():
     if collective:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def particle_bench_sharded(matcher_cls, synth, shard, torch, dist, dev, dev_index, rank, world, backend,
+                           all_reduce, fence, steps=20, warmup=3):
+    """BASELINE.json configs[4] ("cfg-5"): 1,000,000 particles x 720 beams on the 801x801
+    NDT, particles sharded contiguously over the ranks.  One step = ParticleFilter::measure
+    (reference src/particle_filter.cpp:78-89 + updateStatistics :163-218): every rank scores
+    its range and reduces its 8 moment sums on the device, ONE all-reduce of the [N, 8]
+    table gives every rank the total particle weight and the moments, the rank normalises
+    its weights and forms mean / covariance on the device, and the theta variance -- the
+    reference's second pass -- is a 1-double all-reduce.  KLD resampling is host code
+    outside the timed region, as BASELINE.json says."""
+    import numpy as np
+    m = matcher_cls(dev_index)
+    m.initialize("global_scan_matcher", **synth.matcher_params(5))
+    m.addScans(synth.map_scans(5))
+    _, pts, _ = synth.query_scan(5)
+    parts = synth.particles(5)
+    n_total = len(parts)
+    begin, end = shard.shard_range(n_total, rank, world)
+    n_beams = m.prepare_beams(pts)
+    stream = torch.cuda.current_stream(dev)
+    m.set_stream(stream.cuda_stream)
+    d_parts = torch.from_numpy(parts[begin:end].copy()).to(dev)
+    n_local = end - begin
+    d_w = torch.zeros(max(n_local, 1), dtype=torch.float64, device=dev)
+    table = torch.zeros((world, shard.POSE_STATS), dtype=torch.float64, device=dev)
+    d_sum = torch.zeros(shard.POSE_STATS, dtype=torch.float64, device=dev)
+    d_out = torch.zeros(8, dtype=torch.float64, device=dev)
+    d_var = torch.zeros(1, dtype=torch.float64, device=dev)
+
+    def step():
+        table.zero_()
+        if n_local:
+            m.score_poses_launch(d_parts.data_ptr(), n_local, d_w.data_ptr(), table[rank].data_ptr())
+        all_reduce(table, dist.ReduceOp.SUM)                   # total particle weight + moments
+        torch.sum(table, dim=0, out=d_sum)                      # rank order, every rank the same
+        if n_local:
+            m.pf_finalize_launch(d_parts.data_ptr(), n_local, d_w.data_ptr(), d_sum.data_ptr(),
+                                 d_out.data_ptr())
+        d_var.copy_(d_out[7:8])
+        all_reduce(d_var, dist.ReduceOp.SUM)                    # theta variance, second pass
+
+    for _ in range(warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    all_reduce(t, dist.ReduceOp.MAX)
+    ms = float(t[0]) / steps * 1e3
+    out_h = d_out.cpu().numpy()
+    units = n_total * n_beams
+    res = {"workload": "cfg-5 (BASELINE.json configs[4]): 1000000 particles x 720 beams, 801x801 NDT @0.25 m, "
+                       "particles sharded over %d GPU(s) + weight-sum all-reduce" % world,
+           "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": ms,
+           "value": units / (ms * 1e-3), "unit": "candidate-beams/s", "scaling": "strong",
+           "units_per_step": units, "variant": m.last_variant(),
+           "collectives_per_step": "all-reduce [N,8] moment sums + all-reduce [1] theta variance",
+           "result": {"sum_w": float(out_h[0]), "mean": [float(v) for v in out_h[1:4]],
+                      "cov_xx_xy_yy": [float(v) for v in out_h[4:7]],
+                      "theta_variance": float(d_var.cpu()[0])}}
+    m.set_stream(None)
+    m.close()
+    return res
 
 
 if __name__ == "__main__":
