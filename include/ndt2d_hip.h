@@ -109,6 +109,12 @@ int ndt2d_set_search(ndt2d_handle h, double pose_x, double pose_y, const double 
                      const double * cos_th, const double * sin_th, size_t n_th,
                      const double * dlin, size_t n_lin);
 
+/* ndt2d_set_beams + ndt2d_set_search in one call: both travel in ONE staged copy (a
+ * small search is a few tens of microseconds; every copy command costs ~3 us). */
+int ndt2d_set_search_beams(ndt2d_handle h, const double * beams_xy, size_t n_beams, double pose_x,
+                           double pose_y, const double * dth, const double * cos_th,
+                           const double * sin_th, size_t n_th, const double * dlin, size_t n_lin);
+
 /* Result of one (possibly sharded) matchScan search,
  * src/scan_matcher_ndt.cpp:103-143.  Candidate flat index =
  * (i_theta * n_lin + i_x) * n_lin + i_y, the reference's loop order. */
@@ -140,7 +146,9 @@ int ndt2d_match_launch(ndt2d_handle h, size_t th_begin, size_t th_end, double * 
  * src/scan_matcher_ndt.cpp:103-119), d_scores is local: step k of this call first. */
 int ndt2d_match_launch_strided(ndt2d_handle h, size_t th_first, size_t th_stride,
                                size_t th_count, double * d_scores, double * d_record);
-/* Wait for the last ndt2d_match_launch and copy its result to the host. */
+/* Wait for the last ndt2d_match_launch and return its result.  (The final reduction
+ * writes the record into host-coherent pinned memory and then raises a flag there; the
+ * host spins on the flag, which returns ~4 us sooner than a stream synchronisation.) */
 int ndt2d_match_fetch(ndt2d_handle h, ndt2d_match_result * out);
 /* launch + fetch; h_scores (host pointer, optional) receives the slab scores. */
 int ndt2d_match(ndt2d_handle h, size_t th_begin, size_t th_end, double * h_scores,
@@ -157,7 +165,11 @@ int ndt2d_match(ndt2d_handle h, size_t th_begin, size_t th_end, double * h_score
 #define NDT2D_POSE_STATS_DOUBLES 8
 int ndt2d_score_poses_launch(ndt2d_handle h, const double * d_poses_xyt, size_t n_poses,
                              double * d_scores, double * d_stats);
-/* Host-pointer convenience: H2D poses, launch, D2H scores (+ stats). */
+/* Host-pointer convenience: H2D poses, launch, D2H scores (+ stats).  Up to 8 poses
+ * (scorePoints / scoreScan call it with ONE) take a block-per-pose kernel whose poses are
+ * kernel arguments and whose scores land in host-coherent memory: one launch, no copy,
+ * bit-identical scores.  Buffers from ndt2d_host_alloc are read / written by the kernel
+ * in place (no copy is queued). */
 int ndt2d_score_poses(ndt2d_handle h, const double * h_poses_xyt, size_t n_poses,
                       double * h_scores, double * h_stats);
 
@@ -296,6 +308,17 @@ int ndt2d_device_free(ndt2d_handle h, void * d_ptr);
 int ndt2d_copy_to_device(ndt2d_handle h, void * d_dst, const void * h_src, size_t bytes);
 int ndt2d_copy_to_host(ndt2d_handle h, void * h_dst, const void * d_src, size_t bytes);
 
+/* Pinned, GPU-mapped host memory: poses / weights buffers allocated here are read and
+ * written by the kernels of the host-pointer entry points directly over PCIe (no staging
+ * copy, no copy command); the C++ ParticleFilter mirror keeps its particles in it. */
+int ndt2d_host_alloc(ndt2d_handle h, size_t bytes, void ** out);
+int ndt2d_host_free(ndt2d_handle h, void * ptr);
+
+/* HIP events around the dominant kernel of every launch (ndt2d_last_launch_ms /
+ * ndt2d_launch_history_ms) are recorded by default; a latency-critical host (the
+ * pluginlib shim) turns them off: the pair costs ~4.5 us per call. */
+int ndt2d_set_timing(ndt2d_handle h, int enabled);
+
 /* Block until everything launched on the context's stream has finished. */
 int ndt2d_synchronize(ndt2d_handle h);
 /* GPU time (HIP events on the launch stream) of the dominant kernel -- the
@@ -312,13 +335,16 @@ int ndt2d_launch_history_ms(ndt2d_handle h, float * ms_out, size_t capacity, siz
 /* Tuning / introspection: name of the kernel variant the last launch used. */
 const char * ndt2d_last_variant(ndt2d_handle h);
 /* "auto" (the default) picks the candidate mapping of the match search by the size
- * of the lattice: wave-per-candidate below 160,000 candidates (the plugin's
- * default search), lane-per-candidate above.  Both give the oracle's result; they
- * differ from each other in the last bits of a score (summation order).
+ * of the lattice: lane-per-candidate with the beams split across the waves of a block
+ * ("small") below 4,096 (theta, 8x8 patch) work items -- the plugin's default search is
+ * 720 -- and lane-per-candidate with persistent waves ("lane") above; wave-per-candidate
+ * ("wave") where neither applies (search windows beyond 256 cells, NaN beams).  All give
+ * the oracle's result; they differ from each other in the last bits of a score
+ * (summation order).
  * Force a kernel variant (testing / A-B measurement): "auto", "lds", "global"
- * (grid placement), "wave", "wave-lds", "wave-global", "lane" (candidate mapping
- * of the match search), "lane-noskip" (the lane mapping with every term
- * evaluated: the bit-exactness control of its skipping), "dense" (particle
+ * (grid placement), "wave", "wave-lds", "wave-global", "lane", "small" (candidate mapping
+ * of the match search), "lane-noskip" / "small-noskip" (the lane mappings with every term
+ * evaluated: the bit-exactness controls of their skipping), "dense" (particle
  * scoring without compaction), "compact-exact" (particle scoring with the exact
  * FP64 phase A: the bit-exactness control of the FP32 screen). */
 int ndt2d_set_variant(ndt2d_handle h, const char * name);

@@ -81,6 +81,7 @@ SIGNATURES = {
     "ndt2d_has_grid": (C.c_int, [_vp]),
     "ndt2d_set_beams": (C.c_int, [_vp, _dp, _sz]),
     "ndt2d_set_search": (C.c_int, [_vp, _d, _d, _dp, _dp, _dp, _sz, _dp, _sz]),
+    "ndt2d_set_search_beams": (C.c_int, [_vp, _dp, _sz, _d, _d, _dp, _dp, _dp, _sz, _dp, _sz]),
     "ndt2d_match_launch": (C.c_int, [_vp, _sz, _sz, _vp, _vp]),
     "ndt2d_match_launch_strided": (C.c_int, [_vp, _sz, _sz, _sz, _vp, _vp]),
     "ndt2d_match_fetch": (C.c_int, [_vp, C.POINTER(MatchResult)]),
@@ -109,6 +110,9 @@ SIGNATURES = {
     "ndt2d_copy_to_device": (C.c_int, [_vp, _vp, _vp, _sz]),
     "ndt2d_copy_to_host": (C.c_int, [_vp, _vp, _vp, _sz]),
     "ndt2d_launch_history_ms": (C.c_int, [_vp, C.POINTER(C.c_float), _sz, _szp]),
+    "ndt2d_host_alloc": (C.c_int, [_vp, _sz, C.POINTER(_vp)]),
+    "ndt2d_host_free": (C.c_int, [_vp, _vp]),
+    "ndt2d_set_timing": (C.c_int, [_vp, C.c_int]),
     "ndt2d_synchronize": (C.c_int, [_vp]),
     "ndt2d_last_launch_ms": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "ndt2d_last_variant": (C.c_char_p, [_vp]),

@@ -22,7 +22,7 @@
 // with -ffp-contract=off; '/' and sqrt are correctly rounded).
 #include <hipcub/hipcub.hpp>
 
-#include "ndt2d_device_fn.h"
+#include "ndt2d_lane_fn.h"
 
 namespace ndt2d
 {
@@ -199,6 +199,56 @@ __global__ void __launch_bounds__(256) bits_kernel(const double * cells_lds_imag
   bits[w] = v;
 }
 
+// The scorer layouts of a grid given as cells6 records {mean, information, n} (the
+// host build's output, ndt2d_set_grid): what cells_kernel writes for a device build.
+__global__ void __launch_bounds__(256) pack_cells_kernel(const double * cells6, uint32_t ncell,
+                                                         double * cells_lds_image,
+                                                         double * cells_global)
+{
+  const uint32_t cell = blockIdx.x * 256 + threadIdx.x;
+  if (cell > ncell) return;
+  // h = -0.5 * information (exact); sentinel for cells that cannot score (n < 5,
+  // src/ndt_model.cpp:107) and for record ncell ("outside")
+  double rec[kCellDoubles] = {1.0e300, 0.0, -1.0, 0.0, -1.0, 0.0};
+  if (cell < ncell)
+  {
+    const double * c = cells6 + static_cast<size_t>(cell) * 6;
+    if (!(c[5] < 5.0))
+    {
+      rec[0] = c[0];
+      rec[1] = c[1];
+      rec[2] = -0.5 * c[2];
+      rec[3] = -0.5 * c[3];
+      rec[4] = -0.5 * c[4];
+      rec[5] = 1.0;
+    }
+  }
+  double * l = cells_lds_image + static_cast<size_t>(cell) * kCellDoubles;
+  double * gl = cells_global + static_cast<size_t>(cell) * kCellStrideGlobal;
+#pragma unroll
+  for (int k = 0; k < kCellDoubles; ++k)
+  {
+    l[k] = rec[k];
+    gl[k] = rec[k];
+  }
+  gl[6] = 0.0;
+  gl[7] = 0.0;
+}
+
+// One occupancy-map byte per grid cell, for the grid extended by one cell on every
+// side ([size_y + 2][size_x + 2], cell (cx, cy) at (cy + 1) * (size_x + 2) + cx + 1):
+// the byte the lane-per-candidate search's map holds at one map cell per grid cell
+// (ndt2d_lane_fn.h, sub_cell_byte with sub_log2 = 0).  It depends on the grid only, so
+// it is prepared once here and the small-lattice search copies its window from it.
+__global__ void __launch_bounds__(256) cell_bytes_kernel(const GridDesc g, uint8_t * bytes)
+{
+  const uint32_t w = g.size_x + 2, h = g.size_y + 2;
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= w * h) return;
+  const int32_t cx = static_cast<int32_t>(i % w) - 1, cy = static_cast<int32_t>(i / w) - 1;
+  bytes[i] = sub_cell_byte(g, cx, cy, 0, 0, 0);
+}
+
 int key_bits(uint32_t ncell)
 {
   int b = 1;
@@ -243,10 +293,37 @@ hipError_t launch_build_grid(const BuildArgs & a, hipStream_t stream)
                      a.vals_out, a.seg_begin, a.seg_begin + (ncell + 1));
   e = hipGetLastError();
   if (e != hipSuccess) return e;
+  return launch_grid_tail(a.grid, a.cells_lds_image, a.occ_bits, a.cell_bytes, stream);
+}
+
+// occupancy bitmap + per-cell map bytes from the packed records
+hipError_t launch_grid_tail(const GridDesc & geometry, const double * cells_lds_image,
+                            uint32_t * occ_bits, uint8_t * cell_bytes, hipStream_t stream)
+{
+  const uint32_t ncell = geometry.ncell;
   const uint32_t n_words = (ncell + 1 + 31) / 32;
   hipLaunchKernelGGL(bits_kernel, dim3((n_words + 255) / 256), dim3(256), 0, stream,
-                     a.cells_lds_image, ncell, n_words, a.occ_bits);
+                     cells_lds_image, ncell, n_words, occ_bits);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  GridDesc g = geometry;
+  g.cells_lds_image = cells_lds_image;
+  g.occ_bits = occ_bits;
+  const uint32_t n_bytes = (g.size_x + 2) * (g.size_y + 2);
+  hipLaunchKernelGGL(cell_bytes_kernel, dim3((n_bytes + 255) / 256), dim3(256), 0, stream, g,
+                     cell_bytes);
   return hipGetLastError();
+}
+
+hipError_t launch_pack_grid(const GridDesc & geometry, const double * cells6,
+                            double * cells_lds_image, double * cells_global, uint32_t * occ_bits,
+                            uint8_t * cell_bytes, hipStream_t stream)
+{
+  hipLaunchKernelGGL(pack_cells_kernel, dim3((geometry.ncell + 1 + 255) / 256), dim3(256), 0,
+                     stream, cells6, geometry.ncell, cells_lds_image, cells_global);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  return launch_grid_tail(geometry, cells_lds_image, occ_bits, cell_bytes, stream);
 }
 
 }  // namespace ndt2d

@@ -48,6 +48,7 @@ struct ndt2d_context
   DeviceBuffer cells_lds_image;
   DeviceBuffer cells_global;
   DeviceBuffer occ_bits;  // uint32 words stored in a double buffer
+  DeviceBuffer cell_bytes;  // per-cell occupancy-map bytes of the extended grid
   DeviceBuffer cells6;    // raw {mean, information, n} records (introspection)
   // device NDT build scratch + host staging that must outlive the async copies
   DeviceBuffer b_points, b_scans, b_offsets, b_world, b_keys, b_vals, b_temp, b_seg;
@@ -56,7 +57,21 @@ struct ndt2d_context
 
   DeviceBuffer beams;
   size_t n_beams = 0;
-  PinnedStage stage_beams, stage_tables;
+  PinnedStage stage_beams, stage_tables, stage_grid, stage_call;
+  // where the launches read beams and tables: the buffers of ndt2d_set_beams /
+  // ndt2d_set_search, or one buffer filled by a single copy (ndt2d_set_search_beams)
+  const double * beams_ptr = nullptr;
+  const double * tables_ptr = nullptr;
+  DeviceBuffer call_dev;
+
+  // Results of small calls go straight into host-coherent pinned memory, followed by a
+  // sequence number the host spins on (a stream synchronisation costs ~4 us more):
+  //   [0..11] match record   [16] match flag   [24] score flag   [32..95] scores
+  double * host_res = nullptr;      // host address
+  double * host_res_dev = nullptr;  // the same memory as the GPU addresses it
+  unsigned long long seq = 0;       // last sequence number handed out
+  unsigned long long match_seq = 0; // ... to the pending match launch
+  uint32_t * done_counter = nullptr;
 
   DeviceBuffer tables;  // dth | cos | sin | dlin
   size_t n_th = 0, n_lin = 0;
@@ -76,6 +91,7 @@ struct ndt2d_context
   hipEvent_t ring0[NDT2D_TIMING_HISTORY] = {}, ring1[NDT2D_TIMING_HISTORY] = {};
   uint64_t n_timed_launches = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;  // the current launch's pair
+  bool timing = true;   // record the event pairs (ndt2d_set_timing)
   bool timed = false;
   int last_kernels = 0;
   const char * last_variant = "";
@@ -199,6 +215,67 @@ ndt2d::MotionParams motion_params(double dx, double dy, double dth, const double
   return p;
 }
 
+constexpr int kHostResDoubles = 128;
+constexpr int kScoreFlagSlot = 24;
+constexpr int kScoreSlot = 32;
+
+int ensure_host_res(ndt2d_context * h)
+{
+  if (h->host_res != nullptr) return NDT2D_OK;
+  void * p = nullptr;
+  NDT2D_HIP(h, hipHostMalloc(&p, kHostResDoubles * sizeof(double),
+                             hipHostMallocCoherent | hipHostMallocMapped));
+  std::memset(p, 0, kHostResDoubles * sizeof(double));
+  void * d = nullptr;
+  hipError_t e = hipHostGetDevicePointer(&d, p, 0);
+  if (e != hipSuccess)
+  {
+    (void)hipHostFree(p);
+    return fail_hip(h, e, "hipHostGetDevicePointer");
+  }
+  void * counter = nullptr;
+  e = hipMalloc(&counter, 256);
+  if (e != hipSuccess)
+  {
+    (void)hipHostFree(p);
+    return fail_hip(h, e, "hipMalloc");
+  }
+  e = hipMemsetAsync(counter, 0, 256, h->stream);
+  if (e != hipSuccess) return fail_hip(h, e, "hipMemsetAsync");
+  h->host_res = static_cast<double *>(p);
+  h->host_res_dev = static_cast<double *>(d);
+  h->done_counter = static_cast<uint32_t *>(counter);
+  return NDT2D_OK;
+}
+
+// Wait until the kernel that was given `seq` has published its results at `slot`:
+// spin on the flag for a while (the GPU writes it over PCIe into coherent host memory;
+// ~4 us sooner than a stream synchronisation returns), then fall back to the stream.
+int wait_host_flag(ndt2d_context * h, int slot, unsigned long long seq)
+{
+  volatile unsigned long long * flag =
+    reinterpret_cast<volatile unsigned long long *>(h->host_res + slot);
+  for (int outer = 0; outer < 64; ++outer)
+  {
+    for (int i = 0; i < 2048; ++i)
+    {
+      if (*flag == seq)
+      {
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        return NDT2D_OK;
+      }
+      __builtin_ia32_pause();
+    }
+    // a failed launch / faulted kernel never raises the flag: ask the stream now and then
+    const hipError_t q = hipStreamQuery(h->stream);
+    if (q != hipErrorNotReady && q != hipSuccess) return fail_hip(h, q, "hipStreamQuery");
+  }
+  NDT2D_HIP(h, hipStreamSynchronize(h->stream));
+  if (*flag != seq) return fail(h, NDT2D_ERR_HIP, "result flag was not raised");
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  return NDT2D_OK;
+}
+
 // Take the next pair of timing events (created on first use) as h->ev0 / h->ev1.
 int next_timing_slot(ndt2d_context * h)
 {
@@ -209,6 +286,34 @@ int next_timing_slot(ndt2d_context * h)
   h->ev1 = h->ring1[slot];
   ++h->n_timed_launches;
   return NDT2D_OK;
+}
+
+// The address a kernel can use for host memory allocated with ndt2d_host_alloc
+// (pinned, mapped); nullptr for ordinary (pageable) host memory.
+template <class T>
+T * device_view(T * host_ptr)
+{
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, host_ptr) != hipSuccess)
+  {
+    (void)hipGetLastError();   // pageable memory: "invalid value", not an error here
+    return nullptr;
+  }
+  if (attr.type != hipMemoryTypeHost || attr.devicePointer == nullptr) return nullptr;
+  return static_cast<T *>(attr.devicePointer);
+}
+
+// max |beam|; an infinite reach (NaN / inf beam) disables the windowed lane mapping
+double beam_reach(const double * beams_xy, size_t n_beams)
+{
+  double rmax = 0.0;
+  for (size_t i = 0; i < n_beams; ++i)
+  {
+    const double r = std::hypot(beams_xy[2 * i], beams_xy[2 * i + 1]);
+    if (r > rmax) rmax = r;
+    if (std::isnan(r)) rmax = std::numeric_limits<double>::infinity();
+  }
+  return rmax;
 }
 
 bool is_pow2(double v)
@@ -223,7 +328,7 @@ bool is_pow2(double v)
 
 extern "C" {
 
-int ndt2d_abi_version(void) { return 1; }
+int ndt2d_abi_version(void) { return 2; }
 
 int ndt2d_create(ndt2d_handle * out, int device_id)
 {
@@ -260,7 +365,13 @@ int ndt2d_destroy(ndt2d_handle h)
   release(h->cells_lds_image);
   release(h->cells_global);
   release(h->occ_bits);
+  release(h->cell_bytes);
   release(h->cells6);
+  release(h->call_dev);
+  release(h->stage_grid);
+  release(h->stage_call);
+  if (h->host_res != nullptr) (void)hipHostFree(h->host_res);
+  if (h->done_counter != nullptr) (void)hipFree(h->done_counter);
   release(h->b_points);
   release(h->b_scans);
   release(h->b_offsets);
@@ -328,58 +439,40 @@ int ndt2d_set_grid(ndt2d_handle h, const double * cells6, uint32_t size_x, uint3
   // below leaves the context without a grid, never with dangling pointers.
   h->has_grid = false;
 
-  // Pack: h = -0.5 * information (exact); cells with n < 5 cannot score
-  // (reference src/ndt_model.cpp:107) and get the sentinel record.
-  std::vector<double> lds_image(static_cast<size_t>(ncell + 1) * kCellDoubles);
-  std::vector<double> glb(static_cast<size_t>(ncell + 1) * kCellStrideGlobal, 0.0);
-  // occupancy bitmap: bit i = cell i can score; ncell + 1 bits, padded to whole doubles
-  std::vector<uint32_t> bits(((static_cast<size_t>(ncell) + 1 + 31) / 32 + 1) & ~size_t(1), 0u);
-  for (uint32_t i = 0; i <= ncell; ++i)
-  {
-    double rec[kCellDoubles] = {1.0e300, 0.0, -1.0, 0.0, -1.0, 0.0};
-    if (i < ncell && !(cells6[6 * static_cast<size_t>(i) + 5] < 5.0))
-    {
-      bits[i >> 5] |= 1u << (i & 31u);
-      const double * c = cells6 + 6 * static_cast<size_t>(i);
-      rec[0] = c[0];
-      rec[1] = c[1];
-      rec[2] = -0.5 * c[2];
-      rec[3] = -0.5 * c[3];
-      rec[4] = -0.5 * c[4];
-      rec[5] = 1.0;
-    }
-    std::memcpy(&lds_image[static_cast<size_t>(i) * kCellDoubles], rec, sizeof(rec));
-    std::memcpy(&glb[static_cast<size_t>(i) * kCellStrideGlobal], rec, sizeof(rec));
-  }
-  int rc = ensure(h, h->cells_lds_image, lds_image.size());
-  if (rc != NDT2D_OK) return rc;
-  rc = ensure(h, h->cells_global, glb.size());
-  if (rc != NDT2D_OK) return rc;
-  NDT2D_HIP(h, hipMemcpyAsync(h->cells_lds_image.ptr, lds_image.data(),
-                              lds_image.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  NDT2D_HIP(h, hipMemcpyAsync(h->cells_global.ptr, glb.data(), glb.size() * sizeof(double),
-                              hipMemcpyHostToDevice, h->stream));
-  rc = ensure(h, h->occ_bits, bits.size() / 2);
-  if (rc != NDT2D_OK) return rc;
-  NDT2D_HIP(h, hipMemcpyAsync(h->occ_bits.ptr, bits.data(), bits.size() * sizeof(uint32_t),
-                              hipMemcpyHostToDevice, h->stream));
-  rc = ensure(h, h->cells6, static_cast<size_t>(ncell) * 6);
-  if (rc != NDT2D_OK) return rc;
-  NDT2D_HIP(h, hipMemcpyAsync(h->cells6.ptr, cells6, static_cast<size_t>(ncell) * 6 * sizeof(double),
-                              hipMemcpyHostToDevice, h->stream));
-  NDT2D_HIP(h, hipStreamSynchronize(h->stream));  // host staging vectors go out of scope
+  // The cells6 records travel once, through pinned staging (the caller's buffer is
+  // free on return); the device derives the layouts the scorers read -- packed records
+  // h = -0.5 * information with the sentinel for cells that cannot score (n < 5,
+  // reference src/ndt_model.cpp:107), their 64-byte-stride copy, the occupancy bitmap
+  // and the per-cell map bytes -- in ndt2d_build.hip.  Asynchronous on the stream.
+  int rc;
+  const size_t n6 = static_cast<size_t>(ncell) * 6;
+  if ((rc = ensure(h, h->cells6, n6)) != NDT2D_OK) return rc;
+  if ((rc = ensure(h, h->cells_lds_image, static_cast<size_t>(ncell + 1) * kCellDoubles)) != NDT2D_OK) return rc;
+  if ((rc = ensure(h, h->cells_global, static_cast<size_t>(ncell + 1) * kCellStrideGlobal)) != NDT2D_OK) return rc;
+  if ((rc = ensure(h, h->occ_bits, ((static_cast<size_t>(ncell) + 1 + 31) / 32 + 2) / 2)) != NDT2D_OK) return rc;
+  if ((rc = ensure(h, h->cell_bytes, (static_cast<size_t>(size_x) + 2) * (size_y + 2) / 8 + 1)) != NDT2D_OK) return rc;
+  if ((rc = stage_acquire(h, h->stage_grid, n6)) != NDT2D_OK) return rc;
+  std::memcpy(h->stage_grid.ptr, cells6, n6 * sizeof(double));
+  if ((rc = stage_submit(h, h->stage_grid, h->cells6.ptr, n6)) != NDT2D_OK) return rc;
 
-  h->grid.cells_lds_image = h->cells_lds_image.ptr;
-  h->grid.cells_global = h->cells_global.ptr;
-  h->grid.occ_bits = reinterpret_cast<const uint32_t *>(h->occ_bits.ptr);
-  h->grid.size_x = size_x;
-  h->grid.size_y = size_y;
-  h->grid.ncell = ncell;
-  h->grid.cell_size = cell_size;
-  h->grid.pow2 = is_pow2(cell_size) ? 1 : 0;
-  h->grid.inv_cell_size = 1.0 / cell_size;
-  h->grid.origin_x = origin_x;
-  h->grid.origin_y = origin_y;
+  GridDesc g{};
+  g.size_x = size_x;
+  g.size_y = size_y;
+  g.ncell = ncell;
+  g.cell_size = cell_size;
+  g.pow2 = is_pow2(cell_size) ? 1 : 0;
+  g.inv_cell_size = 1.0 / cell_size;
+  g.origin_x = origin_x;
+  g.origin_y = origin_y;
+  hipError_t e = ndt2d::launch_pack_grid(g, h->cells6.ptr, h->cells_lds_image.ptr, h->cells_global.ptr,
+                                         reinterpret_cast<uint32_t *>(h->occ_bits.ptr),
+                                         reinterpret_cast<uint8_t *>(h->cell_bytes.ptr), h->stream);
+  if (e != hipSuccess) return fail_hip(h, e, "launch_pack_grid");
+  g.cells_lds_image = h->cells_lds_image.ptr;
+  g.cells_global = h->cells_global.ptr;
+  g.occ_bits = reinterpret_cast<const uint32_t *>(h->occ_bits.ptr);
+  g.cell_bytes = reinterpret_cast<const uint8_t *>(h->cell_bytes.ptr);
+  h->grid = g;
   h->has_grid = true;
   return NDT2D_OK;
 }
@@ -451,6 +544,7 @@ int ndt2d_build_grid(ndt2d_handle h, double ndt_resolution, double range_max,
   if ((rc = ensure(h, h->cells_lds_image, static_cast<size_t>(ncell + 1) * kCellDoubles)) != NDT2D_OK) return rc;
   if ((rc = ensure(h, h->cells_global, static_cast<size_t>(ncell + 1) * kCellStrideGlobal)) != NDT2D_OK) return rc;
   if ((rc = ensure(h, h->occ_bits, ((static_cast<size_t>(ncell) + 1 + 31) / 32 + 2) / 2)) != NDT2D_OK) return rc;
+  if ((rc = ensure(h, h->cell_bytes, (static_cast<size_t>(size_x) + 2) * (size_y + 2) / 8 + 1)) != NDT2D_OK) return rc;
 
   if (n_points > 0)
   {
@@ -491,6 +585,7 @@ int ndt2d_build_grid(ndt2d_handle h, double ndt_resolution, double range_max,
   a.cells_lds_image = h->cells_lds_image.ptr;
   a.cells_global = h->cells_global.ptr;
   a.occ_bits = reinterpret_cast<uint32_t *>(h->occ_bits.ptr);
+  a.cell_bytes = reinterpret_cast<uint8_t *>(h->cell_bytes.ptr);
   if (int trc = next_timing_slot(h); trc != NDT2D_OK) return trc;
   NDT2D_HIP(h, hipEventRecord(h->ev0, h->stream));
   hipError_t e = ndt2d::launch_build_grid(a, h->stream);
@@ -503,6 +598,7 @@ int ndt2d_build_grid(ndt2d_handle h, double ndt_resolution, double range_max,
   g.cells_lds_image = h->cells_lds_image.ptr;
   g.cells_global = h->cells_global.ptr;
   g.occ_bits = reinterpret_cast<const uint32_t *>(h->occ_bits.ptr);
+  g.cell_bytes = reinterpret_cast<const uint8_t *>(h->cell_bytes.ptr);
   h->grid = g;
   h->has_grid = true;
   return NDT2D_OK;
@@ -555,17 +651,11 @@ int ndt2d_set_beams(ndt2d_handle h, const double * beams_xy, size_t n_beams)
   rc = stage_submit(h, h->stage_beams, h->beams.ptr, 2 * n_beams);
   if (rc != NDT2D_OK) return rc;
   h->n_beams = n_beams;
+  h->beams_ptr = h->beams.ptr;
   // a search prepared for other beams must be set up again (ndt2d_set_search) before
   // ndt2d_match_launch: its caller pairs the tables with THESE beams
   h->has_search = false;
-  h->beam_rmax = 0.0;
-  for (size_t i = 0; i < n_beams; ++i)
-  {
-    const double r = std::hypot(beams_xy[2 * i], beams_xy[2 * i + 1]);
-    if (r > h->beam_rmax) h->beam_rmax = r;
-    if (std::isnan(r)) h->beam_rmax = std::numeric_limits<double>::infinity();
-  }
-  // an infinite reach (NaN / inf beam) disables the windowed lane mapping
+  h->beam_rmax = beam_reach(beams_xy, n_beams);
   return NDT2D_OK;
 }
 
@@ -592,6 +682,52 @@ int ndt2d_set_search(ndt2d_handle h, double pose_x, double pose_y, const double 
   std::memcpy(t + 3 * n_th, dlin, n_lin * sizeof(double));
   rc = stage_submit(h, h->stage_tables, h->tables.ptr, n_tab);
   if (rc != NDT2D_OK) return rc;
+  h->n_th = n_th;
+  h->n_lin = n_lin;
+  h->dlin_absmax = 0.0;
+  for (size_t i = 0; i < n_lin; ++i)
+  {
+    if (std::fabs(dlin[i]) > h->dlin_absmax) h->dlin_absmax = std::fabs(dlin[i]);
+  }
+  h->pose_x = pose_x;
+  h->pose_y = pose_y;
+  h->tables_ptr = h->tables.ptr;
+  h->has_search = true;
+  return NDT2D_OK;
+}
+
+int ndt2d_set_search_beams(ndt2d_handle h, const double * beams_xy, size_t n_beams, double pose_x,
+                           double pose_y, const double * dth, const double * cos_th,
+                           const double * sin_th, size_t n_th, const double * dlin, size_t n_lin)
+{
+  if (h == nullptr) return NDT2D_ERR_INVALID;
+  if (beams_xy == nullptr || n_beams == 0 || n_beams > (1u << 20) || dth == nullptr ||
+      cos_th == nullptr || sin_th == nullptr || dlin == nullptr || n_th == 0 || n_lin == 0 ||
+      n_th > (1u << 24) || n_lin > 46340)
+  {
+    return fail(h, NDT2D_ERR_INVALID, "ndt2d_set_search_beams: bad argument");
+  }
+  NDT2D_HIP(h, hipSetDevice(h->device));
+  // one staging buffer, one copy: [beams 2n][dth | cos | sin  3 n_th][dlin n_lin]
+  const size_t n_tab = 3 * n_th + n_lin;
+  const size_t n_all = 2 * n_beams + n_tab;
+  int rc = ensure(h, h->call_dev, n_all);
+  if (rc != NDT2D_OK) return rc;
+  rc = stage_acquire(h, h->stage_call, n_all);
+  if (rc != NDT2D_OK) return rc;
+  double * t = h->stage_call.ptr;
+  std::memcpy(t, beams_xy, 2 * n_beams * sizeof(double));
+  t += 2 * n_beams;
+  std::memcpy(t, dth, n_th * sizeof(double));
+  std::memcpy(t + n_th, cos_th, n_th * sizeof(double));
+  std::memcpy(t + 2 * n_th, sin_th, n_th * sizeof(double));
+  std::memcpy(t + 3 * n_th, dlin, n_lin * sizeof(double));
+  rc = stage_submit(h, h->stage_call, h->call_dev.ptr, n_all);
+  if (rc != NDT2D_OK) return rc;
+  h->n_beams = n_beams;
+  h->beam_rmax = beam_reach(beams_xy, n_beams);
+  h->beams_ptr = h->call_dev.ptr;
+  h->tables_ptr = h->call_dev.ptr + 2 * n_beams;
   h->n_th = n_th;
   h->n_lin = n_lin;
   h->dlin_absmax = 0.0;
@@ -634,12 +770,12 @@ int ndt2d_match_launch_strided(ndt2d_handle h, size_t th_first, size_t th_stride
 
   ndt2d::MatchArgs a{};
   a.grid = h->grid;
-  a.beams_xy = h->beams.ptr;
+  a.beams_xy = h->beams_ptr;
   a.n_beams = static_cast<uint32_t>(h->n_beams);
-  a.dth = h->tables.ptr;
-  a.cos_th = h->tables.ptr + h->n_th;
-  a.sin_th = h->tables.ptr + 2 * h->n_th;
-  a.dlin = h->tables.ptr + 3 * h->n_th;
+  a.dth = h->tables_ptr;
+  a.cos_th = h->tables_ptr + h->n_th;
+  a.sin_th = h->tables_ptr + 2 * h->n_th;
+  a.dlin = h->tables_ptr + 3 * h->n_th;
   a.dlin_absmax = h->dlin_absmax;
   a.beam_rmax = h->beam_rmax;
   a.n_th = static_cast<uint32_t>(h->n_th);
@@ -662,13 +798,20 @@ int ndt2d_match_launch_strided(ndt2d_handle h, size_t th_first, size_t th_stride
     outer = h->outer.ptr;
   }
 
+  rc = ensure_host_res(h);
+  if (rc != NDT2D_OK) return rc;
   ndt2d::LaunchInfo info{"", 0};
-  if (int trc = next_timing_slot(h); trc != NDT2D_OK) return trc;
-  NDT2D_HIP(h, hipEventRecord(h->ev0, h->stream));
+  if (h->timing)
+  {
+    if (int trc = next_timing_slot(h); trc != NDT2D_OK) return trc;
+    NDT2D_HIP(h, hipEventRecord(h->ev0, h->stream));
+  }
+  h->match_seq = ++h->seq;
   hipError_t e = ndt2d::launch_match(a, h->ws_match.ptr, outer, h->record.ptr, d_record,
-                                     h->force_variant, h->stream, h->ev1, &info);
+                                     h->host_res_dev, h->match_seq, h->force_variant, h->stream,
+                                     h->timing ? h->ev1 : nullptr, &info);
   if (e != hipSuccess) return fail_hip(h, e, "launch_match");
-  h->timed = true;
+  h->timed = h->timing;
   h->last_kernels = info.n_kernels;
   h->last_variant = info.variant;
   h->match_pending = true;
@@ -681,9 +824,11 @@ int ndt2d_match_fetch(ndt2d_handle h, ndt2d_match_result * out)
   if (h == nullptr || out == nullptr) return NDT2D_ERR_INVALID;
   if (!h->match_pending) return fail(h, NDT2D_ERR_STATE, "ndt2d_match_fetch: nothing launched");
   NDT2D_HIP(h, hipSetDevice(h->device));
+  // the final reduction wrote the record into host-coherent memory, then its flag
+  int rc = wait_host_flag(h, ndt2d::kHostFlagSlot, h->match_seq);
+  if (rc != NDT2D_OK) return rc;
   double rec[NDT2D_MATCH_RECORD_DOUBLES];
-  NDT2D_HIP(h, hipMemcpyAsync(rec, h->record.ptr, sizeof(rec), hipMemcpyDeviceToHost, h->stream));
-  NDT2D_HIP(h, hipStreamSynchronize(h->stream));
+  for (int k = 0; k < NDT2D_MATCH_RECORD_DOUBLES; ++k) rec[k] = h->host_res[k];
   out->best_score = rec[0];
   out->best_index = rec[1] < 0.0 ? NDT2D_NO_INDEX : static_cast<uint64_t>(rec[1]);
   for (int k = 0; k < 10; ++k) out->acc[k] = rec[2 + k];
@@ -715,6 +860,7 @@ int ndt2d_match(ndt2d_handle h, size_t th_begin, size_t th_end, double * h_score
   {
     NDT2D_HIP(h, hipMemcpyAsync(h_scores, d_scores, n_scores * sizeof(double),
                                 hipMemcpyDeviceToHost, h->stream));
+    NDT2D_HIP(h, hipStreamSynchronize(h->stream));
   }
   return ndt2d_match_fetch(h, out);
 }
@@ -735,7 +881,7 @@ int ndt2d_score_poses_launch(ndt2d_handle h, const double * d_poses_xyt, size_t 
 
   ndt2d::PosesArgs a{};
   a.grid = h->grid;
-  a.beams_xy = h->beams.ptr;
+  a.beams_xy = h->beams_ptr;
   a.n_beams = static_cast<uint32_t>(h->n_beams);
   a.poses_xyt = d_poses_xyt;
   a.n_poses = n_poses;
@@ -743,12 +889,15 @@ int ndt2d_score_poses_launch(ndt2d_handle h, const double * d_poses_xyt, size_t 
   a.beam_rmax = h->beam_rmax;
 
   ndt2d::LaunchInfo info{"", 0};
-  if (int trc = next_timing_slot(h); trc != NDT2D_OK) return trc;
-  NDT2D_HIP(h, hipEventRecord(h->ev0, h->stream));
+  if (h->timing)
+  {
+    if (int trc = next_timing_slot(h); trc != NDT2D_OK) return trc;
+    NDT2D_HIP(h, hipEventRecord(h->ev0, h->stream));
+  }
   hipError_t e = ndt2d::launch_score_poses(a, h->ws_poses.ptr, d_stats, h->force_variant,
-                                           h->stream, h->ev1, &info);
+                                           h->stream, h->timing ? h->ev1 : nullptr, &info);
   if (e != hipSuccess) return fail_hip(h, e, "launch_score_poses");
-  h->timed = true;
+  h->timed = h->timing;
   h->last_kernels = info.n_kernels;
   h->last_variant = info.variant;
   return NDT2D_OK;
@@ -763,20 +912,70 @@ int ndt2d_score_poses(ndt2d_handle h, const double * h_poses_xyt, size_t n_poses
     return fail(h, NDT2D_ERR_INVALID, "ndt2d_score_poses: bad argument");
   }
   if (!h->has_grid) return fail(h, NDT2D_ERR_NO_GRID, "ndt2d_score_poses: no grid");
+  if (h->n_beams == 0) return fail(h, NDT2D_ERR_STATE, "ndt2d_score_poses: set_beams first");
   NDT2D_HIP(h, hipSetDevice(h->device));
-  int rc = ensure(h, h->tmp_poses, 3 * n_poses);
-  if (rc != NDT2D_OK) return rc;
-  rc = ensure(h, h->tmp_scores, n_poses);
-  if (rc != NDT2D_OK) return rc;
+  int rc;
+
+  // A handful of poses (scorePoints / scoreScan: ONE pose): a block per pose and a
+  // thread per beam, poses as kernel arguments, scores written straight into
+  // host-coherent memory behind a flag the host spins on -- one launch, no copies.
+  if (h_stats == nullptr && n_poses <= ndt2d::kFewPoses && h->force_variant == ndt2d::kVariantAuto)
+  {
+    ndt2d::PosesArgs a{};
+    a.grid = h->grid;
+    a.beams_xy = h->beams_ptr;
+    a.n_beams = static_cast<uint32_t>(h->n_beams);
+    a.poses_xyt = nullptr;
+    a.n_poses = n_poses;
+    a.beam_rmax = h->beam_rmax;
+    if (ndt2d::score_few_supported(a, 64 * 1024))
+    {
+      if ((rc = ensure_host_res(h)) != NDT2D_OK) return rc;
+      a.scores = h->host_res_dev + kScoreSlot;
+      ndt2d::FewPoses few{};
+      std::memcpy(few.xyt, h_poses_xyt, 3 * n_poses * sizeof(double));
+      const unsigned long long seq = ++h->seq;
+      hipError_t e = ndt2d::launch_score_few(
+        a, &few, reinterpret_cast<unsigned long long *>(h->host_res_dev + kScoreFlagSlot), seq,
+        h->done_counter, h->stream);
+      if (e != hipSuccess) return fail_hip(h, e, "launch_score_few");
+      h->timed = false;
+      h->last_kernels = 1;
+      h->last_variant = h->grid.pow2 ? "poses/block-per-pose/pow2" : "poses/block-per-pose/div";
+      if ((rc = wait_host_flag(h, kScoreFlagSlot, seq)) != NDT2D_OK) return rc;
+      for (size_t i = 0; i < n_poses; ++i) h_scores[i] = h->host_res[kScoreSlot + i];
+      return NDT2D_OK;
+    }
+  }
+
   rc = ensure(h, h->stats, NDT2D_POSE_STATS_DOUBLES);
   if (rc != NDT2D_OK) return rc;
-  NDT2D_HIP(h, hipMemcpyAsync(h->tmp_poses.ptr, h_poses_xyt, 3 * n_poses * sizeof(double),
-                              hipMemcpyHostToDevice, h->stream));
-  rc = ndt2d_score_poses_launch(h, h->tmp_poses.ptr, n_poses, h->tmp_scores.ptr,
-                                h_stats != nullptr ? h->stats.ptr : nullptr);
+  // Pinned host memory (ndt2d_host_alloc) is addressed by the kernels directly: the
+  // poses are read over PCIe once, the scores written once, no copy is queued.
+  const double * d_poses = device_view(h_poses_xyt);
+  double * d_scores = device_view(h_scores);
+  if (d_poses == nullptr)
+  {
+    rc = ensure(h, h->tmp_poses, 3 * n_poses);
+    if (rc != NDT2D_OK) return rc;
+    NDT2D_HIP(h, hipMemcpyAsync(h->tmp_poses.ptr, h_poses_xyt, 3 * n_poses * sizeof(double),
+                                hipMemcpyHostToDevice, h->stream));
+    d_poses = h->tmp_poses.ptr;
+  }
+  const bool copy_scores = d_scores == nullptr;
+  if (copy_scores)
+  {
+    rc = ensure(h, h->tmp_scores, n_poses);
+    if (rc != NDT2D_OK) return rc;
+    d_scores = h->tmp_scores.ptr;
+  }
+  rc = ndt2d_score_poses_launch(h, d_poses, n_poses, d_scores, h_stats != nullptr ? h->stats.ptr : nullptr);
   if (rc != NDT2D_OK) return rc;
-  NDT2D_HIP(h, hipMemcpyAsync(h_scores, h->tmp_scores.ptr, n_poses * sizeof(double),
-                              hipMemcpyDeviceToHost, h->stream));
+  if (copy_scores)
+  {
+    NDT2D_HIP(h, hipMemcpyAsync(h_scores, d_scores, n_poses * sizeof(double), hipMemcpyDeviceToHost,
+                                h->stream));
+  }
   if (h_stats != nullptr)
   {
     NDT2D_HIP(h, hipMemcpyAsync(h_stats, h->stats.ptr, NDT2D_POSE_STATS_DOUBLES * sizeof(double),
@@ -1087,6 +1286,7 @@ int ndt2d_set_beams_from_ranges(ndt2d_handle h, const float * h_ranges, size_t n
   if (use > 0)
   {
     h->n_beams = use;
+    h->beams_ptr = h->beams.ptr;
     h->beam_rmax = info[2];
   }
   return NDT2D_OK;
@@ -1261,6 +1461,34 @@ int ndt2d_copy_to_host(ndt2d_handle h, void * h_dst, const void * d_src, size_t 
   return NDT2D_OK;
 }
 
+int ndt2d_set_timing(ndt2d_handle h, int enabled)
+{
+  if (h == nullptr) return NDT2D_ERR_INVALID;
+  h->timing = enabled != 0;
+  if (!h->timing) h->timed = false;
+  return NDT2D_OK;
+}
+
+int ndt2d_host_alloc(ndt2d_handle h, size_t bytes, void ** out)
+{
+  if (h == nullptr || out == nullptr) return NDT2D_ERR_INVALID;
+  *out = nullptr;
+  if (bytes == 0) return fail(h, NDT2D_ERR_INVALID, "ndt2d_host_alloc: zero size");
+  NDT2D_HIP(h, hipSetDevice(h->device));
+  NDT2D_HIP(h, hipHostMalloc(out, bytes, hipHostMallocMapped | hipHostMallocPortable));
+  return NDT2D_OK;
+}
+
+int ndt2d_host_free(ndt2d_handle h, void * ptr)
+{
+  if (h == nullptr) return NDT2D_ERR_INVALID;
+  if (ptr == nullptr) return NDT2D_OK;
+  NDT2D_HIP(h, hipSetDevice(h->device));
+  NDT2D_HIP(h, hipStreamSynchronize(h->stream));  // nothing in flight may still use it
+  NDT2D_HIP(h, hipHostFree(ptr));
+  return NDT2D_OK;
+}
+
 int ndt2d_synchronize(ndt2d_handle h)
 {
   if (h == nullptr) return NDT2D_ERR_INVALID;
@@ -1311,6 +1539,8 @@ int ndt2d_set_variant(ndt2d_handle h, const char * name)
   else if (std::strcmp(name, "wave-global") == 0) h->force_variant = ndt2d::kVariantWave | ndt2d::kVariantGlobal;
   else if (std::strcmp(name, "lane") == 0) h->force_variant = ndt2d::kVariantLane;
   else if (std::strcmp(name, "lane-noskip") == 0) h->force_variant = ndt2d::kVariantLane | ndt2d::kVariantNoSkip;
+  else if (std::strcmp(name, "small") == 0) h->force_variant = ndt2d::kVariantSmall;
+  else if (std::strcmp(name, "small-noskip") == 0) h->force_variant = ndt2d::kVariantSmall | ndt2d::kVariantNoSkip;
   else if (std::strcmp(name, "dense") == 0) h->force_variant = ndt2d::kVariantDense;
   else if (std::strcmp(name, "compact-exact") == 0) h->force_variant = ndt2d::kVariantNoSkip;
   else return fail(h, NDT2D_ERR_INVALID, "ndt2d_set_variant: unknown variant");

@@ -237,11 +237,12 @@ std::vector<double> search_offsets(double size, double res)
 }
 
 // Subsampling of matchScan / scorePoints, reference src/scan_matcher_ndt.cpp:95-96,110.
-std::vector<double> subsample(const double * pts, size_t n_points, size_t laser_max_beams)
+void subsample_into(std::vector<double> & out, const double * pts, size_t n_points,
+                    size_t laser_max_beams)
 {
   const size_t use = std::min(laser_max_beams, n_points);
-  std::vector<double> out(2 * use);
-  if (use == 0) return out;
+  out.resize(2 * use);
+  if (use == 0) return;
   const double scan_step = static_cast<double>(n_points) / use;
   for (size_t i = 0; i < use; ++i)
   {
@@ -249,7 +250,6 @@ std::vector<double> subsample(const double * pts, size_t n_points, size_t laser_
     out[2 * i] = pts[2 * idx];
     out[2 * i + 1] = pts[2 * idx + 1];
   }
-  return out;
 }
 
 // ROS angles::normalize_angle / shortest_angular_distance (unpinned dependency
@@ -279,6 +279,13 @@ struct ndt2d_matcher
   std::vector<double> beams, dth, dlin;
   size_t n_use = 0;               // beams in use (the N of `best / N`, :148)
   bool search_ready = false;
+  // `beams` is what the device context currently holds as its beams: a scoring call
+  // that arrives with the same points again (the unchanged ParticleFilter::measure
+  // calls scorePoints once per particle with one scan, src/particle_filter.cpp:81-87;
+  // the mapper calls scoreScan and matchScan on one scan, src/ndt_mapper.cpp:514-515)
+  // skips the upload.  The matcher must be the only writer of its context's beams.
+  bool beams_on_device = false;
+  std::vector<double> scratch_beams, cos_th, sin_th;
 };
 
 namespace
@@ -296,9 +303,11 @@ int dev_fail(ndt2d_matcher * m, int code, const char * what)
 }
 
 // The visited offsets of the search and the per-theta cos/sin (reference
-// src/scan_matcher_ndt.cpp:103-107,117,119), uploaded once the beams are on the device.
-int prepare_tables(ndt2d_matcher * m, const double * scan_pose_xyt, size_t use, size_t * n_th_out,
-                   size_t * n_lin_out)
+// src/scan_matcher_ndt.cpp:103-107,117,119).  host_beams != nullptr: they are uploaded
+// together with the beams in one copy; nullptr: the beams are on the device already
+// (LaserScan conversion) and only the tables travel.
+int prepare_tables(ndt2d_matcher * m, const double * scan_pose_xyt, size_t use,
+                   const double * host_beams, size_t * n_th_out, size_t * n_lin_out)
 {
   m->dth = search_offsets(m->angular_size, m->angular_res);
   m->dlin = search_offsets(m->linear_size, m->linear_res);
@@ -308,16 +317,51 @@ int prepare_tables(ndt2d_matcher * m, const double * scan_pose_xyt, size_t use, 
   m->search_ready = false;
   if (use == 0 || n_th == 0 || n_lin == 0 || !m->have_ndt) return NDT2D_OK;  // nothing to upload
 
-  std::vector<double> cos_th(n_th), sin_th(n_th);
+  m->cos_th.resize(n_th);
+  m->sin_th.resize(n_th);
   for (size_t i = 0; i < n_th; ++i)
   {
     // reference src/scan_matcher_ndt.cpp:106-107
-    ndt2d_cos_sin(scan_pose_xyt[2] + m->dth[i], &cos_th[i], &sin_th[i]);
+    ndt2d_cos_sin(scan_pose_xyt[2] + m->dth[i], &m->cos_th[i], &m->sin_th[i]);
   }
-  int rc = ndt2d_set_search(m->dev, scan_pose_xyt[0], scan_pose_xyt[1], m->dth.data(), cos_th.data(),
-                            sin_th.data(), n_th, m->dlin.data(), n_lin);
-  if (rc != NDT2D_OK) return dev_fail(m, rc, "ndt2d_set_search");
+  int rc;
+  if (host_beams != nullptr)
+  {
+    rc = ndt2d_set_search_beams(m->dev, host_beams, use, scan_pose_xyt[0], scan_pose_xyt[1],
+                                m->dth.data(), m->cos_th.data(), m->sin_th.data(), n_th,
+                                m->dlin.data(), n_lin);
+    if (rc != NDT2D_OK) return dev_fail(m, rc, "ndt2d_set_search_beams");
+    m->beams_on_device = true;
+  }
+  else
+  {
+    rc = ndt2d_set_search(m->dev, scan_pose_xyt[0], scan_pose_xyt[1], m->dth.data(),
+                          m->cos_th.data(), m->sin_th.data(), n_th, m->dlin.data(), n_lin);
+    if (rc != NDT2D_OK) return dev_fail(m, rc, "ndt2d_set_search");
+  }
   m->search_ready = true;
+  return NDT2D_OK;
+}
+
+// Subsample `points` (src/scan_matcher_ndt.cpp:165-166,171) and make them the device
+// context's beams -- unless they are exactly what it holds already.  *use_out = beams.
+int stage_beams(ndt2d_matcher * m, const double * points_xy, size_t n_points, size_t * use_out)
+{
+  subsample_into(m->scratch_beams, points_xy, n_points, m->laser_max_beams);
+  const size_t use = m->scratch_beams.size() / 2;
+  *use_out = use;
+  if (use == 0) return NDT2D_OK;
+  if (m->beams_on_device && m->beams.size() == m->scratch_beams.size() &&
+      std::memcmp(m->beams.data(), m->scratch_beams.data(), m->beams.size() * sizeof(double)) == 0)
+  {
+    return NDT2D_OK;   // same scan as the last call: the beams are there
+  }
+  m->search_ready = false;  // the device beams are replaced: a prepared search is void
+  m->beams_on_device = false;
+  int rc = ndt2d_set_beams(m->dev, m->scratch_beams.data(), use);
+  if (rc != NDT2D_OK) return dev_fail(m, rc, "ndt2d_set_beams");
+  m->beams.swap(m->scratch_beams);
+  m->beams_on_device = true;
   return NDT2D_OK;
 }
 
@@ -456,17 +500,13 @@ int ndt2d_matcher_prepare_search(ndt2d_matcher * m, const double * scan_pose_xyt
 {
   if (m == nullptr || scan_pose_xyt == nullptr) return NDT2D_ERR_INVALID;
   if (n_points > 0 && points_xy == nullptr) return mfail(m, NDT2D_ERR_INVALID, "null points");
-  m->beams = subsample(points_xy, n_points, m->laser_max_beams);
+  subsample_into(m->beams, points_xy, n_points, m->laser_max_beams);
   const size_t use = m->beams.size() / 2;
   m->n_use = use;
   if (n_beams_out != nullptr) *n_beams_out = use;
   m->search_ready = false;
-  if (use > 0 && m->have_ndt)
-  {
-    int rc = ndt2d_set_beams(m->dev, m->beams.data(), use);
-    if (rc != NDT2D_OK) return dev_fail(m, rc, "ndt2d_set_beams");
-  }
-  return prepare_tables(m, scan_pose_xyt, use, n_th_out, n_lin_out);
+  m->beams_on_device = false;
+  return prepare_tables(m, scan_pose_xyt, use, m->beams.data(), n_th_out, n_lin_out);
 }
 
 int ndt2d_matcher_finish_match(ndt2d_matcher * m, const double * record, double * pose_inout,
@@ -609,9 +649,10 @@ int ndt2d_matcher_match_laser_scan(ndt2d_matcher * m, const double * scan_pose_x
   if (rc != NDT2D_OK) return dev_fail(m, rc, "ndt2d_set_beams_from_ranges");
   if (n_points_out != nullptr) *n_points_out = n_points;
   m->beams.clear();
+  m->beams_on_device = false;   // the device holds beams the host has no copy of
   m->n_use = use;
   size_t n_th = 0, n_lin = 0;
-  rc = prepare_tables(m, scan_pose_xyt, use, &n_th, &n_lin);
+  rc = prepare_tables(m, scan_pose_xyt, use, nullptr, &n_th, &n_lin);
   if (rc != NDT2D_OK) return rc;
   double record[NDT2D_MATCH_RECORD_DOUBLES] = {0, -1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (m->search_ready)
@@ -641,17 +682,15 @@ int ndt2d_matcher_score_poses(ndt2d_matcher * m, const double * points_xy, size_
     return NDT2D_OK;
   }
   if (n_points > 0 && points_xy == nullptr) return mfail(m, NDT2D_ERR_INVALID, "null points");
-  const std::vector<double> beams = subsample(points_xy, n_points, m->laser_max_beams);
-  const size_t use = beams.size() / 2;
+  size_t use = 0;
+  int rc = stage_beams(m, points_xy, n_points, &use);
+  if (rc != NDT2D_OK) return rc;
   if (use == 0)
   {
     // score = 0.0 / 0 (:177)
     for (size_t i = 0; i < n_poses; ++i) scores_out[i] = std::numeric_limits<double>::quiet_NaN();
     return NDT2D_OK;
   }
-  m->search_ready = false;  // the device beams are replaced: a prepared search is void
-  int rc = ndt2d_set_beams(m->dev, beams.data(), use);
-  if (rc != NDT2D_OK) return dev_fail(m, rc, "ndt2d_set_beams");
   rc = ndt2d_score_poses(m->dev, poses_xyt, n_poses, scores_out, nullptr);
   if (rc != NDT2D_OK) return dev_fail(m, rc, "ndt2d_score_poses");
   return NDT2D_OK;
@@ -662,14 +701,10 @@ int ndt2d_matcher_prepare_beams(ndt2d_matcher * m, const double * points_xy, siz
 {
   if (m == nullptr) return NDT2D_ERR_INVALID;
   if (n_points > 0 && points_xy == nullptr) return mfail(m, NDT2D_ERR_INVALID, "null points");
-  m->beams = subsample(points_xy, n_points, m->laser_max_beams);
-  const size_t use = m->beams.size() / 2;
+  size_t use = 0;
+  int rc = stage_beams(m, points_xy, n_points, &use);
   if (n_beams_out != nullptr) *n_beams_out = use;
-  if (use == 0) return NDT2D_OK;
-  m->search_ready = false;  // the device beams are replaced: a prepared search is void
-  int rc = ndt2d_set_beams(m->dev, m->beams.data(), use);
-  if (rc != NDT2D_OK) return dev_fail(m, rc, "ndt2d_set_beams");
-  return NDT2D_OK;
+  return rc;
 }
 
 int ndt2d_matcher_score_points(ndt2d_matcher * m, const double * points_xy, size_t n_points,
@@ -700,10 +735,9 @@ int ndt2d_matcher_pf_measure(ndt2d_matcher * m, const double * particles_xyt,
     // weights_[i] = scorePoints(points, particle_i) (particle_filter.cpp:81-87), then
     // updateStatistics (:163-218), all on the device
     if (points_xy == nullptr) return mfail(m, NDT2D_ERR_INVALID, "null points");
-    const std::vector<double> beams = subsample(points_xy, n_points, m->laser_max_beams);
-    m->search_ready = false;  // the device beams are replaced: a prepared search is void
-    int rc = ndt2d_set_beams(m->dev, beams.data(), beams.size() / 2);
-    if (rc != NDT2D_OK) return dev_fail(m, rc, "ndt2d_set_beams");
+    size_t use = 0;
+    int rc = stage_beams(m, points_xy, n_points, &use);
+    if (rc != NDT2D_OK) return rc;
     double out[NDT2D_PF_RESULT_DOUBLES];
     rc = ndt2d_pf_measure(m->dev, particles_xyt, n_particles, weights_out, out);
     if (rc != NDT2D_OK) return dev_fail(m, rc, "ndt2d_pf_measure");

@@ -38,6 +38,9 @@ struct GridDesc
   const double * cells_lds_image;  // [ncell + 1][kCellDoubles], source of the LDS fill
   const double * cells_global;     // [ncell + 1][kCellStrideGlobal]
   const uint32_t * occ_bits;       // bit i = cell i holds a distribution; ncell + 1 bits (last = 0)
+  // [size_y + 2][size_x + 2] occupancy-map bytes of the grid extended by one cell on
+  // every side (ndt2d_build.hip, cell_bytes_kernel); may be null (no small-lattice search)
+  const uint8_t * cell_bytes;
   uint32_t size_x, size_y, ncell;
   double cell_size;
   double inv_cell_size;  // exact iff pow2
@@ -99,9 +102,18 @@ struct BuildArgs
   double * cells_lds_image;   // [ncell + 1][kCellDoubles] out
   double * cells_global;      // [ncell + 1][kCellStrideGlobal] out
   uint32_t * occ_bits;        // out
+  uint8_t * cell_bytes;       // out: [size_y + 2][size_x + 2]
 };
 size_t build_sort_temp_bytes(uint32_t n_points, uint32_t ncell);
 hipError_t launch_build_grid(const BuildArgs & args, hipStream_t stream);
+// The scorer layouts of a grid uploaded as cells6 records (ndt2d_set_grid): packed
+// records in both strides, occupancy bitmap, per-cell map bytes.  `geometry` carries
+// size / cell size / origin only.
+hipError_t launch_pack_grid(const GridDesc & geometry, const double * cells6,
+                            double * cells_lds_image, double * cells_global, uint32_t * occ_bits,
+                            uint8_t * cell_bytes, hipStream_t stream);
+hipError_t launch_grid_tail(const GridDesc & geometry, const double * cells_lds_image,
+                            uint32_t * occ_bits, uint8_t * cell_bytes, hipStream_t stream);
 
 struct LaunchInfo
 {
@@ -117,9 +129,14 @@ size_t match_workspace_doubles(const MatchArgs & args);
 // tiny final reduction, so the caller can time the dominant kernel alone.
 // outer (optional): scratch of match_lane_outer_doubles() doubles; without it the
 // lane-per-candidate mapping is not available.
+// host_record (optional, device-visible host-coherent memory): receives the record and
+// then, at host_record[kHostFlagSlot], `seq` as a 64-bit integer -- a host may spin on
+// it instead of synchronising the stream.
+constexpr int kHostFlagSlot = 16;
 hipError_t launch_match(const MatchArgs & args, double * workspace, double * outer,
-                        double * record_out, double * record_out2, int force_variant,
-                        hipStream_t stream, hipEvent_t ev_main_done, LaunchInfo * info);
+                        double * record_out, double * record_out2, double * host_record,
+                        unsigned long long seq, int force_variant, hipStream_t stream,
+                        hipEvent_t ev_main_done, LaunchInfo * info);
 
 size_t poses_workspace_doubles(uint64_t n_poses);
 hipError_t launch_score_poses(const PosesArgs & args, double * workspace, double * stats_out,
@@ -214,6 +231,14 @@ hipError_t launch_match_lane(const MatchArgs & args, double * outer, double * wo
                              uint32_t max_workers, int cus, size_t lds_per_block, bool no_skip,
                              hipStream_t stream, uint32_t * n_workers_out, bool * lds_records_out);
 
+// Small-lattice search (ndt2d_match_small.hip): a block per (theta, up to P patches),
+// its waves split the beams; needs grid.cell_bytes.  workspace receives one record per
+// (theta, patch) item, *n_records_out of them.
+bool match_small_supported(const MatchArgs & args, size_t lds_per_block);
+hipError_t launch_match_small(const MatchArgs & args, double * workspace, int cus,
+                              size_t lds_per_block, bool no_skip, hipStream_t stream,
+                              uint32_t * n_records_out);
+
 // Particle scoring with per-wave compaction of the occupied (pose, beam) pairs
 // (ndt2d_poses_compact.hip).
 bool poses_compact_supported(const PosesArgs & args, size_t lds_per_block);
@@ -222,9 +247,26 @@ bool poses_compact_supported(const PosesArgs & args, size_t lds_per_block);
 hipError_t launch_poses_compact(const PosesArgs & args, int cus, bool screen, hipStream_t stream,
                                 uint32_t * blocks_out);
 
+// Scoring of a handful of poses, a block per pose and a thread per beam
+// (ndt2d_poses_compact.hip, score_few_kernel); bit-identical to the batched kernel.
+constexpr uint32_t kFewPoses = 8;        // poses that travel as kernel arguments
+constexpr uint32_t kFewPosesMax = 64;    // poses this kernel is used for
+constexpr int kFewThreads = 256;
+struct FewPoses
+{
+  double xyt[3 * kFewPoses];
+};
+bool score_few_supported(const PosesArgs & args, size_t lds_per_block);
+// args.poses_xyt == nullptr: the poses are few->xyt.  flag / seq / done_counter: see
+// the kernel (flag may be null).
+hipError_t launch_score_few(const PosesArgs & args, const FewPoses * few,
+                            unsigned long long * flag, unsigned long long seq,
+                            uint32_t * done_counter, hipStream_t stream);
+
 // force_variant: grid placement in the low bits, candidate mapping above them
 enum { kVariantAuto = 0, kVariantLds = 1, kVariantGlobal = 2, kVariantGridMask = 3,
-       kVariantWave = 4, kVariantLane = 8, kVariantDense = 16, kVariantNoSkip = 32 };
+       kVariantWave = 4, kVariantLane = 8, kVariantDense = 16, kVariantNoSkip = 32,
+       kVariantSmall = 64 };
 // Work items of the lane-per-candidate search are handed out by kItemShards counters
 // (one address takes ~88 atomics/us; a launch issues up to tens of thousands), each in
 // a cache line of its own.
@@ -233,8 +275,12 @@ constexpr uint32_t kItemShardStride = 64;   // in uint32: 256 bytes
 // The lane-per-candidate search leaves one record per work item (theta x 8x8 patch);
 // lattices with more items than this (1.5 GB of records) take the wave mapping.
 constexpr uint64_t kMaxLaneItems = 1ull << 24;
-// launch_match: lattices with fewer candidates than this take the wave-per-candidate mapping
-constexpr uint64_t kWaveMappingBelow = 160000;
+// launch_match: lattices with fewer (theta, 8x8 patch) items than this take the
+// small-lattice search (beams split across the waves of a block); it can hold
+// kSmallMaxItems.  Above, the lane-per-candidate search; the wave-per-candidate mapping
+// serves what neither can (windows beyond 256 cells, > 2^24 items).
+constexpr uint64_t kSmallBelowItems = 4096;
+constexpr uint64_t kSmallMaxItems = 8192;
 
 }  // namespace ndt2d
 

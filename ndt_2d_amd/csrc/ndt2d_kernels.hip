@@ -187,7 +187,9 @@ __global__ void __launch_bounds__(kMatchThreads) match_kernel(const MatchArgs a)
 // `out`.
 __global__ void __launch_bounds__(256) match_reduce_kernel(const double * partials, uint32_t n,
                                                            uint32_t per_block, double * out,
-                                                           double * out2, int final)
+                                                           double * out2, int final,
+                                                           double * host_out,
+                                                           unsigned long long seq)
 {
   __shared__ double sh[256 * kRecord];
   const int t = threadIdx.x;
@@ -236,10 +238,21 @@ __global__ void __launch_bounds__(256) match_reduce_kernel(const double * partia
       if (t == 1 && !(sh[0] < 0.0)) val = -1.0;
       out[t] = val;
       if (out2 != nullptr) out2[t] = val;
+      if (host_out != nullptr) host_out[t] = val;
     }
     else
     {
       out[static_cast<size_t>(blockIdx.x) * kRecord + t] = val;
+    }
+  }
+  if (final && host_out != nullptr)
+  {
+    // the record has left for host memory before the flag does
+    __threadfence_system();
+    __syncthreads();
+    if (t == 0)
+    {
+      *reinterpret_cast<volatile unsigned long long *>(host_out + kHostFlagSlot) = seq;
     }
   }
 }
@@ -456,8 +469,9 @@ size_t match_workspace_doubles(const MatchArgs & args)
 }
 
 hipError_t launch_match(const MatchArgs & args_in, double * workspace, double * outer,
-                        double * record_out, double * record_out2, int force_variant,
-                        hipStream_t stream, hipEvent_t ev_main_done, LaunchInfo * info)
+                        double * record_out, double * record_out2, double * host_record,
+                        unsigned long long seq, int force_variant, hipStream_t stream,
+                        hipEvent_t ev_main_done, LaunchInfo * info)
 {
   MatchArgs args = args_in;
   if (args.n_beams == 0) return hipErrorInvalidValue;
@@ -473,26 +487,44 @@ hipError_t launch_match(const MatchArgs & args_in, double * workspace, double * 
   if (force_grid == kVariantGlobal) use_lds = false;
   if (force_grid == kVariantLds && !use_lds) return hipErrorInvalidValue;
 
-  // Candidate mapping: lane-per-candidate (8 x 8 patch per wave, occupancy
-  // early-out) whenever its LDS image fits, else wave-per-candidate.
+  // Candidate mapping.  Lane-per-candidate (an 8 x 8 patch of translations per wave,
+  // occupancy-map look-up, bit-exact skipping) whenever its LDS image fits: the
+  // small-lattice form (a block per theta step and up to P patches, beams split across
+  // its waves, no pre-kernel) below kSmallBelowItems work items, the persistent
+  // large-lattice form above.  Otherwise wave-per-candidate.
+  // (the choice follows the whole lattice, so every shard of a search makes the same one
+  // and a candidate's score has the same bits whichever rank evaluates it)
+  const uint64_t p1 = (args.n_lin + 7) / 8;
+  const uint64_t items = static_cast<uint64_t>(args.n_th) * p1 * p1;
   bool use_lane = outer != nullptr && force_grid != kVariantGlobal &&
                   match_lane_supported(args, lim.lds_per_block);
-  if (force_variant & kVariantWave) use_lane = false;
-  // A small lattice gives the lane mapping fewer work items (theta x 8x8 patches) than
-  // the chip has SIMDs, and each of them walks all the beams one after the other: its
-  // time is then n_beams x ~0.36 us whatever the lattice.  The wave mapping spreads the
-  // beams over the lanes and takes candidates x beams / 5e11 s, which is less below
-  // ~180 k candidates (experiments/small_search_sweep.py: the plugin's default search,
-  // 35,280 candidates x 100 beams, 21 us instead of 51 us).
-  const uint64_t candidates =
-    static_cast<uint64_t>(args.th_end - args.th_begin) * args.n_lin * args.n_lin;
-  if (!(force_variant & kVariantLane) && candidates < kWaveMappingBelow) use_lane = false;
-  if ((force_variant & kVariantLane) && !use_lane) return hipErrorInvalidValue;
+  bool use_small = force_grid == kVariantAuto && match_small_supported(args, lim.lds_per_block);
+  if (force_variant & kVariantWave) use_lane = use_small = false;
+  if (force_variant & kVariantSmall)
+  {
+    if (!use_small) return hipErrorInvalidValue;
+    use_lane = false;
+  }
+  else if (force_variant & kVariantLane)
+  {
+    if (!use_lane) return hipErrorInvalidValue;
+    use_small = false;
+  }
+  else if (use_small && use_lane)
+  {
+    if (items < kSmallBelowItems) use_lane = false; else use_small = false;
+  }
 
   hipError_t e;
   uint32_t n_workers = 0;
   bool lane_lds_records = true;
-  if (use_lane)
+  if (use_small)
+  {
+    e = launch_match_small(args, workspace, lim.cus, lim.lds_per_block,
+                           (force_variant & kVariantNoSkip) != 0, stream, &n_workers);
+    if (e != hipSuccess) return e;
+  }
+  else if (use_lane)
   {
     e = launch_match_lane(args, outer, workspace, kMaxMatchBlocks * kMatchWaves, lim.cus,
                           lim.lds_per_block, (force_variant & kVariantNoSkip) != 0, stream,
@@ -547,18 +579,25 @@ hipError_t launch_match(const MatchArgs & args_in, double * workspace, double * 
     const uint32_t per_block = (n_workers + 255) / 256;
     const uint32_t stage_blocks = (n_workers + per_block - 1) / per_block;
     hipLaunchKernelGGL(match_reduce_kernel, dim3(stage_blocks), dim3(256), 0, stream, records,
-                       n_workers, per_block, staged, static_cast<double *>(nullptr), 0);
+                       n_workers, per_block, staged, static_cast<double *>(nullptr), 0,
+                       static_cast<double *>(nullptr), 0ull);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     records = staged;
     n_workers = stage_blocks;
   }
   hipLaunchKernelGGL(match_reduce_kernel, dim3(1), dim3(256), 0, stream, records, n_workers,
-                     n_workers, record_out, record_out2, 1);
+                     n_workers, record_out, record_out2, 1, host_record, seq);
   e = hipGetLastError();
   if (info != nullptr)
   {
-    if (use_lane)
+    if (use_small)
+    {
+      info->variant = pow2 ? "match/lane-per-candidate/small-lattice/pow2"
+                           : "match/lane-per-candidate/small-lattice/div";
+      info->n_kernels = 2;
+    }
+    else if (use_lane)
     {
       info->variant = lane_lds_records ? (pow2 ? "match/lane-per-candidate/lds-grid/pow2"
                                                : "match/lane-per-candidate/lds-grid/div")

@@ -42,7 +42,7 @@
 
 #include <type_traits>
 
-#include "ndt2d_device_fn.h"
+#include "ndt2d_lane_fn.h"
 
 namespace ndt2d
 {
@@ -53,77 +53,6 @@ namespace
 constexpr uint32_t kDynamicItemsFromBeams = 256;
 constexpr int kLaneThreads = 1024;       // large searches: one block per CU
 constexpr int kLaneThreadsSmall = 256;   // small searches: spread the few work items over more CUs
-constexpr int kPatch = 8;            // patch is kPatch x kPatch candidates = one wave
-constexpr int kUnroll = 8;  // beams per look-up group
-// map coordinates are 8.16 fixed point
-constexpr double kFracScale = 65536.0;
-constexpr int kMapStride = 256;      // map row stride in bytes = 2^8 cells
-constexpr int kMaxMapCells = 256;    // cell coordinate is one byte
-constexpr uint32_t kNearUnits = 4;   // guard band around cell boundaries, in 2^-16 cells
-// widening of a map sub-cell's box (fraction of a sub-cell) when its exponent bound
-// is taken: 16 x the rounding of the fixed-point coordinate that selects it
-constexpr double kBoxMargin = 1.0 / 1024.0;
-constexpr double kTwo24 = 16777216.0;
-constexpr double kTwo52 = 4503599627370496.0;
-constexpr double kNearBias = kNearUnits * (kTwo24 + 1.0);  // +kNearUnits on both packed fractions
-static_assert(kNearUnits == 4, "the near test masks bits 3..15 of the biased fractions");
-
-struct LaneGeom
-{
-  int32_t pad;     // border cells on every side of the window in the map
-  // The map is kept at 2^sub_log2 sub-cells per cell (as fine as the one-byte
-  // coordinate and LDS allow): the finer the sub-cell, the tighter its bound on the
-  // exponent, so fewer beams next to walls take the exact path.
-  int32_t sub_log2;
-  double unit_scale;  // fixed-point units per cell = 2^16 << sub_log2
-  int32_t map_h;   // ((win_h + 2 * pad) << sub_log2) rows of kMapStride bytes
-  // Window of grid cells the map covers: every point this search can produce
-  // (scan pose +- (longest beam + largest offset)) lies inside it or outside the
-  // grid.  For small grids it is the whole grid.
-  int32_t win_x0, win_y0, win_w, win_h;
-  double k_min, k_max_x, k_max_y;  // clamp of the per-beam fixed-point coordinate
-  int32_t no_skip;  // control mode: every beam takes the exact path
-};
-
-// Upper bound of Cell::score's exponent e(p) = q^T h q, q = p - mean (h = -0.5 *
-// information, packed record rec) over the box [x0, x1] x [y0, y1].  For a
-// negative definite h the form is concave: its maximum over the box is 0 at the
-// mean if the box holds it, else it lies on one of the four edges, where the
-// restriction is a concave parabola whose clamped vertex is found in closed form.
-// Anything else (NaN / degenerate information) returns +inf: no claim.  The slack
-// covers the rounding of this evaluation and of the reference's own.
-__device__ __forceinline__ double exponent_upper_bound(const double * rec, double x0, double x1,
-                                                       double y0, double y1)
-{
-  const double mx = rec[0], my = rec[1], h00 = rec[2], h01 = rec[3], h11 = rec[4];
-  if (!(h00 < 0.0 && h11 < 0.0 && h00 * h11 - h01 * h01 > 0.0)) return HUGE_VAL;
-  const double a0 = x0 - mx, a1 = x1 - mx, b0 = y0 - my, b1 = y1 - my;
-  double best;
-  if (a0 <= 0.0 && a1 >= 0.0 && b0 <= 0.0 && b1 >= 0.0)
-  {
-    best = 0.0;
-  }
-  else
-  {
-    best = -HUGE_VAL;
-    const double qa[2] = {a0, a1}, qb[2] = {b0, b1};
-#pragma unroll
-    for (int k = 0; k < 2; ++k)
-    {
-      // edge x = const: maximise over q1 in [b0, b1]
-      double q0 = qa[k];
-      double q1 = fmin(fmax(-h01 * q0 / h11, b0), b1);
-      best = fmax(best, h00 * q0 * q0 + 2.0 * h01 * q0 * q1 + h11 * q1 * q1);
-      // edge y = const: maximise over q0 in [a0, a1]
-      q1 = qb[k];
-      q0 = fmin(fmax(-h01 * q1 / h00, a0), a1);
-      best = fmax(best, h00 * q0 * q0 + 2.0 * h01 * q0 * q1 + h11 * q1 * q1);
-    }
-  }
-  const double am = fmax(fabs(a0), fabs(a1)), bm = fmax(fabs(b0), fabs(b1));
-  const double magnitude = fabs(h00) * am * am + 2.0 * fabs(h01) * am * bm + fabs(h11) * bm * bm;
-  return best + (1e-9 * magnitude + 1e-6);
-}
 
 // points_outer for the slab (reference :106-115) plus the packed fixed-point
 // map coordinate of each rotated beam:
@@ -141,7 +70,6 @@ __global__ void __launch_bounds__(256) outer_table_kernel(const MatchArgs a, dou
 {
   {
     const GridDesc & g = a.grid;
-    const int32_t sx = static_cast<int32_t>(g.size_x), sy = static_cast<int32_t>(g.size_y);
     const uint32_t n_map = static_cast<uint32_t>(kMapStride) * geo.map_h;
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_map; i += gridDim.x * 256)
     {
@@ -152,43 +80,9 @@ __global__ void __launch_bounds__(256) outer_table_kernel(const MatchArgs a, dou
       const int32_t mx = static_cast<int32_t>(i & (kMapStride - 1));
       const int32_t my = static_cast<int32_t>(i >> 8);
       const int32_t sub = 1 << geo.sub_log2;
-      const double sub_size = g.cell_size / static_cast<double>(sub);
       const int32_t cx = (mx >> geo.sub_log2) - geo.pad + geo.win_x0;
       const int32_t cy = (my >> geo.sub_log2) - geo.pad + geo.win_y0;
-      const int32_t lx = mx & (sub - 1), ly = my & (sub - 1);
-      const double x0 = g.origin_x + (static_cast<double>(cx) * sub + lx - kBoxMargin) * sub_size;
-      const double y0 = g.origin_y + (static_cast<double>(cy) * sub + ly - kBoxMargin) * sub_size;
-      const double x1 = x0 + (1.0 + 2.0 * kBoxMargin) * sub_size;
-      const double y1 = y0 + (1.0 + 2.0 * kBoxMargin) * sub_size;
-      uint32_t self = 0;
-      double bound = -HUGE_VAL;
-      for (int32_t b = (ly == 0 ? -1 : 0); b <= (ly == sub - 1 ? 1 : 0); ++b)
-      {
-        for (int32_t c = (lx == 0 ? -1 : 0); c <= (lx == sub - 1 ? 1 : 0); ++c)
-        {
-          const int32_t nx = cx + c, ny = cy + b;
-          if (nx >= 0 && nx < sx && ny >= 0 && ny < sy)
-          {
-            const uint32_t cell = static_cast<uint32_t>(ny * sx + nx);
-            const uint32_t o = (g.occ_bits[cell >> 5] >> (cell & 31u)) & 1u;
-            if (b == 0 && c == 0) self = o;
-            if (o != 0)
-            {
-              const double e = exponent_upper_bound(g.cells_lds_image + static_cast<size_t>(cell) * kCellDoubles,
-                                                    x0, x1, y0, y1);
-              bound = !(e <= bound) ? e : bound;   // NaN-propagating max
-            }
-          }
-        }
-      }
-      // level 0: no distribution can be hit from here; level l >= 1: every exponent
-      // reachable from this sub-cell is <= l - 63 (level 63: no claim)
-      uint32_t level = 0;
-      if (bound > -HUGE_VAL || bound != bound)
-      {
-        level = !(bound <= 0.0) ? 63u : (bound < -62.0 ? 1u : static_cast<uint32_t>(63 + static_cast<int32_t>(ceil(bound))));
-      }
-      map_out[i] = static_cast<uint8_t>(self | (level != 0 ? 2u : 0u) | (level << 2));
+      map_out[i] = sub_cell_byte(g, cx, cy, mx & (sub - 1), my & (sub - 1), geo.sub_log2);
     }
   }
 
@@ -215,150 +109,6 @@ __global__ void __launch_bounds__(256) outer_table_kernel(const MatchArgs a, dou
     o.z = kTwo52 + (rint(ky) * kTwo24 + rint(kx));
     o.w = 0.0;
     outer[i] = o;
-  }
-}
-
-struct LaneCtx
-{
-  uint32_t lds_cells_address;  // LDS byte address of the packed records (behind the map)
-  uint32_t sub_log2;           // map sub-cell -> map cell: shift right
-  // map cell (col, row) -> grid cell index: row * size_x + col - idx_bias,
-  // idx_bias = (pad - win_y0) * size_x + (pad - win_x0), modulo 2^32
-  uint32_t idx_bias;
-  uint32_t size_x;
-};
-
-// U consecutive beams of one patch; o[] holds their table rows, dxy the lane's
-// packed fixed-point offset.
-// The map sits at LDS address 0 (the kernel's only LDS is its dynamic block, whose
-// first bytes are the map; checked at kernel entry), so the packed cell bytes ARE
-// the address: reading through an absolute LDS pointer saves the per-beam
-// v_add_u32 of the array base that indexing a __shared__ array costs.
-__device__ __forceinline__ uint32_t lds_byte_at(uint32_t address)
-{
-  typedef const __attribute__((address_space(3))) uint8_t * lds_byte_ptr;
-  return *reinterpret_cast<lds_byte_ptr>(address);
-}
-
-// Cell::score's exponent against packed record idx of the LDS copy, addressed with
-// 32-bit LDS arithmetic (one v_mad_u32_u24; idx < 2^24 for any grid that fits LDS).
-__device__ __forceinline__ double lds_record_exponent(uint32_t cells_address, uint32_t idx,
-                                                      double px, double py)
-{
-  typedef const __attribute__((address_space(3), aligned(16))) double * lds_double_ptr;
-  const lds_double_ptr rec = reinterpret_cast<lds_double_ptr>(
-    __umul24(idx, static_cast<uint32_t>(kCellDoubles * sizeof(double))) + cells_address);
-  return record_exponent(rec[0], rec[1], rec[2], rec[3], rec[4], px, py);
-}
-
-// Per-lane skip state.  Terms whose exponent is below skip_below cannot change
-// the lane's sum (bit-exact skip); skip_level is the same threshold on the map's
-// scale, pre-shifted to the byte's layout: a map byte below it promises an
-// exponent below skip_below.  Both only ever rise with the sum, so they are
-// refreshed after a group of beams that added something, not per beam.
-struct SkipState
-{
-  double skip_below;
-  uint32_t skip_level;
-};
-
-__device__ __forceinline__ SkipState skip_state(double sum, int32_t no_skip)
-{
-  SkipState s;
-  if (no_skip)
-  {
-    s.skip_below = -HUGE_VAL;
-    s.skip_level = 0;
-    return s;
-  }
-  s.skip_below = negligible_below(sum);
-  // level l promises e <= l - 63; l <= ceil(T) + 62 then gives e <= ceil(T) - 1 < T
-  const int32_t l = static_cast<int32_t>(ceil(s.skip_below)) + 63;
-  s.skip_level = static_cast<uint32_t>(min(max(l, 1), 63)) << 2;
-  return s;
-}
-
-template <int U, bool POW2, bool LDS_RECORDS>
-__device__ __forceinline__ void lane_beams(const GridDesc & g, const LaneCtx & c,
-                                           const double4 (&o)[U], double dx, double dy,
-                                           double dxy, double & sum, SkipState & skip,
-                                           int32_t no_skip)
-{
-  const double skip_below = skip.skip_below;
-  const uint32_t skip_level = skip.skip_level;
-  uint32_t lo[U], hi[U], m[U];
-  uint32_t top = 0;
-#pragma unroll
-  for (int u = 0; u < U; ++u)
-  {
-    const double s = o[u].z + dxy;  // exact: integers below 2^53
-    lo[u] = static_cast<uint32_t>(__double2loint(s));
-    hi[u] = static_cast<uint32_t>(__double2hiint(s));
-    // byte 0 <- lo.byte2 (cell x), byte 1 <- hi.byte1 (cell y), bytes 2,3 <- 0
-    m[u] = lds_byte_at(__builtin_amdgcn_perm(hi[u], lo[u], 0x0c0c0502u));
-    top = max(top, m[u]);
-  }
-  if (wave_any(top >= skip_level))
-  {
-    bool added = false;
-    // have the beams' end points on their way before the first exact evaluation needs
-    // them (left to itself the compiler loads each pair inside its own branch)
-#pragma unroll
-    for (int u = 0; u < U; ++u) asm volatile("" : : "s"(o[u].x), "s"(o[u].y));
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-    {
-      // Lanes below their level are negligible whatever cell they are in: they do
-      // not keep the wave on this path.  (If the wave stays for another lane, their
-      // term is still evaluated exactly -- and, being negligible, changes nothing.)
-      // The wave-level tests combine the compares' lane masks as 64-bit integers in
-      // scalar registers; a ballot of a combined bool would round-trip through a
-      // vector register.
-      const uint64_t live_mask = __builtin_amdgcn_ballot_w64(m[u] >= skip_level);
-      if (live_mask != 0ull)
-      {
-        // within kNearUnits of a unit boundary on either axis: one more exact f64 add
-        // biases both 16-bit fractions at once, then (frac + 4) mod 2^16 < 8 is
-        // "bits 3..15 clear"; the y fraction straddles the two words (bytes 3, 4)
-        const double sn = __hiloint2double(static_cast<int>(hi[u]), static_cast<int>(lo[u])) + kNearBias;
-        const uint32_t nlo = static_cast<uint32_t>(__double2loint(sn));
-        const uint32_t nhi = static_cast<uint32_t>(__double2hiint(sn));
-        const uint32_t tx = nlo & 0xfff8u;
-        const uint32_t ty = __builtin_amdgcn_perm(nhi, nlo, 0x0c0c0403u) & 0xfff8u;
-        const bool occ = (m[u] & 1u) != 0;
-        const uint64_t near_mask =
-          (__builtin_amdgcn_ballot_w64(min(tx, ty) == 0u) | (no_skip != 0 ? ~0ull : 0ull)) & live_mask;
-        const uint64_t occ_mask = __builtin_amdgcn_ballot_w64(occ) & live_mask;
-        if ((occ_mask | near_mask) != 0ull)
-        {
-          // points_inner (:121-125) and Cell::score, exact
-          const double px = o[u].x + dx;
-          const double py = o[u].y + dy;
-          uint32_t idx;
-          if (near_mask != 0ull)
-          {
-            idx = cell_index<POW2>(g, px, py);
-          }
-          else
-          {
-            // interior of a cell: the look-up cell is the reference's cell,
-            // row * size_x + column with the window's offset folded into idx_bias
-            const uint32_t col = ((lo[u] >> 16) & 0xffu) >> c.sub_log2;
-            const uint32_t row = ((hi[u] >> 8) & 0xffu) >> c.sub_log2;
-            idx = occ ? __umul24(row, c.size_x) + (col - c.idx_bias) : g.ncell;
-          }
-          const double e = LDS_RECORDS ? lds_record_exponent(c.lds_cells_address, idx, px, py)
-                                       : indexed_exponent<false>(g, nullptr, idx, px, py);
-          // !(e < bound) also keeps NaN exponents (degenerate cells) on the exact path
-          if (wave_any(!(e < skip_below)))
-          {
-            sum += exp_score(e);
-            added = true;
-          }
-        }
-      }
-    }
-    if (added) skip = skip_state(sum, no_skip);
   }
 }
 
@@ -530,73 +280,6 @@ __global__ void __launch_bounds__(THREADS) match_lane_kernel(
       for (int k = 0; k < 10; ++k) out[2 + k] = acc[k];
     }
   }
-}
-
-// Window of grid cells [lo, hi] reachable along one axis, clipped to the grid.
-bool axis_window(double pose, double reach, double origin, double inv_cell, uint32_t size,
-                 int32_t * lo, int32_t * n)
-{
-  const double a = std::floor((pose - reach - origin) * inv_cell) - 1.0;
-  const double b = std::floor((pose + reach - origin) * inv_cell) + 1.0;
-  if (!(a == a) || !(b == b)) return false;  // NaN
-  double lo_c = a < 0.0 ? 0.0 : a;
-  double hi_c = b > static_cast<double>(size) - 1.0 ? static_cast<double>(size) - 1.0 : b;
-  if (lo_c > hi_c)
-  {
-    // nothing of the grid is reachable: any one-cell window will do
-    lo_c = hi_c = (a < 0.0 ? 0.0 : static_cast<double>(size) - 1.0);
-  }
-  *lo = static_cast<int32_t>(lo_c);
-  *n = static_cast<int32_t>(hi_c - lo_c) + 1;
-  return true;
-}
-
-// Map geometry for a search; false if the byte-per-axis cell coordinate cannot
-// hold the padded window.
-bool lane_geometry(const MatchArgs & args, size_t lds_per_block, LaneGeom * geo, size_t * map_bytes)
-{
-  const double lin_cells = args.dlin_absmax * args.grid.inv_cell_size;
-  if (!(lin_cells >= 0.0) || lin_cells > kMaxMapCells) return false;
-  if (!(args.beam_rmax >= 0.0) || !std::isfinite(args.beam_rmax)) return false;
-  const int32_t pad = static_cast<int32_t>(2.0 * lin_cells) + 3;
-  // points_inner = R * beam + pose + (dx, dy): within beam_rmax + |d|max of the pose per axis
-  const double reach = args.beam_rmax + args.dlin_absmax;
-  if (!axis_window(args.pose_x, reach, args.grid.origin_x, args.grid.inv_cell_size,
-                   args.grid.size_x, &geo->win_x0, &geo->win_w) ||
-      !axis_window(args.pose_y, reach, args.grid.origin_y, args.grid.inv_cell_size,
-                   args.grid.size_y, &geo->win_y0, &geo->win_h))
-  {
-    return false;
-  }
-  const uint64_t need_w = static_cast<uint64_t>(geo->win_w) + 2 * pad;
-  const uint64_t need_h = static_cast<uint64_t>(geo->win_h) + 2 * pad;
-  if (need_w > kMaxMapCells || need_h > kMaxMapCells) return false;
-  geo->pad = pad;
-  // finest sub-cell resolution whose coordinates fit one byte and whose map leaves
-  // room in LDS for the cell records whenever the coarsest map would
-  const size_t grid_bytes = static_cast<size_t>(args.grid.ncell + 1) * kCellDoubles * sizeof(double);
-  const bool records_fit = grid_bytes + kMapStride * need_h <= lds_per_block;
-  // (a small search does not repay copying a 16x larger map into every block)
-  const uint64_t p1 = (args.n_lin + kPatch - 1) / kPatch;
-  const bool small_search = static_cast<uint64_t>(args.th_end - args.th_begin) * p1 * p1 < 4096;
-  int sub_log2 = small_search ? 0 : 2;
-  for (; sub_log2 > 0; --sub_log2)
-  {
-    const uint64_t w = need_w << sub_log2, h = need_h << sub_log2;
-    if (w > kMaxMapCells || h > kMaxMapCells) continue;
-    const size_t bytes = static_cast<size_t>(kMapStride) * h + (records_fit ? grid_bytes : 0);
-    if (bytes <= lds_per_block) break;
-  }
-  geo->sub_log2 = sub_log2;
-  geo->unit_scale = kFracScale * static_cast<double>(1 << sub_log2);
-  geo->map_h = static_cast<int32_t>(need_h << sub_log2);
-  // lanes add |d| <= lin_cells * unit_scale (+0.5 rounding); one cell of margin each side
-  const double reach_units = (lin_cells + 1.0) * geo->unit_scale;
-  geo->k_min = reach_units;
-  geo->k_max_x = static_cast<double>(need_w - 1) * geo->unit_scale - reach_units;
-  geo->k_max_y = static_cast<double>(need_h - 1) * geo->unit_scale - reach_units;
-  *map_bytes = static_cast<size_t>(kMapStride) * geo->map_h;
-  return true;
 }
 
 bool lane_records_in_lds(const MatchArgs & args, size_t map_bytes, size_t lds_per_block)

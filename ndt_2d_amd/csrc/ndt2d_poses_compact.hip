@@ -452,6 +452,75 @@ score_poses_compact_kernel(const PosesArgs a, const uint32_t split)
   }
 }
 
+// A handful of poses -- ScanMatcherNDT::scorePoints / scoreScan called for ONE pose
+// (reference src/scan_matcher_ndt.cpp:151-178; the unchanged ParticleFilter::measure
+// calls it once per particle, src/particle_filter.cpp:81-87): one block per pose, a
+// thread per beam, so the call costs a launch and a few microseconds instead of a
+// lane walking all the beams.  The terms are then added in the order the batched
+// kernel above adds them -- chunk sums c_j in beam order, ((c_0 + c_1) + c_2) + ... --
+// so scorePoints(points, pose) == scorePoses(points, [pose])[0] bit for bit.
+// poses: device array, or (poses == nullptr) the values in `few` (kernel arguments:
+// no upload for up to kFewPoses poses).  flag (optional, host-coherent memory):
+// receives `seq` once every score is written, for a host that spins instead of
+// synchronising the stream.
+template <bool POW2>
+__global__ void __launch_bounds__(kFewThreads) score_few_kernel(const PosesArgs a, const FewPoses few,
+                                                                unsigned long long * flag,
+                                                                unsigned long long seq,
+                                                                uint32_t * done_counter)
+{
+  extern __shared__ __align__(16) double lds[];
+  double * terms = lds;                         // [n_beams]
+  double * chunk_sums = lds + a.n_beams;        // [kChunks]
+  const GridDesc & g = a.grid;
+  const uint32_t i = blockIdx.x;
+  const double * pose = a.poses_xyt != nullptr ? a.poses_xyt + 3 * static_cast<size_t>(i) : few.xyt + 3 * i;
+  const double x = pose[0], y = pose[1], th = pose[2];
+  // toEigen(pose): AngleAxisd(theta, Z) -> [[c,-s],[s,c]] (conversions.hpp:64-68)
+  double s, c;
+  sincos(th, &s, &c);
+  for (uint32_t k = threadIdx.x; k < a.n_beams; k += kFewThreads)
+  {
+    const double2 p = reinterpret_cast<const double2 *>(a.beams_xy)[k];
+    // p = t * (x, y, 1) (:172-173)
+    const double px = x + (c * p.x - s * p.y);
+    const double py = y + (s * p.x + c * p.y);
+    const double e = indexed_exponent<false>(g, nullptr, cell_index<POW2>(g, px, py), px, py);
+    terms[k] = exp_score(e);
+  }
+  __syncthreads();
+  const uint32_t chunk_len = (a.n_beams + kChunks - 1) / kChunks;
+  if (threadIdx.x < kChunks)
+  {
+    const uint32_t k0 = min(threadIdx.x * chunk_len, a.n_beams);
+    const uint32_t k1 = min(k0 + chunk_len, a.n_beams);
+    double csum = 0.0;
+    for (uint32_t k = k0; k < k1; ++k) csum += terms[k];
+    chunk_sums[threadIdx.x] = csum;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    double sum = chunk_sums[0];
+#pragma unroll
+    for (int j = 1; j < kChunks; ++j) sum += chunk_sums[j];
+    // score = sum of (-likelihood) / n  ==  -(sum) / n (:175-177)
+    a.scores[i] = -sum / static_cast<double>(a.n_beams);
+    if (flag != nullptr)
+    {
+      // the last block to finish publishes: scores first, then the flag
+      __threadfence_system();
+      const uint32_t arrived = atomicAdd(done_counter, 1u) + 1u;
+      if (arrived == gridDim.x)
+      {
+        *done_counter = 0u;
+        __threadfence_system();
+        *reinterpret_cast<volatile unsigned long long *>(flag) = seq;
+      }
+    }
+  }
+}
+
 size_t compact_lds_bytes(const PosesArgs & args, int threads, uint32_t split)
 {
   const size_t fixed = threads == 1024 ? CompactLayout<1024>::kFixedDoubles
@@ -504,6 +573,34 @@ hipError_t launch_compact(const PosesArgs & args, uint32_t blocks, uint32_t spli
 }
 
 }  // namespace
+
+bool score_few_supported(const PosesArgs & args, size_t lds_per_block)
+{
+  return args.n_poses <= kFewPosesMax &&
+         (static_cast<size_t>(args.n_beams) + kChunks) * sizeof(double) <= lds_per_block;
+}
+
+hipError_t launch_score_few(const PosesArgs & args, const FewPoses * few,
+                            unsigned long long * flag, unsigned long long seq,
+                            uint32_t * done_counter, hipStream_t stream)
+{
+  static const FewPoses none = {};
+  const size_t lds_bytes = (static_cast<size_t>(args.n_beams) + kChunks) * sizeof(double);
+  auto launch = [&](auto kernel) -> hipError_t {
+    if (lds_bytes > 48 * 1024)
+    {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         static_cast<int>(lds_bytes));
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kernel, dim3(static_cast<uint32_t>(args.n_poses)), dim3(kFewThreads),
+                       lds_bytes, stream, args, few != nullptr ? *few : none, flag, seq,
+                       done_counter);
+    return hipGetLastError();
+  };
+  return args.grid.pow2 ? launch(score_few_kernel<true>) : launch(score_few_kernel<false>);
+}
 
 bool poses_compact_supported(const PosesArgs & args, size_t lds_per_block)
 {

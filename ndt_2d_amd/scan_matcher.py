@@ -81,8 +81,32 @@ class ScanMatcherNDT:
 
     def close(self):
         if getattr(self, "_m", None):
+            for ptr in getattr(self, "_pinned", []):
+                self._L.ndt2d_host_free(self.device_handle, ptr)
+            self._pinned = []
             self._L.ndt2d_matcher_destroy(self._m)
             self._m = None
+
+    def host_alloc(self, shape):
+        """float64 array in pinned, GPU-mapped host memory (ndt2d_host_alloc): the
+        host-pointer entry points read / write such buffers in place over PCIe instead
+        of staging and copying them.  Owned by the matcher (freed by close())."""
+        shape = (shape,) if np.isscalar(shape) else tuple(shape)
+        n = int(np.prod(shape))
+        ptr = C.c_void_p()
+        self._dev_check(self._L.ndt2d_host_alloc(self.device_handle, max(n, 1) * 8, C.byref(ptr)),
+                        "ndt2d_host_alloc")
+        if not hasattr(self, "_pinned"):
+            self._pinned = []
+        self._pinned.append(ptr)
+        buf = (C.c_double * max(n, 1)).from_address(ptr.value)
+        return np.ctypeslib.as_array(buf)[:n].reshape(shape)
+
+    def set_timing(self, enabled):
+        """HIP events around every launch (last_launch_ms) on / off; the pluginlib shim
+        runs with them off (~4.5 us per call)."""
+        self._dev_check(self._L.ndt2d_set_timing(self.device_handle, 1 if enabled else 0),
+                        "ndt2d_set_timing")
 
     def __del__(self):
         try:
@@ -216,11 +240,14 @@ class ScanMatcherNDT:
 
     # -- additive batched interface ------------------------------------------------
 
-    def scorePoses(self, points, poses):
-        """scores[i] == scorePoints(points, poses[i]), one launch."""
+    def scorePoses(self, points, poses, out=None):
+        """scores[i] == scorePoints(points, poses[i]), one launch.  `poses` / `out` from
+        host_alloc() are used in place by the kernel (no copies)."""
         pts = _f64(points, (-1, 2))
         ps = _f64(poses, (-1, 3))
-        out = np.zeros(len(ps), dtype=np.float64)
+        if out is None:
+            out = np.zeros(len(ps), dtype=np.float64)
+        assert out.dtype == np.float64 and out.flags.c_contiguous and out.size == len(ps)
         self._check(self._L.ndt2d_matcher_score_poses(self._m, dptr(pts), len(pts), dptr(ps),
                                                       len(ps), dptr(out)), "scorePoses")
         return out

@@ -62,20 +62,21 @@ def test_random_case(seed):
         gpu.set_build_mode(build)
         gpu.addScans(scans)
         assert np.array_equal(gpu.grid()[0], ref.ndt.cells6(), equal_nan=True), (seed, build)
-    lane_scores = None
-    for variant in ("lane", "lane-noskip", "wave", "wave-global"):
+    exact = {}
+    for variant in ("lane", "lane-noskip", "small", "small-noskip", "wave", "wave-global", "auto"):
         gpu.set_variant(variant)
         try:
             got = gpu.matchScan(scan_pose, query, want_scores=True)
         except Exception as e:
-            # the lane mapping may not apply (map window too large for byte coordinates)
-            assert variant.startswith("lane") and "launch_match" in str(e), (seed, variant, e)
+            # the lane mappings may not apply (map window too large for byte coordinates,
+            # more work items than the small-lattice form holds)
+            assert variant.startswith(("lane", "small")) and "launch_match" in str(e), (seed, variant, e)
             continue
-        if variant == "lane":
-            lane_scores = got["scores"]
-        elif variant == "lane-noskip":
-            # the skipping of the lane mapping never changes a bit
-            assert np.array_equal(got["scores"], lane_scores, equal_nan=True), seed
+        if variant in ("lane", "small"):
+            exact[variant] = got["scores"]
+        elif variant.endswith("-noskip"):
+            # the skipping of the lane mappings never changes a bit
+            assert np.array_equal(got["scores"], exact[variant[:-7]], equal_nan=True), (seed, variant)
         assert got["n_candidates"] == exp["n_candidates"], (seed, variant)
         assert np.array_equal(np.isnan(got["scores"]), np.isnan(exp["scores"])), (seed, variant)
         assert np.allclose(got["scores"], exp["scores"], rtol=0, atol=1e-9, equal_nan=True), (seed, variant)
@@ -90,6 +91,8 @@ def test_random_case(seed):
             assert np.allclose(got["covariance"], exp["covariance"], rtol=1e-7, atol=1e-12,
                                equal_nan=True), (seed, variant)
     gpu.set_variant("auto")
+    # a handful of poses take the block-per-pose kernel: bit-identical to the batch
+    few = gpu.scorePoses(query, poses[:5])
     w_by = {}
     for variant in ("auto", "compact-exact", "dense"):
         gpu.set_variant(variant)
@@ -98,4 +101,5 @@ def test_random_case(seed):
         assert np.allclose(w, w_exp, rtol=0, atol=1e-9, equal_nan=True), (seed, variant)
     # the FP32 screening of the particle kernel never changes a bit
     assert np.array_equal(w_by["auto"], w_by["compact-exact"], equal_nan=True), seed
+    assert np.array_equal(few, w_by["auto"][:5], equal_nan=True), seed
     gpu.set_variant("auto")

@@ -79,7 +79,7 @@ def test_cfg1_match_vs_oracle_and_golden(cfg1):
     assert np.array_equal(got["pose"], g["pose"])
     assert abs(got["score"] - float(g["score"])) < TOL_TIGHT
     assert np.allclose(got["covariance"], g["covariance"], rtol=1e-9, atol=0)
-    assert "lds-grid" in gpu.last_variant()
+    assert "small-lattice" in gpu.last_variant()
 
 
 def test_score_scan_and_score_points(cfg1):
@@ -203,6 +203,7 @@ def test_kernel_variants_agree(cfg1):
     got = {}
     try:
         for name, tag in [("lane", "lane-per-candidate/lds-grid"),
+                          ("small", "lane-per-candidate/small-lattice"),
                           ("wave-lds", "wave-per-candidate/lds-grid"),
                           ("wave-global", "wave-per-candidate/global-grid")]:
             gpu.set_variant(name)
@@ -217,6 +218,9 @@ def test_kernel_variants_agree(cfg1):
     d_wave = np.abs(got["wave-lds"]["scores"] - exp["scores"])
     assert d_lane.max() <= d_wave.max() + 1e-13
     assert d_lane.max() < 1e-12
+    # the small-lattice form adds in-order chunk sums in chunk order
+    assert np.abs(got["small"]["scores"] - exp["scores"]).max() < 1e-12
+    assert got["small"]["best_index"] == got["lane"]["best_index"] == exp["best_index"]
 
 
 @pytest.mark.parametrize("cfg,override", [
@@ -246,6 +250,101 @@ def test_lane_skipping_is_bit_exact(cfg, override):
     assert (fast["scores"] < 0).sum() > 100          # the search does hit the map
     exp = ref.matchScan(guess, pts, want_scores=True)
     _check_match(full, exp, min(720, len(pts)))
+
+
+@pytest.mark.parametrize("cfg,override", [
+    (1, {}),
+    (1, dict(laser_max_beams=100, search_linear_size=0.05, search_linear_resolution=0.005,
+             search_angular_size=0.1, search_angular_resolution=0.0025)),      # plugin defaults
+    (1, dict(laser_max_beams=7, search_linear_size=0.1, search_angular_size=0.02)),   # one short group
+    (1, dict(ndt_resolution=0.1, search_linear_size=0.3, search_angular_size=0.1)),
+    (1, dict(ndt_resolution=0.3, search_linear_size=0.2, search_angular_size=0.05)),  # true division
+    (3, dict(search_angular_size=0.05, search_linear_size=0.1)),            # windowed 201 x 201 map
+])
+def test_small_lattice_skipping_is_bit_exact(cfg, override):
+    """The small-lattice search (beams split across the waves of a block) with all
+    skipping disabled gives bit-identical candidate scores, and both give the oracle's
+    result; a second run gives the same bits (fixed-order combination of the chunks)."""
+    gpu, ref, _, guess, pts = _pair(cfg, **override)
+    try:
+        gpu.set_variant("small")
+        fast = gpu.matchScan(guess, pts, want_scores=True)
+        assert "small-lattice" in gpu.last_variant(), gpu.last_variant()
+        again = gpu.matchScan(guess, pts, want_scores=True)
+        gpu.set_variant("small-noskip")
+        full = gpu.matchScan(guess, pts, want_scores=True)
+    finally:
+        gpu.set_variant("auto")
+    assert np.array_equal(fast["scores"], full["scores"])
+    assert np.array_equal(fast["scores"], again["scores"])
+    assert fast["best_index"] == full["best_index"] and fast["score"] == full["score"]
+    assert np.array_equal(fast["covariance"], full["covariance"], equal_nan=True)
+    assert np.array_equal(fast["covariance"], again["covariance"], equal_nan=True)
+    exp = ref.matchScan(guess, pts, want_scores=True)
+    _check_match(fast, exp, min(gpu.params["laser_max_beams"], len(pts)))
+
+
+def test_timing_events_can_be_switched_off(cfg1):
+    """ndt2d_set_timing(0) (what the pluginlib shim does): same results, no event pair."""
+    gpu, _, _, guess, pts = cfg1
+    want = gpu.matchScan(guess, pts)
+    L = _capi.lib()
+    assert L.ndt2d_set_timing(gpu.device_handle, 0) == _capi.OK
+    try:
+        got = gpu.matchScan(guess, pts)
+        with pytest.raises(_capi.Ndt2dError):
+            gpu.last_launch_ms()
+    finally:
+        assert L.ndt2d_set_timing(gpu.device_handle, 1) == _capi.OK
+    assert got["best_index"] == want["best_index"] and got["score"] == want["score"]
+    assert np.array_equal(got["covariance"], want["covariance"])
+    gpu.matchScan(guess, pts)
+    assert gpu.last_launch_ms()[0] > 0.0
+
+
+def test_replaced_beams_void_a_prepared_search(cfg1):
+    """prepare_search(); a scoring call with ANOTHER scan; match_launch() must fail loudly
+    instead of searching with the wrong beams -- and with the SAME scan it must work (the
+    matcher recognises the beams it already holds and uploads nothing)."""
+    gpu, _, _, guess, pts = cfg1
+    n_th, _, _ = gpu.prepare_search(guess, pts)
+    gpu.match_launch(0, n_th)
+    want = gpu.match_fetch()
+    gpu.scorePoses(pts, np.array([[0.1, 0.0, 0.0], [0.0, 0.1, 0.2]]))   # same scan
+    gpu.match_launch(0, n_th)
+    assert np.array_equal(gpu.match_fetch(), want)
+    gpu.scorePoints(pts[::2], (0.0, 0.0, 0.0))                           # another scan
+    with pytest.raises(_capi.Ndt2dError):
+        gpu.match_launch(0, n_th)
+    gpu.prepare_search(guess, pts)
+    gpu.match_launch(0, n_th)
+    assert np.array_equal(gpu.match_fetch(), want)
+
+
+def test_few_poses_take_the_block_per_pose_kernel_bit_identically():
+    """scorePoints / scoreScan (ONE pose) and up to 8 poses run a block-per-pose kernel
+    whose sums are built in the batched kernel's order: bit-identical scores."""
+    gpu, ref, _, guess, pts = _pair(3)
+    parts = synth.particles(3, 256)
+    parts[:128, :2] = guess[:2] + parts[:128, :2] / 23.0 * 0.4
+    parts[:128, 2] = guess[2] + parts[:128, 2] / np.pi * 0.1
+    batch = gpu.scorePoses(pts, parts)
+    assert "compact" in gpu.last_variant()
+    assert (batch < 0).sum() > 100
+    for i in range(0, 256, 7):
+        assert gpu.scorePoints(pts, parts[i]) == batch[i]
+        assert "block-per-pose" in gpu.last_variant()
+    for n in (2, 5, 8):
+        assert np.array_equal(gpu.scorePoses(pts, parts[:n]), batch[:n])
+        assert "block-per-pose" in gpu.last_variant()
+    assert np.array_equal(gpu.scorePoses(pts, parts[:9]), batch[:9])
+    assert gpu.scoreScan(guess, pts) == gpu.scorePoses(pts, [guess])[0]
+    w_ref = O.pf_measure(ref, parts[:32], pts)
+    assert np.max(np.abs(batch[:32] - w_ref)) < TOL_TIGHT
+    # fewer beams than chunks, one beam
+    for sub in (pts[:5], pts[100:101]):
+        assert gpu.scorePoints(sub, parts[3]) == gpu.scorePoses(sub, parts[:16])[3]
+        assert abs(gpu.scorePoints(sub, parts[3]) - ref.scorePoints(sub, parts[3])) < TOL_TIGHT
 
 
 def test_launch_timing_history(cfg1):
@@ -472,9 +571,18 @@ def test_match_scan_on_a_large_map_uses_the_windowed_lane_kernel():
             _check_match(a, b, 720)
     finally:
         gpu.set_variant("auto")
-    # same search through the wave-per-candidate kernel (records gathered from HBM),
-    # which is what a lattice this small gets by default
+    # left to itself the library gives a lattice this small the small-lattice form of the
+    # lane mapping (window copied from the per-cell map bytes, records gathered from HBM)
     alt = gpu.matchScan(wrong, pts, want_scores=True)
+    assert "small-lattice" in gpu.last_variant(), gpu.last_variant()
+    _check_match(alt, exp, 720)
+    for pose in [(-24.0, 20.0, 0.5), (60.0, 60.0, 0.0)]:
+        _check_match(gpu.matchScan(pose, pts, want_scores=True),
+                     ref.matchScan(pose, pts, want_scores=True), 720)
+    # and the wave-per-candidate kernel (records gathered from HBM through L2)
+    gpu.set_variant("wave")
+    alt = gpu.matchScan(wrong, pts, want_scores=True)
+    gpu.set_variant("auto")
     assert "wave-per-candidate/global-grid" in gpu.last_variant()
     _check_match(alt, exp, 720)
     for pose in [(-24.0, 20.0, 0.5), (60.0, 60.0, 0.0)]:
@@ -483,11 +591,13 @@ def test_match_scan_on_a_large_map_uses_the_windowed_lane_kernel():
 
 
 def test_mapping_follows_the_lattice_size(cfg1):
-    """Small lattices (the plugin's defaults, cfg-1) take the wave-per-candidate mapping,
-    large ones the lane-per-candidate mapping; both give the oracle's result."""
+    """Small lattices (the plugin's defaults, cfg-1) take the small-lattice form of the
+    lane-per-candidate mapping (beams split across the waves of a block), large ones the
+    persistent form; a search whose window exceeds the one-byte map coordinate takes the
+    wave-per-candidate mapping.  All give the oracle's result."""
     gpu, ref, _, guess, pts = _pair(1)
     got = gpu.matchScan(guess, pts, want_scores=True)
-    assert "wave-per-candidate" in gpu.last_variant(), gpu.last_variant()
+    assert "small-lattice" in gpu.last_variant(), gpu.last_variant()
     exp = ref.matchScan(guess, pts, want_scores=True)
     _check_match(got, exp, 720)
     big, ref_big, _, _, _ = _pair(1, search_linear_size=0.25, search_linear_resolution=0.01,

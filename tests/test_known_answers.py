@@ -92,7 +92,7 @@ def test_host_ndt_build_reproduces_the_known_cells(ka):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", ["auto", "wave", "lane", "lane-noskip"])
+@pytest.mark.parametrize("variant", ["auto", "wave", "lane", "lane-noskip", "small", "small-noskip"])
 def test_gpu_reproduces_the_known_answers(ka, variant):
     from ndt_2d_amd import ScanMatcherNDT
     gpu = ScanMatcherNDT(0)
