@@ -304,15 +304,39 @@ def default_search_bench(matcher_cls, synth, device_index, reps=300):
     batch_ms, _ = med(lambda: m.scorePoses(pts, poses), n=100)
     units = 35280 * 100
     m.close()
+    # the same calls from a plain-C host (what the pluginlib shim pays: no interpreter)
+    c_host = None
+    probe = os.path.join(_ROOT, "ndt_2d_amd", "ndt2d_latency_probe")
+    if os.path.exists(probe):
+        import subprocess
+        r = subprocess.run([probe], capture_output=True, text=True, timeout=300)
+        if r.returncode == 0:
+            c_host = json.loads(r.stdout.strip().splitlines()[-1])
+    out = default_search_record(units, match_ms, match_p99, kernel_ms, n_kernels, variant, score_ms,
+                                points_ms, add_ms, cycle_ms, cycle_p99, loop_ms, batch_ms)
+    if c_host is not None:
+        out["c_host"] = dict(c_host, what="ndt_2d_amd/tools/latency_probe.c: the same calls through the C-ABI "
+                                          "from a C program, medians of 2000 (500 for addScans / the cycle)")
+        out["match_scan_ms"] = c_host["match_scan_us"] * 1e-3
+        out["mapper_cycle_ms"] = c_host["mapper_cycle_us"] * 1e-3
+        out["match_scan_value"] = units / (c_host["match_scan_us"] * 1e-6)
+        out["headline_source"] = "c_host (python_host holds the ctypes figures)"
+    return out
+
+
+def default_search_record(units, match_ms, match_p99, kernel_ms, n_kernels, variant, score_ms, points_ms,
+                          add_ms, cycle_ms, cycle_p99, loop_ms, batch_ms):
+    python_host = {"match_scan_ms": match_ms, "match_scan_p99_ms": match_p99, "score_scan_ms": score_ms,
+                   "score_points_call_us": points_ms * 1e3, "add_scans_ms": add_ms,
+                   "mapper_cycle_ms": cycle_ms, "mapper_cycle_p99_ms": cycle_p99,
+                   "measure_500_particles_unchanged_loop_ms": loop_ms,
+                   "measure_500_particles_batched_ms": batch_ms,
+                   "note": "the calls made from Python: ctypes overhead (~3-5 us per call) included"}
     return {"workload": "plugin defaults: 100 of 720 beams, 21x21x80 = 35,280 candidates, 41x41 NDT from 9 scans",
-            "match_scan_ms": match_ms, "match_scan_p99_ms": match_p99,
-            "match_scan_kernel_ms": kernel_ms, "kernels_per_call": n_kernels, "kernel_variant": variant,
+            "match_scan_ms": match_ms, "mapper_cycle_ms": cycle_ms,
             "match_scan_value": units / (match_ms * 1e-3),
-            "score_scan_ms": score_ms, "score_points_call_us": points_ms * 1e3,
-            "add_scans_ms": add_ms, "mapper_cycle_ms": cycle_ms, "mapper_cycle_p99_ms": cycle_p99,
-            "measure_500_particles_unchanged_loop_ms": loop_ms,
-            "measure_500_particles_batched_ms": batch_ms,
-            "note": "Python ctypes call overhead (~3-5 us per call) included"}
+            "match_scan_kernel_ms": kernel_ms, "kernels_per_call": n_kernels, "kernel_variant": variant,
+            "headline_source": "python_host", "python_host": python_host}
 
 
 def in_grid_share(np, synth, params, guess, pts, grid, samples=2000000):

@@ -110,7 +110,10 @@ int ndt2d_set_search(ndt2d_handle h, double pose_x, double pose_y, const double 
                      const double * dlin, size_t n_lin);
 
 /* ndt2d_set_beams + ndt2d_set_search in one call: both travel in ONE staged copy (a
- * small search is a few tens of microseconds; every copy command costs ~3 us). */
+ * small search is a few tens of microseconds; every copy command costs ~3 us).
+ * beams_xy == NULL: the n_beams beams the context already holds stay (the caller knows
+ * they are this scan's: ndt2d_matcher_* compares), and the tables are only staged --
+ * a small-lattice search takes them as kernel arguments, so such a call copies nothing. */
 int ndt2d_set_search_beams(ndt2d_handle h, const double * beams_xy, size_t n_beams, double pose_x,
                            double pose_y, const double * dth, const double * cos_th,
                            const double * sin_th, size_t n_th, const double * dlin, size_t n_lin);

@@ -52,6 +52,10 @@ def build_all(force=False, verbose=False, jobs=4):
     stale = _stale_sources(force)
     if not stale and os.path.exists(LIB_PATH) and \
             os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(_obj(s)) for s in SOURCES):
+        probe_src = os.path.join(_PKG, "tools", "latency_probe.c")
+        if not os.path.exists(PROBE_PATH) or os.path.getmtime(PROBE_PATH) < max(
+                os.path.getmtime(probe_src), os.path.getmtime(LIB_PATH)):
+            build_tools(verbose)
         return LIB_PATH
 
     def compile_one(src):
@@ -72,7 +76,23 @@ def build_all(force=False, verbose=False, jobs=4):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    build_tools(verbose)
     return LIB_PATH
+
+
+PROBE_PATH = os.path.join(_PKG, "ndt2d_latency_probe")
+
+
+def build_tools(verbose=False):
+    """The plain-C latency probe (ndt_2d_amd/tools/latency_probe.c): the C-ABI as a C
+    host calls it, used by bench.py's default_search leg."""
+    src = os.path.join(_PKG, "tools", "latency_probe.c")
+    cmd = ["gcc", "-O2", "-std=c99", "-Wall", "-Wextra", "-I", os.path.join(_ROOT, "include"), src,
+           "-L", _PKG, "-lndt2d_hip", "-lm", "-Wl,-rpath," + _PKG, "-o", PROBE_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return PROBE_PATH
 
 
 if __name__ == "__main__":

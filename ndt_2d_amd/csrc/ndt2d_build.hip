@@ -16,7 +16,8 @@
 //                      then Cell::compute (:65-103), and writes the cell in all the
 //                      layouts the scorers read (cells6, LDS image, 64-byte gather
 //                      copy)
-//   5. bits_kernel     occupancy bitmap, one thread per 32 cells
+//      (the occupancy bitmap comes from the waves' ballots), then cell_bytes_kernel: the
+//      per-cell occupancy-map bytes the small-lattice search copies
 //
 // Everything is IEEE double with the reference's operation order (file compiled
 // with -ffp-contract=off; '/' and sqrt are correctly rounded).
@@ -93,12 +94,41 @@ __device__ __forceinline__ void symmetric_eigenvalues(double a, double b, double
   *e1 = (d + p) - z;
 }
 
+// One packed record in both strides, and -- from the wave's ballot -- the two words of
+// the occupancy bitmap its 64 cells fill (bit i = cell i can score; bits >= ncell are 0).
+// Called by every thread of the wave, also those past the last record (cell > ncell).
+__device__ __forceinline__ void write_scorer_record(uint32_t ncell, uint32_t cell,
+                                                    const double (&rec)[kCellDoubles],
+                                                    double * cells_lds_image, double * cells_global,
+                                                    uint32_t * occ_bits)
+{
+  if (cell <= ncell)
+  {
+    double * l = cells_lds_image + static_cast<size_t>(cell) * kCellDoubles;
+    double * gl = cells_global + static_cast<size_t>(cell) * kCellStrideGlobal;
+#pragma unroll
+    for (int k = 0; k < kCellDoubles; ++k)
+    {
+      l[k] = rec[k];
+      gl[k] = rec[k];
+    }
+    gl[6] = 0.0;
+    gl[7] = 0.0;
+  }
+  const uint64_t mask = __builtin_amdgcn_ballot_w64(cell < ncell && rec[5] != 0.0);
+  const uint32_t n_words = (ncell + 1 + 31) / 32;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t word = (cell >> 5) & ~1u;     // first word of this wave's 64 cells
+  if (lane == 0 && word < n_words) occ_bits[word] = static_cast<uint32_t>(mask);
+  if (lane == 1 && word + 1 < n_words) occ_bits[word + 1] = static_cast<uint32_t>(mask >> 32);
+}
+
 __global__ void __launch_bounds__(256) cells_kernel(const BuildArgs a, const uint32_t * sorted_vals,
                                                     const uint32_t * seg_begin,
                                                     const uint32_t * seg_end)
 {
   const uint32_t cell = blockIdx.x * 256 + threadIdx.x;
-  if (cell > a.grid.ncell) return;
+  // (threads past the last record stay: the wave's ballot writes its occupancy words)
 
   double n = 0.0, mean_x = 0.0, mean_y = 0.0, cxx = 0.0, cxy = 0.0, cyy = 0.0;
   double ixx = 0.0, ixy = 0.0, iyy = 0.0;
@@ -170,43 +200,16 @@ __global__ void __launch_bounds__(256) cells_kernel(const BuildArgs a, const uin
     rec[4] = -0.5 * iyy;
     rec[5] = 1.0;
   }
-  double * l = a.cells_lds_image + static_cast<size_t>(cell) * kCellDoubles;
-  double * gl = a.cells_global + static_cast<size_t>(cell) * kCellStrideGlobal;
-#pragma unroll
-  for (int k = 0; k < kCellDoubles; ++k)
-  {
-    l[k] = rec[k];
-    gl[k] = rec[k];
-  }
-  gl[6] = 0.0;
-  gl[7] = 0.0;
-}
-
-__global__ void __launch_bounds__(256) bits_kernel(const double * cells_lds_image, uint32_t ncell,
-                                                   uint32_t n_words, uint32_t * bits)
-{
-  const uint32_t w = blockIdx.x * 256 + threadIdx.x;
-  if (w >= n_words) return;
-  uint32_t v = 0;
-  for (uint32_t k = 0; k < 32; ++k)
-  {
-    const uint32_t cell = w * 32 + k;
-    if (cell < ncell && cells_lds_image[static_cast<size_t>(cell) * kCellDoubles + 5] != 0.0)
-    {
-      v |= 1u << k;
-    }
-  }
-  bits[w] = v;
+  write_scorer_record(a.grid.ncell, cell, rec, a.cells_lds_image, a.cells_global, a.occ_bits);
 }
 
 // The scorer layouts of a grid given as cells6 records {mean, information, n} (the
 // host build's output, ndt2d_set_grid): what cells_kernel writes for a device build.
 __global__ void __launch_bounds__(256) pack_cells_kernel(const double * cells6, uint32_t ncell,
                                                          double * cells_lds_image,
-                                                         double * cells_global)
+                                                         double * cells_global, uint32_t * occ_bits)
 {
   const uint32_t cell = blockIdx.x * 256 + threadIdx.x;
-  if (cell > ncell) return;
   // h = -0.5 * information (exact); sentinel for cells that cannot score (n < 5,
   // src/ndt_model.cpp:107) and for record ncell ("outside")
   double rec[kCellDoubles] = {1.0e300, 0.0, -1.0, 0.0, -1.0, 0.0};
@@ -223,16 +226,7 @@ __global__ void __launch_bounds__(256) pack_cells_kernel(const double * cells6, 
       rec[5] = 1.0;
     }
   }
-  double * l = cells_lds_image + static_cast<size_t>(cell) * kCellDoubles;
-  double * gl = cells_global + static_cast<size_t>(cell) * kCellStrideGlobal;
-#pragma unroll
-  for (int k = 0; k < kCellDoubles; ++k)
-  {
-    l[k] = rec[k];
-    gl[k] = rec[k];
-  }
-  gl[6] = 0.0;
-  gl[7] = 0.0;
+  write_scorer_record(ncell, cell, rec, cells_lds_image, cells_global, occ_bits);
 }
 
 // One occupancy-map byte per grid cell, for the grid extended by one cell on every
@@ -242,11 +236,45 @@ __global__ void __launch_bounds__(256) pack_cells_kernel(const double * cells6, 
 // it is prepared once here and the small-lattice search copies its window from it.
 __global__ void __launch_bounds__(256) cell_bytes_kernel(const GridDesc g, uint8_t * bytes)
 {
+  // 16 lanes (one DPP row) per cell, lane j < 9 takes neighbour j of the 3 x 3 block: the
+  // bound is a maximum over the neighbours that can score, each a closed form with a few
+  // divisions -- nine of them one after the other in one lane was the whole kernel's time
   const uint32_t w = g.size_x + 2, h = g.size_y + 2;
-  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= w * h) return;
-  const int32_t cx = static_cast<int32_t>(i % w) - 1, cy = static_cast<int32_t>(i / w) - 1;
-  bytes[i] = sub_cell_byte(g, cx, cy, 0, 0, 0);
+  const uint32_t i = (blockIdx.x * 256 + threadIdx.x) >> 4;
+  const uint32_t j = threadIdx.x & 15u;
+  const bool live = i < w * h;
+  const int32_t cx = static_cast<int32_t>(live ? i % w : 0) - 1, cy = static_cast<int32_t>(live ? i / w : 0) - 1;
+  // the sub-cell box of sub_cell_byte() at one sub-cell per cell
+  const double x0 = g.origin_x + (static_cast<double>(cx) - kBoxMargin) * g.cell_size;
+  const double y0 = g.origin_y + (static_cast<double>(cy) - kBoxMargin) * g.cell_size;
+  const double x1 = x0 + (1.0 + 2.0 * kBoxMargin) * g.cell_size;
+  const double y1 = y0 + (1.0 + 2.0 * kBoxMargin) * g.cell_size;
+  double bound = -HUGE_VAL;
+  uint32_t self = 0;
+  if (live && j < 9)
+  {
+    const int32_t nx = cx + static_cast<int32_t>(j % 3) - 1, ny = cy + static_cast<int32_t>(j / 3) - 1;
+    if (nx >= 0 && nx < static_cast<int32_t>(g.size_x) && ny >= 0 && ny < static_cast<int32_t>(g.size_y))
+    {
+      const uint32_t cell = static_cast<uint32_t>(ny) * g.size_x + static_cast<uint32_t>(nx);
+      if ((g.occ_bits[cell >> 5] >> (cell & 31u)) & 1u)
+      {
+        if (j == 4) self = 1;
+        bound = exponent_upper_bound(g.cells_lds_image + static_cast<size_t>(cell) * kCellDoubles, x0, x1, y0, y1);
+      }
+    }
+  }
+  // NaN-propagating maximum over the row (a NaN bound means "no claim")
+  uint32_t nan_any = bound != bound ? 1u : 0u;
+  double m = bound != bound ? -HUGE_VAL : bound;
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1)
+  {
+    m = fmax(m, __shfl_xor(m, off, 16));
+    nan_any |= static_cast<uint32_t>(__shfl_xor(static_cast<int>(nan_any), off, 16));
+    self |= static_cast<uint32_t>(__shfl_xor(static_cast<int>(self), off, 16));
+  }
+  if (live && j == 0) bytes[i] = map_byte(self, nan_any ? NAN : m);
 }
 
 int key_bits(uint32_t ncell)
@@ -300,18 +328,11 @@ hipError_t launch_build_grid(const BuildArgs & a, hipStream_t stream)
 hipError_t launch_grid_tail(const GridDesc & geometry, const double * cells_lds_image,
                             uint32_t * occ_bits, uint8_t * cell_bytes, hipStream_t stream)
 {
-  const uint32_t ncell = geometry.ncell;
-  const uint32_t n_words = (ncell + 1 + 31) / 32;
-  hipLaunchKernelGGL(bits_kernel, dim3((n_words + 255) / 256), dim3(256), 0, stream,
-                     cells_lds_image, ncell, n_words, occ_bits);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return e;
   GridDesc g = geometry;
   g.cells_lds_image = cells_lds_image;
   g.occ_bits = occ_bits;
   const uint32_t n_bytes = (g.size_x + 2) * (g.size_y + 2);
-  hipLaunchKernelGGL(cell_bytes_kernel, dim3((n_bytes + 255) / 256), dim3(256), 0, stream, g,
-                     cell_bytes);
+  hipLaunchKernelGGL(cell_bytes_kernel, dim3((n_bytes + 15) / 16), dim3(256), 0, stream, g, cell_bytes);
   return hipGetLastError();
 }
 
@@ -320,7 +341,7 @@ hipError_t launch_pack_grid(const GridDesc & geometry, const double * cells6,
                             uint8_t * cell_bytes, hipStream_t stream)
 {
   hipLaunchKernelGGL(pack_cells_kernel, dim3((geometry.ncell + 1 + 255) / 256), dim3(256), 0,
-                     stream, cells6, geometry.ncell, cells_lds_image, cells_global);
+                     stream, cells6, geometry.ncell, cells_lds_image, cells_global, occ_bits);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   return launch_grid_tail(geometry, cells_lds_image, occ_bits, cell_bytes, stream);

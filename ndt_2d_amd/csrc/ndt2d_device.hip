@@ -49,7 +49,9 @@ struct ndt2d_context
   DeviceBuffer cells_global;
   DeviceBuffer occ_bits;  // uint32 words stored in a double buffer
   DeviceBuffer cell_bytes;  // per-cell occupancy-map bytes of the extended grid
-  DeviceBuffer cells6;    // raw {mean, information, n} records (introspection)
+  DeviceBuffer compact;     // [cells6 | compact records | cell ranks]: ndt2d_set_grid's upload
+  DeviceBuffer cells6;    // raw {mean, information, n} records of a device-built grid
+  const double * cells6_ptr = nullptr;  // ... of the installed grid, wherever they live
   // device NDT build scratch + host staging that must outlive the async copies
   DeviceBuffer b_points, b_scans, b_offsets, b_world, b_keys, b_vals, b_temp, b_seg;
   std::vector<double> stage_scans;
@@ -74,6 +76,9 @@ struct ndt2d_context
   uint32_t * done_counter = nullptr;
 
   DeviceBuffer tables;  // dth | cos | sin | dlin
+  // ndt2d_set_search keeps the tables in its pinned staging buffer and leaves the upload
+  // to the launch: the small-lattice search takes them as kernel arguments (no copy)
+  bool tables_uploaded = false;
   size_t n_th = 0, n_lin = 0;
   double pose_x = 0.0, pose_y = 0.0;
   double dlin_absmax = 0.0;
@@ -366,6 +371,7 @@ int ndt2d_destroy(ndt2d_handle h)
   release(h->cells_global);
   release(h->occ_bits);
   release(h->cell_bytes);
+  release(h->compact);
   release(h->cells6);
   release(h->call_dev);
   release(h->stage_grid);
@@ -446,14 +452,55 @@ int ndt2d_set_grid(ndt2d_handle h, const double * cells6, uint32_t size_x, uint3
   // and the per-cell map bytes -- in ndt2d_build.hip.  Asynchronous on the stream.
   int rc;
   const size_t n6 = static_cast<size_t>(ncell) * 6;
-  if ((rc = ensure(h, h->cells6, n6)) != NDT2D_OK) return rc;
+  // Small maps also get the records of the cells that can score in compacted form, with
+  // a cell -> record table (the small-lattice search keeps both in LDS): built here, on
+  // the pass over the cells that copies them into the staging buffer anyway.
+  uint32_t n_occ = 0;
+  const bool compactable = ncell < 65535u;
+  if (compactable)
+  {
+    for (uint32_t i = 0; i < ncell; ++i) n_occ += !(cells6[6 * static_cast<size_t>(i) + 5] < 5.0) ? 1u : 0u;
+  }
+  const size_t n_compact = compactable ? static_cast<size_t>(n_occ + 1) * kCellDoubles : 0;
+  // (uint16 in doubles, whole 16-byte pieces: the kernel copies it with 16-byte loads)
+  const size_t n_rank = compactable ? (static_cast<size_t>(ncell) + 1 + 7) / 8 * 2 : 0;
+  const size_t n_upload = n6 + n_compact + n_rank;
+  if ((rc = ensure(h, h->compact, n_upload)) != NDT2D_OK) return rc;
   if ((rc = ensure(h, h->cells_lds_image, static_cast<size_t>(ncell + 1) * kCellDoubles)) != NDT2D_OK) return rc;
   if ((rc = ensure(h, h->cells_global, static_cast<size_t>(ncell + 1) * kCellStrideGlobal)) != NDT2D_OK) return rc;
   if ((rc = ensure(h, h->occ_bits, ((static_cast<size_t>(ncell) + 1 + 31) / 32 + 2) / 2)) != NDT2D_OK) return rc;
   if ((rc = ensure(h, h->cell_bytes, (static_cast<size_t>(size_x) + 2) * (size_y + 2) / 8 + 1)) != NDT2D_OK) return rc;
-  if ((rc = stage_acquire(h, h->stage_grid, n6)) != NDT2D_OK) return rc;
+  if ((rc = stage_acquire(h, h->stage_grid, n_upload)) != NDT2D_OK) return rc;
   std::memcpy(h->stage_grid.ptr, cells6, n6 * sizeof(double));
-  if ((rc = stage_submit(h, h->stage_grid, h->cells6.ptr, n6)) != NDT2D_OK) return rc;
+  if (compactable)
+  {
+    double * recs = h->stage_grid.ptr + n6;
+    uint16_t * rank = reinterpret_cast<uint16_t *>(recs + n_compact);
+    uint32_t k = 0;
+    for (uint32_t i = 0; i < ncell; ++i)
+    {
+      const double * c = cells6 + 6 * static_cast<size_t>(i);
+      if (!(c[5] < 5.0))
+      {
+        double * r = recs + static_cast<size_t>(k) * kCellDoubles;
+        r[0] = c[0];
+        r[1] = c[1];
+        r[2] = -0.5 * c[2];
+        r[3] = -0.5 * c[3];
+        r[4] = -0.5 * c[4];
+        r[5] = 1.0;
+        rank[i] = static_cast<uint16_t>(k++);
+      }
+      else
+      {
+        rank[i] = static_cast<uint16_t>(n_occ);
+      }
+    }
+    rank[ncell] = static_cast<uint16_t>(n_occ);
+    static const double sentinel[kCellDoubles] = {1.0e300, 0.0, -1.0, 0.0, -1.0, 0.0};
+    std::memcpy(recs + static_cast<size_t>(n_occ) * kCellDoubles, sentinel, sizeof(sentinel));
+  }
+  if ((rc = stage_submit(h, h->stage_grid, h->compact.ptr, n_upload)) != NDT2D_OK) return rc;
 
   GridDesc g{};
   g.size_x = size_x;
@@ -464,7 +511,8 @@ int ndt2d_set_grid(ndt2d_handle h, const double * cells6, uint32_t size_x, uint3
   g.inv_cell_size = 1.0 / cell_size;
   g.origin_x = origin_x;
   g.origin_y = origin_y;
-  hipError_t e = ndt2d::launch_pack_grid(g, h->cells6.ptr, h->cells_lds_image.ptr, h->cells_global.ptr,
+  h->cells6_ptr = h->compact.ptr;
+  hipError_t e = ndt2d::launch_pack_grid(g, h->cells6_ptr, h->cells_lds_image.ptr, h->cells_global.ptr,
                                          reinterpret_cast<uint32_t *>(h->occ_bits.ptr),
                                          reinterpret_cast<uint8_t *>(h->cell_bytes.ptr), h->stream);
   if (e != hipSuccess) return fail_hip(h, e, "launch_pack_grid");
@@ -472,6 +520,12 @@ int ndt2d_set_grid(ndt2d_handle h, const double * cells6, uint32_t size_x, uint3
   g.cells_global = h->cells_global.ptr;
   g.occ_bits = reinterpret_cast<const uint32_t *>(h->occ_bits.ptr);
   g.cell_bytes = reinterpret_cast<const uint8_t *>(h->cell_bytes.ptr);
+  if (compactable)
+  {
+    g.compact_records = h->compact.ptr + n6;
+    g.cell_rank = reinterpret_cast<const uint16_t *>(h->compact.ptr + n6 + n_compact);
+    g.n_occ = n_occ;
+  }
   h->grid = g;
   h->has_grid = true;
   return NDT2D_OK;
@@ -599,6 +653,7 @@ int ndt2d_build_grid(ndt2d_handle h, double ndt_resolution, double range_max,
   g.cells_global = h->cells_global.ptr;
   g.occ_bits = reinterpret_cast<const uint32_t *>(h->occ_bits.ptr);
   g.cell_bytes = reinterpret_cast<const uint8_t *>(h->cell_bytes.ptr);
+  h->cells6_ptr = h->cells6.ptr;
   h->grid = g;
   h->has_grid = true;
   return NDT2D_OK;
@@ -618,7 +673,7 @@ int ndt2d_get_grid(ndt2d_handle h, double * cells6_out, size_t capacity_cells, u
   {
     if (capacity_cells < h->grid.ncell) return fail(h, NDT2D_ERR_INVALID, "ndt2d_get_grid: capacity");
     NDT2D_HIP(h, hipSetDevice(h->device));
-    NDT2D_HIP(h, hipMemcpyAsync(cells6_out, h->cells6.ptr,
+    NDT2D_HIP(h, hipMemcpyAsync(cells6_out, h->cells6_ptr,
                                 static_cast<size_t>(h->grid.ncell) * 6 * sizeof(double),
                                 hipMemcpyDeviceToHost, h->stream));
     NDT2D_HIP(h, hipStreamSynchronize(h->stream));
@@ -680,8 +735,7 @@ int ndt2d_set_search(ndt2d_handle h, double pose_x, double pose_y, const double 
   std::memcpy(t + n_th, cos_th, n_th * sizeof(double));
   std::memcpy(t + 2 * n_th, sin_th, n_th * sizeof(double));
   std::memcpy(t + 3 * n_th, dlin, n_lin * sizeof(double));
-  rc = stage_submit(h, h->stage_tables, h->tables.ptr, n_tab);
-  if (rc != NDT2D_OK) return rc;
+  h->tables_uploaded = false;   // ndt2d_match_launch uploads them if its kernel reads HBM
   h->n_th = n_th;
   h->n_lin = n_lin;
   h->dlin_absmax = 0.0;
@@ -701,7 +755,16 @@ int ndt2d_set_search_beams(ndt2d_handle h, const double * beams_xy, size_t n_bea
                            const double * sin_th, size_t n_th, const double * dlin, size_t n_lin)
 {
   if (h == nullptr) return NDT2D_ERR_INVALID;
-  if (beams_xy == nullptr || n_beams == 0 || n_beams > (1u << 20) || dth == nullptr ||
+  if (beams_xy == nullptr)
+  {
+    // the beams the context holds stay: only the tables change (and need no copy yet)
+    if (n_beams == 0 || n_beams != h->n_beams || h->beams_ptr == nullptr)
+    {
+      return fail(h, NDT2D_ERR_STATE, "ndt2d_set_search_beams: no such beams on the device");
+    }
+    return ndt2d_set_search(h, pose_x, pose_y, dth, cos_th, sin_th, n_th, dlin, n_lin);
+  }
+  if (n_beams == 0 || n_beams > (1u << 20) || dth == nullptr ||
       cos_th == nullptr || sin_th == nullptr || dlin == nullptr || n_th == 0 || n_lin == 0 ||
       n_th > (1u << 24) || n_lin > 46340)
   {
@@ -728,6 +791,7 @@ int ndt2d_set_search_beams(ndt2d_handle h, const double * beams_xy, size_t n_bea
   h->beam_rmax = beam_reach(beams_xy, n_beams);
   h->beams_ptr = h->call_dev.ptr;
   h->tables_ptr = h->call_dev.ptr + 2 * n_beams;
+  h->tables_uploaded = true;
   h->n_th = n_th;
   h->n_lin = n_lin;
   h->dlin_absmax = 0.0;
@@ -786,8 +850,25 @@ int ndt2d_match_launch_strided(ndt2d_handle h, size_t th_first, size_t th_stride
   a.pose_x = h->pose_x;
   a.pose_y = h->pose_y;
   a.scores = d_scores;
-  rc = ensure(h, h->ws_match, ndt2d::match_workspace_doubles(a));
-  if (rc != NDT2D_OK) return rc;
+  if (!h->tables_uploaded)
+  {
+    a.host_tables = h->stage_tables.ptr;
+    if (ndt2d::match_needs_device_tables(a, !(h->force_variant & ndt2d::kVariantWave), h->force_variant))
+    {
+      rc = stage_submit(h, h->stage_tables, h->tables.ptr, 3 * h->n_th + h->n_lin);
+      if (rc != NDT2D_OK) return rc;
+      h->tables_uploaded = true;
+      a.host_tables = nullptr;
+    }
+  }
+  {
+    // the head of the workspace holds counters the kernels expect to find at zero (they
+    // leave them so): a fresh allocation is cleared once
+    const size_t cap_before = h->ws_match.cap;
+    rc = ensure(h, h->ws_match, ndt2d::match_workspace_doubles(a));
+    if (rc != NDT2D_OK) return rc;
+    if (h->ws_match.cap != cap_before) NDT2D_HIP(h, hipMemsetAsync(h->ws_match.ptr, 0, 4096, h->stream));
+  }
 
   // scratch for the rotated-beam table of the lane-per-candidate mapping
   double * outer = nullptr;

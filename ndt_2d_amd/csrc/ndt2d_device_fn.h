@@ -240,6 +240,21 @@ __device__ __forceinline__ double wave_sum_to_last_lane(double v)
   return v;
 }
 
+// Results for a spinning host go to host-coherent memory with system-scope stores
+// (write-through, no cache line kept), and the flag follows once they have been
+// acknowledged: a __threadfence_system() instead would write back the whole L2 first.
+__device__ __forceinline__ void store_host(double * p, double v)
+{
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// by ONE lane, after the block's store_host() calls and a barrier
+__device__ __forceinline__ void raise_host_flag(double * flag_slot, unsigned long long seq)
+{
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __hip_atomic_store(reinterpret_cast<unsigned long long *>(flag_slot), seq, __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // (score, index) ordering of the reference's `if (score < best_score)` scan in
 // loop order (src/scan_matcher_ndt.cpp:128): lower score wins, ties go to the
 // lower flat index.

@@ -307,10 +307,10 @@ int dev_fail(ndt2d_matcher * m, int code, const char * what)
 // together with the beams in one copy; nullptr: the beams are on the device already
 // (LaserScan conversion) and only the tables travel.
 int prepare_tables(ndt2d_matcher * m, const double * scan_pose_xyt, size_t use,
-                   const double * host_beams, size_t * n_th_out, size_t * n_lin_out)
+                   const double * host_beams, bool beams_cached, size_t * n_th_out,
+                   size_t * n_lin_out)
 {
-  m->dth = search_offsets(m->angular_size, m->angular_res);
-  m->dlin = search_offsets(m->linear_size, m->linear_res);
+  // (the visited offsets depend on the parameters only: computed by initialize())
   const size_t n_th = m->dth.size(), n_lin = m->dlin.size();
   if (n_th_out != nullptr) *n_th_out = n_th;
   if (n_lin_out != nullptr) *n_lin_out = n_lin;
@@ -325,7 +325,7 @@ int prepare_tables(ndt2d_matcher * m, const double * scan_pose_xyt, size_t use,
     ndt2d_cos_sin(scan_pose_xyt[2] + m->dth[i], &m->cos_th[i], &m->sin_th[i]);
   }
   int rc;
-  if (host_beams != nullptr)
+  if (host_beams != nullptr || beams_cached)
   {
     rc = ndt2d_set_search_beams(m->dev, host_beams, use, scan_pose_xyt[0], scan_pose_xyt[1],
                                 m->dth.data(), m->cos_th.data(), m->sin_th.data(), n_th,
@@ -383,6 +383,8 @@ int ndt2d_matcher_create(ndt2d_matcher ** out, int device_id)
     return NDT2D_ERR_INVALID;
   }
   m->dev = dev;
+  m->dth = search_offsets(m->angular_size, m->angular_res);
+  m->dlin = search_offsets(m->linear_size, m->linear_res);
   *out = m;
   return NDT2D_OK;
 }
@@ -416,6 +418,9 @@ int ndt2d_matcher_initialize(ndt2d_matcher * m, double ndt_resolution,
   m->linear_size = search_linear_size;
   m->laser_max_beams = laser_max_beams;
   m->range_max = range_max;
+  m->dth = search_offsets(m->angular_size, m->angular_res);
+  m->dlin = search_offsets(m->linear_size, m->linear_res);
+  m->search_ready = false;
   return NDT2D_OK;
 }
 
@@ -500,13 +505,23 @@ int ndt2d_matcher_prepare_search(ndt2d_matcher * m, const double * scan_pose_xyt
 {
   if (m == nullptr || scan_pose_xyt == nullptr) return NDT2D_ERR_INVALID;
   if (n_points > 0 && points_xy == nullptr) return mfail(m, NDT2D_ERR_INVALID, "null points");
-  subsample_into(m->beams, points_xy, n_points, m->laser_max_beams);
-  const size_t use = m->beams.size() / 2;
+  subsample_into(m->scratch_beams, points_xy, n_points, m->laser_max_beams);
+  const size_t use = m->scratch_beams.size() / 2;
   m->n_use = use;
   if (n_beams_out != nullptr) *n_beams_out = use;
   m->search_ready = false;
-  m->beams_on_device = false;
-  return prepare_tables(m, scan_pose_xyt, use, m->beams.data(), n_th_out, n_lin_out);
+  // the scan scoreScan was just called with (src/ndt_mapper.cpp:514-515)?  Then the
+  // device holds these beams already and only the tables are new.
+  const bool same = m->beams_on_device && use > 0 && m->beams.size() == m->scratch_beams.size() &&
+                    std::memcmp(m->beams.data(), m->scratch_beams.data(),
+                                m->beams.size() * sizeof(double)) == 0;
+  if (!same)
+  {
+    m->beams.swap(m->scratch_beams);
+    m->beams_on_device = false;
+  }
+  return prepare_tables(m, scan_pose_xyt, use, same ? nullptr : m->beams.data(), same, n_th_out,
+                        n_lin_out);
 }
 
 int ndt2d_matcher_finish_match(ndt2d_matcher * m, const double * record, double * pose_inout,
@@ -652,7 +667,7 @@ int ndt2d_matcher_match_laser_scan(ndt2d_matcher * m, const double * scan_pose_x
   m->beams_on_device = false;   // the device holds beams the host has no copy of
   m->n_use = use;
   size_t n_th = 0, n_lin = 0;
-  rc = prepare_tables(m, scan_pose_xyt, use, nullptr, &n_th, &n_lin);
+  rc = prepare_tables(m, scan_pose_xyt, use, nullptr, false, &n_th, &n_lin);
   if (rc != NDT2D_OK) return rc;
   double record[NDT2D_MATCH_RECORD_DOUBLES] = {0, -1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (m->search_ready)

@@ -41,6 +41,14 @@ struct GridDesc
   // [size_y + 2][size_x + 2] occupancy-map bytes of the grid extended by one cell on
   // every side (ndt2d_build.hip, cell_bytes_kernel); may be null (no small-lattice search)
   const uint8_t * cell_bytes;
+  // Compacted records of the cells that can score, for small maps installed from the host
+  // (ndt2d_set_grid): compact_records[n_occ + 1][kCellDoubles] (the last one the
+  // sentinel) and cell_rank[ncell + 1] = a cell's record in it (n_occ for cells that
+  // cannot score and for "outside").  A few KB that every block of the small-lattice
+  // search keeps in LDS.  n_occ == 0: not available.
+  const double * compact_records;
+  const uint16_t * cell_rank;
+  uint32_t n_occ;
   uint32_t size_x, size_y, ncell;
   double cell_size;
   double inv_cell_size;  // exact iff pow2
@@ -66,6 +74,10 @@ struct MatchArgs
   uint32_t th_stride;
   double pose_x, pose_y;
   double * scores;          // optional, slab-local flat order
+  // The search tables [dth | cos | sin (n_th each) | dlin (n_lin)] in HOST memory when
+  // they have not been uploaded (then dth .. dlin above point at buffers the upload
+  // would fill): a launch that passes them as kernel arguments needs no copy.
+  const double * host_tables;
   double * partials;        // [n_workers][NDT2D_MATCH_RECORD_DOUBLES]
   uint32_t * next_item;     // work-item counters of the lane-per-candidate search (kItemShards, kItemShardStride apart)
   uint32_t chunk;           // candidates per work item
@@ -133,6 +145,11 @@ size_t match_workspace_doubles(const MatchArgs & args);
 // then, at host_record[kHostFlagSlot], `seq` as a 64-bit integer -- a host may spin on
 // it instead of synchronising the stream.
 constexpr int kHostFlagSlot = 16;
+// Whether launch_match with these arguments reads the search tables from device memory
+// (false: the small-lattice search takes them as kernel arguments from args.host_tables).
+bool match_needs_device_tables(const MatchArgs & args, bool outer_available, int force_variant);
+// doubles of search tables that fit the small-lattice search's kernel arguments
+constexpr uint32_t kArgTableDoubles = 416;
 hipError_t launch_match(const MatchArgs & args, double * workspace, double * outer,
                         double * record_out, double * record_out2, double * host_record,
                         unsigned long long seq, int force_variant, hipStream_t stream,
@@ -231,13 +248,16 @@ hipError_t launch_match_lane(const MatchArgs & args, double * outer, double * wo
                              uint32_t max_workers, int cus, size_t lds_per_block, bool no_skip,
                              hipStream_t stream, uint32_t * n_workers_out, bool * lds_records_out);
 
-// Small-lattice search (ndt2d_match_small.hip): a block per (theta, up to P patches),
-// its waves split the beams; needs grid.cell_bytes.  workspace receives one record per
-// (theta, patch) item, *n_records_out of them.
+// Small-lattice search (ndt2d_match_small.hip): a block per (theta, up to P tiles of 64
+// candidates), its waves split the beams; needs grid.cell_bytes.  The launch includes the
+// final reduction: workspace takes one record per (theta, tile), the block that finishes
+// last (tickets: one zeroed uint32) writes the result record(s) as launch_match does.
 bool match_small_supported(const MatchArgs & args, size_t lds_per_block);
-hipError_t launch_match_small(const MatchArgs & args, double * workspace, int cus,
-                              size_t lds_per_block, bool no_skip, hipStream_t stream,
-                              uint32_t * n_records_out);
+bool match_small_takes_arg_tables(const MatchArgs & args);
+hipError_t launch_match_small(const MatchArgs & args, double * workspace, uint32_t * tickets,
+                              int cus, size_t lds_per_block, bool no_skip, double * record_out,
+                              double * record_out2, double * host_record, unsigned long long seq,
+                              hipStream_t stream);
 
 // Particle scoring with per-wave compaction of the occupied (pose, beam) pairs
 // (ndt2d_poses_compact.hip).

@@ -187,9 +187,7 @@ __global__ void __launch_bounds__(kMatchThreads) match_kernel(const MatchArgs a)
 // `out`.
 __global__ void __launch_bounds__(256) match_reduce_kernel(const double * partials, uint32_t n,
                                                            uint32_t per_block, double * out,
-                                                           double * out2, int final,
-                                                           double * host_out,
-                                                           unsigned long long seq)
+                                                           double * out2, int final)
 {
   __shared__ double sh[256 * kRecord];
   const int t = threadIdx.x;
@@ -238,22 +236,77 @@ __global__ void __launch_bounds__(256) match_reduce_kernel(const double * partia
       if (t == 1 && !(sh[0] < 0.0)) val = -1.0;
       out[t] = val;
       if (out2 != nullptr) out2[t] = val;
-      if (host_out != nullptr) host_out[t] = val;
     }
     else
     {
       out[static_cast<size_t>(blockIdx.x) * kRecord + t] = val;
     }
   }
-  if (final && host_out != nullptr)
+}
+
+// Last reduction stage, latency-shaped (it ends every matchScan call): 11 waves, wave 0
+// reduces the (score, index) pairs, wave 1 + k the accumulator column k; a lane adds the
+// records lane, lane + 64, ... in order and the wave finishes over the DPP network --
+// fixed order, no LDS, no barrier before the results are written.  It applies "no
+// candidate scored below 0 -> no index" and writes the record to out (device), out2
+// (device, optional) and host_out (host-coherent memory, optional) followed there by
+// `seq` at host_out[kHostFlagSlot], which the host spins on.
+constexpr int kFinalThreads = 11 * kWave;
+__global__ void __launch_bounds__(kFinalThreads) match_reduce_final_kernel(
+  const double * partials, uint32_t n, double * out, double * out2, double * host_out,
+  unsigned long long seq)
+{
+  const uint32_t lane = threadIdx.x & (kWave - 1);
+  const uint32_t wave = threadIdx.x >> 6;
+  if (wave == 0)
   {
-    // the record has left for host memory before the flag does
-    __threadfence_system();
-    __syncthreads();
-    if (t == 0)
+    double bs = 0.0, bi = kNoIndex;
+    for (uint32_t r = lane; r < n; r += kWave)
     {
-      *reinterpret_cast<volatile unsigned long long *>(host_out + kHostFlagSlot) = seq;
+      const double2 p = *reinterpret_cast<const double2 *>(partials + static_cast<size_t>(r) * kRecord);
+      if (better(p.x, p.y, bs, bi))
+      {
+        bs = p.x;
+        bi = p.y;
+      }
     }
+    wave_best_to_last_lane(bs, bi);
+    if (lane == kWave - 1)
+    {
+      if (!(bs < 0.0)) bi = -1.0;
+      out[0] = bs;
+      out[1] = bi;
+      if (out2 != nullptr)
+      {
+        out2[0] = bs;
+        out2[1] = bi;
+      }
+      if (host_out != nullptr)
+      {
+        store_host(host_out + 0, bs);
+        store_host(host_out + 1, bi);
+      }
+    }
+  }
+  else
+  {
+    const uint32_t k = 1 + wave;   // columns 2 .. 11
+    double v = 0.0;
+    for (uint32_t r = lane; r < n; r += kWave) v += partials[static_cast<size_t>(r) * kRecord + k];
+    v = wave_sum_to_last_lane(v);
+    if (lane == kWave - 1)
+    {
+      out[k] = v;
+      if (out2 != nullptr) out2[k] = v;
+      if (host_out != nullptr) store_host(host_out + k, v);
+    }
+  }
+  if (host_out != nullptr)
+  {
+    // every wave's store has been acknowledged before the flag leaves
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) raise_host_flag(host_out + kHostFlagSlot, seq);
   }
 }
 
@@ -468,6 +521,45 @@ size_t match_workspace_doubles(const MatchArgs & args)
   return kWorkspaceHead + static_cast<size_t>(records) * kRecord;
 }
 
+namespace
+{
+
+enum class Mapping { kInvalid, kSmall, kLane, kWave };
+
+// Candidate mapping.  Lane-per-candidate (64 translations of one theta step per wave,
+// occupancy-map look-up, bit-exact skipping) whenever its LDS image fits: the
+// small-lattice form (a block per theta step and up to P tiles, beams split across its
+// waves, no pre-kernel, final reduction in the same launch) below kSmallBelowItems work
+// items, the persistent large-lattice form above.  Otherwise wave-per-candidate.
+// (The choice follows the whole lattice, so every shard of a search makes the same one
+// and a candidate's score has the same bits whichever rank evaluates it.)
+Mapping choose_mapping(const MatchArgs & args, bool outer_available, int force_variant,
+                       const DeviceLimits & lim)
+{
+  const int force_grid = force_variant & kVariantGridMask;
+  const uint64_t p1 = (args.n_lin + 7) / 8;
+  const uint64_t items = static_cast<uint64_t>(args.n_th) * p1 * p1;
+  bool use_lane = outer_available && force_grid != kVariantGlobal &&
+                  match_lane_supported(args, lim.lds_per_block);
+  bool use_small = force_grid == kVariantAuto && match_small_supported(args, lim.lds_per_block);
+  if (force_variant & kVariantWave) use_lane = use_small = false;
+  if (force_variant & kVariantSmall) return use_small ? Mapping::kSmall : Mapping::kInvalid;
+  if (force_variant & kVariantLane) return use_lane ? Mapping::kLane : Mapping::kInvalid;
+  if (use_small && use_lane) return items < kSmallBelowItems ? Mapping::kSmall : Mapping::kLane;
+  if (use_small) return Mapping::kSmall;
+  if (use_lane) return Mapping::kLane;
+  return Mapping::kWave;
+}
+
+}  // namespace
+
+bool match_needs_device_tables(const MatchArgs & args, bool outer_available, int force_variant)
+{
+  if (args.n_beams == 0) return true;
+  return !(choose_mapping(args, outer_available, force_variant, device_limits()) == Mapping::kSmall &&
+           match_small_takes_arg_tables(args));
+}
+
 hipError_t launch_match(const MatchArgs & args_in, double * workspace, double * outer,
                         double * record_out, double * record_out2, double * host_record,
                         unsigned long long seq, int force_variant, hipStream_t stream,
@@ -487,44 +579,37 @@ hipError_t launch_match(const MatchArgs & args_in, double * workspace, double * 
   if (force_grid == kVariantGlobal) use_lds = false;
   if (force_grid == kVariantLds && !use_lds) return hipErrorInvalidValue;
 
-  // Candidate mapping.  Lane-per-candidate (an 8 x 8 patch of translations per wave,
-  // occupancy-map look-up, bit-exact skipping) whenever its LDS image fits: the
-  // small-lattice form (a block per theta step and up to P patches, beams split across
-  // its waves, no pre-kernel) below kSmallBelowItems work items, the persistent
-  // large-lattice form above.  Otherwise wave-per-candidate.
-  // (the choice follows the whole lattice, so every shard of a search makes the same one
-  // and a candidate's score has the same bits whichever rank evaluates it)
-  const uint64_t p1 = (args.n_lin + 7) / 8;
-  const uint64_t items = static_cast<uint64_t>(args.n_th) * p1 * p1;
-  bool use_lane = outer != nullptr && force_grid != kVariantGlobal &&
-                  match_lane_supported(args, lim.lds_per_block);
-  bool use_small = force_grid == kVariantAuto && match_small_supported(args, lim.lds_per_block);
-  if (force_variant & kVariantWave) use_lane = use_small = false;
-  if (force_variant & kVariantSmall)
-  {
-    if (!use_small) return hipErrorInvalidValue;
-    use_lane = false;
-  }
-  else if (force_variant & kVariantLane)
-  {
-    if (!use_lane) return hipErrorInvalidValue;
-    use_small = false;
-  }
-  else if (use_small && use_lane)
-  {
-    if (items < kSmallBelowItems) use_lane = false; else use_small = false;
-  }
+  const Mapping mapping = choose_mapping(args, outer != nullptr, force_variant, lim);
+  if (mapping == Mapping::kInvalid) return hipErrorInvalidValue;
+  const bool use_small = mapping == Mapping::kSmall;
+  const bool use_lane = mapping == Mapping::kLane;
 
   hipError_t e;
   uint32_t n_workers = 0;
   bool lane_lds_records = true;
   if (use_small)
   {
-    e = launch_match_small(args, workspace, lim.cus, lim.lds_per_block,
-                           (force_variant & kVariantNoSkip) != 0, stream, &n_workers);
+    // search and final reduction in one launch; the ticket counter sits beside the lane
+    // search's first work-item counter (a word that search never touches): zero when the
+    // workspace is allocated, left at zero by every launch
+    e = launch_match_small(args, workspace, args.next_item + 1, lim.cus,
+                           lim.lds_per_block, (force_variant & kVariantNoSkip) != 0, record_out,
+                           record_out2, host_record, seq, stream);
     if (e != hipSuccess) return e;
+    if (ev_main_done != nullptr)
+    {
+      e = hipEventRecord(ev_main_done, stream);
+      if (e != hipSuccess) return e;
+    }
+    if (info != nullptr)
+    {
+      info->variant = pow2 ? "match/lane-per-candidate/small-lattice/pow2"
+                           : "match/lane-per-candidate/small-lattice/div";
+      info->n_kernels = 1;
+    }
+    return hipSuccess;
   }
-  else if (use_lane)
+  if (use_lane)
   {
     e = launch_match_lane(args, outer, workspace, kMaxMatchBlocks * kMatchWaves, lim.cus,
                           lim.lds_per_block, (force_variant & kVariantNoSkip) != 0, stream,
@@ -579,25 +664,18 @@ hipError_t launch_match(const MatchArgs & args_in, double * workspace, double * 
     const uint32_t per_block = (n_workers + 255) / 256;
     const uint32_t stage_blocks = (n_workers + per_block - 1) / per_block;
     hipLaunchKernelGGL(match_reduce_kernel, dim3(stage_blocks), dim3(256), 0, stream, records,
-                       n_workers, per_block, staged, static_cast<double *>(nullptr), 0,
-                       static_cast<double *>(nullptr), 0ull);
+                       n_workers, per_block, staged, static_cast<double *>(nullptr), 0);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     records = staged;
     n_workers = stage_blocks;
   }
-  hipLaunchKernelGGL(match_reduce_kernel, dim3(1), dim3(256), 0, stream, records, n_workers,
-                     n_workers, record_out, record_out2, 1, host_record, seq);
+  hipLaunchKernelGGL(match_reduce_final_kernel, dim3(1), dim3(kFinalThreads), 0, stream, records,
+                     n_workers, record_out, record_out2, host_record, seq);
   e = hipGetLastError();
   if (info != nullptr)
   {
-    if (use_small)
-    {
-      info->variant = pow2 ? "match/lane-per-candidate/small-lattice/pow2"
-                           : "match/lane-per-candidate/small-lattice/div";
-      info->n_kernels = 2;
-    }
-    else if (use_lane)
+    if (use_lane)
     {
       info->variant = lane_lds_records ? (pow2 ? "match/lane-per-candidate/lds-grid/pow2"
                                                : "match/lane-per-candidate/lds-grid/div")

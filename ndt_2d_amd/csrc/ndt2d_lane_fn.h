@@ -142,6 +142,7 @@ __device__ __forceinline__ uint8_t sub_cell_byte(const GridDesc & g, int32_t cx,
 
 struct LaneCtx
 {
+  uint32_t rank_address;       // LDS byte address of the cell -> compact record table (COMPACT)
   uint32_t lds_cells_address;  // LDS byte address of the packed records (behind the map)
   uint32_t sub_log2;           // map sub-cell -> map cell: shift right
   // map cell (col, row) -> grid cell index: row * size_x + col - idx_bias,
@@ -160,6 +161,12 @@ __device__ __forceinline__ uint32_t lds_byte_at(uint32_t address)
 {
   typedef const __attribute__((address_space(3))) uint8_t * lds_byte_ptr;
   return *reinterpret_cast<lds_byte_ptr>(address);
+}
+
+__device__ __forceinline__ uint32_t lds_u16_at(uint32_t address)
+{
+  typedef const __attribute__((address_space(3))) uint16_t * lds_u16_ptr;
+  return *reinterpret_cast<lds_u16_ptr>(address);
 }
 
 // Cell::score's exponent against packed record idx of the LDS copy, addressed with
@@ -203,7 +210,9 @@ __device__ __forceinline__ SkipState skip_state(double sum, int32_t no_skip)
 // SCALAR_ROWS: the rows o[] are wave-uniform values held in scalar registers (the
 // large search reads them with scalar loads); false: they sit in vector registers
 // (the small search broadcasts them from LDS).
-template <int U, bool POW2, bool LDS_RECORDS, bool SCALAR_ROWS = true>
+// COMPACT (with LDS_RECORDS): the LDS records are the compacted ones, addressed through
+// the cell -> record table at c.rank_address (uint16 per grid cell, also in LDS).
+template <int U, bool POW2, bool LDS_RECORDS, bool SCALAR_ROWS = true, bool COMPACT = false>
 __device__ __forceinline__ void lane_beams(const GridDesc & g, const LaneCtx & c,
                                            const double4 (&o)[U], double dx, double dy,
                                            double dxy, double & sum, SkipState & skip,
@@ -275,6 +284,7 @@ __device__ __forceinline__ void lane_beams(const GridDesc & g, const LaneCtx & c
             const uint32_t row = ((hi[u] >> 8) & 0xffu) >> c.sub_log2;
             idx = occ ? __umul24(row, c.size_x) + (col - c.idx_bias) : g.ncell;
           }
+          if (COMPACT) idx = lds_u16_at(c.rank_address + 2u * idx);
           const double e = LDS_RECORDS ? lds_record_exponent(c.lds_cells_address, idx, px, py)
                                        : indexed_exponent<false>(g, nullptr, idx, px, py);
           // !(e < bound) also keeps NaN exponents (degenerate cells) on the exact path

@@ -139,6 +139,7 @@ __global__ void __launch_bounds__(THREADS) match_lane_kernel(
   __syncthreads();
 
   LaneCtx c;
+  c.rank_address = 0;
   c.lds_cells_address = static_cast<uint32_t>(geo.map_h) * kMapStride;
   c.sub_log2 = static_cast<uint32_t>(geo.sub_log2);
   c.idx_bias = static_cast<uint32_t>(geo.pad - geo.win_y0) * g.size_x +

@@ -25,7 +25,25 @@
 //
 // A candidate's sum is therefore a fixed-order sum of in-order chunk sums: deterministic,
 // independent of timing, and within a few ulps of the reference's single running sum.
-// Records are reduced by match_reduce_kernel exactly as for the other mappings.
+//
+// Tiles.  The 64 candidates of a wave are an 8 x 8 patch of translations, or -- for
+// lattices of at most 32 x 32 translations, the node's own -- 64 consecutive candidates
+// of the theta step in the reference's visiting order (a 21 x 21 lattice is 7 such tiles
+// but 9 patches with a quarter of their lanes idle; the tile still spans a fraction of a
+// cell, which is what the wave-uniform skipping needs).
+//
+// Final reduction in the same launch.  The search ends every matchScan call, and a second
+// launch for a few hundred records costs more than the records do (launch gap + 8 us on
+// its own).  Records are stored with agent-scope 8-byte atomics; the block that draws the
+// last ticket of the launch reads them back the same way (the valid both-sides form of
+// MI355X_MICROARCH.md: no L2 write-back, no stale L1/L2 line) and reduces them in a fixed
+// order -- which block that is leaves no trace in the result -- applying "no candidate
+// scored below 0 -> no index" and writing the result record to HBM and, behind a flag,
+// to host-coherent memory.
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
+
 #include "ndt2d_lane_fn.h"
 
 namespace ndt2d
@@ -40,26 +58,71 @@ constexpr uint32_t kRowDoubles = 4;           // {ox, oy, K, -}: two 16-byte LDS
 
 struct SmallPlan
 {
-  uint32_t patches_per_block;   // P: patch slots of a block (all of one theta step)
-  uint32_t chunks;              // C: beam chunks = waves per patch slot
+  uint32_t patches_per_block;   // P: tile slots of a block (all of one theta step)
+  uint32_t chunks;              // C: beam chunks = waves per tile slot
   uint32_t chunk_beams;         // beams per chunk (a multiple of kUnroll)
-  uint32_t blocks_per_theta;    // ceil(patches / P)
+  uint32_t blocks_per_theta;    // ceil(tiles / P)
   uint32_t need_w;              // map columns in use: window + 2 * pad
+  uint32_t tiles;               // tiles of one theta step
+  uint32_t linear;              // tiles are runs of 64 consecutive candidates, not 8 x 8 patches
+  uint32_t no_tail;             // (experiments) leave out the final reduction
 };
 
-template <bool POW2>
+// What the launch's last block needs for the final reduction.
+struct SmallFinal
+{
+  uint32_t * tickets;           // one counter, zero between launches
+  double * record_out;          // device, 12 doubles
+  double * record_out2;         // device, optional
+  double * host_out;            // host-coherent, optional; flag at host_out[kHostFlagSlot]
+  unsigned long long seq;
+};
+
+// The search tables as kernel arguments: [dth | cos | sin (n_th each) | dlin (n_lin)].
+struct SmallTables
+{
+  double v[kArgTableDoubles];
+};
+
+__device__ __forceinline__ void store_agent(double * p, double v)
+{
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double load_agent(const double * p)
+{
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// COMPACT: the grid came with compacted records (GridDesc::compact_records, small maps
+// installed from the host): the block keeps them and the cell -> record table in LDS, so
+// an exact evaluation reads its record from LDS instead of gathering it through L2 -- in
+// the node's own searches (tight lattice around a good guess) nearly every beam is one.
+// ARG_TABLES: the search tables arrive as kernel arguments (`tab`), not through a.dth ..
+// a.dlin: a matchScan whose beams the device already holds then needs no copy at all.
+template <bool POW2, bool COMPACT, bool ARG_TABLES>
 __global__ void __launch_bounds__(kSmallMaxWaves * kWave) match_small_kernel(const MatchArgs a,
                                                                              const LaneGeom geo,
-                                                                             const SmallPlan plan)
+                                                                             const SmallPlan plan,
+                                                                             const SmallFinal fin,
+                                                                             const SmallTables tab)
 {
-  // LDS: [map, at offset 0 so that the packed cell bytes are the address][rows][partials]
+  auto table = [&](uint32_t which, uint32_t i) -> double {
+    // which: 0 dth, 1 cos, 2 sin (index: theta step); 3 dlin (index: translation)
+    if (ARG_TABLES) return tab.v[which * a.n_th + i];
+    return (which == 0 ? a.dth : which == 1 ? a.cos_th : which == 2 ? a.sin_th : a.dlin)[i];
+  };
+  // LDS: [map, at offset 0 so that the packed cell bytes are the address]
+  //      [COMPACT: cell ranks (uint16), compact records][rows][partials]
   extern __shared__ __align__(16) double lds[];
   const GridDesc & g = a.grid;
   if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();
   uint8_t * lds_map = reinterpret_cast<uint8_t *>(lds);
   const uint32_t map_bytes = static_cast<uint32_t>(geo.map_h) * kMapStride;
-  double * rows = lds + map_bytes / sizeof(double);
-  double * partials = rows + static_cast<size_t>(a.n_beams) * kRowDoubles;
+  const uint32_t rank_bytes = COMPACT ? ((g.ncell + 1) * 2 + 15) & ~15u : 0u;
+  const uint32_t compact_bytes = COMPACT ? (g.n_occ + 1) * kCellDoubles * static_cast<uint32_t>(sizeof(double)) : 0u;
+  double * rows = lds + (map_bytes + rank_bytes + compact_bytes) / sizeof(double);
+  double * partials = rows + max(static_cast<size_t>(a.n_beams) * kRowDoubles,
+                                 static_cast<size_t>(kSmallMaxWaves) * kRecord);
 
   const uint32_t n_threads = blockDim.x;
   const uint32_t t_local = blockIdx.x / plan.blocks_per_theta;
@@ -68,23 +131,36 @@ __global__ void __launch_bounds__(kSmallMaxWaves * kWave) match_small_kernel(con
 
   // map window: one byte per grid cell, copied from the grid's extended byte image;
   // cells further than one cell outside the grid cannot be reached by anything: 0
+  // (a wave per map row, a lane per column)
   {
     const int32_t ew = static_cast<int32_t>(g.size_x) + 2, eh = static_cast<int32_t>(g.size_y) + 2;
-    const uint32_t n = plan.need_w * static_cast<uint32_t>(geo.map_h);
-    for (uint32_t i = threadIdx.x; i < n; i += n_threads)
+    const uint32_t n_waves = n_threads >> 6;
+    for (uint32_t my = threadIdx.x >> 6; my < static_cast<uint32_t>(geo.map_h); my += n_waves)
     {
-      const uint32_t my = i / plan.need_w, mx = i - my * plan.need_w;
-      const int32_t ex = static_cast<int32_t>(mx) - geo.pad + geo.win_x0 + 1;
       const int32_t ey = static_cast<int32_t>(my) - geo.pad + geo.win_y0 + 1;
-      uint8_t v = 0;
-      if (ex >= 0 && ex < ew && ey >= 0 && ey < eh) v = g.cell_bytes[ey * ew + ex];
-      lds_map[my * kMapStride + mx] = v;
+      for (uint32_t mx = threadIdx.x & 63u; mx < plan.need_w; mx += 64u)
+      {
+        const int32_t ex = static_cast<int32_t>(mx) - geo.pad + geo.win_x0 + 1;
+        uint8_t v = 0;
+        if (ex >= 0 && ex < ew && ey >= 0 && ey < eh) v = g.cell_bytes[ey * ew + ex];
+        lds_map[my * kMapStride + mx] = v;
+      }
     }
+  }
+  if (COMPACT)
+  {
+    // ranks and records are contiguous in HBM ([records][ranks]) and 16-byte aligned
+    const uint4 * src_rank = reinterpret_cast<const uint4 *>(g.cell_rank);
+    uint4 * dst_rank = reinterpret_cast<uint4 *>(lds_map + map_bytes);
+    for (uint32_t i = threadIdx.x; i < rank_bytes / 16; i += n_threads) dst_rank[i] = src_rank[i];
+    const double2 * src_rec = reinterpret_cast<const double2 *>(g.compact_records);
+    double2 * dst_rec = reinterpret_cast<double2 *>(lds_map + map_bytes + rank_bytes);
+    for (uint32_t i = threadIdx.x; i < compact_bytes / 16; i += n_threads) dst_rec[i] = src_rec[i];
   }
   // points_outer (:106-115) and the packed fixed-point map coordinate of each beam
   {
-    const double ct = a.cos_th[ith];
-    const double st = a.sin_th[ith];
+    const double ct = table(1, ith);
+    const double st = table(2, ith);
     for (uint32_t b = threadIdx.x; b < a.n_beams; b += n_threads)
     {
       const double2 p = reinterpret_cast<const double2 *>(a.beams_xy)[b];
@@ -106,7 +182,8 @@ __global__ void __launch_bounds__(kSmallMaxWaves * kWave) match_small_kernel(con
   __syncthreads();
 
   LaneCtx c;
-  c.lds_cells_address = 0;   // records are gathered from the 64-byte-stride HBM copy
+  c.rank_address = map_bytes;
+  c.lds_cells_address = map_bytes + rank_bytes;   // (not COMPACT: records are gathered from HBM)
   c.sub_log2 = 0;
   c.idx_bias = static_cast<uint32_t>(geo.pad - geo.win_y0) * g.size_x +
                static_cast<uint32_t>(geo.pad - geo.win_x0);
@@ -117,20 +194,29 @@ __global__ void __launch_bounds__(kSmallMaxWaves * kWave) match_small_kernel(con
   const uint32_t slot = wave / plan.chunks;
   const uint32_t chunk = wave - slot * plan.chunks;
   const uint32_t n_lin = a.n_lin;
-  const uint32_t patches_1d = (n_lin + kPatch - 1) / kPatch;
-  const uint32_t patches = patches_1d * patches_1d;
-  const uint32_t patch = first_patch + slot;
-  const bool active = slot < plan.patches_per_block && patch < patches;
+  const uint32_t tile = first_patch + slot;
+  const bool active = slot < plan.patches_per_block && tile < plan.tiles;
 
-  const uint32_t lx = lane >> 3, ly = lane & 7;
-  const uint32_t pxi = active ? patch / patches_1d : 0;
-  const uint32_t pyi = active ? patch - pxi * patches_1d : 0;
-  const uint32_t ix = pxi * kPatch + lx;
-  const uint32_t iy = pyi * kPatch + ly;
+  // lane -> candidate (ix, iy) of the theta step
+  uint32_t ix, iy;
+  if (plan.linear)
+  {
+    const uint32_t f = (active ? tile : 0u) * kWave + lane;
+    ix = f / n_lin;
+    iy = f - ix * n_lin;
+  }
+  else
+  {
+    const uint32_t patches_1d = (n_lin + kPatch - 1) / kPatch;
+    const uint32_t pxi = active ? tile / patches_1d : 0;
+    const uint32_t pyi = active ? tile - pxi * patches_1d : 0;
+    ix = pxi * kPatch + (lane >> 3);
+    iy = pyi * kPatch + (lane & 7);
+  }
   const bool valid = active & (ix < n_lin) & (iy < n_lin);
-  // lanes beyond the lattice edge shadow the edge candidate and are dropped below
-  const double dx = a.dlin[min(ix, n_lin - 1)];
-  const double dy = a.dlin[min(iy, n_lin - 1)];
+  // lanes beyond the lattice edge shadow an edge candidate and are dropped below
+  const double dx = table(3, min(ix, n_lin - 1));
+  const double dy = table(3, min(iy, n_lin - 1));
 
   if (active)
   {
@@ -147,12 +233,12 @@ __global__ void __launch_bounds__(kSmallMaxWaves * kWave) match_small_kernel(con
       double4 o[kUnroll];
 #pragma unroll
       for (int u = 0; u < kUnroll; ++u) o[u] = row[b + u];
-      lane_beams<kUnroll, POW2, false, false>(g, c, o, dx, dy, dxy, sum, skip, geo.no_skip);
+      lane_beams<kUnroll, POW2, COMPACT, false, COMPACT>(g, c, o, dx, dy, dxy, sum, skip, geo.no_skip);
     }
     for (; b < b1; ++b)
     {
       const double4 one[1] = {row[b]};
-      lane_beams<1, POW2, false, false>(g, c, one, dx, dy, dxy, sum, skip, geo.no_skip);
+      lane_beams<1, POW2, COMPACT, false, COMPACT>(g, c, one, dx, dy, dxy, sum, skip, geo.no_skip);
     }
     partials[wave * kWave + lane] = sum;
   }
@@ -181,7 +267,7 @@ __global__ void __launch_bounds__(kSmallMaxWaves * kWave) match_small_kernel(con
         best_i = static_cast<double>(static_cast<uint64_t>(ith) * per_theta + in_theta);
       }
       // k += x x^T score, u += x score, s += score (:137-140)
-      const double dt = a.dth[ith];
+      const double dt = table(0, ith);
       acc[0] = (dx * dx) * score;
       acc[1] = (dx * dy) * score;
       acc[2] = (dx * dt) * score;
@@ -199,52 +285,205 @@ __global__ void __launch_bounds__(kSmallMaxWaves * kWave) match_small_kernel(con
     for (int k = 0; k < 10; ++k) acc[k] = wave_sum_to_last_lane(acc[k]);
     if (lane == kWave - 1)
     {
-      double * out = a.partials + (static_cast<size_t>(t_local) * patches + patch) * kRecord;
-      out[0] = best_s;
-      out[1] = best_i;
+      double * out = a.partials + (static_cast<size_t>(t_local) * plan.tiles + tile) * kRecord;
+      store_agent(out + 0, best_s);
+      store_agent(out + 1, best_i);
 #pragma unroll
-      for (int k = 0; k < 10; ++k) out[2 + k] = acc[k];
+      for (int k = 0; k < 10; ++k) store_agent(out + 2 + k, acc[k]);
     }
+  }
+
+  // ---- final reduction by the block that draws the launch's last ticket ----
+  // (every wave's record stores have been acknowledged before it passes the barrier)
+  // (the ticket travels through the partial-sum area, free again after the barrier: a
+  // static __shared__ variable would push the map off LDS offset 0)
+  uint32_t * ticket_slot = reinterpret_cast<uint32_t *>(partials);
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    *ticket_slot = __hip_atomic_fetch_add(fin.tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (*ticket_slot != gridDim.x - 1) return;
+  if (plan.no_tail)   // experiments/small_plan_sweep.py: the search without its reduction
+  {
+    if (threadIdx.x == 0) __hip_atomic_store(fin.tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+
+  // Every lane takes whole records (r = thread, thread + n_threads, ...; the 12 loads of a
+  // record in flight together: one trip to memory for a few hundred records), each wave
+  // reduces its lanes over the DPP network, the waves' results meet in LDS and thread 0
+  // adds them in wave order.  Fixed order throughout.
+  const uint32_t n_records = gridDim.x / plan.blocks_per_theta * plan.tiles;
+  const uint32_t n_waves = n_threads >> 6;
+  double bs = 0.0, bi = kNoIndex;
+  double acc[10];
+#pragma unroll
+  for (int k = 0; k < 10; ++k) acc[k] = 0.0;
+  for (uint32_t r = threadIdx.x; r < n_records; r += n_threads)
+  {
+    const double * p = a.partials + static_cast<size_t>(r) * kRecord;
+    double v[kRecord];
+#pragma unroll
+    for (int k = 0; k < kRecord; ++k) v[k] = load_agent(p + k);
+    if (better(v[0], v[1], bs, bi))
+    {
+      bs = v[0];
+      bi = v[1];
+    }
+#pragma unroll
+    for (int k = 0; k < 10; ++k) acc[k] += v[2 + k];
+  }
+  wave_best_to_last_lane(bs, bi);
+#pragma unroll
+  for (int k = 0; k < 10; ++k) acc[k] = wave_sum_to_last_lane(acc[k]);
+  double * wave_out = rows;   // [n_waves][kRecord], the rotated-beam rows are done with
+  if (lane == kWave - 1)
+  {
+    wave_out[wave * kRecord + 0] = bs;
+    wave_out[wave * kRecord + 1] = bi;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) wave_out[wave * kRecord + 2 + k] = acc[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < kRecord)
+  {
+    const uint32_t k = threadIdx.x;
+    double val;
+    if (k < 2)
+    {
+      double s0 = wave_out[0], i0 = wave_out[1];
+      for (uint32_t w = 1; w < n_waves; ++w)
+      {
+        const double sw = wave_out[w * kRecord], iw = wave_out[w * kRecord + 1];
+        if (better(sw, iw, s0, i0))
+        {
+          s0 = sw;
+          i0 = iw;
+        }
+      }
+      val = k == 0 ? s0 : (s0 < 0.0 ? i0 : -1.0);   // no candidate scored below 0: no index
+    }
+    else
+    {
+      val = wave_out[k];
+      for (uint32_t w = 1; w < n_waves; ++w) val += wave_out[w * kRecord + k];
+    }
+    fin.record_out[k] = val;
+    if (fin.record_out2 != nullptr) fin.record_out2[k] = val;
+    if (fin.host_out != nullptr) store_host(fin.host_out + k, val);
+  }
+  if (threadIdx.x == 0) __hip_atomic_store(fin.tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (fin.host_out != nullptr && wave == 0)
+  {
+    // the record (lanes 0..11 of this wave) has been acknowledged before the flag leaves
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) raise_host_flag(fin.host_out + kHostFlagSlot, fin.seq);
   }
 }
 
-size_t small_lds_bytes(const MatchArgs & args, const LaneGeom & geo, uint32_t waves)
+size_t small_compact_bytes(const MatchArgs & args)
 {
-  return static_cast<size_t>(geo.map_h) * kMapStride +
-         static_cast<size_t>(args.n_beams) * kRowDoubles * sizeof(double) +
-         static_cast<size_t>(waves) * kWave * sizeof(double);
+  return ((static_cast<size_t>(args.grid.ncell) + 1) * 2 + 15) / 16 * 16 +
+         (static_cast<size_t>(args.grid.n_occ) + 1) * kCellDoubles * sizeof(double);
 }
 
-// How a lattice is cut into blocks: enough waves to fill the chip's wave slots once
-// (4 per SIMD at this kernel's register budget), every wave with whole look-up groups.
-// The cut follows the WHOLE lattice (n_th), not the theta steps of this launch: a
+size_t small_lds_bytes(const MatchArgs & args, const LaneGeom & geo, uint32_t waves, bool compact)
+{
+  // (the rows' area is reused by the final reduction for one record per wave)
+  size_t row_doubles = static_cast<size_t>(args.n_beams) * kRowDoubles;
+  if (row_doubles < static_cast<size_t>(kSmallMaxWaves) * kRecord) row_doubles = kSmallMaxWaves * kRecord;
+  return static_cast<size_t>(geo.map_h) * kMapStride + (compact ? small_compact_bytes(args) : 0) +
+         row_doubles * sizeof(double) + static_cast<size_t>(waves) * kWave * sizeof(double);
+}
+
+// records in LDS when the grid has compacted ones and the block's image stays small
+// enough for two blocks per CU
+bool small_use_compact(const MatchArgs & args, const LaneGeom & geo)
+{
+  return args.grid.n_occ > 0 && args.grid.compact_records != nullptr &&
+         small_lds_bytes(args, geo, kSmallMaxWaves, true) <= 72 * 1024;
+}
+
+// tiles (waves' worth of candidates) of one theta step
+constexpr uint32_t kSmallLinearBelow = 32;
+uint32_t small_tiles(uint32_t n_lin)
+{
+  if (n_lin <= kSmallLinearBelow) return (n_lin * n_lin + kWave - 1) / kWave;
+  const uint32_t p1 = (n_lin + kPatch - 1) / kPatch;
+  return p1 * p1;
+}
+
+// How a lattice is cut into blocks, every wave with whole look-up groups.  The cut follows the WHOLE lattice (n_th), not the theta steps of this launch: a
 // candidate's chunks, hence the bits of its score, are the same whichever rank of a
 // sharded search evaluates it.
 SmallPlan small_plan(const MatchArgs & args, const LaneGeom & geo, int cus)
 {
-  const uint32_t p1 = (args.n_lin + kPatch - 1) / kPatch;
-  const uint32_t patches = p1 * p1;
-  const uint64_t items = static_cast<uint64_t>(args.n_th) * patches;
+  SmallPlan plan{};
+  plan.linear = args.n_lin <= kSmallLinearBelow ? 1u : 0u;
+  plan.tiles = small_tiles(args.n_lin);
+  plan.need_w = static_cast<uint32_t>(geo.win_w + 2 * geo.pad);
+  plan.no_tail = std::getenv("NDT2D_SMALL_NOTAIL") != nullptr ? 1u : 0u;
   const uint32_t groups = (args.n_beams + kUnroll - 1) / kUnroll;
-  const uint64_t wave_slots = static_cast<uint64_t>(cus) * 16;
-  uint64_t c = items > 0 ? wave_slots / items : 1;
-  if (c < 1) c = 1;
-  if (c > static_cast<uint64_t>(kSmallMaxWaves)) c = kSmallMaxWaves;
-  if (c > groups) c = groups;
-  const uint32_t chunk_groups = (groups + static_cast<uint32_t>(c) - 1) / static_cast<uint32_t>(c);
-  SmallPlan plan;
+  // Pick (C beam chunks per tile, P tiles per block), P * C <= 16 waves.  Measured
+  // (experiments/small_plan_sweep.py): a wave's time is its number of look-up groups
+  // whatever shares its CU (the look-up -> exact-evaluation chains are latency bound),
+  // plus about one group's worth of block setup; blocks beyond what the CUs hold at once
+  // (16 wave slots each) wait for another round.  So: minimise rounds x (1 + groups per
+  // wave); between equals, the fewer and larger blocks.
+  const uint64_t n_th = args.n_th;
+  uint64_t best_cost = 0;
+  uint32_t best_c = 1, best_p = 1;
+  for (uint32_t c = 1; c <= static_cast<uint32_t>(kSmallMaxWaves) && c <= groups; ++c)
+  {
+    const uint32_t chunk_groups = (groups + c - 1) / c;
+    if ((groups + chunk_groups - 1) / chunk_groups != c) continue;   // same cut as a smaller c
+    for (uint32_t p = 1; p * c <= static_cast<uint32_t>(kSmallMaxWaves) && p <= plan.tiles; ++p)
+    {
+      const uint64_t blocks = n_th * ((plan.tiles + p - 1) / p);
+      const uint64_t resident = static_cast<uint64_t>(cus) * (static_cast<uint32_t>(kSmallMaxWaves) / (p * c));
+      const uint64_t rounds = (blocks + resident - 1) / resident;
+      const uint64_t cost = rounds * (1 + chunk_groups);
+      if (best_cost == 0 || cost < best_cost || (cost == best_cost && p * c >= best_p * best_c))
+      {
+        best_cost = cost;
+        best_c = c;
+        best_p = p;
+      }
+    }
+  }
+  if (const char * env = std::getenv("NDT2D_SMALL_CHUNKS"))   // tuning knobs for
+  {                                                             // experiments/small_plan_sweep.py
+    const uint32_t c = static_cast<uint32_t>(std::atoi(env));
+    if (c >= 1 && c <= static_cast<uint32_t>(kSmallMaxWaves)) best_c = c < groups ? c : groups;
+    best_p = kSmallMaxWaves / best_c;
+  }
+  if (const char * env = std::getenv("NDT2D_SMALL_PATCHES"))
+  {
+    const uint32_t p = static_cast<uint32_t>(std::atoi(env));
+    if (p >= 1 && p * best_c <= static_cast<uint32_t>(kSmallMaxWaves)) best_p = p;
+  }
+  const uint32_t chunk_groups = (groups + best_c - 1) / best_c;
   plan.chunks = (groups + chunk_groups - 1) / chunk_groups;
   plan.chunk_beams = chunk_groups * kUnroll;
-  uint32_t p = kSmallMaxWaves / plan.chunks;
-  if (p > patches) p = patches;
+  uint32_t p = best_p;
+  if (p * plan.chunks > static_cast<uint32_t>(kSmallMaxWaves)) p = kSmallMaxWaves / plan.chunks;
+  if (p > plan.tiles) p = plan.tiles;
   if (p < 1) p = 1;
   plan.patches_per_block = p;
-  plan.blocks_per_theta = (patches + p - 1) / p;
-  plan.need_w = static_cast<uint32_t>(geo.win_w + 2 * geo.pad);
+  plan.blocks_per_theta = (plan.tiles + p - 1) / p;
   return plan;
 }
 
 }  // namespace
+
+bool match_small_takes_arg_tables(const MatchArgs & args)
+{
+  return args.host_tables != nullptr &&
+         3 * static_cast<uint64_t>(args.n_th) + args.n_lin <= kArgTableDoubles;
+}
 
 bool match_small_supported(const MatchArgs & args, size_t lds_per_block)
 {
@@ -256,12 +495,13 @@ bool match_small_supported(const MatchArgs & args, size_t lds_per_block)
   const uint64_t p1 = (args.n_lin + kPatch - 1) / kPatch;
   const uint64_t items = static_cast<uint64_t>(args.th_end - args.th_begin) * p1 * p1;
   return items <= kSmallMaxItems && args.grid.size_x < (1u << 24) && args.grid.ncell < (1u << 24) &&
-         small_lds_bytes(args, geo, kSmallMaxWaves) <= lds_per_block;
+         small_lds_bytes(args, geo, kSmallMaxWaves, false) <= lds_per_block;
 }
 
-hipError_t launch_match_small(const MatchArgs & args_in, double * workspace, int cus,
-                              size_t lds_per_block, bool no_skip, hipStream_t stream,
-                              uint32_t * n_records_out)
+hipError_t launch_match_small(const MatchArgs & args_in, double * workspace, uint32_t * tickets,
+                              int cus, size_t lds_per_block, bool no_skip, double * record_out,
+                              double * record_out2, double * host_record, unsigned long long seq,
+                              hipStream_t stream)
 {
   MatchArgs args = args_in;
   args.partials = workspace;
@@ -275,7 +515,20 @@ hipError_t launch_match_small(const MatchArgs & args_in, double * workspace, int
   const SmallPlan plan = small_plan(args, geo, cus);
   const uint32_t waves = plan.patches_per_block * plan.chunks;
   const uint32_t blocks = (args.th_end - args.th_begin) * plan.blocks_per_theta;
-  const size_t lds_bytes = small_lds_bytes(args, geo, waves);
+  SmallFinal fin;
+  fin.tickets = tickets;
+  fin.record_out = record_out;
+  fin.record_out2 = record_out2;
+  fin.host_out = host_record;
+  fin.seq = seq;
+  const bool arg_tables = match_small_takes_arg_tables(args);
+  SmallTables tab;
+  if (arg_tables)
+  {
+    std::memcpy(tab.v, args.host_tables, (3 * static_cast<size_t>(args.n_th) + args.n_lin) * sizeof(double));
+  }
+  const bool compact = small_use_compact(args, geo);
+  const size_t lds_bytes = small_lds_bytes(args, geo, waves, compact);
   auto launch = [&](auto kernel) -> hipError_t {
     if (lds_bytes > 48 * 1024)
     {
@@ -284,13 +537,18 @@ hipError_t launch_match_small(const MatchArgs & args_in, double * workspace, int
                                           static_cast<int>(lds_bytes));
       if (e2 != hipSuccess) return e2;
     }
-    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(waves * kWave), lds_bytes, stream, args, geo, plan);
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(waves * kWave), lds_bytes, stream, args, geo, plan, fin, tab);
     return hipGetLastError();
   };
-  const hipError_t e = args.grid.pow2 ? launch(match_small_kernel<true>) : launch(match_small_kernel<false>);
-  const uint32_t p1 = (args.n_lin + kPatch - 1) / kPatch;
-  if (n_records_out != nullptr) *n_records_out = (args.th_end - args.th_begin) * p1 * p1;
-  return e;
+  auto pick = [&](auto pow2_tag, auto compact_tag) -> hipError_t {
+    constexpr bool P2 = decltype(pow2_tag)::value;
+    constexpr bool CP = decltype(compact_tag)::value;
+    return arg_tables ? launch(match_small_kernel<P2, CP, true>) : launch(match_small_kernel<P2, CP, false>);
+  };
+  using T = std::true_type;
+  using F = std::false_type;
+  return compact ? (args.grid.pow2 ? pick(T{}, T{}) : pick(F{}, T{}))
+                 : (args.grid.pow2 ? pick(T{}, F{}) : pick(F{}, F{}));
 }
 
 }  // namespace ndt2d

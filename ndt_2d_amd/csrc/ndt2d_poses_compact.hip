@@ -505,17 +505,26 @@ __global__ void __launch_bounds__(kFewThreads) score_few_kernel(const PosesArgs 
 #pragma unroll
     for (int j = 1; j < kChunks; ++j) sum += chunk_sums[j];
     // score = sum of (-likelihood) / n  ==  -(sum) / n (:175-177)
-    a.scores[i] = -sum / static_cast<double>(a.n_beams);
-    if (flag != nullptr)
+    const double score = -sum / static_cast<double>(a.n_beams);
+    if (flag == nullptr)
     {
-      // the last block to finish publishes: scores first, then the flag
-      __threadfence_system();
-      const uint32_t arrived = atomicAdd(done_counter, 1u) + 1u;
+      a.scores[i] = score;
+    }
+    else
+    {
+      // scores go to host-coherent memory; the block that finishes last raises the flag,
+      // after every block's store has been acknowledged
+      store_host(a.scores + i, score);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      uint32_t arrived = gridDim.x;
+      if (gridDim.x > 1)
+      {
+        arrived = __hip_atomic_fetch_add(done_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+      }
       if (arrived == gridDim.x)
       {
-        *done_counter = 0u;
-        __threadfence_system();
-        *reinterpret_cast<volatile unsigned long long *>(flag) = seq;
+        if (gridDim.x > 1) __hip_atomic_store(done_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        raise_host_flag(reinterpret_cast<double *>(flag), seq);
       }
     }
   }

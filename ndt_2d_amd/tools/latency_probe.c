@@ -1,0 +1,158 @@
+/* Call latencies of the node's default workload through the C-ABI, without an
+ * interpreter in the way: what the pluginlib shim (ndt_2d_amd/plugin/) pays per call.
+ *
+ * The plugin's default parameters (reference src/scan_matcher_ndt.cpp:37-44): 100 of 720
+ * beams, 21 x 21 x 80 = 35,280 candidates, against the NDT of 9 scans of the synthetic
+ * 8 x 8 m room (SURVEY.md 8d, cfg-1's map).  Per accepted scan the mapper runs
+ * reset + addScans + scoreScan + matchScan (src/ndt_mapper.cpp:508-515); the unchanged
+ * ParticleFilter::measure calls scorePoints once per particle (src/particle_filter.cpp:
+ * 81-87).  Prints one JSON object with medians in microseconds.
+ *
+ *   gcc -O2 -std=c99 -I include ndt_2d_amd/tools/latency_probe.c -L ndt_2d_amd -lndt2d_hip -lm
+ */
+#define _POSIX_C_SOURCE 199309L
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "ndt2d_hip.h"
+
+static double now_us(void)
+{
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
+}
+
+static int cmp(const void * a, const void * b)
+{
+  const double x = *(const double *)a, y = *(const double *)b;
+  return (x > y) - (x < y);
+}
+
+#define N_SCANS 9
+#define N_BEAMS 720
+#define REPS 2000
+
+static ndt2d_matcher * m;
+static double map_poses[3 * N_SCANS], map_pts[2 * N_BEAMS * N_SCANS];
+static size_t map_off[N_SCANS + 1];
+static double scan_pts[2 * N_BEAMS];
+static const double guess[3] = {0.11, -0.05, 0.02};
+static double pf_poses[3 * 500];
+
+static void op_match(void)
+{
+  double pose[3] = {0, 0, 0}, cov[9], score;
+  if (ndt2d_matcher_match_scan(m, guess, scan_pts, N_BEAMS, pose, cov, &score) != NDT2D_OK) exit(3);
+}
+static void op_score_scan(void)
+{
+  double score;
+  if (ndt2d_matcher_score_scan(m, guess, scan_pts, N_BEAMS, &score) != NDT2D_OK) exit(4);
+}
+static void op_add(void)
+{
+  if (ndt2d_matcher_reset(m) != NDT2D_OK) exit(5);
+  if (ndt2d_matcher_add_scans(m, map_poses, map_pts, map_off, N_SCANS) != NDT2D_OK) exit(6);
+}
+static void op_cycle(void)
+{
+  op_add();
+  op_score_scan();
+  op_match();
+}
+static void op_pf_loop(void)
+{
+  for (int i = 0; i < 500; ++i)
+  {
+    double w;
+    if (ndt2d_matcher_score_points(m, scan_pts, N_BEAMS, pf_poses + 3 * i, &w) != NDT2D_OK) exit(7);
+  }
+}
+static void op_pf_batch(void)
+{
+  static double w[500];
+  if (ndt2d_matcher_score_poses(m, scan_pts, N_BEAMS, pf_poses, 500, w) != NDT2D_OK) exit(8);
+}
+
+static void measure(void (*op)(void), int reps, double * median, double * p99)
+{
+  double * t = (double *)malloc(sizeof(double) * (size_t)reps);
+  for (int i = 0; i < reps / 10 + 5; ++i) op();
+  for (int i = 0; i < reps; ++i)
+  {
+    const double t0 = now_us();
+    op();
+    t[i] = now_us() - t0;
+  }
+  qsort(t, (size_t)reps, sizeof(double), cmp);
+  *median = t[reps / 2];
+  *p99 = t[(int)(reps * 0.99)];
+  free(t);
+}
+
+int main(void)
+{
+  /* cfg-1's world and map (ndt_2d_amd/synth.py): room 8 x 8 m, pillars at (+-2, +-2),
+   * 9 map scans on a 3 x 3 lattice of pitch 0.25 m, seeds 1000003 + k; query scan from
+   * (0.13, -0.07, 0.031), seed 101 */
+  const ndt2d_world world = {4.0, 4.0, 0.25};
+  int k = 0;
+  for (int j = -1; j <= 1; ++j)       /* y outer, x inner, seed 1 * 1000003 + index */
+  {
+    for (int i = -1; i <= 1; ++i, ++k)
+    {
+      map_poses[3 * k] = 0.25 * i;
+      map_poses[3 * k + 1] = 0.25 * j;
+      map_poses[3 * k + 2] = 0.0;
+      if (ndt2d_synth_scan(&world, map_poses + 3 * k, N_BEAMS, 0.01, 1000003u + (unsigned)k,
+                           map_pts + 2 * N_BEAMS * k) != NDT2D_OK)
+        return 1;
+      map_off[k] = (size_t)N_BEAMS * (size_t)k;
+    }
+  }
+  map_off[N_SCANS] = (size_t)N_BEAMS * N_SCANS;
+  const double truth[3] = {0.13, -0.07, 0.031};
+  if (ndt2d_synth_scan(&world, truth, N_BEAMS, 0.01, 101u, scan_pts) != NDT2D_OK) return 1;
+  double u[1500];
+  ndt2d_synth_uniform(303u, 1500, u);
+  for (int i = 0; i < 500; ++i)
+  {
+    pf_poses[3 * i] = (u[3 * i] - 0.5) * 7.0;
+    pf_poses[3 * i + 1] = (u[3 * i + 1] - 0.5) * 7.0;
+    pf_poses[3 * i + 2] = (u[3 * i + 2] - 0.5) * 6.28;
+  }
+
+  int rc = ndt2d_matcher_create(&m, 0);
+  if (rc != NDT2D_OK)
+  {
+    fprintf(stderr, "ndt2d_matcher_create -> %d (no GPU: there is no CPU fallback)\n", rc);
+    return 2;
+  }
+  /* the plugin's defaults; range_max 4.75 as in cfg-1 */
+  ndt2d_matcher_initialize(m, 0.25, 0.0025, 0.1, 0.005, 0.05, 100, 4.75);
+  ndt2d_set_timing(ndt2d_matcher_device(m), 0);   /* as the shim does */
+  op_add();
+
+  double med[6], p99[6];
+  measure(op_match, REPS, &med[0], &p99[0]);
+  measure(op_score_scan, REPS, &med[1], &p99[1]);
+  measure(op_add, REPS / 4, &med[2], &p99[2]);
+  measure(op_cycle, REPS / 4, &med[3], &p99[3]);
+  measure(op_pf_loop, 20, &med[4], &p99[4]);
+  measure(op_pf_batch, REPS / 4, &med[5], &p99[5]);
+  double pose[3] = {0, 0, 0}, cov[9], score;
+  ndt2d_matcher_match_scan(m, guess, scan_pts, N_BEAMS, pose, cov, &score);
+  printf("{\"match_scan_us\": %.2f, \"match_scan_p99_us\": %.2f, \"score_scan_us\": %.2f, "
+         "\"add_scans_us\": %.2f, \"mapper_cycle_us\": %.2f, \"mapper_cycle_p99_us\": %.2f, "
+         "\"measure_500_particles_unchanged_loop_us\": %.1f, \"score_points_call_us\": %.2f, "
+         "\"measure_500_particles_batched_us\": %.2f, \"variant\": \"%s\", "
+         "\"check_pose\": [%.17g, %.17g, %.17g], \"check_score\": %.17g}\n",
+         med[0], p99[0], med[1], med[2], med[3], p99[3], med[4], med[4] / 500.0, med[5],
+         ndt2d_last_variant(ndt2d_matcher_device(m)), pose[0], pose[1], pose[2], score);
+  ndt2d_matcher_destroy(m);
+  return 0;
+}

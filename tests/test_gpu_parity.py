@@ -356,7 +356,7 @@ def test_launch_timing_history(cfg1):
     hist = gpu.launch_history_ms(5)
     last, n_kernels = gpu.last_launch_ms()
     assert len(hist) == 5 and all(0.0 < t < 50.0 for t in hist)
-    assert hist[-1] == last and n_kernels >= 2
+    assert hist[-1] == last and n_kernels >= 1
     assert len(gpu.launch_history_ms(3)) == 3
     gpu.match_fetch()
     # the ring keeps the last 256 launches
