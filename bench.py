@@ -51,10 +51,28 @@ CPU_BASELINE_FILE = os.path.join(_ROOT, "profiles", "r02_cpu_baselines.json")
 # the reported baseline only -- never on the product path)
 # --------------------------------------------------------------------------------------
 
+def granted_cpus():
+    """CPUs this process may actually use: the cgroup quota when there is one (the GPU
+    box shows 256 logical CPUs and grants 16; 256 OpenMP threads then run slower than 16)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(params, scans, guess, pts):
     """SURVEY.md 8(d) "CPU path timing" on this box's host cores: the oracle's matchScan
-    on the cfg-2 lattice.  All cores: the FULL lattice (1.44e9 units), 1 warm-up + median
-    of 5, the (theta, dx) strips dealt to OpenMP threads.  Single thread (the reference's
+    on the cfg-2 lattice.  All cores the container grants (cgroup quota): the FULL lattice
+    (1.44e9 units), 1 warm-up + median of 5, the (theta, dx) strips dealt to OpenMP threads.  Single thread (the reference's
     own execution model): every 4th theta of the same lattice (3.6e8 units), 1 warm-up +
     median of 3 -- the full-lattice single-thread medians (8 s per run) are in the
     committed profiles/r02_cpu_baselines.json, quoted under `committed`."""
@@ -72,7 +90,7 @@ def cpu_baseline(params, scans, guess, pts):
         n_lin = len(O.search_offsets(p["search_linear_size"], p["search_linear_resolution"]))
         return n_th * n_lin * n_lin * min(p["laser_max_beams"], len(pts)), (n_th, n_lin)
 
-    cores = os.cpu_count() or 1
+    cores = granted_cpus()
     ref = matcher(params)
     u_all, (n_th, n_lin) = units(params)
     times, used = [], 0
@@ -104,7 +122,7 @@ def cpu_baseline(params, scans, guess, pts):
         "single_thread_sample": "%dx%dx%d candidates (every 4th theta), 1 thread -- the reference's own "
                                 "execution model -- 1 warm-up + median of 3 (%.3f s)"
                                 % (n_th1, n_lin, n_lin, t_one),
-        "host_logical_cpus": cores,
+        "host_logical_cpus": os.cpu_count(), "cpus_granted_by_cgroup": cores,
     }
     try:
         with open(CPU_BASELINE_FILE) as f:
@@ -133,9 +151,10 @@ def roofline(kernel, kernel_ms, units, n_cu, pmc, expected_dispatch_note):
     pass of this same workload; the count is a property of the workload, not of the run)
     / the kernel's average duration measured live with HIP events on the launch stream;
     peak = SIMDs x clock / 4 cycles per FP64 / VOP3 wave-instruction, at the clock the
-    chip sustained under this kernel in the PMC pass (SQ_BUSY_CU_CYCLES / CUs / duration;
-    it clocks to its power budget, MI355X_MICROARCH.md "DVFS").  frac_pmc is the same
-    fraction from the counters alone: SQ_INSTS_VALU x 4 / (4 x SQ_BUSY_CU_CYCLES)."""
+    chip sustained in THIS run: the workload's busy cycles (SQ_BUSY_CU_CYCLES / CUs, same
+    pass) / the live duration.  So frac = SQ_INSTS_VALU x 4 / (4 x SQ_BUSY_CU_CYCLES), the
+    fraction of the kernel's SIMD cycles in which a VALU instruction issues, reproducible
+    from profiles/ alone (frac_pmc); frac_at_max_clock prices it against 2.4 GHz."""
     t = kernel_ms * 1e-3
     alg_bytes = units * BYTES_PER_UNIT
     hbm = {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s", "achieved": None, "frac": None,
@@ -153,10 +172,12 @@ def roofline(kernel, kernel_ms, units, n_cu, pmc, expected_dispatch_note):
         roof["note"] = "profiles/r02_pmc.json has no counters for this kernel"
         return roof, hbm
     n_simd = 4 * n_cu
+    # cycles are the workload's (counted under the profiler), time is this run's: the clock
+    # the chip sustained here is their ratio (it clocks to its power budget; the profiled
+    # passes run ~6 % slower, MI355X_MICROARCH.md "DVFS")
     busy_cycles = k["SQ_BUSY_CU_CYCLES"] / n_cu            # per-CU busy cycles of one launch
+    clock = busy_cycles / t
     dur_pmc = k.get("avg_duration_ns", {}).get("sq1")
-    clock = busy_cycles / (dur_pmc * 1e-9) if dur_pmc else MAX_CLOCK_HZ
-    clock = min(clock, MAX_CLOCK_HZ)
     achieved = k["SQ_INSTS_VALU"] / t / 1e9
     peak = n_simd * clock / VALU_CYCLES_PER_INST / 1e9
     roof.update(
@@ -164,6 +185,7 @@ def roofline(kernel, kernel_ms, units, n_cu, pmc, expected_dispatch_note):
         frac_pmc=k["SQ_INSTS_VALU"] * VALU_CYCLES_PER_INST / (4.0 * k["SQ_BUSY_CU_CYCLES"]),
         frac_at_max_clock=achieved / (n_simd * MAX_CLOCK_HZ / VALU_CYCLES_PER_INST / 1e9),
         sustained_clock_GHz=clock / 1e9,
+        clock_in_pmc_pass_GHz=(busy_cycles / (dur_pmc * 1e-9) / 1e9) if dur_pmc else None,
         valu_insts_per_launch=k["SQ_INSTS_VALU"],
         valu_insts_per_unit=k["SQ_INSTS_VALU"] * 64.0 / units,
         source="profiles/r02_pmc.json (experiments/profile_r02.sh) + live HIP-event kernel time; "
@@ -179,7 +201,7 @@ def roofline(kernel, kernel_ms, units, n_cu, pmc, expected_dispatch_note):
         roof["fp64_flops_frac"] = flops / t / 1e12 / FP64_PEAK_TFLOPS
         roof["fp64_share_of_valu_insts"] = sum(f64) / k["SQ_INSTS_VALU"]
     if "SQ_THREAD_CYCLES_VALU" in k and "SQ_ACTIVE_INST_VALU" in k and k["SQ_ACTIVE_INST_VALU"] > 0:
-        roof["avg_active_lanes"] = k["SQ_THREAD_CYCLES_VALU"] / k["SQ_ACTIVE_INST_VALU"] / 4.0
+        roof["avg_active_lanes"] = k["SQ_THREAD_CYCLES_VALU"] / k["SQ_ACTIVE_INST_VALU"]
     if "FETCH_SIZE" in k and "WRITE_SIZE" in k:
         # FETCH_SIZE doubled: gfx950 tallies 128-B requests at 64 B (MI355X_MICROARCH.md, HBM)
         traffic = (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0

@@ -60,3 +60,117 @@ def test_sharded_match_scan_equals_single_gpu(tmp_path, world):
         assert np.array_equal(got["pose"], want["pose"])
         assert abs(float(got["score"]) - want["score"]) < 1e-12
         assert np.allclose(got["covariance"], want["covariance"], rtol=1e-9, atol=0)
+
+
+def _nccl_worker(out_path):
+    """One rank, backend nccl (= RCCL): the collectives of the production path run for
+    real -- process group on the GPU, all-reduce of device tensors."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = "29631"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+
+    from ndt_2d_amd import ScanMatcherNDT, pf_measure, synth
+    from ndt_2d_amd import dist as shard
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    m = ScanMatcherNDT(0)
+    m.initialize("global_scan_matcher", **synth.matcher_params(1))
+    m.addScans(synth.map_scans(1))
+    guess, pts, _ = synth.query_scan(1)
+    res = shard.match_scan_sharded(m, guess, pts, 0, 1, dist)
+    # an all-reduce of the record table through RCCL itself (world 1: identity, but the
+    # whole code path -- device tensor, RCCL stream hand-off -- runs)
+    table = torch.zeros((1, shard.MATCH_RECORD), dtype=torch.float64, device="cuda:0")
+    n_th, _, _ = m.prepare_search(guess, pts)
+    m.match_launch(0, n_th, record_ptr=table[0].data_ptr())
+    m.synchronize()
+    dist.all_reduce(table, op=dist.ReduceOp.SUM)
+    rec = table.cpu().numpy()[0]
+    # sharded particle statistics: [1, 8] all-reduce + the 1-double theta-variance
+    # all-reduce of finish_particle_statistics on a DEVICE tensor
+    parts = synth.particles(3, 4096)
+    parts[:, :2] *= 4.0 / 23.0
+    d_parts = torch.from_numpy(parts).cuda()
+    d_w = torch.zeros(len(parts), dtype=torch.float64, device="cuda:0")
+    stats = torch.zeros((1, shard.POSE_STATS), dtype=torch.float64, device="cuda:0")
+    m.prepare_beams(pts)
+    m.score_poses_launch(d_parts.data_ptr(), len(parts), d_w.data_ptr(), stats[0].data_ptr())
+    m.synchronize()
+    dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+    w, mean, cov = shard.finish_particle_statistics(stats.cpu().numpy(), d_w.cpu().numpy(), parts, 0.0,
+                                                    dist=dist, device=torch.device("cuda", 0))
+    w1, mean1, cov1 = pf_measure(m, parts, pts)
+    np.savez(out_path, score=res["score"], pose=res["pose"], best_index=res["best_index"],
+             covariance=res["covariance"], rec=rec, w=w, mean=mean, cov=cov, w1=w1, mean1=mean1, cov1=cov1)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_single_rank_runs_the_production_collectives(tmp_path):
+    """the RCCL path of dist.py (nccl backend: device tensors, no host
+    detour) had only ever run under gloo.  One rank is all a 1-GPU box allows."""
+    from ndt_2d_amd import ScanMatcherNDT, synth
+    out = os.path.join(str(tmp_path), "nccl.npz")
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_nccl_worker, args=(out,))
+    p.start()
+    p.join(timeout=600)
+    assert p.exitcode == 0
+    got = np.load(out)
+    m = ScanMatcherNDT(0)
+    m.initialize("single", **synth.matcher_params(1))
+    m.addScans(synth.map_scans(1))
+    guess, pts, _ = synth.query_scan(1)
+    want = m.matchScan(guess, pts)
+    assert int(got["best_index"]) == want["best_index"] == int(got["rec"][1])
+    assert np.array_equal(got["pose"], want["pose"])
+    assert float(got["score"]) == want["score"]
+    assert np.array_equal(got["covariance"], want["covariance"])
+    assert np.allclose(got["w"], got["w1"], rtol=1e-12, atol=0)
+    assert np.allclose(got["mean"], got["mean1"], rtol=1e-12, atol=1e-15)
+    assert np.allclose(got["cov"], got["cov1"], rtol=1e-9, atol=1e-13)
+
+
+def test_bench_with_eight_ranks_on_one_gpu_finds_the_cfg4_winner():
+    """bench.py --gpus 8 exactly as the driver launches it (torch.distributed.run, 8 ranks),
+    except that the ranks share this box's one GPU and exchange through gloo
+    (NDT2D_BENCH_BACKEND=gloo): BASELINE.json configs[3] strong-scaled over 8 round-robin
+    theta shares must return the oracle's winner over the whole 315.5M-candidate lattice
+    (tests/golden/big_winners.json), and configs[4]'s sharded particle statistics must
+    agree with the single-process run."""
+    import json
+    import subprocess
+    env = dict(os.environ, NDT2D_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+           "--master-addr", "127.0.0.1", "--master-port", "29641", os.path.join(ROOT, "bench.py"),
+           "--gpus", "8", "--steps", "2", "--warmup", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    with open(os.path.join(HERE, "golden", "big_winners.json")) as f:
+        want = json.load(f)["cfg4"]
+    assert line["n_gpus"] == 8 and line["scaling"] == "strong"
+    assert "configs[3]" in line["config"]["workload"]
+    assert line["config"]["candidates"] == want["n_candidates"] == 315508257
+    assert line["match_result"]["best_index"] == want["best_index"]
+    assert [float(v).hex() for v in line["match_result"]["pose"]] == want["pose_hex"]
+    assert abs(line["match_result"]["score"] - want["score"]) < 1e-9
+    assert line["single_gpu_same_workload"]["ms_per_step"] > 0
+    pf = line["particle_filter"]
+    assert "configs[4]" in pf["workload"] and pf["n_gpus"] == 8
+    # the same statistics from one process
+    env1 = dict(env, NDT2D_BENCH_FORCE_COLLECTIVE="1")
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "cfg2", "--steps", "2",
+                         "--warmup", "1", "--no-cpu-baseline", "--no-default-search"],
+                        capture_output=True, text=True, timeout=1200, env=env1, cwd=ROOT)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    one = json.loads(r1.stdout.strip().splitlines()[-1])["particle_filter_cfg5"]["result"]
+    assert pf["result"]["sum_w"] == pytest.approx(one["sum_w"], rel=1e-12)
+    assert np.allclose(pf["result"]["mean"], one["mean"], rtol=1e-10, atol=1e-13)
+    assert np.allclose(pf["result"]["cov_xx_xy_yy"], one["cov_xx_xy_yy"], rtol=1e-9)
+    assert pf["result"]["theta_variance"] == pytest.approx(one["theta_variance"], rel=1e-10)
