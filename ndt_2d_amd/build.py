@@ -59,9 +59,15 @@ def build_all(force=False, verbose=False, jobs=4):
         return LIB_PATH
 
     def compile_one(src):
-        cmd = [hipcc(), "--offload-arch=" + ARCH] + FLAGS + [
-            "-I", os.path.join(_ROOT, "include"), "-I", _CSRC, "-c",
-            os.path.join(_CSRC, src), "-o", _obj(src)]
+        if src.endswith(".cpp"):
+            # host-only translation unit (no HIP headers): the host compiler, which also
+            # knows function multiversioning (the AVX2 clone of the NDT build loop)
+            cmd = ["g++"] + FLAGS + ["-I", os.path.join(_ROOT, "include"), "-I", _CSRC, "-c",
+                                     os.path.join(_CSRC, src), "-o", _obj(src)]
+        else:
+            cmd = [hipcc(), "--offload-arch=" + ARCH] + FLAGS + [
+                "-I", os.path.join(_ROOT, "include"), "-I", _CSRC, "-c",
+                os.path.join(_CSRC, src), "-o", _obj(src)]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -49,14 +49,19 @@ struct HostCell
   double cov_xx = 0.0, cov_xy = 0.0, cov_yy = 0.0;
   double info_xx = 0.0, info_xy = 0.0, info_yy = 0.0;
 
-  // Cell::addPoint, reference src/ndt_model.cpp:50-63
-  void add(double x, double y)
+  // Cell::addPoint, reference src/ndt_model.cpp:50-63.  The five running values are
+  // consecutive doubles updated by one expression shape, (v * n + t) / n1: the AVX2
+  // clone of NDT::addScan below does them as packed operations (each lane the same
+  // IEEE operation as the scalar code, so the results are bit-identical).
+  __attribute__((always_inline)) void add(double x, double y)
   {
+    typedef double v4d __attribute__((vector_size(32)));
     const double n1 = n + 1;
-    mean_x = (mean_x * n + x) / n1;
-    mean_y = (mean_y * n + y) / n1;
-    corr_xx = (corr_xx * n + x * x) / n1;
-    corr_xy = (corr_xy * n + x * y) / n1;
+    v4d v;
+    std::memcpy(&v, &mean_x, sizeof(v));             // mean_x, mean_y, corr_xx, corr_xy
+    const v4d t = {x, y, x * x, x * y};
+    v = (v * n + t) / n1;
+    std::memcpy(&mean_x, &v, sizeof(v));
     corr_yy = (corr_yy * n + y * y) / n1;
     n += 1;
     valid = false;
@@ -125,26 +130,55 @@ class HostNdt
 public:
   // NDT::NDT, reference src/ndt_model.cpp:118-126
   HostNdt(double cell_size, double size_x, double size_y, double origin_x, double origin_y)
-  : cell_size_(cell_size),
-    size_x_(static_cast<size_t>((size_x / cell_size) + 1)),
-    size_y_(static_cast<size_t>((size_y / cell_size) + 1)),
-    origin_x_(origin_x),
-    origin_y_(origin_y),
-    cells_(size_x_ * size_y_)
   {
+    reset(cell_size, size_x, size_y, origin_x, origin_y);
+  }
+
+  // A new, empty NDT in this object's storage: the mapper rebuilds its local NDT for
+  // every scan (src/ndt_mapper.cpp:508-509) with the same geometry more often than not,
+  // and of its cells only the few hundred that received points need clearing.
+  void reset(double cell_size, double size_x, double size_y, double origin_x, double origin_y)
+  {
+    const size_t sx = static_cast<size_t>((size_x / cell_size) + 1);
+    const size_t sy = static_cast<size_t>((size_y / cell_size) + 1);
+    if (sx == size_x_ && sy == size_y_ && cells_.size() == sx * sy)
+    {
+      for (const uint32_t i : touched_) cells_[i] = HostCell();
+    }
+    else
+    {
+      cells_.assign(sx * sy, HostCell());
+    }
+    touched_.clear();
+    {
+      int e = 0;
+      pow2_ = cell_size > 0.0 && std::isfinite(cell_size) && std::frexp(cell_size, &e) == 0.5 &&
+              std::fpclassify(cell_size) == FP_NORMAL && std::fpclassify(1.0 / cell_size) == FP_NORMAL;
+      inv_cell_size_ = 1.0 / cell_size;
+    }
+    cell_size_ = cell_size;
+    size_x_ = sx;
+    size_y_ = sy;
+    origin_x_ = origin_x;
+    origin_y_ = origin_y;
   }
 
   // NDT::getIndex, reference src/ndt_model.cpp:203-218
-  long index(double x, double y) const
+  __attribute__((always_inline)) long index(double x, double y) const
   {
     if (x < origin_x_ || y < origin_y_) return -1;
-    const unsigned int gx = static_cast<unsigned int>(static_cast<long long>((x - origin_x_) / cell_size_));
-    const unsigned int gy = static_cast<unsigned int>(static_cast<long long>((y - origin_y_) / cell_size_));
+    // (a power-of-two cell size: multiplying by its exact reciprocal is the correctly
+    // rounded quotient, bit-identical to the reference's divide)
+    const double fx = pow2_ ? (x - origin_x_) * inv_cell_size_ : (x - origin_x_) / cell_size_;
+    const double fy = pow2_ ? (y - origin_y_) * inv_cell_size_ : (y - origin_y_) / cell_size_;
+    const unsigned int gx = static_cast<unsigned int>(static_cast<long long>(fx));
+    const unsigned int gy = static_cast<unsigned int>(static_cast<long long>(fy));
     if (gx >= size_x_ || gy >= size_y_) return -1;
     return static_cast<long>(gy * size_x_ + gx);
   }
 
   // NDT::addScan, reference src/ndt_model.cpp:132-152
+  __attribute__((target_clones("avx2", "default")))
   void add_scan(double pose_x, double pose_y, double pose_theta, const double * pts, size_t n)
   {
     double cos_th, sin_th;
@@ -157,14 +191,20 @@ public:
       wx += px * cos_th - py * sin_th;
       wy += px * sin_th + py * cos_th;
       const long i = index(wx, wy);
-      if (i >= 0) cells_[static_cast<size_t>(i)].add(wx, wy);
+      if (i >= 0)
+      {
+        HostCell & c = cells_[static_cast<size_t>(i)];
+        if (c.n == 0.0) touched_.push_back(static_cast<uint32_t>(i));
+        c.add(wx, wy);
+      }
     }
   }
 
-  // NDT::compute, reference src/ndt_model.cpp:154-160
+  // NDT::compute, reference src/ndt_model.cpp:154-160 (a cell without points returns
+  // at once there: only the cells that received points are visited here)
   void compute()
   {
-    for (auto & c : cells_) c.compute();
+    for (const uint32_t i : touched_) cells_[i].compute();
   }
 
   void pack6(double * out) const
@@ -189,16 +229,19 @@ public:
   size_t ncell() const { return cells_.size(); }
 
 private:
-  double cell_size_;
-  size_t size_x_, size_y_;
-  double origin_x_, origin_y_;
+  double cell_size_ = 0.0, inv_cell_size_ = 0.0;
+  bool pow2_ = false;
+  size_t size_x_ = 0, size_y_ = 0;
+  double origin_x_ = 0.0, origin_y_ = 0.0;
   std::vector<HostCell> cells_;
+  std::vector<uint32_t> touched_;   // cells that hold at least one point
 };
 
 // ScanMatcherNDT::addScans' extent + NDT build, reference src/scan_matcher_ndt.cpp:49-74.
 // max_x_/max_y_ start at numeric_limits<double>::min(), as the reference has it.
 std::unique_ptr<HostNdt> build_ndt(double resolution, double range_max, const double * poses,
-                                   const double * pts, const size_t * offsets, size_t n_scans)
+                                   const double * pts, const size_t * offsets, size_t n_scans,
+                                   std::unique_ptr<HostNdt> reuse = nullptr)
 {
   double min_x = std::numeric_limits<double>::max();
   double max_x = std::numeric_limits<double>::min();
@@ -211,8 +254,15 @@ std::unique_ptr<HostNdt> build_ndt(double resolution, double range_max, const do
     min_y = std::min(poses[3 * k + 1] - range_max, min_y);
     max_y = std::max(poses[3 * k + 1] + range_max, max_y);
   }
-  std::unique_ptr<HostNdt> ndt(
-    new HostNdt(resolution, (max_x - min_x), (max_y - min_y), min_x, min_y));
+  std::unique_ptr<HostNdt> ndt = std::move(reuse);
+  if (ndt)
+  {
+    ndt->reset(resolution, (max_x - min_x), (max_y - min_y), min_x, min_y);
+  }
+  else
+  {
+    ndt.reset(new HostNdt(resolution, (max_x - min_x), (max_y - min_y), min_x, min_y));
+  }
   for (size_t k = 0; k < n_scans; ++k)
   {
     ndt->add_scan(poses[3 * k], poses[3 * k + 1], poses[3 * k + 2], pts + 2 * offsets[k],
@@ -273,6 +323,7 @@ struct ndt2d_matcher
   size_t laser_max_beams = 100;
   double range_max = 0.0;
   std::unique_ptr<HostNdt> ndt;   // host copy; empty when the NDT was built on the device
+  std::unique_ptr<HostNdt> spare; // the storage of the NDT that reset() dropped, for the next build
   bool have_ndt = false;          // `ndt_` is set (reference scan_matcher_ndt.hpp:102)
   int build_mode = 0;             // 0 auto, 1 host, 2 device
   // state of the last prepare_search (subsampled beams + visited offsets)
@@ -456,7 +507,9 @@ int ndt2d_matcher_add_scans(ndt2d_matcher * m, const double * poses_xyt,
     m->have_ndt = true;
     return NDT2D_OK;
   }
-  m->ndt = build_ndt(m->resolution, m->range_max, poses_xyt, points_xy, offsets, n_scans);
+  if (m->ndt) m->spare = std::move(m->ndt);
+  m->ndt = build_ndt(m->resolution, m->range_max, poses_xyt, points_xy, offsets, n_scans,
+                     std::move(m->spare));
   const size_t ncell = m->ndt->ncell();
   if (ncell == 0 || m->ndt->size_x() > 0xffffffffull || m->ndt->size_y() > 0xffffffffull)
   {
@@ -492,7 +545,7 @@ int ndt2d_matcher_set_build_mode(ndt2d_matcher * m, const char * mode)
 int ndt2d_matcher_reset(ndt2d_matcher * m)
 {
   if (m == nullptr) return NDT2D_ERR_INVALID;
-  m->ndt.reset();
+  if (m->ndt) m->spare = std::move(m->ndt);   // `ndt_.reset()`; the storage serves the next addScans
   m->have_ndt = false;
   return ndt2d_clear_grid(m->dev);
 }
