@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Where a block of the small-lattice search spends its time: per-wave shader-clock stamps
+(block start, setup done, beams done, barrier passed, records written) from a library
+built with -DNDT2D_SMALL_TRACE (experiments/build_trace_lib.sh -> experiments/bin/trace.so;
+run with NDT2D_HIP_LIB pointing at it).
+
+    NDT2D_HIP_LIB=experiments/bin/trace.so python experiments/small_trace.py [defaults|d720|cfg1]
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from ndt_2d_amd import ScanMatcherNDT, synth  # noqa: E402
+
+which = sys.argv[1] if len(sys.argv) > 1 else "defaults"
+over = {"defaults": dict(search_linear_size=0.05, search_linear_resolution=0.005, search_angular_size=0.1,
+                         search_angular_resolution=0.0025, laser_max_beams=100),
+        "d720": dict(search_linear_size=0.05, search_linear_resolution=0.005, search_angular_size=0.1,
+                     search_angular_resolution=0.0025),
+        "cfg1": {}}[which]
+m = ScanMatcherNDT(0)
+m.initialize("m", **synth.matcher_params(1, **over))
+m.addScans(synth.map_scans(1))
+guess, pts, _ = synth.query_scan(1)
+n_th, n_lin, n_b = m.prepare_search(guess, pts)
+buf = torch.zeros(8192 * 16 * 8, dtype=torch.float64, device="cuda:0")
+for _ in range(5):
+    m.match_launch(0, n_th, scores_ptr=buf.data_ptr())
+m.synchronize()
+t = buf.cpu().numpy().reshape(-1, 16, 8)
+used = t[:, :, 0].max(axis=1) > 0
+t = t[used]
+act = t[:, :, 6] > 0
+t0 = t[:, :, 0][act].min()
+print("%s: %d blocks, %d active waves per block (max)" % (which, len(t), int(act.sum(axis=1).max())))
+clk = 100e6   # s_memtime / readcyclecounter ticks: 100 MHz constant clock on gfx9
+rel = lambda k: (t[:, :, k][act] - t0) / clk * 1e6
+for name, k in (("block start", 0), ("setup done", 1), ("beams done", 2), ("barrier passed", 3), ("records written", 4)):
+    v = rel(k)
+    print("  %-16s min %7.2f  median %7.2f  max %7.2f us" % (name, v.min(), np.median(v), v.max()))
+d_setup = (t[:, :, 1] - t[:, :, 0])[act] / clk * 1e6
+d_main = (t[:, :, 2] - t[:, :, 1])[act] / clk * 1e6
+d_wait = (t[:, :, 3] - t[:, :, 2])[act] / clk * 1e6
+print("  per wave: setup %.2f (max %.2f)  beams %.2f (min %.2f max %.2f)  waiting at the barrier %.2f (max %.2f) us"
+      % (d_setup.mean(), d_setup.max(), d_main.mean(), d_main.min(), d_main.max(), d_wait.mean(), d_wait.max()))

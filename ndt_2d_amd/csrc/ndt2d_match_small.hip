@@ -15,7 +15,8 @@
 //           {ox, oy, K} and copies its window of the per-cell map bytes prepared when
 //           the grid was installed (ndt2d_build.hip, cell_bytes_kernel) -- no pre-kernel;
 //   wave w  = (patch slot w / C, beam chunk w % C): lane = candidate of the patch, the
-//           wave adds the likelihoods of its chunk of beams in beam order, with the same
+//           wave adds the likelihoods of its chunk of beams -- the look-up groups w % C,
+//           w % C + C, ... of four beams each -- in beam order, with the same
 //           two-instruction map look-up / bit-exact skipping / exact reference arithmetic
 //           as the large kernel (ndt2d_lane_fn.h);
 //   combine the C partial sums of a candidate are added in chunk order,
@@ -53,6 +54,9 @@ namespace
 {
 
 constexpr int kSmallMaxWaves = 16;
+// beams per look-up group: 4 (the large search uses 8) keeps the kernel at 78 VGPRs = 6
+// waves per SIMD; the search is latency bound, so the resident waves are what counts
+constexpr int kSmallUnroll = 4;
 constexpr uint32_t kSmallMaxBeams = 2048;     // 64 KB of LDS rows
 constexpr uint32_t kRowDoubles = 4;           // {ox, oy, K, -}: two 16-byte LDS reads
 
@@ -60,7 +64,7 @@ struct SmallPlan
 {
   uint32_t patches_per_block;   // P: tile slots of a block (all of one theta step)
   uint32_t chunks;              // C: beam chunks = waves per tile slot
-  uint32_t chunk_beams;         // beams per chunk (a multiple of kUnroll)
+  uint32_t chunk_beams;         // beams per chunk (a multiple of kSmallUnroll)
   uint32_t blocks_per_theta;    // ceil(tiles / P)
   uint32_t need_w;              // map columns in use: window + 2 * pad
   uint32_t tiles;               // tiles of one theta step
@@ -114,6 +118,9 @@ __global__ void __launch_bounds__(kSmallMaxWaves * kWave) match_small_kernel(con
   // LDS: [map, at offset 0 so that the packed cell bytes are the address]
   //      [COMPACT: cell ranks (uint16), compact records][rows][partials]
   extern __shared__ __align__(16) double lds[];
+#ifdef NDT2D_SMALL_TRACE
+  const unsigned long long t_start = __builtin_readcyclecounter();
+#endif
   const GridDesc & g = a.grid;
   if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();
   uint8_t * lds_map = reinterpret_cast<uint8_t *>(lds);
@@ -180,6 +187,9 @@ __global__ void __launch_bounds__(kSmallMaxWaves * kWave) match_small_kernel(con
     }
   }
   __syncthreads();
+#ifdef NDT2D_SMALL_TRACE
+  const unsigned long long t_setup = __builtin_readcyclecounter();
+#endif
 
   LaneCtx c;
   c.rank_address = map_bytes;
@@ -222,27 +232,39 @@ __global__ void __launch_bounds__(kSmallMaxWaves * kWave) match_small_kernel(con
   {
     const double inv_scaled = g.inv_cell_size * geo.unit_scale;
     const double dxy = rint(dy * inv_scaled) * kTwo24 + rint(dx * inv_scaled);
-    const uint32_t b0 = min(chunk * plan.chunk_beams, a.n_beams);
-    const uint32_t b1 = min(b0 + plan.chunk_beams, a.n_beams);
+    // Chunk j walks the look-up groups j, j + C, j + 2C, ... (in that order): beams that
+    // are expensive -- the sectors of the scan that face walls inside the map -- are then
+    // spread over all the chunks instead of making one wave the block waits for.
     const double4 * row = reinterpret_cast<const double4 *>(rows);
     double sum = 0.0;
     SkipState skip = skip_state(0.0, geo.no_skip);
-    uint32_t b = b0;
-    for (; b + kUnroll <= b1; b += kUnroll)
+    for (uint32_t b = chunk * kSmallUnroll; b < a.n_beams; b += plan.chunks * kSmallUnroll)
     {
-      double4 o[kUnroll];
+      if (b + kSmallUnroll <= a.n_beams)
+      {
+        double4 o[kSmallUnroll];
 #pragma unroll
-      for (int u = 0; u < kUnroll; ++u) o[u] = row[b + u];
-      lane_beams<kUnroll, POW2, COMPACT, false, COMPACT>(g, c, o, dx, dy, dxy, sum, skip, geo.no_skip);
-    }
-    for (; b < b1; ++b)
-    {
-      const double4 one[1] = {row[b]};
-      lane_beams<1, POW2, COMPACT, false, COMPACT>(g, c, one, dx, dy, dxy, sum, skip, geo.no_skip);
+        for (int u = 0; u < kSmallUnroll; ++u) o[u] = row[b + u];
+        lane_beams<kSmallUnroll, POW2, COMPACT, false, COMPACT>(g, c, o, dx, dy, dxy, sum, skip, geo.no_skip);
+      }
+      else
+      {
+        for (uint32_t t = b; t < a.n_beams; ++t)
+        {
+          const double4 one[1] = {row[t]};
+          lane_beams<1, POW2, COMPACT, false, COMPACT>(g, c, one, dx, dy, dxy, sum, skip, geo.no_skip);
+        }
+      }
     }
     partials[wave * kWave + lane] = sum;
   }
+#ifdef NDT2D_SMALL_TRACE
+  const unsigned long long t_main = __builtin_readcyclecounter();
+#endif
   __syncthreads();
+#ifdef NDT2D_SMALL_TRACE
+  const unsigned long long t_barrier = __builtin_readcyclecounter();
+#endif
 
   if (active && chunk == 0)
   {
@@ -278,7 +300,9 @@ __global__ void __launch_bounds__(kSmallMaxWaves * kWave) match_small_kernel(con
       acc[7] = dy * score;
       acc[8] = dt * score;
       acc[9] = score;
+#ifndef NDT2D_SMALL_TRACE
       if (a.scores != nullptr) a.scores[static_cast<uint64_t>(t_local) * per_theta + in_theta] = score;
+#endif
     }
     wave_best_to_last_lane(best_s, best_i);
 #pragma unroll
@@ -298,6 +322,22 @@ __global__ void __launch_bounds__(kSmallMaxWaves * kWave) match_small_kernel(con
   // (the ticket travels through the partial-sum area, free again after the barrier: a
   // static __shared__ variable would push the map off LDS offset 0)
   uint32_t * ticket_slot = reinterpret_cast<uint32_t *>(partials);
+#ifdef NDT2D_SMALL_TRACE
+  // experiments/small_trace.py: per wave {block start, setup done, beams done, barrier
+  // passed, records written} in shader clocks, into the (otherwise unused) scores array
+  if (a.scores != nullptr && lane == 0)
+  {
+    double * tr = a.scores + (static_cast<size_t>(blockIdx.x) * kSmallMaxWaves + wave) * 8;
+    tr[0] = static_cast<double>(t_start);
+    tr[1] = static_cast<double>(t_setup);
+    tr[2] = static_cast<double>(t_main);
+    tr[3] = static_cast<double>(t_barrier);
+    tr[4] = static_cast<double>(__builtin_readcyclecounter());
+    tr[5] = static_cast<double>(__builtin_amdgcn_s_getreg((3 << 11) | (4 << 6) | 20));  // XCC_ID
+    tr[6] = active ? 1.0 : 0.0;
+    tr[7] = static_cast<double>(chunk);
+  }
+#endif
   __syncthreads();
   if (threadIdx.x == 0)
   {
@@ -416,9 +456,10 @@ uint32_t small_tiles(uint32_t n_lin)
   return p1 * p1;
 }
 
-// How a lattice is cut into blocks, every wave with whole look-up groups.  The cut follows the WHOLE lattice (n_th), not the theta steps of this launch: a
-// candidate's chunks, hence the bits of its score, are the same whichever rank of a
-// sharded search evaluates it.
+// How a lattice is cut into blocks, every wave with whole look-up groups.  The cut
+// depends on the beams and the lattice's translations only, never on the theta steps of
+// this launch: a candidate's chunks, hence the bits of its score, are the same whichever
+// rank of a sharded search evaluates it.
 SmallPlan small_plan(const MatchArgs & args, const LaneGeom & geo, int cus)
 {
   SmallPlan plan{};
@@ -426,34 +467,25 @@ SmallPlan small_plan(const MatchArgs & args, const LaneGeom & geo, int cus)
   plan.tiles = small_tiles(args.n_lin);
   plan.need_w = static_cast<uint32_t>(geo.win_w + 2 * geo.pad);
   plan.no_tail = std::getenv("NDT2D_SMALL_NOTAIL") != nullptr ? 1u : 0u;
-  const uint32_t groups = (args.n_beams + kUnroll - 1) / kUnroll;
-  // Pick (C beam chunks per tile, P tiles per block), P * C <= 16 waves.  Measured
-  // (experiments/small_plan_sweep.py): a wave's time is its number of look-up groups
-  // whatever shares its CU (the look-up -> exact-evaluation chains are latency bound),
-  // plus about one group's worth of block setup; blocks beyond what the CUs hold at once
-  // (16 wave slots each) wait for another round.  So: minimise rounds x (1 + groups per
-  // wave); between equals, the fewer and larger blocks.
-  const uint64_t n_th = args.n_th;
-  uint64_t best_cost = 0;
-  uint32_t best_c = 1, best_p = 1;
-  for (uint32_t c = 1; c <= static_cast<uint32_t>(kSmallMaxWaves) && c <= groups; ++c)
+  const uint32_t groups = (args.n_beams + kSmallUnroll - 1) / kSmallUnroll;
+  // (C beam chunks per tile, P tiles per block), P * C <= 16 waves.  Measured over the
+  // plans of three shapes (experiments/small_plan_sweep.py; per-wave stamps:
+  // experiments/small_trace.py): a wave needs ~0.36 us per beam whatever shares its SIMD up
+  // to two waves, and a block ~3.4 us of setup.  Eight chunks -- two waves per SIMD -- are
+  // the best cut of a 720-beam scan, each tile a block of its own (more, smaller blocks
+  // balance better once a block runs for tens of microseconds); a 100-beam scan is cut
+  // into chunks of five groups and three tiles share a block's setup.  The plan depends on
+  // the beams and the lattice only, never on the launch's share of it.
+  uint32_t best_c = (groups + 4) / 5;
+  if (best_c > 8) best_c = 8;
+  if (best_c < 1) best_c = 1;
+  uint32_t best_p = 1;
   {
-    const uint32_t chunk_groups = (groups + c - 1) / c;
-    if ((groups + chunk_groups - 1) / chunk_groups != c) continue;   // same cut as a smaller c
-    for (uint32_t p = 1; p * c <= static_cast<uint32_t>(kSmallMaxWaves) && p <= plan.tiles; ++p)
-    {
-      const uint64_t blocks = n_th * ((plan.tiles + p - 1) / p);
-      const uint64_t resident = static_cast<uint64_t>(cus) * (static_cast<uint32_t>(kSmallMaxWaves) / (p * c));
-      const uint64_t rounds = (blocks + resident - 1) / resident;
-      const uint64_t cost = rounds * (1 + chunk_groups);
-      if (best_cost == 0 || cost < best_cost || (cost == best_cost && p * c >= best_p * best_c))
-      {
-        best_cost = cost;
-        best_c = c;
-        best_p = p;
-      }
-    }
+    const uint32_t cg = (groups + best_c - 1) / best_c;
+    const uint32_t chunks = (groups + cg - 1) / cg;
+    if (cg < 12) best_p = static_cast<uint32_t>(kSmallMaxWaves) / chunks;
   }
+  (void)cus;
   if (const char * env = std::getenv("NDT2D_SMALL_CHUNKS"))   // tuning knobs for
   {                                                             // experiments/small_plan_sweep.py
     const uint32_t c = static_cast<uint32_t>(std::atoi(env));
@@ -467,7 +499,7 @@ SmallPlan small_plan(const MatchArgs & args, const LaneGeom & geo, int cus)
   }
   const uint32_t chunk_groups = (groups + best_c - 1) / best_c;
   plan.chunks = (groups + chunk_groups - 1) / chunk_groups;
-  plan.chunk_beams = chunk_groups * kUnroll;
+  plan.chunk_beams = chunk_groups * kSmallUnroll;
   uint32_t p = best_p;
   if (p * plan.chunks > static_cast<uint32_t>(kSmallMaxWaves)) p = kSmallMaxWaves / plan.chunks;
   if (p > plan.tiles) p = plan.tiles;
