@@ -555,8 +555,8 @@ def main():
     if rank == 0:
         avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
         pmc = load_pmc()
-        lane = "lane" in variant
-        kname = "match_lane_kernel" if lane else "match_kernel"
+        kname = ("match_lane_compact_kernel" if "compact-records" in variant else
+                 "match_lane_kernel" if "lane" in variant else "match_kernel")
         roof, hbm = roofline(kname, avg_kernel_ms, my_units, n_cu, pmc if cfg == 2 and world == 1 else None,
                              "counters of the cfg-2 launch of the same bench command")
         grid = m.grid()

@@ -12,7 +12,7 @@ import json
 import os
 import sys
 
-KERNELS = ("match_lane_kernel", "match_kernel", "match_small_kernel", "score_poses_compact_kernel",
+KERNELS = ("match_lane_compact_kernel", "match_lane_kernel", "match_kernel", "match_small_kernel", "score_poses_compact_kernel",
            "outer_table_kernel", "match_reduce_kernel", "score_one_kernel")
 
 

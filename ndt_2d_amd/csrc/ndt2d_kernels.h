@@ -246,7 +246,7 @@ bool match_lane_supported(const MatchArgs & args, size_t lds_per_block);
 // / negligible-term skipping) -- the bit-exactness control for the skipping logic.
 hipError_t launch_match_lane(const MatchArgs & args, double * outer, double * workspace,
                              uint32_t max_workers, int cus, size_t lds_per_block, bool no_skip,
-                             hipStream_t stream, uint32_t * n_workers_out, bool * lds_records_out);
+                             hipStream_t stream, uint32_t * n_workers_out, int * records_mode_out);
 
 // Small-lattice search (ndt2d_match_small.hip): a block per (theta, up to P tiles of 64
 // candidates), its waves split the beams; needs grid.cell_bytes.  The launch includes the

@@ -586,7 +586,7 @@ hipError_t launch_match(const MatchArgs & args_in, double * workspace, double * 
 
   hipError_t e;
   uint32_t n_workers = 0;
-  bool lane_lds_records = true;
+  int lane_records_mode = 1;
   if (use_small)
   {
     // search and final reduction in one launch; the ticket counter sits beside the lane
@@ -613,7 +613,7 @@ hipError_t launch_match(const MatchArgs & args_in, double * workspace, double * 
   {
     e = launch_match_lane(args, outer, workspace, kMaxMatchBlocks * kMatchWaves, lim.cus,
                           lim.lds_per_block, (force_variant & kVariantNoSkip) != 0, stream,
-                          &n_workers, &lane_lds_records);
+                          &n_workers, &lane_records_mode);
     if (e != hipSuccess) return e;
   }
   else
@@ -677,10 +677,12 @@ hipError_t launch_match(const MatchArgs & args_in, double * workspace, double * 
   {
     if (use_lane)
     {
-      info->variant = lane_lds_records ? (pow2 ? "match/lane-per-candidate/lds-grid/pow2"
-                                               : "match/lane-per-candidate/lds-grid/div")
-                                       : (pow2 ? "match/lane-per-candidate/lds-map+global-records/pow2"
-                                               : "match/lane-per-candidate/lds-map+global-records/div");
+      info->variant =
+        lane_records_mode == 2   ? "match/lane-per-candidate/lds-grid/compact-records/pow2"
+        : lane_records_mode == 1 ? (pow2 ? "match/lane-per-candidate/lds-grid/pow2"
+                                         : "match/lane-per-candidate/lds-grid/div")
+                                 : (pow2 ? "match/lane-per-candidate/lds-map+global-records/pow2"
+                                         : "match/lane-per-candidate/lds-map+global-records/div");
       info->n_kernels = 3;
     }
     else

@@ -39,6 +39,7 @@
 // bit-identical to the unskipped evaluation (variant "lane-noskip" is that
 // evaluation; the tests compare the two bitwise).
 #include <cmath>
+#include <cstdlib>
 
 #include <type_traits>
 
@@ -53,6 +54,7 @@ namespace
 constexpr uint32_t kDynamicItemsFromBeams = 256;
 constexpr int kLaneThreads = 1024;       // large searches: one block per CU
 constexpr int kLaneThreadsSmall = 256;   // small searches: spread the few work items over more CUs
+constexpr int kLaneThreadsCompact = 768; // compacted records: two blocks per CU, six waves per SIMD
 
 // points_outer for the slab (reference :106-115) plus the packed fixed-point
 // map coordinate of each rotated beam:
@@ -112,10 +114,14 @@ __global__ void __launch_bounds__(256) outer_table_kernel(const MatchArgs a, dou
   }
 }
 
-template <int THREADS, bool POW2, bool LDS_RECORDS, bool DYNAMIC_ITEMS>
-__global__ void __launch_bounds__(THREADS) match_lane_kernel(
-  const MatchArgs a, const double4 * __restrict__ outer, const uint8_t * __restrict__ map_image,
-  const LaneGeom geo)
+// COMPACT (with LDS_RECORDS): instead of the whole grid's records the block keeps the
+// compacted records of the cells that can score and the cell -> record table
+// (GridDesc::compact_records / cell_rank): at cfg-2 15 KB instead of 81 KB, so that two
+// blocks share a CU (match_lane_compact_kernel below).
+template <int THREADS, bool POW2, bool LDS_RECORDS, bool DYNAMIC_ITEMS, bool COMPACT>
+__device__ __forceinline__ void match_lane_body(
+  const MatchArgs & a, const double4 * __restrict__ outer, const uint8_t * __restrict__ map_image,
+  const LaneGeom & geo)
 {
   // LDS image: padded occupancy map of the window (at offset 0, so the packed
   // cell bytes are the LDS address) followed, if they fit (LDS_RECORDS), by the
@@ -126,9 +132,24 @@ __global__ void __launch_bounds__(THREADS) match_lane_kernel(
   uint8_t * lds_map = reinterpret_cast<uint8_t *>(lds);
   // lds_byte_at() addresses the map absolutely: it must start at LDS offset 0
   if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();
-  double * lds_cells = lds + (static_cast<size_t>(geo.map_h) * kMapStride) / sizeof(double);
+  const uint32_t map_bytes = static_cast<uint32_t>(geo.map_h) * kMapStride;
+  const uint32_t rank_bytes = COMPACT ? ((g.ncell + 1) * 2 + 15) & ~15u : 0u;
+  double * lds_cells = lds + (map_bytes + rank_bytes) / sizeof(double);
 
-  if (LDS_RECORDS) stage_grid_to_lds(g, lds_cells);
+  if (COMPACT)
+  {
+    const uint4 * src_rank = reinterpret_cast<const uint4 *>(g.cell_rank);
+    uint4 * dst_rank = reinterpret_cast<uint4 *>(lds_map + map_bytes);
+    for (uint32_t i = threadIdx.x; i < rank_bytes / 16; i += THREADS) dst_rank[i] = src_rank[i];
+    const uint32_t n2 = (g.n_occ + 1) * kCellDoubles / 2;
+    const double2 * src = reinterpret_cast<const double2 *>(g.compact_records);
+    double2 * dst = reinterpret_cast<double2 *>(lds_cells);
+    for (uint32_t i = threadIdx.x; i < n2; i += THREADS) dst[i] = src[i];
+  }
+  else if (LDS_RECORDS)
+  {
+    stage_grid_to_lds(g, lds_cells);
+  }
   {
     // the map image was built by the pre-kernel; kMapStride * map_h is a multiple of 16
     const uint32_t n16 = static_cast<uint32_t>(kMapStride) * geo.map_h / 16;
@@ -139,8 +160,8 @@ __global__ void __launch_bounds__(THREADS) match_lane_kernel(
   __syncthreads();
 
   LaneCtx c;
-  c.rank_address = 0;
-  c.lds_cells_address = static_cast<uint32_t>(geo.map_h) * kMapStride;
+  c.rank_address = map_bytes;
+  c.lds_cells_address = map_bytes + rank_bytes;
   c.sub_log2 = static_cast<uint32_t>(geo.sub_log2);
   c.idx_bias = static_cast<uint32_t>(geo.pad - geo.win_y0) * g.size_x +
                static_cast<uint32_t>(geo.pad - geo.win_x0);
@@ -197,12 +218,12 @@ __global__ void __launch_bounds__(THREADS) match_lane_kernel(
       double4 o[kUnroll];
 #pragma unroll
       for (int u = 0; u < kUnroll; ++u) o[u] = row[b + u];
-      lane_beams<kUnroll, POW2, LDS_RECORDS>(g, c, o, dx, dy, dxy, sum, skip, geo.no_skip);
+      lane_beams<kUnroll, POW2, LDS_RECORDS, true, COMPACT>(g, c, o, dx, dy, dxy, sum, skip, geo.no_skip);
     }
     for (; b < a.n_beams; ++b)
     {
       const double4 one[1] = {row[b]};
-      lane_beams<1, POW2, LDS_RECORDS>(g, c, one, dx, dy, dxy, sum, skip, geo.no_skip);
+      lane_beams<1, POW2, LDS_RECORDS, true, COMPACT>(g, c, one, dx, dy, dxy, sum, skip, geo.no_skip);
     }
 
     if (valid)
@@ -283,6 +304,26 @@ __global__ void __launch_bounds__(THREADS) match_lane_kernel(
   }
 }
 
+template <int THREADS, bool POW2, bool LDS_RECORDS, bool DYNAMIC_ITEMS>
+__global__ void __launch_bounds__(THREADS) match_lane_kernel(
+  const MatchArgs a, const double4 * __restrict__ outer, const uint8_t * __restrict__ map_image,
+  const LaneGeom geo)
+{
+  match_lane_body<THREADS, POW2, LDS_RECORDS, DYNAMIC_ITEMS, false>(a, outer, map_image, geo);
+}
+
+// The compacted-records form: 768-thread blocks held to 80 VGPRs, two per CU = six waves
+// per SIMD (a block's waves must spread evenly over the four SIMDs: 640-thread blocks
+// would put six waves of two blocks on one SIMD, which its register file cannot hold).
+__global__ void __launch_bounds__(kLaneThreadsCompact) __attribute__((amdgpu_waves_per_eu(6)))
+match_lane_compact_kernel(const MatchArgs a, const double4 * __restrict__ outer,
+                          const uint8_t * __restrict__ map_image, const LaneGeom geo)
+{
+  match_lane_body<kLaneThreadsCompact, true, true, true, true>(a, outer, map_image, geo);
+}
+
+bool pow2_grid(const MatchArgs & args) { return args.grid.pow2 != 0; }
+
 bool lane_records_in_lds(const MatchArgs & args, size_t map_bytes, size_t lds_per_block)
 {
   const size_t grid_bytes = static_cast<size_t>(args.grid.ncell + 1) * kCellDoubles * sizeof(double);
@@ -312,7 +353,7 @@ bool match_lane_supported(const MatchArgs & args, size_t lds_per_block)
 
 hipError_t launch_match_lane(const MatchArgs & args_in, double * outer, double * workspace,
                              uint32_t max_workers, int cus, size_t lds_per_block, bool no_skip,
-                             hipStream_t stream, uint32_t * n_workers_out, bool * lds_records_out)
+                             hipStream_t stream, uint32_t * n_workers_out, int * records_mode_out)
 {
   MatchArgs args = args_in;
   args.partials = workspace;
@@ -350,10 +391,31 @@ hipError_t launch_match_lane(const MatchArgs & args_in, double * outer, double *
   if (blocks == 0) blocks = 1;
 
   const bool lds_records = lane_records_in_lds(args, map_bytes, lds_per_block);
-  if (lds_records_out != nullptr) *lds_records_out = lds_records;
-  const size_t lds_bytes =
+  size_t lds_bytes =
     map_bytes +
     (lds_records ? static_cast<size_t>(args.grid.ncell + 1) * kCellDoubles * sizeof(double) : 0);
+  // Compacted records: the image shrinks enough for two blocks per CU (A/B knob:
+  // NDT2D_LANE_COMPACT=0 keeps the whole-grid image and one 1024-thread block).
+  const size_t compact_bytes =
+    ((static_cast<size_t>(args.grid.ncell) + 1) * 2 + 15) / 16 * 16 +
+    (static_cast<size_t>(args.grid.n_occ) + 1) * kCellDoubles * sizeof(double);
+  const char * knob = std::getenv("NDT2D_LANE_COMPACT");
+  const bool compact = !small && dynamic_items && pow2_grid(args) && lds_records && args.grid.n_occ > 0 &&
+                       args.grid.compact_records != nullptr &&
+                       2 * (map_bytes + compact_bytes) <= lds_per_block &&
+                       !(knob != nullptr && knob[0] == '0');
+  // 0: records gathered from HBM, 1: the whole grid's records in LDS, 2: compacted records in LDS
+  if (records_mode_out != nullptr) *records_mode_out = compact ? 2 : (lds_records ? 1 : 0);
+  if (compact)
+  {
+    lds_bytes = map_bytes + compact_bytes;
+    const uint32_t wpb = kLaneThreadsCompact / kWave;
+    blocks = static_cast<uint32_t>((n_items + wpb - 1) / wpb);
+    uint32_t cap = 2 * static_cast<uint32_t>(cus);
+    if (cap * wpb > max_workers) cap = max_workers / wpb;
+    if (blocks > cap) blocks = cap;
+    if (blocks == 0) blocks = 1;
+  }
   auto launch = [&](auto kernel, int threads) -> hipError_t {
     if (lds_bytes > 48 * 1024)
     {
@@ -379,8 +441,15 @@ hipError_t launch_match_lane(const MatchArgs & args_in, double * outer, double *
     };
     return dynamic_items ? with_items(std::true_type{}) : with_items(std::false_type{});
   };
-  e = small ? pick(std::integral_constant<int, kLaneThreadsSmall>{})
-            : pick(std::integral_constant<int, kLaneThreads>{});
+  if (compact)
+  {
+    e = launch(match_lane_compact_kernel, kLaneThreadsCompact);
+  }
+  else
+  {
+    e = small ? pick(std::integral_constant<int, kLaneThreadsSmall>{})
+              : pick(std::integral_constant<int, kLaneThreads>{});
+  }
   if (n_workers_out != nullptr)
   {
     *n_workers_out = dynamic_items ? static_cast<uint32_t>(n_items) : blocks * waves_per_block;
