@@ -103,3 +103,51 @@ def test_random_case(seed):
     assert np.array_equal(w_by["auto"], w_by["compact-exact"], equal_nan=True), seed
     assert np.array_equal(few, w_by["auto"][:5], equal_nan=True), seed
     gpu.set_variant("auto")
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_large_lattice(seed):
+    """Lattices of a few thousand work items with 256+ beams: the persistent large-lattice
+    search with dynamically assigned items -- with the compacted records in LDS when the
+    grid is a power-of-two one and two images fit a CU, the whole grid's records or HBM
+    gathers otherwise --
+    against the oracle, its skipping against the unskipped control bit for bit, and the
+    wave mapping."""
+    rng = np.random.default_rng(5000 + seed)
+    params, scans, scan_pose, query, _ = _random_case(rng)
+    params["ndt_resolution"] = float(rng.choice([0.25, 0.25, 0.5, 0.3]))
+    params["search_linear_resolution"] = float(rng.choice([0.01, 0.02]))
+    params["search_linear_size"] = params["search_linear_resolution"] * float(rng.uniform(20, 34))
+    params["search_angular_resolution"] = 0.01
+    params["search_angular_size"] = 0.01 * float(rng.uniform(6, 16))
+    params["laser_max_beams"] = 1000
+    n_q = int(rng.integers(256, 420))
+    query = np.concatenate([rng.uniform(-5, 5, (n_q // 2, 2)),
+                            np.stack([rng.uniform(1, 4, n_q - n_q // 2),
+                                      rng.uniform(-3, 3, n_q - n_q // 2)], axis=1)])
+    ref = O.ScanMatcherNDT()
+    ref.initialize(**params)
+    ref.addScans(scans)
+    exp = ref.matchScan(scan_pose, query, want_scores=True)
+    gpu = ScanMatcherNDT(0)
+    gpu.initialize("fuzz-large", **params)
+    gpu.addScans(scans)
+    got = {}
+    for variant in ("lane", "lane-noskip", "wave", "auto"):
+        gpu.set_variant(variant)
+        got[variant] = r = gpu.matchScan(scan_pose, query, want_scores=True)
+        if variant == "lane":
+            # (compacted records when two images fit a CU's LDS, else the whole grid's, else
+            # gathered from HBM)
+            assert "lane-per-candidate/lds-" in gpu.last_variant(), gpu.last_variant()
+        assert r["n_candidates"] == exp["n_candidates"]
+        assert np.allclose(r["scores"], exp["scores"], rtol=0, atol=1e-9, equal_nan=True), (seed, variant)
+        finite = exp["scores"][~np.isnan(exp["scores"])]
+        if finite.size > 1 and np.sort(finite)[1] - finite.min() > 1e-9:
+            assert r["best_index"] == exp["best_index"], (seed, variant)
+        if abs(np.nansum(exp["scores"])) > 1e-6:
+            assert np.allclose(r["covariance"], exp["covariance"], rtol=1e-7, atol=1e-12, equal_nan=True)
+    gpu.set_variant("auto")
+    assert np.array_equal(got["lane"]["scores"], got["lane-noskip"]["scores"], equal_nan=True), seed
+    assert np.array_equal(got["lane"]["scores"], got["auto"]["scores"], equal_nan=True) or \
+        "small-lattice" in gpu.last_variant()

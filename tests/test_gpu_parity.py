@@ -449,6 +449,8 @@ def test_cfg2_full_size():
     gpu, ref, _, guess, pts = _pair(2)
     got = gpu.matchScan(guess, pts, want_scores=True)
     assert got["n_candidates"] == 2000000
+    # the headline configuration: compacted records in LDS, two blocks per CU
+    assert "lane-per-candidate/lds-grid/compact-records" in gpu.last_variant(), gpu.last_variant()
     exp = ref.matchScan(guess, pts, omp_threads=os.cpu_count())
     want = _big_winner(2)
     assert got["best_index"] == exp["best_index"] == want["best_index"]
