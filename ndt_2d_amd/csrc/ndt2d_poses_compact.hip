@@ -95,7 +95,10 @@ template <int THREADS, bool POW2, bool SCREEN>
 // (4 waves per SIMD = at most 128 VGPRs, also for the 256-thread geometry: the
 // accumulators that no longer fit are spilled on the once-per-pose path, and a CU
 // holds four blocks instead of three)
-__global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4)))
+#ifndef NDT2D_POSES_WAVES_PER_EU
+#define NDT2D_POSES_WAVES_PER_EU 4
+#endif
+__global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NDT2D_POSES_WAVES_PER_EU)))
 score_poses_compact_kernel(const PosesArgs a, const uint32_t split)
 {
   using L = CompactLayout<THREADS>;
