@@ -176,6 +176,14 @@ int ndt2d_score_poses_launch(ndt2d_handle h, const double * d_poses_xyt, size_t 
 int ndt2d_score_poses(ndt2d_handle h, const double * h_poses_xyt, size_t n_poses,
                       double * h_scores, double * h_stats);
 
+/* ndt2d_set_beams + ndt2d_score_poses in one call.  Up to 8 poses and up to 208 beams
+ * (a scoreScan with the plugin's default laser_max_beams = 100) travel as kernel
+ * arguments: one launch, no copy at all, and the kernel leaves the beams in the context's
+ * beam buffer for the calls that follow on the same scan.  Anything larger falls back to
+ * the two calls. */
+int ndt2d_score_poses_beams(ndt2d_handle h, const double * beams_xy, size_t n_beams,
+                            const double * h_poses_xyt, size_t n_poses, double * h_scores);
+
 /* ParticleFilter::updateStatistics (src/particle_filter.cpp:163-218) on the
  * device, from the (all-reduced) moment sums d_stats of ndt2d_score_poses_launch:
  * d_weights[n] are divided by the total weight in place (:171-174) and d_out
@@ -361,7 +369,9 @@ typedef struct ndt2d_matcher ndt2d_matcher;
 int ndt2d_matcher_create(ndt2d_matcher ** out, int device_id);
 int ndt2d_matcher_destroy(ndt2d_matcher * m);
 const char * ndt2d_matcher_last_error(ndt2d_matcher * m);
-/* The device context the matcher drives (for sharded launches / streams). */
+/* The device context the matcher drives (for sharded launches / streams).  The matcher
+ * remembers which beams it put there (a scan that arrives again is not uploaded again):
+ * it must remain the only writer of this context's beams. */
 ndt2d_handle ndt2d_matcher_device(ndt2d_matcher * m);
 
 /* ScanMatcherNDT::initialize (src/scan_matcher_ndt.cpp:35-47): the six

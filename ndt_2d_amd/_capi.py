@@ -88,6 +88,7 @@ SIGNATURES = {
     "ndt2d_match": (C.c_int, [_vp, _sz, _sz, _dp, C.POINTER(MatchResult)]),
     "ndt2d_score_poses_launch": (C.c_int, [_vp, _vp, _sz, _vp, _vp]),
     "ndt2d_score_poses": (C.c_int, [_vp, _dp, _sz, _dp, _dp]),
+    "ndt2d_score_poses_beams": (C.c_int, [_vp, _dp, _sz, _dp, _sz, _dp]),
     "ndt2d_pf_finalize_launch": (C.c_int, [_vp, _vp, _sz, _vp, _vp, _vp]),
     "ndt2d_pf_measure": (C.c_int, [_vp, _dp, _sz, _dp, _dp]),
     "ndt2d_pf_noise_launch": (C.c_int, [_vp, _u64, _u64, _u64, _sz, _vp]),

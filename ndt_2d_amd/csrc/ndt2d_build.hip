@@ -203,45 +203,23 @@ __global__ void __launch_bounds__(256) cells_kernel(const BuildArgs a, const uin
   write_scorer_record(a.grid.ncell, cell, rec, a.cells_lds_image, a.cells_global, a.occ_bits);
 }
 
-// The scorer layouts of a grid given as cells6 records {mean, information, n} (the
-// host build's output, ndt2d_set_grid): what cells_kernel writes for a device build.
-__global__ void __launch_bounds__(256) pack_cells_kernel(const double * cells6, uint32_t ncell,
-                                                         double * cells_lds_image,
-                                                         double * cells_global, uint32_t * occ_bits)
-{
-  const uint32_t cell = blockIdx.x * 256 + threadIdx.x;
-  // h = -0.5 * information (exact); sentinel for cells that cannot score (n < 5,
-  // src/ndt_model.cpp:107) and for record ncell ("outside")
-  double rec[kCellDoubles] = {1.0e300, 0.0, -1.0, 0.0, -1.0, 0.0};
-  if (cell < ncell)
-  {
-    const double * c = cells6 + static_cast<size_t>(cell) * 6;
-    if (!(c[5] < 5.0))
-    {
-      rec[0] = c[0];
-      rec[1] = c[1];
-      rec[2] = -0.5 * c[2];
-      rec[3] = -0.5 * c[3];
-      rec[4] = -0.5 * c[4];
-      rec[5] = 1.0;
-    }
-  }
-  write_scorer_record(ncell, cell, rec, cells_lds_image, cells_global, occ_bits);
-}
-
 // One occupancy-map byte per grid cell, for the grid extended by one cell on every
 // side ([size_y + 2][size_x + 2], cell (cx, cy) at (cy + 1) * (size_x + 2) + cx + 1):
 // the byte the lane-per-candidate search's map holds at one map cell per grid cell
 // (ndt2d_lane_fn.h, sub_cell_byte with sub_log2 = 0).  It depends on the grid only, so
 // it is prepared once here and the small-lattice search copies its window from it.
-__global__ void __launch_bounds__(256) cell_bytes_kernel(const GridDesc g, uint8_t * bytes)
+// FROM_CELLS6: occupancy and records come from the cells6 records themselves (the fused
+// kernel of a host-installed grid, which has no packed records yet); else from the packed
+// records and the bitmap (device build).  lane16 = this thread's lane in its 16-lane row,
+// i = the extended-grid cell the row works on.
+template <bool FROM_CELLS6>
+__device__ __forceinline__ void cell_byte_row(const GridDesc & g, const double * cells6, uint32_t i,
+                                              uint32_t j, uint8_t * bytes)
 {
   // 16 lanes (one DPP row) per cell, lane j < 9 takes neighbour j of the 3 x 3 block: the
   // bound is a maximum over the neighbours that can score, each a closed form with a few
   // divisions -- nine of them one after the other in one lane was the whole kernel's time
   const uint32_t w = g.size_x + 2, h = g.size_y + 2;
-  const uint32_t i = (blockIdx.x * 256 + threadIdx.x) >> 4;
-  const uint32_t j = threadIdx.x & 15u;
   const bool live = i < w * h;
   const int32_t cx = static_cast<int32_t>(live ? i % w : 0) - 1, cy = static_cast<int32_t>(live ? i / w : 0) - 1;
   // the sub-cell box of sub_cell_byte() at one sub-cell per cell
@@ -257,7 +235,17 @@ __global__ void __launch_bounds__(256) cell_bytes_kernel(const GridDesc g, uint8
     if (nx >= 0 && nx < static_cast<int32_t>(g.size_x) && ny >= 0 && ny < static_cast<int32_t>(g.size_y))
     {
       const uint32_t cell = static_cast<uint32_t>(ny) * g.size_x + static_cast<uint32_t>(nx);
-      if ((g.occ_bits[cell >> 5] >> (cell & 31u)) & 1u)
+      if (FROM_CELLS6)
+      {
+        const double * c = cells6 + static_cast<size_t>(cell) * 6;
+        if (!(c[5] < 5.0))
+        {
+          const double rec[5] = {c[0], c[1], -0.5 * c[2], -0.5 * c[3], -0.5 * c[4]};
+          if (j == 4) self = 1;
+          bound = exponent_upper_bound(rec, x0, x1, y0, y1);
+        }
+      }
+      else if ((g.occ_bits[cell >> 5] >> (cell & 31u)) & 1u)
       {
         if (j == 4) self = 1;
         bound = exponent_upper_bound(g.cells_lds_image + static_cast<size_t>(cell) * kCellDoubles, x0, x1, y0, y1);
@@ -275,6 +263,46 @@ __global__ void __launch_bounds__(256) cell_bytes_kernel(const GridDesc g, uint8
     self |= static_cast<uint32_t>(__shfl_xor(static_cast<int>(self), off, 16));
   }
   if (live && j == 0) bytes[i] = map_byte(self, nan_any ? NAN : m);
+}
+
+__global__ void __launch_bounds__(256) cell_bytes_kernel(const GridDesc g, uint8_t * bytes)
+{
+  cell_byte_row<false>(g, nullptr, (blockIdx.x * 256 + threadIdx.x) >> 4, threadIdx.x & 15u, bytes);
+}
+
+// Everything a host-installed grid needs, in ONE launch (the mapper installs a grid per
+// scan): the first pack_blocks blocks write the packed records and the occupancy bitmap,
+// the others the per-cell map bytes -- straight from the cells6 records, so that they do
+// not have to wait for the first.
+__global__ void __launch_bounds__(256) pack_grid_kernel(const GridDesc g, const double * cells6,
+                                                        uint32_t pack_blocks, double * cells_lds_image,
+                                                        double * cells_global, uint32_t * occ_bits,
+                                                        uint8_t * bytes)
+{
+  if (blockIdx.x >= pack_blocks)
+  {
+    cell_byte_row<true>(g, cells6, ((blockIdx.x - pack_blocks) * 256 + threadIdx.x) >> 4,
+                        threadIdx.x & 15u, bytes);
+    return;
+  }
+  const uint32_t cell = blockIdx.x * 256 + threadIdx.x;
+  // h = -0.5 * information (exact); sentinel for cells that cannot score (n < 5,
+  // src/ndt_model.cpp:107) and for record ncell ("outside")
+  double rec[kCellDoubles] = {1.0e300, 0.0, -1.0, 0.0, -1.0, 0.0};
+  if (cell < g.ncell)
+  {
+    const double * c = cells6 + static_cast<size_t>(cell) * 6;
+    if (!(c[5] < 5.0))
+    {
+      rec[0] = c[0];
+      rec[1] = c[1];
+      rec[2] = -0.5 * c[2];
+      rec[3] = -0.5 * c[3];
+      rec[4] = -0.5 * c[4];
+      rec[5] = 1.0;
+    }
+  }
+  write_scorer_record(g.ncell, cell, rec, cells_lds_image, cells_global, occ_bits);
 }
 
 int key_bits(uint32_t ncell)
@@ -340,11 +368,12 @@ hipError_t launch_pack_grid(const GridDesc & geometry, const double * cells6,
                             double * cells_lds_image, double * cells_global, uint32_t * occ_bits,
                             uint8_t * cell_bytes, hipStream_t stream)
 {
-  hipLaunchKernelGGL(pack_cells_kernel, dim3((geometry.ncell + 1 + 255) / 256), dim3(256), 0,
-                     stream, cells6, geometry.ncell, cells_lds_image, cells_global, occ_bits);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  return launch_grid_tail(geometry, cells_lds_image, occ_bits, cell_bytes, stream);
+  const uint32_t pack_blocks = (geometry.ncell + 1 + 255) / 256;
+  const uint32_t n_bytes = (geometry.size_x + 2) * (geometry.size_y + 2);
+  const uint32_t byte_blocks = (n_bytes + 15) / 16;
+  hipLaunchKernelGGL(pack_grid_kernel, dim3(pack_blocks + byte_blocks), dim3(256), 0, stream, geometry,
+                     cells6, pack_blocks, cells_lds_image, cells_global, occ_bits, cell_bytes);
+  return hipGetLastError();
 }
 
 }  // namespace ndt2d

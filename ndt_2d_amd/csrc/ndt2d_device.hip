@@ -984,6 +984,63 @@ int ndt2d_score_poses_launch(ndt2d_handle h, const double * d_poses_xyt, size_t 
   return NDT2D_OK;
 }
 
+int ndt2d_score_poses_beams(ndt2d_handle h, const double * beams_xy, size_t n_beams,
+                            const double * h_poses_xyt, size_t n_poses, double * h_scores)
+{
+  if (h == nullptr) return NDT2D_ERR_INVALID;
+  if (beams_xy == nullptr || n_beams == 0 || n_beams > (1u << 20) || h_poses_xyt == nullptr ||
+      h_scores == nullptr || n_poses == 0)
+  {
+    return fail(h, NDT2D_ERR_INVALID, "ndt2d_score_poses_beams: bad argument");
+  }
+  if (!h->has_grid) return fail(h, NDT2D_ERR_NO_GRID, "ndt2d_score_poses_beams: no grid");
+  NDT2D_HIP(h, hipSetDevice(h->device));
+  if (n_poses <= ndt2d::kFewPoses && n_beams <= ndt2d::kArgBeams &&
+      h->force_variant == ndt2d::kVariantAuto)
+  {
+    // beams AND poses as kernel arguments: one launch, no copy; the kernel leaves the beams
+    // in the context's beam buffer for the calls that follow on this scan
+    int rc = ensure(h, h->beams, 2 * n_beams + 2);
+    if (rc != NDT2D_OK) return rc;
+    if (h->stage_beams.pending)   // the buffer may still be the target of a staged upload
+    {
+      NDT2D_HIP(h, hipEventSynchronize(h->stage_beams.done));
+      h->stage_beams.pending = false;
+    }
+    if ((rc = ensure_host_res(h)) != NDT2D_OK) return rc;
+    ndt2d::PosesArgs a{};
+    a.grid = h->grid;
+    a.beams_xy = h->beams.ptr;
+    a.n_beams = static_cast<uint32_t>(n_beams);
+    a.poses_xyt = nullptr;
+    a.n_poses = n_poses;
+    a.scores = h->host_res_dev + kScoreSlot;
+    if (ndt2d::score_few_supported(a, 64 * 1024))
+    {
+      ndt2d::FewPoses few{};
+      std::memcpy(few.xyt, h_poses_xyt, 3 * n_poses * sizeof(double));
+      const unsigned long long seq = ++h->seq;
+      hipError_t e = ndt2d::launch_score_few(
+        a, &few, reinterpret_cast<unsigned long long *>(h->host_res_dev + kScoreFlagSlot), seq,
+        h->done_counter, beams_xy, h->beams.ptr, h->stream);
+      if (e != hipSuccess) return fail_hip(h, e, "launch_score_few");
+      h->n_beams = n_beams;
+      h->beams_ptr = h->beams.ptr;
+      h->has_search = false;   // see ndt2d_set_beams
+      h->beam_rmax = beam_reach(beams_xy, n_beams);
+      h->timed = false;
+      h->last_kernels = 1;
+      h->last_variant = h->grid.pow2 ? "poses/block-per-pose/pow2" : "poses/block-per-pose/div";
+      if ((rc = wait_host_flag(h, kScoreFlagSlot, seq)) != NDT2D_OK) return rc;
+      for (size_t i = 0; i < n_poses; ++i) h_scores[i] = h->host_res[kScoreSlot + i];
+      return NDT2D_OK;
+    }
+  }
+  int rc = ndt2d_set_beams(h, beams_xy, n_beams);
+  if (rc != NDT2D_OK) return rc;
+  return ndt2d_score_poses(h, h_poses_xyt, n_poses, h_scores, nullptr);
+}
+
 int ndt2d_score_poses(ndt2d_handle h, const double * h_poses_xyt, size_t n_poses,
                       double * h_scores, double * h_stats)
 {
@@ -1018,7 +1075,7 @@ int ndt2d_score_poses(ndt2d_handle h, const double * h_poses_xyt, size_t n_poses
       const unsigned long long seq = ++h->seq;
       hipError_t e = ndt2d::launch_score_few(
         a, &few, reinterpret_cast<unsigned long long *>(h->host_res_dev + kScoreFlagSlot), seq,
-        h->done_counter, h->stream);
+        h->done_counter, nullptr, nullptr, h->stream);
       if (e != hipSuccess) return fail_hip(h, e, "launch_score_few");
       h->timed = false;
       h->last_kernels = 1;

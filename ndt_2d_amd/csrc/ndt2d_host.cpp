@@ -396,8 +396,13 @@ int prepare_tables(ndt2d_matcher * m, const double * scan_pose_xyt, size_t use,
 
 // Subsample `points` (src/scan_matcher_ndt.cpp:165-166,171) and make them the device
 // context's beams -- unless they are exactly what it holds already.  *use_out = beams.
-int stage_beams(ndt2d_matcher * m, const double * points_xy, size_t n_points, size_t * use_out)
+// defer_upload: a changed scan is only noted (*pending_out = true; m->beams holds it):
+// the caller hands it to ndt2d_score_poses_beams, which uploads it or passes it along as
+// kernel arguments.
+int stage_beams(ndt2d_matcher * m, const double * points_xy, size_t n_points, size_t * use_out,
+                bool * pending_out = nullptr)
 {
+  if (pending_out != nullptr) *pending_out = false;
   subsample_into(m->scratch_beams, points_xy, n_points, m->laser_max_beams);
   const size_t use = m->scratch_beams.size() / 2;
   *use_out = use;
@@ -409,6 +414,12 @@ int stage_beams(ndt2d_matcher * m, const double * points_xy, size_t n_points, si
   }
   m->search_ready = false;  // the device beams are replaced: a prepared search is void
   m->beams_on_device = false;
+  if (pending_out != nullptr)
+  {
+    m->beams.swap(m->scratch_beams);
+    *pending_out = true;
+    return NDT2D_OK;
+  }
   int rc = ndt2d_set_beams(m->dev, m->scratch_beams.data(), use);
   if (rc != NDT2D_OK) return dev_fail(m, rc, "ndt2d_set_beams");
   m->beams.swap(m->scratch_beams);
@@ -751,12 +762,21 @@ int ndt2d_matcher_score_poses(ndt2d_matcher * m, const double * points_xy, size_
   }
   if (n_points > 0 && points_xy == nullptr) return mfail(m, NDT2D_ERR_INVALID, "null points");
   size_t use = 0;
-  int rc = stage_beams(m, points_xy, n_points, &use);
+  bool pending = false;
+  int rc = stage_beams(m, points_xy, n_points, &use, &pending);
   if (rc != NDT2D_OK) return rc;
   if (use == 0)
   {
     // score = 0.0 / 0 (:177)
     for (size_t i = 0; i < n_poses; ++i) scores_out[i] = std::numeric_limits<double>::quiet_NaN();
+    return NDT2D_OK;
+  }
+  if (pending)
+  {
+    // a new scan: its beams go to the device with the scoring call itself
+    rc = ndt2d_score_poses_beams(m->dev, m->beams.data(), use, poses_xyt, n_poses, scores_out);
+    if (rc != NDT2D_OK) return dev_fail(m, rc, "ndt2d_score_poses_beams");
+    m->beams_on_device = true;
     return NDT2D_OK;
   }
   rc = ndt2d_score_poses(m->dev, poses_xyt, n_poses, scores_out, nullptr);

@@ -276,12 +276,20 @@ struct FewPoses
 {
   double xyt[3 * kFewPoses];
 };
+constexpr uint32_t kArgBeams = 208;      // beams that travel as kernel arguments (3.3 KB)
+struct FewBeams
+{
+  double xy[2 * kArgBeams];
+};
 bool score_few_supported(const PosesArgs & args, size_t lds_per_block);
 // args.poses_xyt == nullptr: the poses are few->xyt.  flag / seq / done_counter: see
 // the kernel (flag may be null).
+// host_beams (optional, with beams_out): the args.n_beams <= kArgBeams beams in host memory;
+// they travel as kernel arguments and the kernel leaves them in beams_out (device).
 hipError_t launch_score_few(const PosesArgs & args, const FewPoses * few,
                             unsigned long long * flag, unsigned long long seq,
-                            uint32_t * done_counter, hipStream_t stream);
+                            uint32_t * done_counter, const double * host_beams, double * beams_out,
+                            hipStream_t stream);
 
 // force_variant: grid placement in the low bits, candidate mapping above them
 enum { kVariantAuto = 0, kVariantLds = 1, kVariantGlobal = 2, kVariantGridMask = 3,

@@ -34,6 +34,8 @@
 // contribute is queued, in the same order, and a queued pair that turns out to be
 // empty adds exactly +0.0, so the scores are those of the unscreened kernel bit for
 // bit (variant "compact-exact" is that kernel; the tests compare the two).
+#include <cstring>
+
 #include "ndt2d_device_fn.h"
 
 namespace ndt2d
@@ -466,17 +468,26 @@ score_poses_compact_kernel(const PosesArgs a, const uint32_t split)
 // no upload for up to kFewPoses poses).  flag (optional, host-coherent memory):
 // receives `seq` once every score is written, for a host that spins instead of
 // synchronising the stream.
-template <bool POW2>
+// ARG_BEAMS: the (few) beams arrive as kernel arguments too -- a scoreScan on a new scan
+// then queues no copy at all; block 0 also leaves them in beams_out, the context's beam
+// buffer, for the calls that follow on the same scan (matchScan).
+template <bool POW2, bool ARG_BEAMS>
 __global__ void __launch_bounds__(kFewThreads) score_few_kernel(const PosesArgs a, const FewPoses few,
                                                                 unsigned long long * flag,
                                                                 unsigned long long seq,
-                                                                uint32_t * done_counter)
+                                                                uint32_t * done_counter,
+                                                                double * beams_out,
+                                                                const FewBeams arg_beams)
 {
   extern __shared__ __align__(16) double lds[];
   double * terms = lds;                         // [n_beams]
   double * chunk_sums = lds + a.n_beams;        // [kChunks]
   const GridDesc & g = a.grid;
   const uint32_t i = blockIdx.x;
+  if (ARG_BEAMS && i == 0)
+  {
+    for (uint32_t k = threadIdx.x; k < 2 * a.n_beams; k += kFewThreads) beams_out[k] = arg_beams.xy[k];
+  }
   const double * pose = a.poses_xyt != nullptr ? a.poses_xyt + 3 * static_cast<size_t>(i) : few.xyt + 3 * i;
   const double x = pose[0], y = pose[1], th = pose[2];
   // toEigen(pose): AngleAxisd(theta, Z) -> [[c,-s],[s,c]] (conversions.hpp:64-68)
@@ -484,7 +495,16 @@ __global__ void __launch_bounds__(kFewThreads) score_few_kernel(const PosesArgs 
   sincos(th, &s, &c);
   for (uint32_t k = threadIdx.x; k < a.n_beams; k += kFewThreads)
   {
-    const double2 p = reinterpret_cast<const double2 *>(a.beams_xy)[k];
+    double2 p;
+    if (ARG_BEAMS)
+    {
+      p.x = arg_beams.xy[2 * k];
+      p.y = arg_beams.xy[2 * k + 1];
+    }
+    else
+    {
+      p = reinterpret_cast<const double2 *>(a.beams_xy)[k];
+    }
     // p = t * (x, y, 1) (:172-173)
     const double px = x + (c * p.x - s * p.y);
     const double py = y + (s * p.x + c * p.y);
@@ -594,9 +614,14 @@ bool score_few_supported(const PosesArgs & args, size_t lds_per_block)
 
 hipError_t launch_score_few(const PosesArgs & args, const FewPoses * few,
                             unsigned long long * flag, unsigned long long seq,
-                            uint32_t * done_counter, hipStream_t stream)
+                            uint32_t * done_counter, const double * host_beams, double * beams_out,
+                            hipStream_t stream)
 {
   static const FewPoses none = {};
+  const bool arg_beams = host_beams != nullptr && beams_out != nullptr && args.n_beams <= kArgBeams;
+  if (host_beams != nullptr && !arg_beams) return hipErrorInvalidValue;
+  FewBeams fb;
+  if (arg_beams) std::memcpy(fb.xy, host_beams, 2 * static_cast<size_t>(args.n_beams) * sizeof(double));
   const size_t lds_bytes = (static_cast<size_t>(args.n_beams) + kChunks) * sizeof(double);
   auto launch = [&](auto kernel) -> hipError_t {
     if (lds_bytes > 48 * 1024)
@@ -608,10 +633,14 @@ hipError_t launch_score_few(const PosesArgs & args, const FewPoses * few,
     }
     hipLaunchKernelGGL(kernel, dim3(static_cast<uint32_t>(args.n_poses)), dim3(kFewThreads),
                        lds_bytes, stream, args, few != nullptr ? *few : none, flag, seq,
-                       done_counter);
+                       done_counter, beams_out, fb);
     return hipGetLastError();
   };
-  return args.grid.pow2 ? launch(score_few_kernel<true>) : launch(score_few_kernel<false>);
+  if (arg_beams)
+  {
+    return args.grid.pow2 ? launch(score_few_kernel<true, true>) : launch(score_few_kernel<false, true>);
+  }
+  return args.grid.pow2 ? launch(score_few_kernel<true, false>) : launch(score_few_kernel<false, false>);
 }
 
 bool poses_compact_supported(const PosesArgs & args, size_t lds_per_block)

@@ -321,6 +321,31 @@ def test_replaced_beams_void_a_prepared_search(cfg1):
     assert np.array_equal(gpu.match_fetch(), want)
 
 
+@pytest.mark.parametrize("max_beams", [100, 208, 209, 720])
+def test_score_scan_then_match_scan_share_the_beams(max_beams):
+    """The mapper's sequence scoreScan(scan) -> matchScan(scan) (src/ndt_mapper.cpp:514-515):
+    up to 208 beams travel to the device as arguments of the scoring kernel, which leaves
+    them in the context for the search; more are uploaded once.  Either way the search must
+    see exactly this scan's beams -- and a different scan in between must replace them."""
+    gpu, ref, _, guess, pts = _pair(1, laser_max_beams=max_beams, search_linear_size=0.1,
+                                    search_angular_size=0.05)
+    fresh, _, _, _, _ = _pair(1, laser_max_beams=max_beams, search_linear_size=0.1,
+                              search_angular_size=0.05)
+    other = pts[::-1].copy() * 0.9
+    s_other = gpu.scoreScan(guess, other)
+    assert abs(s_other - ref.scoreScan(guess, other)) < TOL_TIGHT
+    s = gpu.scoreScan(guess, pts)
+    assert s == fresh.scorePoses(pts, [guess])[0]
+    assert abs(s - ref.scoreScan(guess, pts)) < TOL_TIGHT
+    got = gpu.matchScan(guess, pts, want_scores=True)
+    want = fresh.matchScan(guess, pts, want_scores=True)
+    assert np.array_equal(got["scores"], want["scores"])
+    assert got["best_index"] == want["best_index"] and got["score"] == want["score"]
+    _check_match(got, ref.matchScan(guess, pts, want_scores=True), min(max_beams, 720))
+    # and the other way round: the search's upload serves the scoring call that follows
+    assert gpu.scoreScan(guess, pts) == s
+
+
 def test_few_poses_take_the_block_per_pose_kernel_bit_identically():
     """scorePoints / scoreScan (ONE pose) and up to 8 poses run a block-per-pose kernel
     whose sums are built in the batched kernel's order: bit-identical scores."""
