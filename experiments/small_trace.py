@@ -35,15 +35,23 @@ t = buf.cpu().numpy().reshape(-1, 16, 8)
 used = t[:, :, 0].max(axis=1) > 0
 t = t[used]
 act = t[:, :, 6] > 0
-t0 = t[:, :, 0][act].min()
+clk = 2.1e9   # shader clock (s_memtime ticks; MI355X_MICROARCH.md), per-XCD time bases
 print("%s: %d blocks, %d active waves per block (max)" % (which, len(t), int(act.sum(axis=1).max())))
-clk = 100e6   # s_memtime / readcyclecounter ticks: 100 MHz constant clock on gfx9
-rel = lambda k: (t[:, :, k][act] - t0) / clk * 1e6
-for name, k in (("block start", 0), ("setup done", 1), ("beams done", 2), ("barrier passed", 3), ("records written", 4)):
-    v = rel(k)
-    print("  %-16s min %7.2f  median %7.2f  max %7.2f us" % (name, v.min(), np.median(v), v.max()))
+# block start / end on the chip-wide 100 MHz clock (the shader clock counters above have
+# a time base per CU)
+starts = np.array([t[b, :, 5][act[b]].min() for b in range(len(t))]) / 100.0
+ends = np.array([t[b, :, 7][act[b]].max() for b in range(len(t))]) / 100.0
+t0 = starts.min()
+late = starts - t0
+print("  block start after the launch's first block: median %.2f  p90 %.2f  max %.2f us; blocks starting > 5 us late: %d"
+      % (np.median(late), np.percentile(late, 90), late.max(), int((late > 5.0).sum())))
+print("  first block start -> last record written: %.1f us; block duration median %.1f  max %.1f us"
+      % (ends.max() - t0, np.median(ends - starts), (ends - starts).max()))
 d_setup = (t[:, :, 1] - t[:, :, 0])[act] / clk * 1e6
 d_main = (t[:, :, 2] - t[:, :, 1])[act] / clk * 1e6
 d_wait = (t[:, :, 3] - t[:, :, 2])[act] / clk * 1e6
-print("  per wave: setup %.2f (max %.2f)  beams %.2f (min %.2f max %.2f)  waiting at the barrier %.2f (max %.2f) us"
-      % (d_setup.mean(), d_setup.max(), d_main.mean(), d_main.min(), d_main.max(), d_wait.mean(), d_wait.max()))
+d_rec = (t[:, :, 4] - t[:, :, 3])[act] / clk * 1e6
+print("  per wave: setup %.2f (max %.2f)  beams %.2f (min %.2f max %.2f)  waiting at the barrier %.2f (max %.2f)"
+      "  combine + record %.2f (max %.2f) us"
+      % (d_setup.mean(), d_setup.max(), d_main.mean(), d_main.min(), d_main.max(), d_wait.mean(), d_wait.max(),
+         d_rec.mean(), d_rec.max()))

@@ -41,6 +41,7 @@
 // order -- which block that is leaves no trace in the result -- applying "no candidate
 // scored below 0 -> no index" and writing the result record to HBM and, behind a flag,
 // to host-coherent memory.
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
@@ -58,7 +59,7 @@ constexpr int kSmallMaxWaves = 16;
 // waves per SIMD; the search is latency bound, so the resident waves are what counts
 constexpr int kSmallUnroll = 4;
 constexpr uint32_t kSmallMaxBeams = 2048;     // 64 KB of LDS rows
-constexpr uint32_t kRowDoubles = 4;           // {ox, oy, K, -}: two 16-byte LDS reads
+constexpr uint32_t kRowDoubles = 3;           // {ox, oy, K}: 24 bytes (at 32, three 720-beam blocks do not fit a CU)
 
 struct SmallPlan
 {
@@ -104,7 +105,8 @@ __device__ __forceinline__ double load_agent(const double * p)
 // ARG_TABLES: the search tables arrive as kernel arguments (`tab`), not through a.dth ..
 // a.dlin: a matchScan whose beams the device already holds then needs no copy at all.
 template <bool POW2, bool COMPACT, bool ARG_TABLES>
-__global__ void __launch_bounds__(kSmallMaxWaves * kWave) match_small_kernel(const MatchArgs a,
+__global__ void __launch_bounds__(kSmallMaxWaves * kWave) __attribute__((amdgpu_waves_per_eu(6)))
+match_small_kernel(const MatchArgs a,
                                                                              const LaneGeom geo,
                                                                              const SmallPlan plan,
                                                                              const SmallFinal fin,
@@ -120,6 +122,7 @@ __global__ void __launch_bounds__(kSmallMaxWaves * kWave) match_small_kernel(con
   extern __shared__ __align__(16) double lds[];
 #ifdef NDT2D_SMALL_TRACE
   const unsigned long long t_start = __builtin_readcyclecounter();
+  const unsigned long long w_start = wall_clock64();   // 100 MHz, one time base for the chip
 #endif
   const GridDesc & g = a.grid;
   if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();
@@ -178,12 +181,9 @@ __global__ void __launch_bounds__(kSmallMaxWaves * kWave) match_small_kernel(con
       // !(k >= min) also catches NaN
       kx = !(kx >= geo.k_min) ? geo.k_min : (kx > geo.k_max_x ? geo.k_max_x : kx);
       ky = !(ky >= geo.k_min) ? geo.k_min : (ky > geo.k_max_y ? geo.k_max_y : ky);
-      double4 o;
-      o.x = ox;
-      o.y = oy;
-      o.z = kTwo52 + (rint(ky) * kTwo24 + rint(kx));
-      o.w = 0.0;
-      reinterpret_cast<double4 *>(rows)[b] = o;
+      rows[kRowDoubles * b + 0] = ox;
+      rows[kRowDoubles * b + 1] = oy;
+      rows[kRowDoubles * b + 2] = kTwo52 + (rint(ky) * kTwo24 + rint(kx));
     }
   }
   __syncthreads();
@@ -235,7 +235,15 @@ __global__ void __launch_bounds__(kSmallMaxWaves * kWave) match_small_kernel(con
     // Chunk j walks the look-up groups j, j + C, j + 2C, ... (in that order): beams that
     // are expensive -- the sectors of the scan that face walls inside the map -- are then
     // spread over all the chunks instead of making one wave the block waits for.
-    const double4 * row = reinterpret_cast<const double4 *>(rows);
+    auto row_at = [&](uint32_t beam) -> double4 {
+      const double * r = rows + kRowDoubles * beam;
+      double4 o;
+      o.x = r[0];
+      o.y = r[1];
+      o.z = r[2];
+      o.w = 0.0;
+      return o;
+    };
     double sum = 0.0;
     SkipState skip = skip_state(0.0, geo.no_skip);
     for (uint32_t b = chunk * kSmallUnroll; b < a.n_beams; b += plan.chunks * kSmallUnroll)
@@ -244,14 +252,14 @@ __global__ void __launch_bounds__(kSmallMaxWaves * kWave) match_small_kernel(con
       {
         double4 o[kSmallUnroll];
 #pragma unroll
-        for (int u = 0; u < kSmallUnroll; ++u) o[u] = row[b + u];
+        for (int u = 0; u < kSmallUnroll; ++u) o[u] = row_at(b + u);
         lane_beams<kSmallUnroll, POW2, COMPACT, false, COMPACT>(g, c, o, dx, dy, dxy, sum, skip, geo.no_skip);
       }
       else
       {
         for (uint32_t t = b; t < a.n_beams; ++t)
         {
-          const double4 one[1] = {row[t]};
+          const double4 one[1] = {row_at(t)};
           lane_beams<1, POW2, COMPACT, false, COMPACT>(g, c, one, dx, dy, dxy, sum, skip, geo.no_skip);
         }
       }
@@ -333,9 +341,9 @@ __global__ void __launch_bounds__(kSmallMaxWaves * kWave) match_small_kernel(con
     tr[2] = static_cast<double>(t_main);
     tr[3] = static_cast<double>(t_barrier);
     tr[4] = static_cast<double>(__builtin_readcyclecounter());
-    tr[5] = static_cast<double>(__builtin_amdgcn_s_getreg((3 << 11) | (4 << 6) | 20));  // XCC_ID
+    tr[5] = static_cast<double>(w_start);
     tr[6] = active ? 1.0 : 0.0;
-    tr[7] = static_cast<double>(chunk);
+    tr[7] = static_cast<double>(wall_clock64());
   }
 #endif
   __syncthreads();
@@ -568,6 +576,14 @@ hipError_t launch_match_small(const MatchArgs & args_in, double * workspace, uin
                                           hipFuncAttributeMaxDynamicSharedMemorySize,
                                           static_cast<int>(lds_bytes));
       if (e2 != hipSuccess) return e2;
+    }
+    if (std::getenv("NDT2D_SMALL_DEBUG") != nullptr)
+    {
+      int per_cu = -1;
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kernel),
+                                                         static_cast<int>(waves * kWave), lds_bytes);
+      std::fprintf(stderr, "match_small: %u blocks x %u waves, %zu B LDS, C=%u P=%u, %d blocks per CU (API)\n",
+                   blocks, waves, lds_bytes, plan.chunks, plan.patches_per_block, per_cu);
     }
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(waves * kWave), lds_bytes, stream, args, geo, plan, fin, tab);
     return hipGetLastError();
