@@ -72,6 +72,11 @@ static void op_pf_loop(void)
     if (ndt2d_matcher_score_points(m, scan_pts, N_BEAMS, pf_poses + 3 * i, &w) != NDT2D_OK) exit(7);
   }
 }
+static void op_pf_measure(void)
+{
+  static double w[500], mean[3], cov[9];
+  if (ndt2d_matcher_pf_measure(m, pf_poses, 500, scan_pts, N_BEAMS, w, mean, cov) != NDT2D_OK) exit(9);
+}
 static void op_pf_batch(void)
 {
   static double w[500];
@@ -137,21 +142,23 @@ int main(void)
   ndt2d_set_timing(ndt2d_matcher_device(m), 0);   /* as the shim does */
   op_add();
 
-  double med[6], p99[6];
+  double med[7], p99[7];
   measure(op_match, REPS, &med[0], &p99[0]);
   measure(op_score_scan, REPS, &med[1], &p99[1]);
   measure(op_add, REPS / 4, &med[2], &p99[2]);
   measure(op_cycle, REPS / 4, &med[3], &p99[3]);
   measure(op_pf_loop, 20, &med[4], &p99[4]);
   measure(op_pf_batch, REPS / 4, &med[5], &p99[5]);
+  measure(op_pf_measure, REPS / 4, &med[6], &p99[6]);
   double pose[3] = {0, 0, 0}, cov[9], score;
   ndt2d_matcher_match_scan(m, guess, scan_pts, N_BEAMS, pose, cov, &score);
   printf("{\"match_scan_us\": %.2f, \"match_scan_p99_us\": %.2f, \"score_scan_us\": %.2f, "
          "\"add_scans_us\": %.2f, \"mapper_cycle_us\": %.2f, \"mapper_cycle_p99_us\": %.2f, "
          "\"measure_500_particles_unchanged_loop_us\": %.1f, \"score_points_call_us\": %.2f, "
-         "\"measure_500_particles_batched_us\": %.2f, \"variant\": \"%s\", "
+         "\"measure_500_particles_batched_us\": %.2f, \"pf_measure_500_particles_us\": %.2f, "
+         "\"variant\": \"%s\", "
          "\"check_pose\": [%.17g, %.17g, %.17g], \"check_score\": %.17g}\n",
-         med[0], p99[0], med[1], med[2], med[3], p99[3], med[4], med[4] / 500.0, med[5],
+         med[0], p99[0], med[1], med[2], med[3], p99[3], med[4], med[4] / 500.0, med[5], med[6],
          ndt2d_last_variant(ndt2d_matcher_device(m)), pose[0], pose[1], pose[2], score);
   ndt2d_matcher_destroy(m);
   return 0;
