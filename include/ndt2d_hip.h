@@ -355,7 +355,8 @@ const char * ndt2d_last_variant(ndt2d_handle h);
  * Force a kernel variant (testing / A-B measurement): "auto", "lds", "global"
  * (grid placement), "wave", "wave-lds", "wave-global", "lane", "small" (candidate mapping
  * of the match search), "lane-noskip" / "small-noskip" (the lane mappings with every term
- * evaluated: the bit-exactness controls of their skipping), "dense" (particle
+ * evaluated: the bit-exactness controls of their skipping), "batched" (pose batches of
+ * at most 2,048 on the batched particle kernel instead of block-per-pose), "dense" (particle
  * scoring without compaction), "compact-exact" (particle scoring with the exact
  * FP64 phase A: the bit-exactness control of the FP32 screen). */
 int ndt2d_set_variant(ndt2d_handle h, const char * name);

@@ -68,7 +68,8 @@ struct ndt2d_context
 
   // Results of small calls go straight into host-coherent pinned memory, followed by a
   // sequence number the host spins on (a stream synchronisation costs ~4 us more):
-  //   [0..11] match record   [16] match flag   [24] score flag   [32..95] scores
+  //   [0..11] match record   [16] match flag   [24] score flag   [32..2079] scores / weights
+  //   [2080..2087] particle statistics
   double * host_res = nullptr;      // host address
   double * host_res_dev = nullptr;  // the same memory as the GPU addresses it
   unsigned long long seq = 0;       // last sequence number handed out
@@ -101,6 +102,7 @@ struct ndt2d_context
   int last_kernels = 0;
   const char * last_variant = "";
   int force_variant = ndt2d::kVariantAuto;
+  bool batched_only = false;   // "batched": small pose batches stay on the batched kernels
 
   bool match_pending = false;
   uint64_t last_candidates = 0;
@@ -220,9 +222,10 @@ ndt2d::MotionParams motion_params(double dx, double dy, double dth, const double
   return p;
 }
 
-constexpr int kHostResDoubles = 128;
 constexpr int kScoreFlagSlot = 24;
-constexpr int kScoreSlot = 32;
+constexpr int kScoreSlot = 32;                                             // scores / weights of a small batch
+constexpr int kPfOutSlot = kScoreSlot + static_cast<int>(ndt2d::kFewPosesMax);   // its statistics
+constexpr int kHostResDoubles = kPfOutSlot + 32;
 
 int ensure_host_res(ndt2d_context * h)
 {
@@ -280,6 +283,14 @@ int wait_host_flag(ndt2d_context * h, int slot, unsigned long long seq)
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
   return NDT2D_OK;
 }
+
+// A small batch of poses (<= kFewPosesMax) through the block-per-pose kernel: one launch,
+// results through host-coherent memory.  arg_beams (optional): the context's new beams,
+// handed to the kernel as arguments (<= kArgBeams) -- the caller has made h->beams large
+// enough.  stats: the whole of ParticleFilter::measure (normalised weights into h_scores,
+// NDT2D_PF_RESULT_DOUBLES into h_out).
+int run_few(ndt2d_context * h, const double * arg_beams, size_t n_beams, const double * h_poses,
+            size_t n_poses, bool stats, double * h_scores, double * h_out);
 
 // Take the next pair of timing events (created on first use) as h->ev0 / h->ev1.
 int next_timing_slot(ndt2d_context * h)
@@ -996,7 +1007,7 @@ int ndt2d_score_poses_beams(ndt2d_handle h, const double * beams_xy, size_t n_be
   if (!h->has_grid) return fail(h, NDT2D_ERR_NO_GRID, "ndt2d_score_poses_beams: no grid");
   NDT2D_HIP(h, hipSetDevice(h->device));
   if (n_poses <= ndt2d::kFewPoses && n_beams <= ndt2d::kArgBeams &&
-      h->force_variant == ndt2d::kVariantAuto)
+      h->force_variant == ndt2d::kVariantAuto && !h->batched_only)
   {
     // beams AND poses as kernel arguments: one launch, no copy; the kernel leaves the beams
     // in the context's beam buffer for the calls that follow on this scan
@@ -1007,32 +1018,17 @@ int ndt2d_score_poses_beams(ndt2d_handle h, const double * beams_xy, size_t n_be
       NDT2D_HIP(h, hipEventSynchronize(h->stage_beams.done));
       h->stage_beams.pending = false;
     }
-    if ((rc = ensure_host_res(h)) != NDT2D_OK) return rc;
-    ndt2d::PosesArgs a{};
-    a.grid = h->grid;
-    a.beams_xy = h->beams.ptr;
-    a.n_beams = static_cast<uint32_t>(n_beams);
-    a.poses_xyt = nullptr;
-    a.n_poses = n_poses;
-    a.scores = h->host_res_dev + kScoreSlot;
-    if (ndt2d::score_few_supported(a, 64 * 1024))
+    ndt2d::PosesArgs probe{};
+    probe.n_beams = static_cast<uint32_t>(n_beams);
+    probe.n_poses = n_poses;
+    if (ndt2d::score_few_supported(probe, 64 * 1024))
     {
-      ndt2d::FewPoses few{};
-      std::memcpy(few.xyt, h_poses_xyt, 3 * n_poses * sizeof(double));
-      const unsigned long long seq = ++h->seq;
-      hipError_t e = ndt2d::launch_score_few(
-        a, &few, reinterpret_cast<unsigned long long *>(h->host_res_dev + kScoreFlagSlot), seq,
-        h->done_counter, beams_xy, h->beams.ptr, h->stream);
-      if (e != hipSuccess) return fail_hip(h, e, "launch_score_few");
+      rc = run_few(h, beams_xy, n_beams, h_poses_xyt, n_poses, false, h_scores, nullptr);
+      if (rc != NDT2D_OK) return rc;
       h->n_beams = n_beams;
       h->beams_ptr = h->beams.ptr;
       h->has_search = false;   // see ndt2d_set_beams
       h->beam_rmax = beam_reach(beams_xy, n_beams);
-      h->timed = false;
-      h->last_kernels = 1;
-      h->last_variant = h->grid.pow2 ? "poses/block-per-pose/pow2" : "poses/block-per-pose/div";
-      if ((rc = wait_host_flag(h, kScoreFlagSlot, seq)) != NDT2D_OK) return rc;
-      for (size_t i = 0; i < n_poses; ++i) h_scores[i] = h->host_res[kScoreSlot + i];
       return NDT2D_OK;
     }
   }
@@ -1054,35 +1050,19 @@ int ndt2d_score_poses(ndt2d_handle h, const double * h_poses_xyt, size_t n_poses
   NDT2D_HIP(h, hipSetDevice(h->device));
   int rc;
 
-  // A handful of poses (scorePoints / scoreScan: ONE pose): a block per pose and a
-  // thread per beam, poses as kernel arguments, scores written straight into
-  // host-coherent memory behind a flag the host spins on -- one launch, no copies.
-  if (h_stats == nullptr && n_poses <= ndt2d::kFewPoses && h->force_variant == ndt2d::kVariantAuto)
+  // A small batch (scorePoints / scoreScan: ONE pose; a particle filter of the node's
+  // default size: <= 500): a block per pose and a thread per beam, the poses as kernel
+  // arguments (<= 8) or through one staged copy, the scores written straight into
+  // host-coherent memory behind a flag the host spins on -- one launch.
+  if (h_stats == nullptr && n_poses <= ndt2d::kFewPosesMax &&
+      h->force_variant == ndt2d::kVariantAuto && !h->batched_only)
   {
-    ndt2d::PosesArgs a{};
-    a.grid = h->grid;
-    a.beams_xy = h->beams_ptr;
-    a.n_beams = static_cast<uint32_t>(h->n_beams);
-    a.poses_xyt = nullptr;
-    a.n_poses = n_poses;
-    a.beam_rmax = h->beam_rmax;
-    if (ndt2d::score_few_supported(a, 64 * 1024))
+    ndt2d::PosesArgs probe{};
+    probe.n_beams = static_cast<uint32_t>(h->n_beams);
+    probe.n_poses = n_poses;
+    if (ndt2d::score_few_supported(probe, 64 * 1024))
     {
-      if ((rc = ensure_host_res(h)) != NDT2D_OK) return rc;
-      a.scores = h->host_res_dev + kScoreSlot;
-      ndt2d::FewPoses few{};
-      std::memcpy(few.xyt, h_poses_xyt, 3 * n_poses * sizeof(double));
-      const unsigned long long seq = ++h->seq;
-      hipError_t e = ndt2d::launch_score_few(
-        a, &few, reinterpret_cast<unsigned long long *>(h->host_res_dev + kScoreFlagSlot), seq,
-        h->done_counter, nullptr, nullptr, h->stream);
-      if (e != hipSuccess) return fail_hip(h, e, "launch_score_few");
-      h->timed = false;
-      h->last_kernels = 1;
-      h->last_variant = h->grid.pow2 ? "poses/block-per-pose/pow2" : "poses/block-per-pose/div";
-      if ((rc = wait_host_flag(h, kScoreFlagSlot, seq)) != NDT2D_OK) return rc;
-      for (size_t i = 0; i < n_poses; ++i) h_scores[i] = h->host_res[kScoreSlot + i];
-      return NDT2D_OK;
+      return run_few(h, nullptr, h->n_beams, h_poses_xyt, n_poses, false, h_scores, nullptr);
     }
   }
 
@@ -1150,7 +1130,20 @@ int ndt2d_pf_measure(ndt2d_handle h, const double * h_poses_xyt, size_t n_poses,
     return fail(h, NDT2D_ERR_INVALID, "ndt2d_pf_measure: bad argument");
   }
   if (!h->has_grid) return fail(h, NDT2D_ERR_NO_GRID, "ndt2d_pf_measure: no grid");
+  if (h->n_beams == 0) return fail(h, NDT2D_ERR_STATE, "ndt2d_pf_measure: set_beams first");
   NDT2D_HIP(h, hipSetDevice(h->device));
+  if (n_poses <= ndt2d::kFewPosesMax && h->force_variant == ndt2d::kVariantAuto && !h->batched_only)
+  {
+    // a filter of the node's size (<= 500 particles by default): scoring and
+    // updateStatistics in ONE launch, weights and result through host-coherent memory
+    ndt2d::PosesArgs probe{};
+    probe.n_beams = static_cast<uint32_t>(h->n_beams);
+    probe.n_poses = n_poses;
+    if (ndt2d::score_few_supported(probe, 64 * 1024))
+    {
+      return run_few(h, nullptr, h->n_beams, h_poses_xyt, n_poses, true, h_weights, h_out);
+    }
+  }
   int rc = ensure(h, h->tmp_poses, 3 * n_poses);
   if (rc != NDT2D_OK) return rc;
   rc = ensure(h, h->tmp_scores, n_poses);
@@ -1295,6 +1288,58 @@ int ndt2d_pf_update(ndt2d_handle h, double * h_poses_xyt, size_t n, double dx, d
 
 namespace
 {
+
+int run_few(ndt2d_context * h, const double * arg_beams, size_t n_beams, const double * h_poses,
+            size_t n_poses, bool stats, double * h_scores, double * h_out)
+{
+  int rc = ensure_host_res(h);
+  if (rc != NDT2D_OK) return rc;
+  ndt2d::PosesArgs a{};
+  a.grid = h->grid;
+  a.beams_xy = arg_beams != nullptr ? h->beams.ptr : h->beams_ptr;
+  a.n_beams = static_cast<uint32_t>(n_beams);
+  a.n_poses = n_poses;
+  a.scores = h->host_res_dev + kScoreSlot;
+  ndt2d::FewPoses few{};
+  if (n_poses <= ndt2d::kFewPoses)
+  {
+    std::memcpy(few.xyt, h_poses, 3 * n_poses * sizeof(double));
+    a.poses_xyt = nullptr;
+  }
+  else
+  {
+    // one staged copy (pinned; the caller's buffer is free on return)
+    if ((rc = ensure(h, h->tmp_poses, 3 * n_poses)) != NDT2D_OK) return rc;
+    if ((rc = stage_acquire(h, h->stage_call, 3 * n_poses)) != NDT2D_OK) return rc;
+    std::memcpy(h->stage_call.ptr, h_poses, 3 * n_poses * sizeof(double));
+    if ((rc = stage_submit(h, h->stage_call, h->tmp_poses.ptr, 3 * n_poses)) != NDT2D_OK) return rc;
+    a.poses_xyt = h->tmp_poses.ptr;
+  }
+  ndt2d::FewOut out{};
+  out.flag = reinterpret_cast<unsigned long long *>(h->host_res_dev + kScoreFlagSlot);
+  out.seq = ++h->seq;
+  out.done_counter = h->done_counter;
+  out.beams_out = arg_beams != nullptr ? h->beams.ptr : nullptr;
+  out.stats = stats ? 1 : 0;
+  if (stats)
+  {
+    if ((rc = ensure(h, h->tmp_scores, n_poses)) != NDT2D_OK) return rc;
+    out.dev_scores = h->tmp_scores.ptr;
+    out.host_out = h->host_res_dev + kPfOutSlot;
+  }
+  hipError_t e = ndt2d::launch_score_few(a, &few, out, arg_beams, h->stream);
+  if (e != hipSuccess) return fail_hip(h, e, "launch_score_few");
+  h->timed = false;
+  h->last_kernels = 1;
+  h->last_variant = h->grid.pow2 ? "poses/block-per-pose/pow2" : "poses/block-per-pose/div";
+  if ((rc = wait_host_flag(h, kScoreFlagSlot, out.seq)) != NDT2D_OK) return rc;
+  std::memcpy(h_scores, h->host_res + kScoreSlot, n_poses * sizeof(double));
+  if (stats)
+  {
+    for (int k = 0; k < NDT2D_PF_RESULT_DOUBLES; ++k) h_out[k] = h->host_res[kPfOutSlot + k];
+  }
+  return NDT2D_OK;
+}
 
 ndt2d::ScanDesc scan_desc(const ndt2d_laser_scan & s)
 {
@@ -1669,7 +1714,9 @@ const char * ndt2d_last_variant(ndt2d_handle h) { return h != nullptr ? h->last_
 int ndt2d_set_variant(ndt2d_handle h, const char * name)
 {
   if (h == nullptr || name == nullptr) return NDT2D_ERR_INVALID;
+  h->batched_only = false;
   if (std::strcmp(name, "auto") == 0) h->force_variant = ndt2d::kVariantAuto;
+  else if (std::strcmp(name, "batched") == 0) h->batched_only = true, h->force_variant = ndt2d::kVariantAuto;
   else if (std::strcmp(name, "lds") == 0) h->force_variant = ndt2d::kVariantLds;
   else if (std::strcmp(name, "global") == 0) h->force_variant = ndt2d::kVariantGlobal;
   else if (std::strcmp(name, "wave") == 0) h->force_variant = ndt2d::kVariantWave;

@@ -240,6 +240,16 @@ __device__ __forceinline__ double wave_sum_to_last_lane(double v)
   return v;
 }
 
+// angles::shortest_angular_distance(from, to) = normalize_angle(to - from),
+// normalize_angle(a) = fmod(a + pi, 2 pi) -/+ pi  (ROS `angles`, used at
+// reference src/particle_filter.cpp:215)
+__device__ __forceinline__ double shortest_angular_distance(double from, double to)
+{
+  const double kPi = 3.14159265358979323846;
+  const double r = fmod((to - from) + kPi, 2.0 * kPi);
+  return r <= 0.0 ? r + kPi : r - kPi;
+}
+
 // Results for a spinning host go to host-coherent memory with system-scope stores
 // (write-through, no cache line kept), and the flag follows once they have been
 // acknowledged: a __threadfence_system() instead would write back the whole L2 first.

@@ -267,10 +267,10 @@ bool poses_compact_supported(const PosesArgs & args, size_t lds_per_block);
 hipError_t launch_poses_compact(const PosesArgs & args, int cus, bool screen, hipStream_t stream,
                                 uint32_t * blocks_out);
 
-// Scoring of a handful of poses, a block per pose and a thread per beam
+// Scoring of a small batch of poses, a block per pose and a thread per beam
 // (ndt2d_poses_compact.hip, score_few_kernel); bit-identical to the batched kernel.
 constexpr uint32_t kFewPoses = 8;        // poses that travel as kernel arguments
-constexpr uint32_t kFewPosesMax = 64;    // poses this kernel is used for
+constexpr uint32_t kFewPosesMax = 2048;  // poses this kernel is used for
 constexpr int kFewThreads = 256;
 struct FewPoses
 {
@@ -281,15 +281,25 @@ struct FewBeams
 {
   double xy[2 * kArgBeams];
 };
+// Where a score_few launch leaves its results.  args.scores: the scores -- or, with
+// `stats`, the normalised weights -- device memory when flag == nullptr, else
+// host-coherent memory with `seq` raised at *flag once everything is there.
+struct FewOut
+{
+  unsigned long long * flag;
+  unsigned long long seq;
+  uint32_t * done_counter;      // one zeroed uint32 (needed with flag != nullptr)
+  double * beams_out;           // device: the beams, when they came as kernel arguments
+  int stats;                    // run ParticleFilter::updateStatistics in the launch's last block
+  double * dev_scores;          // device scratch [n_poses] (stats)
+  double * host_out;            // host-coherent [NDT2D_PF_RESULT_DOUBLES] (stats)
+};
 bool score_few_supported(const PosesArgs & args, size_t lds_per_block);
-// args.poses_xyt == nullptr: the poses are few->xyt.  flag / seq / done_counter: see
-// the kernel (flag may be null).
-// host_beams (optional, with beams_out): the args.n_beams <= kArgBeams beams in host memory;
-// they travel as kernel arguments and the kernel leaves them in beams_out (device).
-hipError_t launch_score_few(const PosesArgs & args, const FewPoses * few,
-                            unsigned long long * flag, unsigned long long seq,
-                            uint32_t * done_counter, const double * host_beams, double * beams_out,
-                            hipStream_t stream);
+// args.poses_xyt == nullptr: the (<= kFewPoses) poses are few->xyt.  host_beams (optional,
+// with out.beams_out): the args.n_beams <= kArgBeams beams in host memory; they travel as
+// kernel arguments and the kernel leaves them in out.beams_out.
+hipError_t launch_score_few(const PosesArgs & args, const FewPoses * few, const FewOut & out,
+                            const double * host_beams, hipStream_t stream);
 
 // force_variant: grid placement in the low bits, candidate mapping above them
 enum { kVariantAuto = 0, kVariantLds = 1, kVariantGlobal = 2, kVariantGridMask = 3,

@@ -700,16 +700,6 @@ hipError_t launch_match(const MatchArgs & args_in, double * workspace, double * 
 namespace
 {
 
-// angles::shortest_angular_distance(from, to) = normalize_angle(to - from),
-// normalize_angle(a) = fmod(a + pi, 2 pi) -/+ pi  (ROS `angles`, used at
-// reference src/particle_filter.cpp:215)
-__device__ __forceinline__ double shortest_angular_distance(double from, double to)
-{
-  const double kPi = 3.14159265358979323846;
-  const double r = fmod((to - from) + kPi, 2.0 * kPi);
-  return r <= 0.0 ? r + kPi : r - kPi;
-}
-
 // ParticleFilter::updateStatistics on the device (reference
 // src/particle_filter.cpp:163-218) from the (all-reduced) moment sums
 //   stats = {sum w, sum w x, sum w y, sum w cos, sum w sin, sum w xx, sum w xy, sum w yy}:

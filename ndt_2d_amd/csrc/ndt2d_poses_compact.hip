@@ -471,22 +471,26 @@ score_poses_compact_kernel(const PosesArgs a, const uint32_t split)
 // ARG_BEAMS: the (few) beams arrive as kernel arguments too -- a scoreScan on a new scan
 // then queues no copy at all; block 0 also leaves them in beams_out, the context's beam
 // buffer, for the calls that follow on the same scan (matchScan).
+//
+// f.stats: the launch is a whole ParticleFilter::measure for a small particle set (the
+// node's default is at most 500, src/ndt_mapper.cpp:81-82): every block leaves its score
+// in f.dev_scores (agent-scope store), and the block that finishes last runs
+// updateStatistics (src/particle_filter.cpp:163-218) over all of them -- total weight,
+// normalised weights, weighted mean, circular mean, x/y covariance, the theta variance of
+// the second pass -- writing weights and result straight to host-coherent memory.
 template <bool POW2, bool ARG_BEAMS>
 __global__ void __launch_bounds__(kFewThreads) score_few_kernel(const PosesArgs a, const FewPoses few,
-                                                                unsigned long long * flag,
-                                                                unsigned long long seq,
-                                                                uint32_t * done_counter,
-                                                                double * beams_out,
+                                                                const FewOut f,
                                                                 const FewBeams arg_beams)
 {
   extern __shared__ __align__(16) double lds[];
   double * terms = lds;                         // [n_beams]
-  double * chunk_sums = lds + a.n_beams;        // [kChunks]
+  double * chunk_sums = lds + a.n_beams;        // [kChunks + 8]: chunk sums, then a scratch row
   const GridDesc & g = a.grid;
   const uint32_t i = blockIdx.x;
   if (ARG_BEAMS && i == 0)
   {
-    for (uint32_t k = threadIdx.x; k < 2 * a.n_beams; k += kFewThreads) beams_out[k] = arg_beams.xy[k];
+    for (uint32_t k = threadIdx.x; k < 2 * a.n_beams; k += kFewThreads) f.beams_out[k] = arg_beams.xy[k];
   }
   const double * pose = a.poses_xyt != nullptr ? a.poses_xyt + 3 * static_cast<size_t>(i) : few.xyt + 3 * i;
   const double x = pose[0], y = pose[1], th = pose[2];
@@ -522,6 +526,7 @@ __global__ void __launch_bounds__(kFewThreads) score_few_kernel(const PosesArgs 
     chunk_sums[threadIdx.x] = csum;
   }
   __syncthreads();
+  uint32_t * last_slot = reinterpret_cast<uint32_t *>(chunk_sums + kChunks);
   if (threadIdx.x == 0)
   {
     double sum = chunk_sums[0];
@@ -529,28 +534,127 @@ __global__ void __launch_bounds__(kFewThreads) score_few_kernel(const PosesArgs 
     for (int j = 1; j < kChunks; ++j) sum += chunk_sums[j];
     // score = sum of (-likelihood) / n  ==  -(sum) / n (:175-177)
     const double score = -sum / static_cast<double>(a.n_beams);
-    if (flag == nullptr)
+    uint32_t is_last = 0;
+    if (f.flag == nullptr)
     {
       a.scores[i] = score;
     }
     else
     {
-      // scores go to host-coherent memory; the block that finishes last raises the flag,
-      // after every block's store has been acknowledged
-      store_host(a.scores + i, score);
+      // scores go to host-coherent memory (or, with f.stats, to the device array the last
+      // block reads); the block that finishes last goes on, after every block's store has
+      // been acknowledged
+      if (f.stats)
+      {
+        __hip_atomic_store(f.dev_scores + i, score, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      else
+      {
+        store_host(a.scores + i, score);
+      }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       uint32_t arrived = gridDim.x;
       if (gridDim.x > 1)
       {
-        arrived = __hip_atomic_fetch_add(done_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        arrived = __hip_atomic_fetch_add(f.done_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
       }
       if (arrived == gridDim.x)
       {
-        if (gridDim.x > 1) __hip_atomic_store(done_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        raise_host_flag(reinterpret_cast<double *>(flag), seq);
+        if (gridDim.x > 1) __hip_atomic_store(f.done_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = 1;
+        if (!f.stats) raise_host_flag(reinterpret_cast<double *>(f.flag), f.seq);
       }
     }
+    *last_slot = is_last;
   }
+  if (!f.stats) return;
+  __syncthreads();
+  if (*last_slot == 0) return;
+
+  // ---- updateStatistics by the last block (src/particle_filter.cpp:163-218) ----
+  const uint32_t n = gridDim.x;
+  const uint32_t lane = threadIdx.x & (kWave - 1);
+  const uint32_t wave = threadIdx.x >> 6;
+  double * row = chunk_sums + kChunks;          // 8 doubles of scratch
+  double * wave_rows = terms;                   // [4 waves][8]: needs n_beams >= 32 or the pad below
+  auto pose_of = [&](uint32_t k, double & px, double & py, double & pt) {
+    const double * q = a.poses_xyt != nullptr ? a.poses_xyt + 3 * static_cast<size_t>(k) : few.xyt + 3 * k;
+    px = q[0];
+    py = q[1];
+    pt = q[2];
+  };
+  // block-wide sum of eight per-thread values, fixed order; the result in row[0..7]
+  auto block_sum8 = [&](double (&v)[8]) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = wave_sum_to_last_lane(v[k]);
+    if (lane == kWave - 1)
+    {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) wave_rows[wave * 8 + k] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 8)
+    {
+      double t = wave_rows[threadIdx.x];
+      for (int w = 1; w < kFewThreads / kWave; ++w) t += wave_rows[w * 8 + threadIdx.x];
+      row[threadIdx.x] = t;
+    }
+    __syncthreads();
+  };
+  double st[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) st[k] = 0.0;
+  for (uint32_t k = threadIdx.x; k < n; k += kFewThreads)
+  {
+    const double w = __hip_atomic_load(f.dev_scores + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    double px, py, pt, ps, pc;
+    pose_of(k, px, py, pt);
+    sincos(pt, &ps, &pc);
+    st[0] += w;
+    st[1] += w * px;
+    st[2] += w * py;
+    st[3] += w * pc;
+    st[4] += w * ps;
+    st[5] += w * px * px;
+    st[6] += w * px * py;
+    st[7] += w * py * py;
+  }
+  block_sum8(st);
+  const double sum_w = row[0];
+  const double mean_x = row[1] / sum_w, mean_y = row[2] / sum_w;
+  const double mean_th = atan2(row[4] / sum_w, row[3] / sum_w);
+  const double cov_xx = row[5] / sum_w - mean_x * mean_x;
+  const double cov_xy = row[6] / sum_w - mean_x * mean_y;
+  const double cov_yy = row[7] / sum_w - mean_y * mean_y;
+  double var[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) var[k] = 0.0;
+  for (uint32_t k = threadIdx.x; k < n; k += kFewThreads)
+  {
+    const double w = __hip_atomic_load(f.dev_scores + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / sum_w;
+    store_host(a.scores + k, w);                               // the normalised weight (:171-174)
+    double px, py, pt;
+    pose_of(k, px, py, pt);
+    const double d = shortest_angular_distance(pt, mean_th);   // (:213-217)
+    var[0] += w * d * d;
+  }
+  block_sum8(var);
+  if (threadIdx.x == 0)
+  {
+    store_host(f.host_out + 0, sum_w);
+    store_host(f.host_out + 1, mean_x);
+    store_host(f.host_out + 2, mean_y);
+    store_host(f.host_out + 3, mean_th);
+    store_host(f.host_out + 4, cov_xx);
+    store_host(f.host_out + 5, cov_xy);
+    store_host(f.host_out + 6, cov_yy);
+    store_host(f.host_out + 7, row[0]);
+  }
+  // every thread's weights have been acknowledged before the flag leaves
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) raise_host_flag(reinterpret_cast<double *>(f.flag), f.seq);
 }
 
 size_t compact_lds_bytes(const PosesArgs & args, int threads, uint32_t split)
@@ -606,23 +710,28 @@ hipError_t launch_compact(const PosesArgs & args, uint32_t blocks, uint32_t spli
 
 }  // namespace
 
-bool score_few_supported(const PosesArgs & args, size_t lds_per_block)
+size_t few_lds_bytes(const PosesArgs & args)
 {
-  return args.n_poses <= kFewPosesMax &&
-         (static_cast<size_t>(args.n_beams) + kChunks) * sizeof(double) <= lds_per_block;
+  // terms (at least the 4 x 8 doubles the statistics pass puts there) + chunk sums + scratch row
+  const size_t terms = args.n_beams < 32 ? 32 : args.n_beams;
+  return (terms + kChunks + 8) * sizeof(double);
 }
 
-hipError_t launch_score_few(const PosesArgs & args, const FewPoses * few,
-                            unsigned long long * flag, unsigned long long seq,
-                            uint32_t * done_counter, const double * host_beams, double * beams_out,
-                            hipStream_t stream)
+bool score_few_supported(const PosesArgs & args, size_t lds_per_block)
+{
+  return args.n_poses <= kFewPosesMax && few_lds_bytes(args) <= lds_per_block;
+}
+
+hipError_t launch_score_few(const PosesArgs & args, const FewPoses * few, const FewOut & out,
+                            const double * host_beams, hipStream_t stream)
 {
   static const FewPoses none = {};
-  const bool arg_beams = host_beams != nullptr && beams_out != nullptr && args.n_beams <= kArgBeams;
+  const bool arg_beams = host_beams != nullptr && out.beams_out != nullptr && args.n_beams <= kArgBeams;
   if (host_beams != nullptr && !arg_beams) return hipErrorInvalidValue;
-  FewBeams fb;
+  if (args.poses_xyt == nullptr && args.n_poses > kFewPoses) return hipErrorInvalidValue;
+  FewBeams fb{};
   if (arg_beams) std::memcpy(fb.xy, host_beams, 2 * static_cast<size_t>(args.n_beams) * sizeof(double));
-  const size_t lds_bytes = (static_cast<size_t>(args.n_beams) + kChunks) * sizeof(double);
+  const size_t lds_bytes = few_lds_bytes(args);
   auto launch = [&](auto kernel) -> hipError_t {
     if (lds_bytes > 48 * 1024)
     {
@@ -632,8 +741,7 @@ hipError_t launch_score_few(const PosesArgs & args, const FewPoses * few,
       if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kernel, dim3(static_cast<uint32_t>(args.n_poses)), dim3(kFewThreads),
-                       lds_bytes, stream, args, few != nullptr ? *few : none, flag, seq,
-                       done_counter, beams_out, fb);
+                       lds_bytes, stream, args, few != nullptr ? *few : none, out, fb);
     return hipGetLastError();
   };
   if (arg_beams)

@@ -94,13 +94,16 @@ def test_random_case(seed):
     # a handful of poses take the block-per-pose kernel: bit-identical to the batch
     few = gpu.scorePoses(query, poses[:5])
     w_by = {}
-    for variant in ("auto", "compact-exact", "dense"):
+    # ("batched": a small batch on the batched, screened kernel all the same)
+    for variant in ("auto", "batched", "compact-exact", "dense"):
         gpu.set_variant(variant)
         w = w_by[variant] = gpu.scorePoses(query, poses)
         assert np.array_equal(np.isnan(w), np.isnan(w_exp)), (seed, variant)
         assert np.allclose(w, w_exp, rtol=0, atol=1e-9, equal_nan=True), (seed, variant)
     # the FP32 screening of the particle kernel never changes a bit
-    assert np.array_equal(w_by["auto"], w_by["compact-exact"], equal_nan=True), seed
+    assert np.array_equal(w_by["batched"], w_by["compact-exact"], equal_nan=True), seed
+    # ... and the block-per-pose kernel of small batches ("auto" here) builds the same sums
+    assert np.array_equal(w_by["auto"], w_by["batched"], equal_nan=True), seed
     assert np.array_equal(few, w_by["auto"][:5], equal_nan=True), seed
     gpu.set_variant("auto")
 

@@ -350,10 +350,10 @@ def test_few_poses_take_the_block_per_pose_kernel_bit_identically():
     """scorePoints / scoreScan (ONE pose) and up to 8 poses run a block-per-pose kernel
     whose sums are built in the batched kernel's order: bit-identical scores."""
     gpu, ref, _, guess, pts = _pair(3)
-    parts = synth.particles(3, 256)
+    parts = synth.particles(3, 4096)
     parts[:128, :2] = guess[:2] + parts[:128, :2] / 23.0 * 0.4
     parts[:128, 2] = guess[2] + parts[:128, 2] / np.pi * 0.1
-    batch = gpu.scorePoses(pts, parts)
+    batch = gpu.scorePoses(pts, parts)     # more than kFewPosesMax: the batched kernel
     assert "compact" in gpu.last_variant()
     assert (batch < 0).sum() > 100
     for i in range(0, 256, 7):
@@ -368,8 +368,39 @@ def test_few_poses_take_the_block_per_pose_kernel_bit_identically():
     assert np.max(np.abs(batch[:32] - w_ref)) < TOL_TIGHT
     # fewer beams than chunks, one beam
     for sub in (pts[:5], pts[100:101]):
-        assert gpu.scorePoints(sub, parts[3]) == gpu.scorePoses(sub, parts[:16])[3]
+        assert gpu.scorePoints(sub, parts[3]) == gpu.scorePoses(sub, parts)[3]
         assert abs(gpu.scorePoints(sub, parts[3]) - ref.scorePoints(sub, parts[3])) < TOL_TIGHT
+
+
+@pytest.mark.parametrize("n", [1, 8, 9, 63, 500, 2048, 2049])
+def test_small_particle_sets_are_measured_in_one_launch(n):
+    """A filter of the node's size (<= 500 particles by default, reference
+    src/ndt_mapper.cpp:81-82): scoring and updateStatistics in one launch of the
+    block-per-pose kernel; scores bit-identical to the batched kernel's, statistics equal to
+    the reference's (src/particle_filter.cpp:163-218).  2049: the batched kernels again."""
+    gpu, ref, _, guess, pts = _pair(3)
+    parts = synth.particles(3, 4096)
+    parts[:2500, :2] = guess[:2] + parts[:2500, :2] / 23.0 * 0.4
+    parts[:2500, 2] = guess[2] + parts[:2500, 2] / np.pi * 0.1
+    batch = gpu.scorePoses(pts, parts)
+    assert "compact" in gpu.last_variant()
+    got = gpu.scorePoses(pts, parts[:n])
+    assert ("block-per-pose" in gpu.last_variant()) == (n <= 2048)
+    assert np.array_equal(got, batch[:n])
+    w_ref = O.pf_measure(ref, parts[:n], pts)
+    assert np.max(np.abs(got - w_ref)) < TOL_TIGHT
+    cov_prev = np.zeros((3, 3))
+    cov_prev[2, 2] = 0.125
+    w, mean, cov = pf_measure(gpu, parts[:n], pts, cov_prev=cov_prev)
+    assert ("block-per-pose" in gpu.last_variant()) == (n <= 2048)
+    w_n, mean_ref, cov_ref = O.pf_update_statistics(parts[:n], w_ref, cov_prev=cov_prev)
+    assert np.allclose(w, w_n, rtol=1e-11, atol=1e-18)
+    assert abs(w.sum() - 1.0) < 1e-12
+    assert np.allclose(mean, mean_ref, rtol=1e-10, atol=1e-12)
+    assert np.allclose(cov, cov_ref, rtol=1e-8, atol=1e-12)
+    # a second call on the same beams (the filter's next measure): same bits
+    w2, mean2, cov2 = pf_measure(gpu, parts[:n], pts, cov_prev=cov_prev)
+    assert np.array_equal(w, w2) and np.array_equal(mean, mean2) and np.array_equal(cov, cov2)
 
 
 def test_launch_timing_history(cfg1):
