@@ -83,6 +83,7 @@ struct ndt2d_context
   size_t n_th = 0, n_lin = 0;
   double pose_x = 0.0, pose_y = 0.0;
   double dlin_absmax = 0.0;
+  double patch_span = -1.0;   // see MatchArgs::patch_span
   double beam_rmax = 0.0;
   bool has_search = false;
 
@@ -282,6 +283,26 @@ int wait_host_flag(ndt2d_context * h, int slot, unsigned long long seq)
   if (*flag != seq) return fail(h, NDT2D_ERR_HIP, "result flag was not raised");
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
   return NDT2D_OK;
+}
+
+// Host-side figures of the translation lattice: its extent and the widest 8-step patch.
+void lattice_extent(ndt2d_context * h, const double * dlin, size_t n_lin)
+{
+  h->dlin_absmax = 0.0;
+  h->patch_span = 0.0;
+  for (size_t i = 0; i < n_lin; ++i)
+  {
+    if (std::fabs(dlin[i]) > h->dlin_absmax) h->dlin_absmax = std::fabs(dlin[i]);
+  }
+  for (size_t i = 0; i < n_lin && h->patch_span >= 0.0; i += 8)
+  {
+    const size_t last = i + 7 < n_lin ? i + 7 : n_lin - 1;
+    for (size_t k = i; k < last; ++k)
+    {
+      if (!(dlin[k + 1] >= dlin[k])) h->patch_span = -1.0;   // not ascending (or NaN): no claim
+    }
+    if (h->patch_span >= 0.0 && dlin[last] - dlin[i] > h->patch_span) h->patch_span = dlin[last] - dlin[i];
+  }
 }
 
 // A small batch of poses (<= kFewPosesMax) through the block-per-pose kernel: one launch,
@@ -749,11 +770,7 @@ int ndt2d_set_search(ndt2d_handle h, double pose_x, double pose_y, const double 
   h->tables_uploaded = false;   // ndt2d_match_launch uploads them if its kernel reads HBM
   h->n_th = n_th;
   h->n_lin = n_lin;
-  h->dlin_absmax = 0.0;
-  for (size_t i = 0; i < n_lin; ++i)
-  {
-    if (std::fabs(dlin[i]) > h->dlin_absmax) h->dlin_absmax = std::fabs(dlin[i]);
-  }
+  lattice_extent(h, dlin, n_lin);
   h->pose_x = pose_x;
   h->pose_y = pose_y;
   h->tables_ptr = h->tables.ptr;
@@ -805,11 +822,7 @@ int ndt2d_set_search_beams(ndt2d_handle h, const double * beams_xy, size_t n_bea
   h->tables_uploaded = true;
   h->n_th = n_th;
   h->n_lin = n_lin;
-  h->dlin_absmax = 0.0;
-  for (size_t i = 0; i < n_lin; ++i)
-  {
-    if (std::fabs(dlin[i]) > h->dlin_absmax) h->dlin_absmax = std::fabs(dlin[i]);
-  }
+  lattice_extent(h, dlin, n_lin);
   h->pose_x = pose_x;
   h->pose_y = pose_y;
   h->has_search = true;
@@ -852,6 +865,7 @@ int ndt2d_match_launch_strided(ndt2d_handle h, size_t th_first, size_t th_stride
   a.sin_th = h->tables_ptr + 2 * h->n_th;
   a.dlin = h->tables_ptr + 3 * h->n_th;
   a.dlin_absmax = h->dlin_absmax;
+  a.patch_span = h->patch_span;
   a.beam_rmax = h->beam_rmax;
   a.n_th = static_cast<uint32_t>(h->n_th);
   a.n_lin = static_cast<uint32_t>(h->n_lin);

@@ -67,6 +67,9 @@ struct MatchArgs
   const double * dlin;      // [n_lin]
   double dlin_absmax;       // max |dlin[i]| (host side copy of the search extent)
   double beam_rmax;         // max |beam| (host side copy of the scan's reach)
+  // max over the 8-step patches i = 0, 8, ... of dlin[i + 7] - dlin[i] (host side); negative
+  // if dlin is not ascending within a patch: the first lane of a patch is then not its corner
+  double patch_span;
   uint32_t n_th, n_lin;
   // theta steps th_begin + k * th_stride, k in [0, th_end - th_begin): a contiguous slab
   // (stride 1) or one rank's share of an interleaved sharding

@@ -45,7 +45,13 @@ struct LaneGeom
   int32_t win_x0, win_y0, win_w, win_h;
   double k_min, k_max_x, k_max_y;  // clamp of the per-beam fixed-point coordinate
   int32_t no_skip;  // control mode: every beam takes the exact path
+  // Patch pre-test (large search): the 64 candidates of a patch lie within box_span + 1
+  // map sub-cells per axis of the patch's first lane; -1: no pre-test (wider patches,
+  // lattices whose first lane is not the patch's corner, the control mode).
+  int32_t box_span;
 };
+
+constexpr int kMaxBoxSpan = 3;   // the pre-test reads a 4 x 4 sub-cell box
 
 // Upper bound of Cell::score's exponent e(p) = q^T h q, q = p - mean (h = -0.5 *
 // information, packed record rec) over the box [x0, x1] x [y0, y1].  For a
@@ -167,6 +173,43 @@ __device__ __forceinline__ uint32_t lds_u16_at(uint32_t address)
 {
   typedef const __attribute__((address_space(3))) uint16_t * lds_u16_ptr;
   return *reinterpret_cast<lds_u16_ptr>(address);
+}
+
+__device__ __forceinline__ uint2 lds_two_dwords_at(uint32_t address)
+{
+  typedef const __attribute__((address_space(3), aligned(4))) uint32_t * lds_u32_ptr;
+  const lds_u32_ptr p = reinterpret_cast<lds_u32_ptr>(address);
+  return make_uint2(p[0], p[1]);
+}
+
+// Patch pre-test, one BEAM per lane: can any of the patch's 64 candidates reach a
+// distribution with this beam?  s is the packed fixed-point coordinate of the beam for
+// the patch's first lane (its corner: the smallest dx and dy); the other lanes' coordinates
+// lie within span sub-cells of it on either axis, so the map bytes of that box decide: all
+// of level 0 (byte < 4: nothing reachable from the sub-cell) means every lane would skip
+// the beam whatever its threshold.  Rows beyond `span` are not read; the columns beyond
+// it are masked.  (Reads past the last map row, possible only for rows the candidates
+// cannot reach, land in the block's own LDS behind the map or return 0.)
+__device__ __forceinline__ bool patch_can_score(double s, int32_t span)
+{
+  const uint32_t lo = static_cast<uint32_t>(__double2loint(s));
+  const uint32_t hi = static_cast<uint32_t>(__double2hiint(s));
+  const uint32_t address = __builtin_amdgcn_perm(hi, lo, 0x0c0c0502u);   // (cell y << 8) | cell x
+  const uint32_t base = address & ~3u;
+  const uint32_t shift = address & 3u;
+  uint32_t any = 0;
+#pragma unroll
+  for (int r = 0; r <= kMaxBoxSpan; ++r)
+  {
+    if (r <= span)
+    {
+      const uint2 w = lds_two_dwords_at(base + static_cast<uint32_t>(r) * kMapStride);
+      any |= __builtin_amdgcn_alignbyte(w.y, w.x, shift);   // bytes x .. x + 3 of the row
+    }
+  }
+  // levels live in bits 2..7 of a byte; keep columns 0 .. span
+  const uint32_t columns = span >= 3 ? 0xfcfcfcfcu : (0xfcfcfcfcu >> (8 * (3 - span)));
+  return (any & columns) != 0u;
 }
 
 // Cell::score's exponent against packed record idx of the LDS copy, addressed with
@@ -367,6 +410,15 @@ inline bool lane_geometry(const MatchArgs & args, size_t lds_per_block, LaneGeom
   geo->k_max_x = static_cast<double>(need_w - 1) * geo->unit_scale - reach_units;
   geo->k_max_y = static_cast<double>(need_h - 1) * geo->unit_scale - reach_units;
   *map_bytes = static_cast<size_t>(kMapStride) * geo->map_h;
+  // lanes differ from the first by rint(d_i * s) - rint(d_0 * s) <= span * s + 1 fixed-point
+  // units per axis; a box that starts in the first lane's sub-cell ends floor of that later
+  geo->box_span = -1;
+  if (args.patch_span >= 0.0)
+  {
+    const double span_units = std::ceil(args.patch_span * args.grid.inv_cell_size * geo->unit_scale) + 2.0;
+    const double sub_cells = std::floor((65535.0 + span_units) / 65536.0);
+    if (sub_cells <= static_cast<double>(kMaxBoxSpan)) geo->box_span = static_cast<int32_t>(sub_cells);
+  }
   return true;
 }
 

@@ -114,6 +114,25 @@ __global__ void __launch_bounds__(256) outer_table_kernel(const MatchArgs a, dou
   }
 }
 
+// Work item -> (theta step of the launch, patch).  Theta steps are visited from the middle
+// of the range outwards: the steps around the scan's own heading are the expensive ones
+// when the guess is any good.
+__device__ __forceinline__ void item_place(uint32_t item, uint32_t patches, uint32_t patches_1d,
+                                           uint32_t th_mid, uint32_t & t, uint32_t & pxi, uint32_t & pyi)
+{
+  const uint32_t rank = item / patches;
+  const uint32_t p = item - rank * patches;
+  t = (rank & 1u) ? th_mid + (rank + 1u) / 2u : th_mid - rank / 2u;
+  pxi = p / patches_1d;
+  pyi = p - pxi * patches_1d;
+}
+
+// The lane's packed fixed-point offset (see the file header).
+__device__ __forceinline__ double packed_offset(double dx, double dy, double inv_scaled)
+{
+  return rint(dy * inv_scaled) * kTwo24 + rint(dx * inv_scaled);
+}
+
 // COMPACT (with LDS_RECORDS): instead of the whole grid's records the block keeps the
 // compacted records of the cells that can score and the cell -> record table
 // (GridDesc::compact_records / cell_rank): at cfg-2 15 KB instead of 81 KB, so that two
@@ -192,38 +211,51 @@ __device__ __forceinline__ void match_lane_body(
   for (int k = 0; k < 10; ++k) acc[k] = 0.0;
   for (uint32_t item = worker; item < n_items;)
   {
-
-    // theta steps are visited from the middle of the range outwards: the steps around
-    // the scan's own heading are the expensive ones when the guess is any good, and
-    // the last items a launch hands out should be cheap ones
-    const uint32_t rank = item / patches;
-    const uint32_t p = item - rank * patches;
-    const uint32_t t = (rank & 1u) ? th_mid + (rank + 1u) / 2u : th_mid - rank / 2u;
-    const uint32_t pxi = p / patches_1d;
-    const uint32_t pyi = p - pxi * patches_1d;
+    uint32_t t, pxi, pyi;
+    item_place(item, patches, patches_1d, th_mid, t, pxi, pyi);
     const uint32_t ix = pxi * kPatch + lx;
     const uint32_t iy = pyi * kPatch + ly;
     const bool valid = (ix < n_lin) & (iy < n_lin);
     // lanes beyond the lattice edge shadow the edge candidate and are dropped below
     const double dx = a.dlin[min(ix, n_lin - 1)];
     const double dy = a.dlin[min(iy, n_lin - 1)];
-    const double dxy = rint(dy * inv_scaled) * kTwo24 + rint(dx * inv_scaled);
+    const double dxy = packed_offset(dx, dy, inv_scaled);
     const double4 * __restrict__ row = outer + static_cast<size_t>(t) * a.n_beams;
 
     double sum = 0.0;
     SkipState skip = skip_state(0.0, geo.no_skip);
-    uint32_t b = 0;
-    for (; b + kUnroll <= a.n_beams; b += kUnroll)
+    // Beams go by in chunks of 64.  First the wave asks, one beam per lane, whether the
+    // patch as a whole can reach a distribution with that beam (patch_can_score: four LDS
+    // reads for 64 beams); four beams out of five cannot, and the groups of eight
+    // consecutive beams none of which can are passed over without a vector instruction.
+    // The others take the per-lane look-up and, where it says so, the exact path -- in
+    // beam order, so a lane's sum is built exactly as before.
+    const double dxy_corner = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(dxy)),
+                                               __builtin_amdgcn_readfirstlane(__double2loint(dxy)));
+    for (uint32_t b0 = 0; b0 < a.n_beams; b0 += kWave)
     {
-      double4 o[kUnroll];
+      uint64_t can_score = ~0ull;
+      if (geo.box_span >= 0)
+      {
+        const double k = row[min(b0 + lane, a.n_beams - 1u)].z;
+        can_score = __builtin_amdgcn_ballot_w64(patch_can_score(k + dxy_corner, geo.box_span));
+      }
+      const uint32_t chunk_end = min(b0 + static_cast<uint32_t>(kWave), a.n_beams);
+      uint32_t b = b0;
+      for (; b + kUnroll <= chunk_end; b += kUnroll, can_score >>= kUnroll)
+      {
+        if ((can_score & ((1ull << kUnroll) - 1ull)) == 0ull) continue;
+        double4 o[kUnroll];
 #pragma unroll
-      for (int u = 0; u < kUnroll; ++u) o[u] = row[b + u];
-      lane_beams<kUnroll, POW2, LDS_RECORDS, true, COMPACT>(g, c, o, dx, dy, dxy, sum, skip, geo.no_skip);
-    }
-    for (; b < a.n_beams; ++b)
-    {
-      const double4 one[1] = {row[b]};
-      lane_beams<1, POW2, LDS_RECORDS, true, COMPACT>(g, c, one, dx, dy, dxy, sum, skip, geo.no_skip);
+        for (int u = 0; u < kUnroll; ++u) o[u] = row[b + u];
+        lane_beams<kUnroll, POW2, LDS_RECORDS, true, COMPACT>(g, c, o, dx, dy, dxy, sum, skip, geo.no_skip);
+      }
+      for (; b < chunk_end; ++b, can_score >>= 1)
+      {
+        if ((can_score & 1ull) == 0ull) continue;
+        const double4 one[1] = {row[b]};
+        lane_beams<1, POW2, LDS_RECORDS, true, COMPACT>(g, c, one, dx, dy, dxy, sum, skip, geo.no_skip);
+      }
     }
 
     if (valid)
@@ -361,6 +393,14 @@ hipError_t launch_match_lane(const MatchArgs & args_in, double * outer, double *
   size_t map_bytes = 0;
   if (!lane_geometry(args, lds_per_block, &geo, &map_bytes)) return hipErrorInvalidValue;
   geo.no_skip = no_skip ? 1 : 0;
+  {
+    // the control mode evaluates every term; NDT2D_LANE_PRETEST=0 is the A/B switch
+    static const bool pretest = [] {
+      const char * v = std::getenv("NDT2D_LANE_PRETEST");
+      return v == nullptr || v[0] != '0';
+    }();
+    if (no_skip || !pretest) geo.box_span = -1;
+  }
   // Items of few beams are too short to repay a reduction, a record and an atomic
   // each (100 beams: static assignment is ~15 % faster; 720 beams: dynamic is 17 %
   // faster, experiments/small_search_sweep.py).
