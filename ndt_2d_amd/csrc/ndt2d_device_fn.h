@@ -107,8 +107,9 @@ __device__ __forceinline__ double exp_of_exponent(double x)
   p = fma3(r, p, 0x1.55555555502a1p-5);
   p = fma3(r, p, 0x1.5555555555511p-3);
   p = fma3(r, p, 0x1.000000000000bp-1);
-  p = fma3(r, p, 1.0);
-  p = fma3(r, p, 1.0);
+  // (the last two constants are the inline operand 1.0: no register holds them)
+  asm("v_fma_f64 %0, %1, %2, 1.0" : "=v"(p) : "v"(r), "v"(p));
+  asm("v_fma_f64 %0, %1, %2, 1.0" : "=v"(p) : "v"(r), "v"(p));
   return ldexp(p, static_cast<int>(n));
 }
 

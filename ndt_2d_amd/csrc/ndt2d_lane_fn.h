@@ -27,8 +27,12 @@ constexpr uint32_t kNearUnits = 4;   // guard band around cell boundaries, in 2^
 constexpr double kBoxMargin = 1.0 / 1024.0;
 constexpr double kTwo24 = 16777216.0;
 constexpr double kTwo52 = 4503599627370496.0;
-constexpr double kNearBias = kNearUnits * (kTwo24 + 1.0);  // +kNearUnits on both packed fractions
-static_assert(kNearUnits == 4, "the near test masks bits 3..15 of the biased fractions");
+// +kNearUnits on both packed fractions.  It is part of every beam's K: a lane within
+// kNearUnits below a boundary then looks its map byte up in the sub-cell across it, whose
+// box (widened by kBoxMargin = 64 units) holds the lane's point just as well, and such a
+// lane is "near" -- it takes the reference's own index arithmetic, not the look-up's cell.
+constexpr double kNearBias = kNearUnits * (kTwo24 + 1.0);
+static_assert(kNearUnits == 4, "near_boundary() tests the biased fraction against 2 * kNearUnits");
 
 struct LaneGeom
 {
@@ -175,6 +179,15 @@ __device__ __forceinline__ uint32_t lds_u16_at(uint32_t address)
   return *reinterpret_cast<lds_u16_ptr>(address);
 }
 
+// Lanes whose 16-bit fraction (the low half of v), biased by kNearUnits, is below
+// 2 * kNearUnits: the lane mask of one 16-bit compare.
+__device__ __forceinline__ uint64_t near_boundary(uint32_t v)
+{
+  uint64_t lanes;
+  asm("v_cmp_gt_u16_e64 %0, 8, %1" : "=s"(lanes) : "v"(v));
+  return lanes;
+}
+
 __device__ __forceinline__ uint2 lds_two_dwords_at(uint32_t address)
 {
   typedef const __attribute__((address_space(3), aligned(4))) uint32_t * lds_u32_ptr;
@@ -297,17 +310,14 @@ __device__ __forceinline__ void lane_beams(const GridDesc & g, const LaneCtx & c
       const uint64_t live_mask = __builtin_amdgcn_ballot_w64(m[u] >= skip_level);
       if (live_mask != 0ull)
       {
-        // within kNearUnits of a unit boundary on either axis: one more exact f64 add
-        // biases both 16-bit fractions at once, then (frac + 4) mod 2^16 < 8 is
-        // "bits 3..15 clear"; the y fraction straddles the two words (bytes 3, 4)
-        const double sn = __hiloint2double(static_cast<int>(hi[u]), static_cast<int>(lo[u])) + kNearBias;
-        const uint32_t nlo = static_cast<uint32_t>(__double2loint(sn));
-        const uint32_t nhi = static_cast<uint32_t>(__double2hiint(sn));
-        const uint32_t tx = nlo & 0xfff8u;
-        const uint32_t ty = __builtin_amdgcn_perm(nhi, nlo, 0x0c0c0403u) & 0xfff8u;
+        // within kNearUnits of a unit boundary on either axis: the beams' coordinates
+        // come with both 16-bit fractions biased by kNearUnits (see kNearBias), so that is
+        // (frac + 4) mod 2^16 < 8, a 16-bit compare per axis; the y fraction straddles
+        // the two words (bytes 3, 4)
+        const uint32_t fy = __builtin_amdgcn_perm(hi[u], lo[u], 0x0c0c0403u);
         const bool occ = (m[u] & 1u) != 0;
         const uint64_t near_mask =
-          (__builtin_amdgcn_ballot_w64(min(tx, ty) == 0u) | (no_skip != 0 ? ~0ull : 0ull)) & live_mask;
+          (near_boundary(lo[u]) | near_boundary(fy) | (no_skip != 0 ? ~0ull : 0ull)) & live_mask;
         const uint64_t occ_mask = __builtin_amdgcn_ballot_w64(occ) & live_mask;
         if ((occ_mask | near_mask) != 0ull)
         {

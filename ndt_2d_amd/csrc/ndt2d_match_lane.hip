@@ -58,7 +58,7 @@ constexpr int kLaneThreadsCompact = 768; // compacted records: two blocks per CU
 
 // points_outer for the slab (reference :106-115) plus the packed fixed-point
 // map coordinate of each rotated beam:
-//   outer[t][b] = {ox, oy, K, 0},   K = 2^52 + ky * 2^24 + kx,
+//   outer[t][b] = {ox, oy, K, 0},   K = 2^52 + ky * 2^24 + kx (+ kNearBias),
 //   k = rint(((o - origin) * inv_cell - window_origin + pad) * 2^16) clamped to [k_min, k_max]
 // so that k + d stays inside the map for every lane offset d.  A clamped beam
 // is further outside the grid than any offset can bring back; it stays in the
@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(256) outer_table_kernel(const MatchArgs a, dou
     // !(k >= min) also catches NaN
     kx = !(kx >= geo.k_min) ? geo.k_min : (kx > geo.k_max_x ? geo.k_max_x : kx);
     ky = !(ky >= geo.k_min) ? geo.k_min : (ky > geo.k_max_y ? geo.k_max_y : ky);
-    o.z = kTwo52 + (rint(ky) * kTwo24 + rint(kx));
+    o.z = kTwo52 + (rint(ky) * kTwo24 + rint(kx)) + kNearBias;
     o.w = 0.0;
     outer[i] = o;
   }

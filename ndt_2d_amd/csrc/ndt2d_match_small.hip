@@ -183,7 +183,7 @@ match_small_kernel(const MatchArgs a,
       ky = !(ky >= geo.k_min) ? geo.k_min : (ky > geo.k_max_y ? geo.k_max_y : ky);
       rows[kRowDoubles * b + 0] = ox;
       rows[kRowDoubles * b + 1] = oy;
-      rows[kRowDoubles * b + 2] = kTwo52 + (rint(ky) * kTwo24 + rint(kx));
+      rows[kRowDoubles * b + 2] = kTwo52 + (rint(ky) * kTwo24 + rint(kx)) + kNearBias;
     }
   }
   __syncthreads();
