@@ -990,6 +990,63 @@ def test_reference_known_answer_through_the_gpu():
     assert got == pytest.approx(0.76592833836492369, rel=1e-12)   # SURVEY.md section 4 digits
 
 
+def test_concurrent_instances_keep_their_results_apart():
+    """Three matcher instances busy at once on three threads -- the node's own small search
+    and a 500-particle measure (results through host-coherent memory behind sequence
+    flags, reductions finished by the last block of a launch) next to a large-lattice
+    search and a batched particle set: every call returns the bits its instance returns on
+    its own."""
+    jobs = {}
+
+    def setup(name, cfg, **override):
+        m = ScanMatcherNDT(0)
+        m.initialize(name, **synth.matcher_params(cfg, **override))
+        m.addScans(synth.map_scans(cfg))
+        guess, pts, _ = synth.query_scan(cfg)
+        return m, guess, pts
+
+    m_small, g_small, p_small = setup("local", 1, laser_max_beams=100, search_linear_size=0.05,
+                                      search_linear_resolution=0.005, search_angular_size=0.1,
+                                      search_angular_resolution=0.0025)
+    m_large, g_large, p_large = setup("global", 2)
+    m_pf, g_pf, p_pf = setup("pf", 3)
+    parts = synth.particles(3, 3000)
+    parts[:1500, :2] = g_pf[:2] + parts[:1500, :2] / 23.0 * 0.4
+
+    def small():
+        r = m_small.matchScan(g_small, p_small)
+        return r["pose"].tobytes() + np.float64(r["score"]).tobytes() + r["covariance"].tobytes()
+
+    def large():
+        r = m_large.matchScan(g_large, p_large)
+        return r["pose"].tobytes() + np.float64(r["score"]).tobytes() + r["covariance"].tobytes()
+
+    def filt():
+        w, mean, cov = pf_measure(m_pf, parts[:500], p_pf)
+        big = m_pf.scorePoses(p_pf, parts)
+        return w.tobytes() + mean.tobytes() + cov.tobytes() + big.tobytes()
+
+    jobs = {"small": (small, 300), "large": (large, 40), "filter": (filt, 150)}
+    alone = {k: f() for k, (f, _) in jobs.items()}
+    assert "small-lattice" in m_small.last_variant() and "compact-records" in m_large.last_variant()
+    errors = []
+
+    def work(name):
+        f, n = jobs[name]
+        try:
+            for i in range(n):
+                if f() != alone[name]:
+                    errors.append((name, i))
+                    return
+        except Exception as e:  # pragma: no cover
+            errors.append((name, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in jobs]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errors, errors
+
+
 def test_empty_scan_gives_nan(cfg1):
     gpu, ref, _, guess, _ = cfg1
     empty = np.zeros((0, 2))
