@@ -23,6 +23,13 @@
 //   48 mantissa bits of the sum are {fy, fx}, so the map address
 //   (cell_y << 8) | cell_x is two bytes of the sum picked by one v_perm_b32.
 //
+// Before any per-lane work the wave asks, ONE BEAM PER LANE, whether the patch as a
+// whole can reach a distribution with that beam: the 64 candidates' coordinates lie
+// within a few sub-cells of the patch's first lane, and if the 4 x 4 box of map bytes
+// there holds level 0 only, every lane would skip the beam (patch_can_score, four LDS
+// reads for 64 beams).  Groups of eight consecutive beams none of which passes are
+// stepped over by a scalar test -- four beams out of five at cfg-2.
+//
 // The map is padded by more cells than any offset reaches and beams are
 // pre-clamped, so no per-lane range check exists.  The map is kept at up to
 // 4 x 4 sub-cells per cell.  Map byte: bit 0 = the cell holds a distribution;
@@ -32,7 +39,8 @@
 // box (63: no claim).  Each lane carries the level below which a term cannot
 // change its sum (RN(s + exp(e)) == s); if every lane's byte is below its level
 // the beam is skipped.  Otherwise lanes within 4 fixed-point units of a boundary
-// are "near"; if any live lane is occupied or near, the wave runs the exact
+// are "near" (K carries a bias of 4 units on both fractions, so the test is a 16-bit
+// compare per axis); if any live lane is occupied or near, the wave runs the exact
 // reference arithmetic (points_inner :121-125, NDT::getIndex
 // src/ndt_model.cpp:203-218 for near lanes, Cell::score :105-116).  Every
 // skipped term is one that leaves the sum unchanged, so the sums are
