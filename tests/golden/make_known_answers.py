@@ -21,7 +21,10 @@ a scenario small enough to follow by hand:
 Expected (JSON, 17 significant digits): the packed cells, all 27 raw scores
 (-sum of likelihoods, :127), the winner's flat index / pose, matchScan's return value
 best/N (:148), the accumulators k, u, s and covariance = k/s + u u^T/s^2 (:137-146),
-and scorePoints at three poses (:156-178).  Differences between this and an IEEE
+scorePoints at three poses (:156-178), and ParticleFilter::measure with its
+updateStatistics (src/particle_filter.cpp:78-89,163-218) for eight particles whose headings
+straddle +-pi: raw and normalised weights, weighted mean, circular mean, x/y covariance and
+the accumulated theta variance.  Differences between this and an IEEE
 double evaluation in the reference's order are rounding only: the tests compare at
 1e-12.  Every point is checked to lie > 1e-6 from a cell boundary, so the cell a
 point falls in does not depend on rounding.
@@ -31,7 +34,7 @@ point falls in does not depend on rounding.
 import json
 import os
 
-from mpmath import mp, mpf, cos, sin, exp, floor
+from mpmath import mp, mpf, atan2, cos, sin, exp, floor, pi
 
 mp.dps = 60
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -59,6 +62,12 @@ BEAMS = [("0.45", "0.35"), ("1.4", "0.05"), ("0.55", "0.6"), ("-0.5", "0.7"), ("
          ("3.6", "0.2")]
 OFFSETS = [mpf("-0.375"), mpf("-0.125"), mpf("0.125")]   # `for (v = -0.375; v < 0.375; v += 0.25)`
 SCORE_POSES = [("0", "0", "0"), ("0.1", "-0.05", "0.3"), ("0.4", "0.2", "-1.1")]
+# ParticleFilter::measure + updateStatistics (src/particle_filter.cpp:78-89,163-218): a
+# particle set whose headings straddle +-pi (circular mean, shortest angular distance)
+PARTICLES = [("0.1", "-0.05", "0.3"), ("0.2", "0.1", "0.1"), ("-0.1", "0.05", "0.5"),
+             ("0.35", "-0.2", "-0.2"), ("1.0", "0.9", "3.05"), ("1.1", "0.8", "-3.1"),
+             ("0.6", "0.3", "1.2"), ("0.15", "-0.1", "0.25")]
+COV_THETA_BEFORE = mpf("0.125")   # cov_(2,2) is accumulated into, never zeroed (:216)
 
 
 def transform(pose, p):
@@ -168,6 +177,39 @@ def main():
         total = -sum(likelihood(transform(ps, b), origin, size_x, size_y, packed) for b in beams)
         score_points.append({"pose": [float(v) for v in pose], "score": f17(total / n)})
 
+    # measure: weights_[i] = scorePoints(points, particle_i) (:81-87), then updateStatistics
+    parts = [tuple(mpf(v) for v in q) for q in PARTICLES]
+    raw = [-sum(likelihood(transform(q, b), origin, size_x, size_y, packed) for b in beams) / n
+           for q in parts]
+    assert sum(1 for w in raw if w != 0) >= 5
+    sum_w = sum(raw)
+    w = [v / sum_w for v in raw]                                   # (:166-174)
+    mean_x = sum(wi * q[0] for wi, q in zip(w, parts))             # (:182-186)
+    mean_y = sum(wi * q[1] for wi, q in zip(w, parts))
+    mean_th = atan2(sum(wi * sin(q[2]) for wi, q in zip(w, parts)),
+                    sum(wi * cos(q[2]) for wi, q in zip(w, parts)))  # (:187-188,200)
+    cov_xx = sum(wi * q[0] * q[0] for wi, q in zip(w, parts)) - mean_x * mean_x   # (:190-210)
+    cov_xy = sum(wi * q[0] * q[1] for wi, q in zip(w, parts)) - mean_x * mean_y
+    cov_yy = sum(wi * q[1] * q[1] for wi, q in zip(w, parts)) - mean_y * mean_y
+
+    def shortest(frm, to):
+        """angles::shortest_angular_distance: to - from wrapped into [-pi, pi]."""
+        d = to - frm
+        d = d - 2 * pi * floor((d + pi) / (2 * pi))
+        assert abs(abs(d) - pi) > mpf("1e-6")
+        return d
+
+    theta_inc = sum(wi * shortest(q[2], mean_th) ** 2 for wi, q in zip(w, parts))   # (:213-217)
+    particles = {
+        "poses": [[float(v) for v in q] for q in PARTICLES],
+        "raw_weights": [f17(v) for v in raw], "sum_weight": f17(sum_w),
+        "weights": [f17(v) for v in w],
+        "mean": [f17(mean_x), f17(mean_y), f17(mean_th)],
+        "cov_before": [[0.0, 0.0, 0.0], [0.0, 0.0, 0.0], [0.0, 0.0, float(COV_THETA_BEFORE)]],
+        "cov": [[f17(cov_xx), f17(cov_xy), 0.0], [f17(cov_xy), f17(cov_yy), 0.0],
+                [0.0, 0.0, f17(COV_THETA_BEFORE + theta_inc)]],
+    }
+
     out = {
         "derivation": "mpmath, 60 digits, tests/golden/make_known_answers.py; no oracle code",
         "params": {"ndt_resolution": 1.0, "range_max": 2.0, "laser_max_beams": 100,
@@ -188,11 +230,13 @@ def main():
                   "k": [[f17(v) for v in row] for row in k], "u": [f17(v) for v in u], "s": f17(s),
                   "covariance": [[f17(v) for v in row] for row in cov]},
         "score_points": score_points,
+        "particles": particles,
     }
     with open(os.path.join(HERE, "known_answers.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
     print("best", best_idx, [float(v) for v in best_pose], f17(best / n))
     print("scores", [round(float(v), 6) for v in scores])
+    print("particle weights", [round(float(v), 6) for v in w], "mean", [round(float(v), 6) for v in (mean_x, mean_y, mean_th)])
 
 
 if __name__ == "__main__":

@@ -83,6 +83,28 @@ def test_oracle_reproduces_the_known_answers(ka):
     assert abs(ref.scoreScan(ka["score_points"][1]["pose"], beams) - ka["score_points"][1]["score"]) < TOL
 
 
+def _check_particles(ka, raw, w, mean, cov):
+    pk = ka["particles"]
+    if raw is not None:
+        assert np.max(np.abs(np.asarray(raw) - pk["raw_weights"])) < TOL
+    assert np.allclose(w, pk["weights"], rtol=1e-11, atol=1e-15)
+    assert np.allclose(mean, pk["mean"], rtol=1e-11, atol=1e-15)
+    cov, want = np.asarray(cov), np.array(pk["cov"])
+    for r, c in ((0, 0), (0, 1), (1, 0), (1, 1), (2, 2)):
+        assert cov[r, c] == pytest.approx(want[r, c], rel=1e-10)
+
+
+def test_oracle_reproduces_the_known_particle_statistics(ka):
+    """ParticleFilter::measure + updateStatistics (src/particle_filter.cpp:78-89,163-218)."""
+    ref = O.ScanMatcherNDT()
+    ref.initialize(**ka["params"])
+    ref.addScans(_scans(ka))
+    pk = ka["particles"]
+    raw = O.pf_measure(ref, np.array(pk["poses"]), np.array(ka["beams"]))
+    w, mean, cov = O.pf_update_statistics(pk["poses"], raw, cov_prev=pk["cov_before"])
+    _check_particles(ka, raw, w, mean, cov)
+
+
 def test_host_ndt_build_reproduces_the_known_cells(ka):
     """addScans' host build of the product library (no GPU needed)."""
     from ndt_2d_amd.scan_matcher import host_build_grid
@@ -119,4 +141,24 @@ def test_gpu_reproduces_the_known_answers(ka, variant):
     assert abs(gpu.scoreScan(ka["score_points"][1]["pose"], beams) - ka["score_points"][1]["score"]) < TOL
     poses = np.array([sp["pose"] for sp in ka["score_points"]])
     assert np.max(np.abs(gpu.scorePoses(beams, poses) - [sp["score"] for sp in ka["score_points"]])) < TOL
+    gpu.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["auto", "batched"])
+def test_gpu_reproduces_the_known_particle_statistics(ka, variant):
+    """measure + updateStatistics on the device: in one launch for a set of this size
+    ("auto": block per particle, statistics by the last block) and through the batched
+    kernels ("batched")."""
+    from ndt_2d_amd import ScanMatcherNDT, pf_measure
+    gpu = ScanMatcherNDT(0)
+    gpu.initialize("known_particles", **ka["params"])
+    gpu.addScans(_scans(ka))
+    pk = ka["particles"]
+    beams = np.array(ka["beams"])
+    gpu.set_variant(variant)
+    raw = gpu.scorePoses(beams, np.array(pk["poses"]))
+    w, mean, cov = pf_measure(gpu, np.array(pk["poses"]), beams, cov_prev=pk["cov_before"])
+    assert ("block-per-pose" in gpu.last_variant()) == (variant == "auto")
+    _check_particles(ka, raw, w, mean, cov)
     gpu.close()
