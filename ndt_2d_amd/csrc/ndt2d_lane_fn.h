@@ -150,9 +150,19 @@ __device__ __forceinline__ uint8_t sub_cell_byte(const GridDesc & g, int32_t cx,
   return map_byte(self, bound);
 }
 
+// LDS bytes of the cell -> compact record table: kRankLead bytes whose last two hold the
+// sentinel's rank -- entry -1, what a lane outside every occupied cell selects with one
+// v_cndmask_b32 and the inline constant -1 -- then a u16 per grid cell and entry ncell
+// (again the sentinel), rounded to 16.
+constexpr uint32_t kRankLead = 16;
+__host__ __device__ inline uint32_t compact_rank_bytes(uint32_t ncell)
+{
+  return kRankLead + (((ncell + 1u) * 2u + 15u) & ~15u);
+}
+
 struct LaneCtx
 {
-  uint32_t rank_address;       // LDS byte address of the cell -> compact record table (COMPACT)
+  uint32_t rank_address;       // LDS byte address of entry 0 of the cell -> compact record table (COMPACT)
   uint32_t lds_cells_address;  // LDS byte address of the packed records (behind the map)
   uint32_t sub_log2;           // map sub-cell -> map cell: shift right
   // map cell (col, row) -> grid cell index: row * size_x + col - idx_bias,
@@ -318,7 +328,8 @@ __device__ __forceinline__ void lane_beams(const GridDesc & g, const LaneCtx & c
         const bool occ = (m[u] & 1u) != 0;
         const uint64_t near_mask =
           (near_boundary(lo[u]) | near_boundary(fy) | (no_skip != 0 ? ~0ull : 0ull)) & live_mask;
-        const uint64_t occ_mask = __builtin_amdgcn_ballot_w64(occ) & live_mask;
+        const uint64_t occ_lanes = __builtin_amdgcn_ballot_w64(occ);
+        const uint64_t occ_mask = occ_lanes & live_mask;
         if ((occ_mask | near_mask) != 0ull)
         {
           // points_inner (:121-125) and Cell::score, exact
@@ -335,7 +346,17 @@ __device__ __forceinline__ void lane_beams(const GridDesc & g, const LaneCtx & c
             // row * size_x + column with the window's offset folded into idx_bias
             const uint32_t col = ((lo[u] >> 16) & 0xffu) >> c.sub_log2;
             const uint32_t row = ((hi[u] >> 8) & 0xffu) >> c.sub_log2;
-            idx = occ ? __umul24(row, c.size_x) + (col - c.idx_bias) : g.ncell;
+            const uint32_t cell = __umul24(row, c.size_x) + (col - c.idx_bias);
+            if (COMPACT)
+            {
+              // entry -1 of the rank table is the sentinel's: one select on the lane mask
+              // the occupancy test left in scalar registers
+              asm("v_cndmask_b32 %0, -1, %1, %2" : "=v"(idx) : "v"(cell), "s"(occ_lanes));
+            }
+            else
+            {
+              idx = occ ? cell : g.ncell;
+            }
           }
           if (COMPACT) idx = lds_u16_at(c.rank_address + 2u * idx);
           const double e = LDS_RECORDS ? lds_record_exponent(c.lds_cells_address, idx, px, py)

@@ -160,14 +160,18 @@ __device__ __forceinline__ void match_lane_body(
   // lds_byte_at() addresses the map absolutely: it must start at LDS offset 0
   if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();
   const uint32_t map_bytes = static_cast<uint32_t>(geo.map_h) * kMapStride;
-  const uint32_t rank_bytes = COMPACT ? ((g.ncell + 1) * 2 + 15) & ~15u : 0u;
+  const uint32_t rank_bytes = COMPACT ? compact_rank_bytes(g.ncell) : 0u;
   double * lds_cells = lds + (map_bytes + rank_bytes) / sizeof(double);
 
   if (COMPACT)
   {
     const uint4 * src_rank = reinterpret_cast<const uint4 *>(g.cell_rank);
-    uint4 * dst_rank = reinterpret_cast<uint4 *>(lds_map + map_bytes);
-    for (uint32_t i = threadIdx.x; i < rank_bytes / 16; i += THREADS) dst_rank[i] = src_rank[i];
+    uint4 * dst_rank = reinterpret_cast<uint4 *>(lds_map + map_bytes + kRankLead);
+    for (uint32_t i = threadIdx.x; i < (rank_bytes - kRankLead) / 16; i += THREADS) dst_rank[i] = src_rank[i];
+    if (threadIdx.x == 0)
+    {
+      reinterpret_cast<uint16_t *>(lds_map + map_bytes + kRankLead)[-1] = static_cast<uint16_t>(g.n_occ);
+    }
     const uint32_t n2 = (g.n_occ + 1) * kCellDoubles / 2;
     const double2 * src = reinterpret_cast<const double2 *>(g.compact_records);
     double2 * dst = reinterpret_cast<double2 *>(lds_cells);
@@ -187,7 +191,7 @@ __device__ __forceinline__ void match_lane_body(
   __syncthreads();
 
   LaneCtx c;
-  c.rank_address = map_bytes;
+  c.rank_address = map_bytes + (COMPACT ? kRankLead : 0u);
   c.lds_cells_address = map_bytes + rank_bytes;
   c.sub_log2 = static_cast<uint32_t>(geo.sub_log2);
   c.idx_bias = static_cast<uint32_t>(geo.pad - geo.win_y0) * g.size_x +
@@ -445,7 +449,7 @@ hipError_t launch_match_lane(const MatchArgs & args_in, double * outer, double *
   // Compacted records: the image shrinks enough for two blocks per CU (A/B knob:
   // NDT2D_LANE_COMPACT=0 keeps the whole-grid image and one 1024-thread block).
   const size_t compact_bytes =
-    ((static_cast<size_t>(args.grid.ncell) + 1) * 2 + 15) / 16 * 16 +
+    compact_rank_bytes(args.grid.ncell) +
     (static_cast<size_t>(args.grid.n_occ) + 1) * kCellDoubles * sizeof(double);
   const char * knob = std::getenv("NDT2D_LANE_COMPACT");
   const bool compact = !small && dynamic_items && pow2_grid(args) && lds_records && args.grid.n_occ > 0 &&

@@ -128,7 +128,7 @@ match_small_kernel(const MatchArgs a,
   if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();
   uint8_t * lds_map = reinterpret_cast<uint8_t *>(lds);
   const uint32_t map_bytes = static_cast<uint32_t>(geo.map_h) * kMapStride;
-  const uint32_t rank_bytes = COMPACT ? ((g.ncell + 1) * 2 + 15) & ~15u : 0u;
+  const uint32_t rank_bytes = COMPACT ? compact_rank_bytes(g.ncell) : 0u;
   const uint32_t compact_bytes = COMPACT ? (g.n_occ + 1) * kCellDoubles * static_cast<uint32_t>(sizeof(double)) : 0u;
   double * rows = lds + (map_bytes + rank_bytes + compact_bytes) / sizeof(double);
   double * partials = rows + max(static_cast<size_t>(a.n_beams) * kRowDoubles,
@@ -161,8 +161,12 @@ match_small_kernel(const MatchArgs a,
   {
     // ranks and records are contiguous in HBM ([records][ranks]) and 16-byte aligned
     const uint4 * src_rank = reinterpret_cast<const uint4 *>(g.cell_rank);
-    uint4 * dst_rank = reinterpret_cast<uint4 *>(lds_map + map_bytes);
-    for (uint32_t i = threadIdx.x; i < rank_bytes / 16; i += n_threads) dst_rank[i] = src_rank[i];
+    uint4 * dst_rank = reinterpret_cast<uint4 *>(lds_map + map_bytes + kRankLead);
+    for (uint32_t i = threadIdx.x; i < (rank_bytes - kRankLead) / 16; i += n_threads) dst_rank[i] = src_rank[i];
+    if (threadIdx.x == 0)
+    {
+      reinterpret_cast<uint16_t *>(lds_map + map_bytes + kRankLead)[-1] = static_cast<uint16_t>(g.n_occ);
+    }
     const double2 * src_rec = reinterpret_cast<const double2 *>(g.compact_records);
     double2 * dst_rec = reinterpret_cast<double2 *>(lds_map + map_bytes + rank_bytes);
     for (uint32_t i = threadIdx.x; i < compact_bytes / 16; i += n_threads) dst_rec[i] = src_rec[i];
@@ -192,7 +196,7 @@ match_small_kernel(const MatchArgs a,
 #endif
 
   LaneCtx c;
-  c.rank_address = map_bytes;
+  c.rank_address = map_bytes + (COMPACT ? kRankLead : 0u);
   c.lds_cells_address = map_bytes + rank_bytes;   // (not COMPACT: records are gathered from HBM)
   c.sub_log2 = 0;
   c.idx_bias = static_cast<uint32_t>(geo.pad - geo.win_y0) * g.size_x +
@@ -434,7 +438,7 @@ match_small_kernel(const MatchArgs a,
 
 size_t small_compact_bytes(const MatchArgs & args)
 {
-  return ((static_cast<size_t>(args.grid.ncell) + 1) * 2 + 15) / 16 * 16 +
+  return compact_rank_bytes(args.grid.ncell) +
          (static_cast<size_t>(args.grid.n_occ) + 1) * kCellDoubles * sizeof(double);
 }
 
