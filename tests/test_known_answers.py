@@ -162,3 +162,66 @@ def test_gpu_reproduces_the_known_particle_statistics(ka, variant):
     assert ("block-per-pose" in gpu.last_variant()) == (variant == "auto")
     _check_particles(ka, raw, w, mean, cov)
     gpu.close()
+
+
+# ---- rows next to the hot path: tests/golden/make_known_answers_next.py
+
+@pytest.fixture(scope="module")
+def ka_next():
+    with open(os.path.join(os.path.dirname(__file__), "golden", "known_answers_next.json")) as f:
+        return json.load(f)
+
+
+def _conversion_args(ka_next):
+    sc = ka_next["scan_conversion"]
+    return sc, dict(ranges=np.array(sc["ranges"], dtype=np.float32), angle_min=sc["angle_min"],
+                    angle_increment=sc["angle_increment"], range_max=sc["range_max"],
+                    laser=tuple(sc["laser"]), motion=tuple(sc["motion"]))
+
+
+def test_oracle_reproduces_the_known_scan_conversion(ka_next):
+    """LaserScan -> Scan with de-skew, both beam orders (src/ndt_mapper.cpp:385-453)."""
+    sc, args = _conversion_args(ka_next)
+    for inverted, key in ((False, "points"), (True, "points_inverted")):
+        got = O.convert_scan(inverted=inverted, **args)
+        assert got.shape == (len(sc[key]), 2)
+        assert np.max(np.abs(got - np.array(sc[key]))) < TOL
+
+
+def test_oracle_reproduces_the_known_motion_samples(ka_next):
+    """MotionModel::sample with given normals, incl. normal_distribution<float>'s float
+    arithmetic, reverse motion and the trans <= 0.01 branch (src/motion_model.cpp:45-83)."""
+    mm = ka_next["motion_model"]
+    z = np.array(mm["z"], dtype=np.float32)
+    for case in mm["cases"]:
+        poses, params = O.motion_sample(*case["motion"], mm["alphas"], mm["poses"], z)
+        assert np.max(np.abs(params - np.array(case["params"]))) < TOL
+        assert np.max(np.abs(poses - np.array(case["poses_after"]))) < TOL
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_the_known_scan_conversion(ka_next):
+    from ndt_2d_amd import ScanMatcherNDT
+    gpu = ScanMatcherNDT(0)
+    gpu.initialize("known_conversion", ndt_resolution=1.0, range_max=10.0)
+    sc, args = _conversion_args(ka_next)
+    for inverted, key in ((False, "points"), (True, "points_inverted")):
+        got = gpu.convertScan(inverted=inverted, **args)
+        assert got.shape == (len(sc[key]), 2)
+        assert np.max(np.abs(got - np.array(sc[key]))) < TOL
+    gpu.close()
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_the_known_motion_samples(ka_next):
+    from ndt_2d_amd import ScanMatcherNDT, pf_update
+    gpu = ScanMatcherNDT(0)
+    gpu.initialize("known_motion", ndt_resolution=1.0, range_max=10.0)
+    mm = ka_next["motion_model"]
+    z = np.array(mm["z"], dtype=np.float32)
+    poses = np.array(mm["poses"])
+    for case in mm["cases"]:
+        after, _, _, _ = pf_update(gpu, poses, np.full(len(poses), 1.0 / len(poses)),
+                                   *case["motion"], mm["alphas"], noise=z)
+        assert np.max(np.abs(after - np.array(case["poses_after"]))) < TOL
+    gpu.close()
