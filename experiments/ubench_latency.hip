@@ -27,6 +27,27 @@ __global__ void k_flag(volatile unsigned long long * host_flag, double * host_re
   if (threadIdx.x == 0) *host_flag = seq;
 }
 
+// the product's pattern: system-scope stores, wait for their acknowledgement, then the flag
+__global__ void k_flag_ack(unsigned long long * host_flag, double * host_rec, unsigned long long seq)
+{
+  if (threadIdx.x < 12) __hip_atomic_store(host_rec + threadIdx.x, (double)seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  if (threadIdx.x == 0) __hip_atomic_store(host_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// record and sequence number in ONE store instruction (16 lanes x 8 B = two 64-byte lines,
+// each carrying a copy of seq in its last word), nothing waited for: does the host ever see
+// a line's seq without the line's data?
+__global__ void k_flag_inline(unsigned long long * host_line, unsigned long long seq)
+{
+  if (threadIdx.x < 16)
+  {
+    const bool is_seq = (threadIdx.x & 7) == 7;
+    const unsigned long long v = is_seq ? seq : (seq * 1000003ull + threadIdx.x);
+    __hip_atomic_store(host_line + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 typedef std::chrono::steady_clock clk;
 static double us(clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); }
 
@@ -79,6 +100,21 @@ int main()
   printf("launch + D2H 96B pinned + sync       %7.2f us\n", med([&] { hipLaunchKernelGGL(k_empty, 1, 64, 0, s, d); hipMemcpyAsync(pin, d, 96, hipMemcpyDeviceToHost, s); hipStreamSynchronize(s); }));
   printf("launch writes pinned-coherent + sync %7.2f us\n", med([&] { ++seq; hipLaunchKernelGGL(k_flag, 1, 64, 0, s, (volatile unsigned long long *)(d_pin_coh + 64), d_pin_coh, seq); hipStreamSynchronize(s); }));
   printf("launch writes pinned + spin on flag  %7.2f us\n", med([&] { ++seq; hipLaunchKernelGGL(k_flag, 1, 64, 0, s, (volatile unsigned long long *)(d_pin_coh + 64), d_pin_coh, seq); while (*flag != seq) { } }));
+  {
+    unsigned long long * uflag = reinterpret_cast<unsigned long long *>(d_pin_coh + 64);
+    printf("launch stores+ack+flag, spin         %7.2f us\n", med([&] { ++seq; hipLaunchKernelGGL(k_flag_ack, 1, 64, 0, s, uflag, d_pin_coh, seq); while (*flag != seq) { } }));
+    volatile unsigned long long * line = reinterpret_cast<volatile unsigned long long *>(pin_coh + 128);
+    unsigned long long * d_line = reinterpret_cast<unsigned long long *>(d_pin_coh + 128);
+    long torn = 0;
+    printf("launch record+seq in one store, spin %7.2f us\n", med([&] {
+      ++seq;
+      hipLaunchKernelGGL(k_flag_inline, 1, 64, 0, s, d_line, seq);
+      while (line[7] != seq || line[15] != seq) { }
+      for (int k = 0; k < 16; ++k)
+        if ((k & 7) != 7 && line[k] != seq * 1000003ull + k) ++torn;
+    }, 20000));
+    printf("   words seen stale behind their line's seq: %ld of %d\n", torn, 20050 * 14);
+  }
   printf("H2D 4KB pinned + launch + spin flag  %7.2f us\n", med([&] { ++seq; hipMemcpyAsync(d, pin, 4096, hipMemcpyHostToDevice, s); hipLaunchKernelGGL(k_flag, 1, 64, 0, s, (volatile unsigned long long *)(d_pin_coh + 64), d_pin_coh, seq); while (*flag != seq) { } }));
   printf("2 launches + spin flag               %7.2f us\n", med([&] { ++seq; hipLaunchKernelGGL(k_empty, 256, 256, 0, s, d); hipLaunchKernelGGL(k_flag, 1, 64, 0, s, (volatile unsigned long long *)(d_pin_coh + 64), d_pin_coh, seq); while (*flag != seq) { } }));
   printf("3 launches + spin flag               %7.2f us\n", med([&] { ++seq; hipLaunchKernelGGL(k_empty, 256, 256, 0, s, d); hipLaunchKernelGGL(k_empty, 256, 256, 0, s, d); hipLaunchKernelGGL(k_flag, 1, 64, 0, s, (volatile unsigned long long *)(d_pin_coh + 64), d_pin_coh, seq); while (*flag != seq) { } }));
