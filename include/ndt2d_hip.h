@@ -349,7 +349,7 @@ const char * ndt2d_last_variant(ndt2d_handle h);
  * of the lattice: lane-per-candidate with the beams split across the waves of a block
  * ("small") below 4,096 (theta, 8x8 patch) work items -- the plugin's default search is
  * 720 -- and lane-per-candidate with persistent waves ("lane") above; wave-per-candidate
- * ("wave") where neither applies (search windows beyond 256 cells, NaN beams).  All give
+ * ("wave") where neither applies (search windows beyond 1,024 cells, NaN beams).  All give
  * the oracle's result; they differ from each other in the last bits of a score
  * (summation order).
  * Force a kernel variant (testing / A-B measurement): "auto", "lds", "global"

@@ -319,7 +319,7 @@ constexpr uint64_t kMaxLaneItems = 1ull << 24;
 // launch_match: lattices with fewer (theta, 8x8 patch) items than this take the
 // small-lattice search (beams split across the waves of a block); it can hold
 // kSmallMaxItems.  Above, the lane-per-candidate search; the wave-per-candidate mapping
-// serves what neither can (windows beyond 256 cells, > 2^24 items).
+// serves what neither can (windows beyond 1,024 cells, > 2^24 items).
 constexpr uint64_t kSmallBelowItems = 4096;
 constexpr uint64_t kSmallMaxItems = 8192;
 

@@ -677,12 +677,20 @@ hipError_t launch_match(const MatchArgs & args_in, double * workspace, double * 
   {
     if (use_lane)
     {
+      // (bit 2 of the mode: the map is one byte per block of grid cells, a window wider
+      // than 256 cells)
+      const bool block_map = (lane_records_mode & 4) != 0;
+      const int records = lane_records_mode & 3;
       info->variant =
-        lane_records_mode == 2   ? "match/lane-per-candidate/lds-grid/compact-records/pow2"
-        : lane_records_mode == 1 ? (pow2 ? "match/lane-per-candidate/lds-grid/pow2"
-                                         : "match/lane-per-candidate/lds-grid/div")
-                                 : (pow2 ? "match/lane-per-candidate/lds-map+global-records/pow2"
-                                         : "match/lane-per-candidate/lds-map+global-records/div");
+        records == 2   ? "match/lane-per-candidate/lds-grid/compact-records/pow2"
+        : records == 1 ? (block_map ? (pow2 ? "match/lane-per-candidate/lds-grid/block-map/pow2"
+                                            : "match/lane-per-candidate/lds-grid/block-map/div")
+                                    : (pow2 ? "match/lane-per-candidate/lds-grid/pow2"
+                                            : "match/lane-per-candidate/lds-grid/div"))
+                       : (block_map ? (pow2 ? "match/lane-per-candidate/lds-map+global-records/block-map/pow2"
+                                            : "match/lane-per-candidate/lds-map+global-records/block-map/div")
+                                    : (pow2 ? "match/lane-per-candidate/lds-map+global-records/pow2"
+                                            : "match/lane-per-candidate/lds-map+global-records/div"));
       info->n_kernels = 3;
     }
     else

@@ -41,8 +41,12 @@ struct LaneGeom
   // coordinate and LDS allow): the finer the sub-cell, the tighter its bound on the
   // exponent, so fewer beams next to walls take the exact path.
   int32_t sub_log2;
-  double unit_scale;  // fixed-point units per cell = 2^16 << sub_log2
-  int32_t map_h;   // ((win_h + 2 * pad) << sub_log2) rows of kMapStride bytes
+  // ... or, for a window wider than 256 cells, at one map cell per 2^block_log2 x
+  // 2^block_log2 block of grid cells (then sub_log2 = 0): the byte speaks for the whole
+  // block, and a lane in a block that can score takes the reference's own index arithmetic.
+  int32_t block_log2;
+  double unit_scale;  // fixed-point units per cell = 2^16 << sub_log2 (>> block_log2)
+  int32_t map_h;   // map rows of kMapStride bytes: (win_h + 2 * pad) << sub_log2 (>> block_log2)
   // Window of grid cells the map covers: every point this search can produce
   // (scan pose +- (longest beam + largest offset)) lies inside it or outside the
   // grid.  For small grids it is the whole grid.
@@ -56,6 +60,7 @@ struct LaneGeom
 };
 
 constexpr int kMaxBoxSpan = 3;   // the pre-test reads a 4 x 4 sub-cell box
+constexpr int kMaxBlockLog2 = 2; // coarsest map: one byte per 4 x 4 grid cells (windows up to 1,024 cells)
 
 // Upper bound of Cell::score's exponent e(p) = q^T h q, q = p - mean (h = -0.5 *
 // information, packed record rec) over the box [x0, x1] x [y0, y1].  For a
@@ -150,6 +155,41 @@ __device__ __forceinline__ uint8_t sub_cell_byte(const GridDesc & g, int32_t cx,
   return map_byte(self, bound);
 }
 
+// Byte of the block of `cells` x `cells` grid cells that starts at (cx0, cy0) -- any part of
+// it may lie outside the grid -- for maps coarser than the grid (LaneGeom::block_log2): the
+// box of the whole block, widened like a sub-cell's, and the maximum of Cell::score's
+// exponent over that box for every cell the widened box overlaps (the block and the ring
+// of cells around it).  bit 0: some cell of the block holds a distribution.
+__device__ __forceinline__ uint8_t block_byte(const GridDesc & g, int32_t cx0, int32_t cy0, int32_t cells)
+{
+  const int32_t sx = static_cast<int32_t>(g.size_x), sy = static_cast<int32_t>(g.size_y);
+  const double size = g.cell_size * static_cast<double>(cells);
+  const double x0 = g.origin_x + static_cast<double>(cx0) * g.cell_size - kBoxMargin * size;
+  const double y0 = g.origin_y + static_cast<double>(cy0) * g.cell_size - kBoxMargin * size;
+  const double x1 = x0 + (1.0 + 2.0 * kBoxMargin) * size;
+  const double y1 = y0 + (1.0 + 2.0 * kBoxMargin) * size;
+  uint32_t self = 0;
+  double bound = -HUGE_VAL;
+  for (int32_t ny = cy0 - 1; ny <= cy0 + cells; ++ny)
+  {
+    for (int32_t nx = cx0 - 1; nx <= cx0 + cells; ++nx)
+    {
+      if (nx >= 0 && nx < sx && ny >= 0 && ny < sy)
+      {
+        const uint32_t cell = static_cast<uint32_t>(ny * sx + nx);
+        if (((g.occ_bits[cell >> 5] >> (cell & 31u)) & 1u) != 0)
+        {
+          if (nx >= cx0 && nx < cx0 + cells && ny >= cy0 && ny < cy0 + cells) self = 1;
+          const double e = exponent_upper_bound(g.cells_lds_image + static_cast<size_t>(cell) * kCellDoubles,
+                                                x0, x1, y0, y1);
+          bound = !(e <= bound) ? e : bound;   // NaN-propagating max
+        }
+      }
+    }
+  }
+  return map_byte(self, bound);
+}
+
 // LDS bytes of the cell -> compact record table: kRankLead bytes whose last two hold the
 // sentinel's rank -- entry -1, what a lane outside every occupied cell selects with one
 // v_cndmask_b32 and the inline constant -1 -- then a u16 per grid cell and entry ncell
@@ -165,6 +205,7 @@ struct LaneCtx
   uint32_t rank_address;       // LDS byte address of entry 0 of the cell -> compact record table (COMPACT)
   uint32_t lds_cells_address;  // LDS byte address of the packed records (behind the map)
   uint32_t sub_log2;           // map sub-cell -> map cell: shift right
+  uint32_t exact_index;        // the map is coarser than the grid: never take a cell from it
   // map cell (col, row) -> grid cell index: row * size_x + col - idx_bias,
   // idx_bias = (pad - win_y0) * size_x + (pad - win_x0), modulo 2^32
   uint32_t idx_bias;
@@ -327,7 +368,7 @@ __device__ __forceinline__ void lane_beams(const GridDesc & g, const LaneCtx & c
         const uint32_t fy = __builtin_amdgcn_perm(hi[u], lo[u], 0x0c0c0403u);
         const bool occ = (m[u] & 1u) != 0;
         const uint64_t near_mask =
-          (near_boundary(lo[u]) | near_boundary(fy) | (no_skip != 0 ? ~0ull : 0ull)) & live_mask;
+          (near_boundary(lo[u]) | near_boundary(fy) | ((no_skip | c.exact_index) != 0 ? ~0ull : 0ull)) & live_mask;
         const uint64_t occ_lanes = __builtin_amdgcn_ballot_w64(occ);
         const uint64_t occ_mask = occ_lanes & live_mask;
         if ((occ_mask | near_mask) != 0ull)
@@ -394,7 +435,7 @@ inline bool axis_window(double pose, double reach, double origin, double inv_cel
 }
 
 // Map geometry for a search; false if the byte-per-axis cell coordinate cannot
-// hold the padded window.
+// hold the padded window even at one map cell per 4 x 4 grid cells.
 // coarse_map: one map cell per grid cell whatever the lattice (the small search copies
 // the per-cell bytes prepared when the grid was installed).
 inline bool lane_geometry(const MatchArgs & args, size_t lds_per_block, LaneGeom * geo,
@@ -403,7 +444,7 @@ inline bool lane_geometry(const MatchArgs & args, size_t lds_per_block, LaneGeom
   const double lin_cells = args.dlin_absmax * args.grid.inv_cell_size;
   if (!(lin_cells >= 0.0) || lin_cells > kMaxMapCells) return false;
   if (!(args.beam_rmax >= 0.0) || !std::isfinite(args.beam_rmax)) return false;
-  const int32_t pad = static_cast<int32_t>(2.0 * lin_cells) + 3;
+  int32_t pad = static_cast<int32_t>(2.0 * lin_cells) + 3;
   // points_inner = R * beam + pose + (dx, dy): within beam_rmax + |d|max of the pose per axis
   const double reach = args.beam_rmax + args.dlin_absmax;
   if (!axis_window(args.pose_x, reach, args.grid.origin_x, args.grid.inv_cell_size,
@@ -413,10 +454,22 @@ inline bool lane_geometry(const MatchArgs & args, size_t lds_per_block, LaneGeom
   {
     return false;
   }
-  const uint64_t need_w = static_cast<uint64_t>(geo->win_w) + 2 * pad;
-  const uint64_t need_h = static_cast<uint64_t>(geo->win_h) + 2 * pad;
-  if (need_w > kMaxMapCells || need_h > kMaxMapCells) return false;
+  uint64_t need_w = static_cast<uint64_t>(geo->win_w) + 2 * pad;
+  uint64_t need_h = static_cast<uint64_t>(geo->win_h) + 2 * pad;
+  // A window beyond the one-byte coordinate: one map cell per block of 2 x 2 or 4 x 4 grid
+  // cells (the border and the window rounded up to whole blocks).
+  int block_log2 = 0;
+  while (need_w > (static_cast<uint64_t>(kMaxMapCells) << block_log2) ||
+         need_h > (static_cast<uint64_t>(kMaxMapCells) << block_log2))
+  {
+    if (++block_log2 > kMaxBlockLog2 || coarse_map) return false;
+    const int32_t cells = 1 << block_log2;
+    pad = (static_cast<int32_t>(2.0 * lin_cells) + 3 + cells - 1) / cells * cells;
+    need_w = (static_cast<uint64_t>(geo->win_w) + 2 * pad + cells - 1) / cells * cells;
+    need_h = (static_cast<uint64_t>(geo->win_h) + 2 * pad + cells - 1) / cells * cells;
+  }
   geo->pad = pad;
+  geo->block_log2 = block_log2;
   // finest sub-cell resolution whose coordinates fit one byte and whose map leaves
   // room in LDS for the cell records whenever the coarsest map would
   const size_t grid_bytes = static_cast<size_t>(args.grid.ncell + 1) * kCellDoubles * sizeof(double);
@@ -424,7 +477,7 @@ inline bool lane_geometry(const MatchArgs & args, size_t lds_per_block, LaneGeom
   // (a small search does not repay copying a 16x larger map into every block)
   const uint64_t p1 = (args.n_lin + kPatch - 1) / kPatch;
   const bool small_search = static_cast<uint64_t>(args.th_end - args.th_begin) * p1 * p1 < 4096;
-  int sub_log2 = (small_search || coarse_map) ? 0 : 2;
+  int sub_log2 = (small_search || coarse_map || block_log2 > 0) ? 0 : 2;
   for (; sub_log2 > 0; --sub_log2)
   {
     const uint64_t w = need_w << sub_log2, h = need_h << sub_log2;
@@ -433,8 +486,8 @@ inline bool lane_geometry(const MatchArgs & args, size_t lds_per_block, LaneGeom
     if (bytes <= lds_per_block) break;
   }
   geo->sub_log2 = sub_log2;
-  geo->unit_scale = kFracScale * static_cast<double>(1 << sub_log2);
-  geo->map_h = static_cast<int32_t>(need_h << sub_log2);
+  geo->unit_scale = kFracScale * static_cast<double>(1 << sub_log2) / static_cast<double>(1 << block_log2);
+  geo->map_h = static_cast<int32_t>((need_h << sub_log2) >> block_log2);
   // lanes add |d| <= lin_cells * unit_scale (+0.5 rounding); one cell of margin each side
   const double reach_units = (lin_cells + 1.0) * geo->unit_scale;
   geo->k_min = reach_units;

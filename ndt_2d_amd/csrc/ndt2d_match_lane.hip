@@ -89,6 +89,13 @@ __global__ void __launch_bounds__(256) outer_table_kernel(const MatchArgs a, dou
       // own, plus the neighbours across a cell boundary it touches)
       const int32_t mx = static_cast<int32_t>(i & (kMapStride - 1));
       const int32_t my = static_cast<int32_t>(i >> 8);
+      if (geo.block_log2 > 0)
+      {
+        // a map cell per block of grid cells
+        const int32_t cells = 1 << geo.block_log2;
+        map_out[i] = block_byte(g, mx * cells - geo.pad + geo.win_x0, my * cells - geo.pad + geo.win_y0, cells);
+        continue;
+      }
       const int32_t sub = 1 << geo.sub_log2;
       const int32_t cx = (mx >> geo.sub_log2) - geo.pad + geo.win_x0;
       const int32_t cy = (my >> geo.sub_log2) - geo.pad + geo.win_y0;
@@ -194,6 +201,7 @@ __device__ __forceinline__ void match_lane_body(
   c.rank_address = map_bytes + (COMPACT ? kRankLead : 0u);
   c.lds_cells_address = map_bytes + rank_bytes;
   c.sub_log2 = static_cast<uint32_t>(geo.sub_log2);
+  c.exact_index = geo.block_log2 > 0 ? 1u : 0u;
   c.idx_bias = static_cast<uint32_t>(geo.pad - geo.win_y0) * g.size_x +
                static_cast<uint32_t>(geo.pad - geo.win_x0);
   c.size_x = g.size_x;
@@ -457,7 +465,11 @@ hipError_t launch_match_lane(const MatchArgs & args_in, double * outer, double *
                        2 * (map_bytes + compact_bytes) <= lds_per_block &&
                        !(knob != nullptr && knob[0] == '0');
   // 0: records gathered from HBM, 1: the whole grid's records in LDS, 2: compacted records in LDS
-  if (records_mode_out != nullptr) *records_mode_out = compact ? 2 : (lds_records ? 1 : 0);
+  // (+4: the map is one byte per block of grid cells)
+  if (records_mode_out != nullptr)
+  {
+    *records_mode_out = (compact ? 2 : (lds_records ? 1 : 0)) | (geo.block_log2 > 0 ? 4 : 0);
+  }
   if (compact)
   {
     lds_bytes = map_bytes + compact_bytes;

@@ -199,6 +199,7 @@ match_small_kernel(const MatchArgs a,
   c.rank_address = map_bytes + (COMPACT ? kRankLead : 0u);
   c.lds_cells_address = map_bytes + rank_bytes;   // (not COMPACT: records are gathered from HBM)
   c.sub_log2 = 0;
+  c.exact_index = 0;
   c.idx_bias = static_cast<uint32_t>(geo.pad - geo.win_y0) * g.size_x +
                static_cast<uint32_t>(geo.pad - geo.win_x0);
   c.size_x = g.size_x;

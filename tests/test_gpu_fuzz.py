@@ -154,3 +154,47 @@ def test_random_large_lattice(seed):
     assert np.array_equal(got["lane"]["scores"], got["lane-noskip"]["scores"], equal_nan=True), seed
     assert np.array_equal(got["lane"]["scores"], got["auto"]["scores"], equal_nan=True) or \
         "small-lattice" in gpu.last_variant()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_wide_window(seed):
+    """Fine NDT cells under a scan that reaches several metres: the search window is wider
+    than 256 cells, the lane mapping's map goes to one byte per 2 x 2 or 4 x 4 block of grid
+    cells (every live lane then takes the reference's own index).  Against the oracle, the
+    skipping against its control bit for bit, and the wave mapping."""
+    rng = np.random.default_rng(9000 + seed)
+    params, scans, scan_pose, _, _ = _random_case(rng)
+    params["ndt_resolution"] = float([0.05, 0.03125, 0.04, 0.03][seed % 4])
+    params["range_max"] = float(rng.uniform(5.0, 7.0))
+    params["search_linear_resolution"] = float(rng.choice([0.01, 0.02]))
+    params["search_linear_size"] = params["search_linear_resolution"] * float(rng.uniform(6, 20))
+    params["search_angular_resolution"] = 0.01
+    params["search_angular_size"] = 0.01 * float(rng.uniform(2, 8))
+    params["laser_max_beams"] = 1000
+    n_q = int(rng.integers(150, 400))
+    query = np.concatenate([rng.uniform(-6, 6, (n_q // 2, 2)),
+                            np.stack([rng.uniform(1, 6, n_q - n_q // 2),
+                                      rng.uniform(-5, 5, n_q - n_q // 2)], axis=1)])
+    reach = np.max(np.hypot(query[:, 0], query[:, 1]))
+    assert 2 * reach / params["ndt_resolution"] > 256
+    ref = O.ScanMatcherNDT()
+    ref.initialize(**params)
+    ref.addScans(scans)
+    exp = ref.matchScan(scan_pose, query, want_scores=True)
+    gpu = ScanMatcherNDT(0)
+    gpu.initialize("fuzz-wide", **params)
+    gpu.addScans(scans)
+    got = {}
+    for variant in ("auto", "lane", "lane-noskip", "wave"):
+        gpu.set_variant(variant)
+        got[variant] = r = gpu.matchScan(scan_pose, query, want_scores=True)
+        if variant.startswith("lane"):
+            assert "lane-per-candidate/lds-" in gpu.last_variant() and "block-map" in gpu.last_variant(), \
+                (seed, gpu.last_variant())
+        assert r["n_candidates"] == exp["n_candidates"]
+        assert np.allclose(r["scores"], exp["scores"], rtol=0, atol=1e-9, equal_nan=True), (seed, variant)
+        finite = exp["scores"][~np.isnan(exp["scores"])]
+        if finite.size > 1 and np.sort(finite)[1] - finite.min() > 1e-9:
+            assert r["best_index"] == exp["best_index"], (seed, variant)
+    gpu.set_variant("auto")
+    assert np.array_equal(got["lane"]["scores"], got["lane-noskip"]["scores"], equal_nan=True), seed

@@ -648,11 +648,42 @@ def test_match_scan_on_a_large_map_uses_the_windowed_lane_kernel():
                      ref.matchScan(pose, pts, want_scores=True), 720)
 
 
+def test_wide_windows_keep_the_lane_mapping():
+    """cfg-5's 801 x 801 map and its scan, whose longest beams reach past 30 m: the search
+    window is wider than the 256 cells a one-byte map coordinate holds, so the map goes to
+    one byte per 2 x 2 (or 4 x 4) block of grid cells and every live lane takes the
+    reference's own index arithmetic.  Same results, skipping still bit-exact."""
+    gpu, ref, _, guess, pts = _pair(5, search_linear_size=0.5, search_linear_resolution=0.05,
+                                    search_angular_size=0.1, search_angular_resolution=0.01)
+    reach = np.max(np.hypot(pts[:, 0], pts[:, 1])) + 0.5
+    assert 2 * reach / 0.25 > 256
+    wrong = guess + np.array([0.16, -0.12, 0.03])
+    exp = ref.matchScan(wrong, pts, want_scores=True)
+    got = gpu.matchScan(wrong, pts, want_scores=True)
+    assert "lane-per-candidate/lds-map+global-records/block-map" in gpu.last_variant(), gpu.last_variant()
+    _check_match(got, exp, 720)
+    gpu.set_variant("lane-noskip")
+    control = gpu.matchScan(wrong, pts, want_scores=True)
+    gpu.set_variant("wave")
+    wave = gpu.matchScan(wrong, pts, want_scores=True)
+    gpu.set_variant("auto")
+    assert np.array_equal(got["scores"], control["scores"])
+    _check_match(wave, exp, 720)
+    # a larger lattice (dynamic work items, the patch pre-test on the coarse map), near the
+    # map's edge and outside it
+    big, ref_big, _, _, _ = _pair(5, search_linear_size=0.8, search_linear_resolution=0.02,
+                                  search_angular_size=0.05, search_angular_resolution=0.005)
+    for pose in (wrong, (-95.0, 90.0, 0.4), (140.0, 0.0, 0.0)):
+        a = big.matchScan(pose, pts, want_scores=True)
+        assert "lane-per-candidate" in big.last_variant() and "block-map" in big.last_variant()
+        _check_match(a, ref_big.matchScan(pose, pts, want_scores=True), 720)
+
+
 def test_mapping_follows_the_lattice_size(cfg1):
     """Small lattices (the plugin's defaults, cfg-1) take the small-lattice form of the
     lane-per-candidate mapping (beams split across the waves of a block), large ones the
-    persistent form; a search whose window exceeds the one-byte map coordinate takes the
-    wave-per-candidate mapping.  All give the oracle's result."""
+    persistent form (a window wider than 1,024 cells would take the wave-per-candidate
+    mapping).  All give the oracle's result."""
     gpu, ref, _, guess, pts = _pair(1)
     got = gpu.matchScan(guess, pts, want_scores=True)
     assert "small-lattice" in gpu.last_variant(), gpu.last_variant()
