@@ -188,6 +188,9 @@ def test_random_wide_window(seed):
     for variant in ("auto", "lane", "lane-noskip", "wave"):
         gpu.set_variant(variant)
         got[variant] = r = gpu.matchScan(scan_pose, query, want_scores=True)
+        if variant == "auto":
+            # (lattices this small are left to the wave mapping)
+            assert "wave-per-candidate" in gpu.last_variant(), (seed, gpu.last_variant())
         if variant.startswith("lane"):
             assert "lane-per-candidate/lds-" in gpu.last_variant() and "block-map" in gpu.last_variant(), \
                 (seed, gpu.last_variant())

@@ -659,20 +659,22 @@ def test_wide_windows_keep_the_lane_mapping():
     assert 2 * reach / 0.25 > 256
     wrong = guess + np.array([0.16, -0.12, 0.03])
     exp = ref.matchScan(wrong, pts, want_scores=True)
+    # (a lattice this small is left to the wave mapping; the lane mapping on request)
+    wave = gpu.matchScan(wrong, pts, want_scores=True)
+    assert "wave-per-candidate" in gpu.last_variant(), gpu.last_variant()
+    _check_match(wave, exp, 720)
+    gpu.set_variant("lane")
     got = gpu.matchScan(wrong, pts, want_scores=True)
     assert "lane-per-candidate/lds-map+global-records/block-map" in gpu.last_variant(), gpu.last_variant()
     _check_match(got, exp, 720)
     gpu.set_variant("lane-noskip")
     control = gpu.matchScan(wrong, pts, want_scores=True)
-    gpu.set_variant("wave")
-    wave = gpu.matchScan(wrong, pts, want_scores=True)
     gpu.set_variant("auto")
     assert np.array_equal(got["scores"], control["scores"])
-    _check_match(wave, exp, 720)
     # a larger lattice (dynamic work items, the patch pre-test on the coarse map), near the
     # map's edge and outside it
-    big, ref_big, _, _, _ = _pair(5, search_linear_size=0.8, search_linear_resolution=0.02,
-                                  search_angular_size=0.05, search_angular_resolution=0.005)
+    big, ref_big, _, _, _ = _pair(5, search_linear_size=1.0, search_linear_resolution=0.02,
+                                  search_angular_size=0.075, search_angular_resolution=0.005)
     for pose in (wrong, (-95.0, 90.0, 0.4), (140.0, 0.0, 0.0)):
         a = big.matchScan(pose, pts, want_scores=True)
         assert "lane-per-candidate" in big.last_variant() and "block-map" in big.last_variant()
