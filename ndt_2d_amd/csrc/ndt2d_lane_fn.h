@@ -16,7 +16,10 @@ namespace
 {
 
 constexpr int kPatch = 8;            // patch is kPatch x kPatch candidates = one wave
-constexpr int kUnroll = 8;  // beams per look-up group
+#ifndef NDT2D_LANE_UNROLL
+#define NDT2D_LANE_UNROLL 8
+#endif
+constexpr int kUnroll = NDT2D_LANE_UNROLL;  // beams per look-up group (a divisor of 64)
 // map coordinates are 8.16 fixed point
 constexpr double kFracScale = 65536.0;
 constexpr int kMapStride = 256;      // map row stride in bytes = 2^8 cells
