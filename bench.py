@@ -276,6 +276,55 @@ def particle_bench_1gpu(matcher_cls, synth, torch, device_index, pmc, n_cu, reps
     return out
 
 
+def cfg1_search_bench(matcher_cls, synth, device_index, with_cpu):
+    """BASELINE.json configs[0], the reference's own CPU-runnable case (17,640 candidates x
+    720 beams): the whole matchScan call on the GPU (host buffers in, results out, medians)
+    and -- the reference's execution model -- the CPU oracle single-threaded on this box's
+    host, in full, 1 warm-up + median of 5; same winner asserted."""
+    params = synth.matcher_params(1)
+    scans = synth.map_scans(1)
+    guess, pts, _ = synth.query_scan(1)
+    m = matcher_cls(device_index)
+    m.initialize("cfg1", **params)
+    m.addScans(scans)
+    for _ in range(5):
+        got = m.matchScan(guess, pts)
+    kernel_ms, _ = m.last_launch_ms()
+    variant = m.last_variant()
+    m.set_timing(False)
+    ts = []
+    for _ in range(200):
+        t0 = time.perf_counter()
+        got = m.matchScan(guess, pts)
+        ts.append(time.perf_counter() - t0)
+    call_ms = statistics.median(ts) * 1e3
+    m.close()
+    units = 17640 * 720
+    out = {"workload": "cfg-1 (BASELINE.json configs[0]): 21 x 21 x 40 = 17,640 candidates x 720 beams, "
+                       "41x41 NDT @0.25 m", "units": units, "gpu_match_scan_ms": call_ms,
+           "gpu_kernel_ms": kernel_ms, "gpu_value": units / (call_ms * 1e-3), "kernel_variant": variant,
+           "score": got["score"], "pose": [float(v) for v in got["pose"]]}
+    if with_cpu:
+        sys.path.insert(0, os.path.join(_ROOT, "tests"))
+        import oracle_lib as O
+        ref = O.ScanMatcherNDT()
+        ref.initialize(**params)
+        ref.addScans(scans)
+        tc = []
+        for i in range(6):
+            t0 = time.perf_counter()
+            exp = ref.matchScan(guess, pts)
+            if i > 0:
+                tc.append(time.perf_counter() - t0)
+        cpu_ms = statistics.median(tc) * 1e3
+        if tuple(exp["pose"]) != tuple(got["pose"]) or abs(exp["score"] - got["score"]) > 1e-9:
+            raise SystemExit("bench.py: cfg-1 result differs from the oracle's")
+        out.update({"cpu_single_thread_ms": cpu_ms, "cpu_value": units / (cpu_ms * 1e-3),
+                    "cpu_kind": "port (oracle/ndt2d_oracle.c, 1 thread: the reference's execution model)",
+                    "gpu_over_cpu": cpu_ms / call_ms})
+    return out
+
+
 def default_search_bench(matcher_cls, synth, device_index, reps=300):
     """The node's actual default workload (reference src/scan_matcher_ndt.cpp:37-44): 100 of
     720 beams, 21 x 21 x 80 = 35,280 candidates, per accepted scan the mapper runs
@@ -612,6 +661,8 @@ def main():
             line["particle_filter_cfg5" if world == 1 else "particle_filter"] = pf5
         if world == 1 and not args.no_default_search:
             line["default_search"] = default_search_bench(ScanMatcherNDT, synth, dev_index)
+            line["cfg1_search"] = cfg1_search_bench(ScanMatcherNDT, synth, dev_index,
+                                                    not args.no_cpu_baseline)
         os.write(json_fd, (json.dumps(line) + "\n").encode())
 
     m.set_stream(None)
