@@ -268,7 +268,13 @@ __device__ __forceinline__ void match_lane_body(
         double4 o[kUnroll];
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) o[u] = row[b + u];
+        // A wave with a flagged group in hand is on the launch's critical path (an item of
+        // 720 exact evaluations takes a wave 0.2 ms even alone); the waves stepping over
+        // unflagged groups or reducing an item's records are not: issue priority while the
+        // group is evaluated (cfg-2: - 3 %).
+        __builtin_amdgcn_s_setprio(3);
         lane_beams<kUnroll, POW2, LDS_RECORDS, true, COMPACT>(g, c, o, dx, dy, dxy, sum, skip, geo.no_skip);
+        __builtin_amdgcn_s_setprio(0);
       }
       for (; b < chunk_end; ++b, can_score >>= 1)
       {
