@@ -910,12 +910,12 @@ int ndt2d_match_launch_strided(ndt2d_handle h, size_t th_first, size_t th_stride
   if (h->timing)
   {
     if (int trc = next_timing_slot(h); trc != NDT2D_OK) return trc;
-    NDT2D_HIP(h, hipEventRecord(h->ev0, h->stream));
   }
   h->match_seq = ++h->seq;
+  // (the event pair brackets the search kernel itself)
   hipError_t e = ndt2d::launch_match(a, h->ws_match.ptr, outer, h->record.ptr, d_record,
                                      h->host_res_dev, h->match_seq, h->force_variant, h->stream,
-                                     h->timing ? h->ev1 : nullptr, &info);
+                                     h->timing ? h->ev0 : nullptr, h->timing ? h->ev1 : nullptr, &info);
   if (e != hipSuccess) return fail_hip(h, e, "launch_match");
   h->timed = h->timing;
   h->last_kernels = info.n_kernels;

@@ -153,10 +153,12 @@ constexpr int kHostFlagSlot = 16;
 bool match_needs_device_tables(const MatchArgs & args, bool outer_available, int force_variant);
 // doubles of search tables that fit the small-lattice search's kernel arguments
 constexpr uint32_t kArgTableDoubles = 416;
+// ev_main_start / ev_main_done (optional): recorded right before and right after the search
+// kernel itself (behind the lane mapping's table pre-kernel, before the reductions).
 hipError_t launch_match(const MatchArgs & args, double * workspace, double * outer,
                         double * record_out, double * record_out2, double * host_record,
                         unsigned long long seq, int force_variant, hipStream_t stream,
-                        hipEvent_t ev_main_done, LaunchInfo * info);
+                        hipEvent_t ev_main_start, hipEvent_t ev_main_done, LaunchInfo * info);
 
 size_t poses_workspace_doubles(uint64_t n_poses);
 hipError_t launch_score_poses(const PosesArgs & args, double * workspace, double * stats_out,
@@ -249,7 +251,7 @@ bool match_lane_supported(const MatchArgs & args, size_t lds_per_block);
 // / negligible-term skipping) -- the bit-exactness control for the skipping logic.
 hipError_t launch_match_lane(const MatchArgs & args, double * outer, double * workspace,
                              uint32_t max_workers, int cus, size_t lds_per_block, bool no_skip,
-                             hipStream_t stream, uint32_t * n_workers_out, int * records_mode_out);
+                             hipStream_t stream, hipEvent_t ev_after_pre_kernel, uint32_t * n_workers_out, int * records_mode_out);
 
 // Small-lattice search (ndt2d_match_small.hip): a block per (theta, up to P tiles of 64
 // candidates), its waves split the beams; needs grid.cell_bytes.  The launch includes the

@@ -565,7 +565,7 @@ bool match_needs_device_tables(const MatchArgs & args, bool outer_available, int
 hipError_t launch_match(const MatchArgs & args_in, double * workspace, double * outer,
                         double * record_out, double * record_out2, double * host_record,
                         unsigned long long seq, int force_variant, hipStream_t stream,
-                        hipEvent_t ev_main_done, LaunchInfo * info)
+                        hipEvent_t ev_main_start, hipEvent_t ev_main_done, LaunchInfo * info)
 {
   MatchArgs args = args_in;
   if (args.n_beams == 0) return hipErrorInvalidValue;
@@ -589,6 +589,11 @@ hipError_t launch_match(const MatchArgs & args_in, double * workspace, double * 
   hipError_t e;
   uint32_t n_workers = 0;
   int lane_records_mode = 1;
+  if (ev_main_start != nullptr && !use_lane)
+  {
+    e = hipEventRecord(ev_main_start, stream);
+    if (e != hipSuccess) return e;
+  }
   if (use_small)
   {
     // search and final reduction in one launch; the ticket counter sits beside the lane
@@ -615,7 +620,7 @@ hipError_t launch_match(const MatchArgs & args_in, double * workspace, double * 
   {
     e = launch_match_lane(args, outer, workspace, kMaxMatchBlocks * kMatchWaves, lim.cus,
                           lim.lds_per_block, (force_variant & kVariantNoSkip) != 0, stream,
-                          &n_workers, &lane_records_mode);
+                          ev_main_start, &n_workers, &lane_records_mode);
     if (e != hipSuccess) return e;
   }
   else

@@ -411,7 +411,8 @@ bool match_lane_supported(const MatchArgs & args, size_t lds_per_block)
 
 hipError_t launch_match_lane(const MatchArgs & args_in, double * outer, double * workspace,
                              uint32_t max_workers, int cus, size_t lds_per_block, bool no_skip,
-                             hipStream_t stream, uint32_t * n_workers_out, int * records_mode_out)
+                             hipStream_t stream, hipEvent_t ev_after_pre_kernel,
+                             uint32_t * n_workers_out, int * records_mode_out)
 {
   MatchArgs args = args_in;
   args.partials = workspace;
@@ -443,6 +444,11 @@ hipError_t launch_match_lane(const MatchArgs & args_in, double * outer, double *
                      reinterpret_cast<double4 *>(outer), map_image, geo);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
+  if (ev_after_pre_kernel != nullptr)
+  {
+    e = hipEventRecord(ev_after_pre_kernel, stream);
+    if (e != hipSuccess) return e;
+  }
 
   // Few work items (the plugin's default lattice is 720 of them): 256-thread blocks
   // put them on four times as many CUs -- as long as every wave still gets at most
