@@ -11,7 +11,7 @@ O=$R/gpurun_out/prof_$TAG
 rm -rf $O && mkdir -p $O
 BENCH="python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-default-search"
 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-default-search > $O/kt.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --steps 200 --warmup 10 --no-cpu-baseline --no-default-search > $O/kt.log 2>&1
 find $O/kt -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats.csv
 pass() {
   name=$1; shift
