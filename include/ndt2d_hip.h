@@ -327,7 +327,9 @@ int ndt2d_host_free(ndt2d_handle h, void * ptr);
 
 /* HIP events around the dominant kernel of every launch (ndt2d_last_launch_ms /
  * ndt2d_launch_history_ms) are recorded by default; a latency-critical host (the
- * pluginlib shim) turns them off: the pair costs ~4.5 us per call. */
+ * pluginlib shim) turns them off: a recorded event holds the stream up for ~5.5 us where
+ * consecutive kernels otherwise start back to back, and the pair costs ~4.5 us of host
+ * time per call. */
 int ndt2d_set_timing(ndt2d_handle h, int enabled);
 
 /* Block until everything launched on the context's stream has finished. */
