@@ -1,0 +1,61 @@
+"""The committed bench line (profiles/r02_bench.json, written by `python bench.py` on an
+MI355X) keeps the driver's contract and agrees with the committed counters and golden
+results.  No GPU needed."""
+import json
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def line():
+    with open(os.path.join(ROOT, "profiles", "r02_bench.json")) as f:
+        return json.load(f)
+
+
+def test_contract_fields(line):
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    with open(os.path.join(ROOT, "BASELINE.json")) as f:
+        base = json.load(f)
+    # (BASELINE.json: "pose-candidates x beams scored /sec; achieved HBM GB/s vs roofline")
+    assert base["metric"].startswith("pose-candidates") and line["metric"].startswith("pose-candidates")
+    assert "scored" in line["metric"] and line["n_gpus"] == 1
+    assert line["dtype"] == "f64" and line["data"] == "synthetic" and line["vs_baseline"] is None
+    assert "cfg-2" in line["config"]["workload"] and "model" not in line["config"]
+    assert line["config"]["units_per_step"] == 2_000_000 * 720
+    # value = units of a step / time of a step
+    assert line["value"] == pytest.approx(line["config"]["units_per_step"] / (line["ms_per_step"] * 1e-3), rel=1e-6)
+
+
+def test_roofline_is_a_fraction_of_something_that_binds(line):
+    r = line["roofline"]
+    assert r["bound"] == "valu_issue" and 0.0 < r["frac"] <= 1.0
+    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-9)
+    # reproducible from the committed counters: SQ_INSTS_VALU * 4 / (4 * SQ_BUSY_CU_CYCLES)
+    with open(os.path.join(ROOT, "profiles", "r02_pmc.json")) as f:
+        pmc = json.load(f)
+    k = pmc["kernels"][r["kernel"]]
+    assert r["frac"] == pytest.approx(k["SQ_INSTS_VALU"] * 4.0 / (4.0 * k["SQ_BUSY_CU_CYCLES"]), rel=1e-6)
+    assert r["valu_insts_per_launch"] == pytest.approx(k["SQ_INSTS_VALU"], rel=1e-9)
+    # the measured HBM side stays a small fraction of the peak; the declared 64 B/unit does not fit under it
+    h = line["roofline_hbm"]
+    assert 0.0 < h["frac"] < 0.1 and h["algorithmic_over_peak"] > 1.0
+    assert h["traffic"] == pytest.approx((2 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024, rel=1e-6)
+
+
+def test_cpu_baseline_and_results(line):
+    c = line["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
+    assert c["single_thread_value"] < c["value"] < line["value"]
+    # the search the bench timed found the oracle's pinned cfg-2 winner
+    with open(os.path.join(ROOT, "tests", "golden", "big_winners.json")) as f:
+        win = json.load(f)["cfg2"]
+    assert line["match_result"]["best_index"] == win["best_index"]
+    assert line["match_result"]["score"] == pytest.approx(win["score"], abs=1e-12)
+    # BASELINE's CPU-runnable config beside its CPU timing
+    c1 = line["cfg1_search"]
+    assert c1["units"] == 17640 * 720 and c1["cpu_single_thread_ms"] > c1["gpu_match_scan_ms"] > 0
