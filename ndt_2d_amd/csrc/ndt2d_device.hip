@@ -31,6 +31,7 @@ struct DeviceBuffer
 struct PinnedStage
 {
   double * ptr = nullptr;
+  double * dev = nullptr;   // the same memory as the device addresses it (kernels may read it in place)
   size_t cap = 0;  // doubles
   hipEvent_t done = nullptr;
   bool pending = false;
@@ -165,16 +166,38 @@ int stage_acquire(ndt2d_context * h, PinnedStage & st, size_t doubles)
     const size_t cap = doubles < 4096 ? 4096 : doubles;
     NDT2D_HIP(h, hipHostMalloc(reinterpret_cast<void **>(&st.ptr), cap * sizeof(double), hipHostMallocDefault));
     st.cap = cap;
+    st.dev = nullptr;
+    if (hipHostGetDevicePointer(reinterpret_cast<void **>(&st.dev), st.ptr, 0) != hipSuccess)
+    {
+      (void)hipGetLastError();
+      st.dev = nullptr;
+    }
   }
+  return NDT2D_OK;
+}
+
+// The copy out of a staging buffer, and the event that tells when the buffer may be written
+// again.  A recorded event holds the stream up for ~5 us (experiments/kernel_gaps.py), so a
+// caller that launches the copy's consumer right away copies first, launches, and marks
+// afterwards (stage_copy + stage_mark): the hold-up then falls behind the call's last
+// kernel, where the host is busy anyway.
+int stage_copy(ndt2d_context * h, PinnedStage & st, double * dst, size_t doubles)
+{
+  NDT2D_HIP(h, hipMemcpyAsync(dst, st.ptr, doubles * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  return NDT2D_OK;
+}
+
+int stage_mark(ndt2d_context * h, PinnedStage & st)
+{
+  NDT2D_HIP(h, hipEventRecord(st.done, h->stream));
+  st.pending = true;
   return NDT2D_OK;
 }
 
 int stage_submit(ndt2d_context * h, PinnedStage & st, double * dst, size_t doubles)
 {
-  NDT2D_HIP(h, hipMemcpyAsync(dst, st.ptr, doubles * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  NDT2D_HIP(h, hipEventRecord(st.done, h->stream));
-  st.pending = true;
-  return NDT2D_OK;
+  const int rc = stage_copy(h, st, dst, doubles);
+  return rc != NDT2D_OK ? rc : stage_mark(h, st);
 }
 
 void release(PinnedStage & st)
@@ -532,7 +555,7 @@ int ndt2d_set_grid(ndt2d_handle h, const double * cells6, uint32_t size_x, uint3
     static const double sentinel[kCellDoubles] = {1.0e300, 0.0, -1.0, 0.0, -1.0, 0.0};
     std::memcpy(recs + static_cast<size_t>(n_occ) * kCellDoubles, sentinel, sizeof(sentinel));
   }
-  if ((rc = stage_submit(h, h->stage_grid, h->compact.ptr, n_upload)) != NDT2D_OK) return rc;
+  if ((rc = stage_copy(h, h->stage_grid, h->compact.ptr, n_upload)) != NDT2D_OK) return rc;
 
   GridDesc g{};
   g.size_x = size_x;
@@ -548,6 +571,7 @@ int ndt2d_set_grid(ndt2d_handle h, const double * cells6, uint32_t size_x, uint3
                                          reinterpret_cast<uint32_t *>(h->occ_bits.ptr),
                                          reinterpret_cast<uint8_t *>(h->cell_bytes.ptr), h->stream);
   if (e != hipSuccess) return fail_hip(h, e, "launch_pack_grid");
+  if ((rc = stage_mark(h, h->stage_grid)) != NDT2D_OK) return rc;   // (behind the kernel, see stage_copy)
   g.cells_lds_image = h->cells_lds_image.ptr;
   g.cells_global = h->cells_global.ptr;
   g.occ_bits = reinterpret_cast<const uint32_t *>(h->occ_bits.ptr);
@@ -1315,6 +1339,7 @@ int run_few(ndt2d_context * h, const double * arg_beams, size_t n_beams, const d
   a.n_poses = n_poses;
   a.scores = h->host_res_dev + kScoreSlot;
   ndt2d::FewPoses few{};
+  bool poses_in_place = false;
   if (n_poses <= ndt2d::kFewPoses)
   {
     std::memcpy(few.xyt, h_poses, 3 * n_poses * sizeof(double));
@@ -1322,12 +1347,22 @@ int run_few(ndt2d_context * h, const double * arg_beams, size_t n_beams, const d
   }
   else
   {
-    // one staged copy (pinned; the caller's buffer is free on return)
+    // through the pinned staging buffer, which the kernel reads in place over PCIe (24 bytes
+    // per block): no copy command, no event; the call returns after the kernel has finished,
+    // so the buffer is free for the next one (the caller's buffer is free on return)
     if ((rc = ensure(h, h->tmp_poses, 3 * n_poses)) != NDT2D_OK) return rc;
     if ((rc = stage_acquire(h, h->stage_call, 3 * n_poses)) != NDT2D_OK) return rc;
     std::memcpy(h->stage_call.ptr, h_poses, 3 * n_poses * sizeof(double));
-    if ((rc = stage_submit(h, h->stage_call, h->tmp_poses.ptr, 3 * n_poses)) != NDT2D_OK) return rc;
-    a.poses_xyt = h->tmp_poses.ptr;
+    if (h->stage_call.dev != nullptr)
+    {
+      a.poses_xyt = h->stage_call.dev;
+      poses_in_place = true;
+    }
+    else
+    {
+      if ((rc = stage_submit(h, h->stage_call, h->tmp_poses.ptr, 3 * n_poses)) != NDT2D_OK) return rc;
+      a.poses_xyt = h->tmp_poses.ptr;
+    }
   }
   ndt2d::FewOut out{};
   out.flag = reinterpret_cast<unsigned long long *>(h->host_res_dev + kScoreFlagSlot);
@@ -1340,6 +1375,7 @@ int run_few(ndt2d_context * h, const double * arg_beams, size_t n_beams, const d
     if ((rc = ensure(h, h->tmp_scores, n_poses)) != NDT2D_OK) return rc;
     out.dev_scores = h->tmp_scores.ptr;
     out.host_out = h->host_res_dev + kPfOutSlot;
+    out.dev_poses = poses_in_place ? h->tmp_poses.ptr : nullptr;
   }
   hipError_t e = ndt2d::launch_score_few(a, &few, out, arg_beams, h->stream);
   if (e != hipSuccess) return fail_hip(h, e, "launch_score_few");

@@ -298,6 +298,9 @@ struct FewOut
   int stats;                    // run ParticleFilter::updateStatistics in the launch's last block
   double * dev_scores;          // device scratch [n_poses] (stats)
   double * host_out;            // host-coherent [NDT2D_PF_RESULT_DOUBLES] (stats)
+  // device scratch [n_poses][3] (stats, optional): every block leaves its pose here, so that
+  // the statistics pass does not read args.poses_xyt -- pinned host memory, over PCIe -- again
+  double * dev_poses;
 };
 bool score_few_supported(const PosesArgs & args, size_t lds_per_block);
 // args.poses_xyt == nullptr: the (<= kFewPoses) poses are few->xyt.  host_beams (optional,

@@ -547,6 +547,12 @@ __global__ void __launch_bounds__(kFewThreads) score_few_kernel(const PosesArgs 
       if (f.stats)
       {
         __hip_atomic_store(f.dev_scores + i, score, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (f.dev_poses != nullptr)
+        {
+          __hip_atomic_store(f.dev_poses + 3 * static_cast<size_t>(i) + 0, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(f.dev_poses + 3 * static_cast<size_t>(i) + 1, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(f.dev_poses + 3 * static_cast<size_t>(i) + 2, th, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
       else
       {
@@ -578,6 +584,14 @@ __global__ void __launch_bounds__(kFewThreads) score_few_kernel(const PosesArgs 
   double * row = chunk_sums + kChunks;          // 8 doubles of scratch
   double * wave_rows = terms;                   // [4 waves][8]: needs n_beams >= 32 or the pad below
   auto pose_of = [&](uint32_t k, double & px, double & py, double & pt) {
+    if (f.dev_poses != nullptr)
+    {
+      const double * q = f.dev_poses + 3 * static_cast<size_t>(k);
+      px = __hip_atomic_load(q + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      py = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      pt = __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
     const double * q = a.poses_xyt != nullptr ? a.poses_xyt + 3 * static_cast<size_t>(k) : few.xyt + 3 * k;
     px = q[0];
     py = q[1];
