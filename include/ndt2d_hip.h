@@ -323,6 +323,8 @@ int ndt2d_copy_to_host(ndt2d_handle h, void * h_dst, const void * d_src, size_t 
  * written by the kernels of the host-pointer entry points directly over PCIe (no staging
  * copy, no copy command); the C++ ParticleFilter mirror keeps its particles in it. */
 int ndt2d_host_alloc(ndt2d_handle h, size_t bytes, void ** out);
+/* h may be NULL once the context that allocated `ptr` has been destroyed (nothing of its
+ * stream can then be in flight): the buffer outlives its context if the caller wants so. */
 int ndt2d_host_free(ndt2d_handle h, void * ptr);
 
 /* HIP events around the dominant kernel of every launch (ndt2d_last_launch_ms /

@@ -97,7 +97,12 @@ def build_tools(verbose=False):
            "-L", _PKG, "-lndt2d_hip", "-lm", "-Wl,-rpath," + _PKG, "-o", PROBE_PATH]
     if verbose:
         print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    try:
+        subprocess.check_call(cmd)
+    except (OSError, subprocess.CalledProcessError) as exc:
+        # a measurement tool, not the product: the library is usable without it
+        print("ndt_2d_amd.build: latency probe not built (%s)" % exc, file=sys.stderr)
+        return None
     return PROBE_PATH
 
 

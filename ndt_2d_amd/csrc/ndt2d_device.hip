@@ -273,7 +273,12 @@ int ensure_host_res(ndt2d_context * h)
     return fail_hip(h, e, "hipMalloc");
   }
   e = hipMemsetAsync(counter, 0, 256, h->stream);
-  if (e != hipSuccess) return fail_hip(h, e, "hipMemsetAsync");
+  if (e != hipSuccess)
+  {
+    (void)hipHostFree(p);
+    (void)hipFree(counter);
+    return fail_hip(h, e, "hipMemsetAsync");
+  }
   h->host_res = static_cast<double *>(p);
   h->host_res_dev = static_cast<double *>(d);
   h->done_counter = static_cast<uint32_t *>(counter);
@@ -1061,6 +1066,12 @@ int ndt2d_score_poses_beams(ndt2d_handle h, const double * beams_xy, size_t n_be
     probe.n_poses = n_poses;
     if (ndt2d::score_few_supported(probe, 64 * 1024))
     {
+      // the kernel overwrites the context's beam buffer: until it has reported back the
+      // context holds no beams (a failed wait must not leave new beams under the old
+      // count and reach)
+      h->n_beams = 0;
+      h->beams_ptr = nullptr;
+      h->has_search = false;
       rc = run_few(h, beams_xy, n_beams, h_poses_xyt, n_poses, false, h_scores, nullptr);
       if (rc != NDT2D_OK) return rc;
       h->n_beams = n_beams;
@@ -1714,8 +1725,13 @@ int ndt2d_host_alloc(ndt2d_handle h, size_t bytes, void ** out)
 
 int ndt2d_host_free(ndt2d_handle h, void * ptr)
 {
-  if (h == nullptr) return NDT2D_ERR_INVALID;
-  if (ptr == nullptr) return NDT2D_OK;
+  if (ptr == nullptr) return h != nullptr ? NDT2D_OK : NDT2D_ERR_INVALID;
+  if (h == nullptr)   // the owning context is gone, and with it everything that could use ptr
+  {
+    const hipError_t e = hipHostFree(ptr);
+    if (e != hipSuccess) (void)hipGetLastError();
+    return e == hipSuccess ? NDT2D_OK : NDT2D_ERR_HIP;
+  }
   NDT2D_HIP(h, hipSetDevice(h->device));
   NDT2D_HIP(h, hipStreamSynchronize(h->stream));  // nothing in flight may still use it
   NDT2D_HIP(h, hipHostFree(ptr));

@@ -178,7 +178,9 @@ public:
   }
 
   // NDT::addScan, reference src/ndt_model.cpp:132-152
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(__clang__)
   __attribute__((target_clones("avx2", "default")))
+#endif
   void add_scan(double pose_x, double pose_y, double pose_theta, const double * pts, size_t n)
   {
     double cos_th, sin_th;

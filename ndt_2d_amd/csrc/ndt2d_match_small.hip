@@ -328,6 +328,10 @@ match_small_kernel(const MatchArgs a,
 #pragma unroll
       for (int k = 0; k < 10; ++k) store_agent(out + 2 + k, acc[k]);
     }
+    // The record must be in L2 before this block's ticket is drawn: the barrier below
+    // is a workgroup-scope release only (it waits on lgkmcnt, not on vmcnt), so the
+    // storing wave itself waits for its stores' acknowledgements first.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
 
   // ---- final reduction by the block that draws the launch's last ticket ----
@@ -538,8 +542,11 @@ bool match_small_supported(const MatchArgs & args, size_t lds_per_block)
   if (!lane_geometry(args, lds_per_block, &geo, &map_bytes, true)) return false;
   if (geo.sub_log2 != 0) return false;
   const uint64_t p1 = (args.n_lin + kPatch - 1) / kPatch;
-  const uint64_t items = static_cast<uint64_t>(args.th_end - args.th_begin) * p1 * p1;
-  return items <= kSmallMaxItems && args.grid.size_x < (1u << 24) && args.grid.ncell < (1u << 24) &&
+  // the WHOLE lattice's work items (as choose_mapping counts them): every shard of a search
+  // must make the same choice, or a candidate's bits would depend on the sharding; a
+  // launch's share never has more items than the lattice, so the workspace bound holds too
+  const uint64_t items = static_cast<uint64_t>(args.n_th) * p1 * p1;
+  return args.th_end - args.th_begin <= args.n_th && items <= kSmallMaxItems && args.grid.size_x < (1u << 24) && args.grid.ncell < (1u << 24) &&
          small_lds_bytes(args, geo, kSmallMaxWaves, false) <= lds_per_block;
 }
 

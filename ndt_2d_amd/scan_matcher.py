@@ -7,6 +7,7 @@ like tests of the reference.  Every score is computed by the HIP kernels
 through the C-ABI; nothing here evaluates a likelihood.
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -66,6 +67,10 @@ def host_build_grid(ndt_resolution, range_max, scans):
     return cells, sx.value, sy.value, ox.value, oy.value
 
 
+def _free_pinned(lib, state, address):
+    lib.ndt2d_host_free(state["handle"], C.c_void_p(address))
+
+
 class ScanMatcherNDT:
     """ndt_2d::ScanMatcherNDT over the MI355X kernels."""
 
@@ -81,25 +86,29 @@ class ScanMatcherNDT:
 
     def close(self):
         if getattr(self, "_m", None):
-            for ptr in getattr(self, "_pinned", []):
-                self._L.ndt2d_host_free(self.device_handle, ptr)
-            self._pinned = []
+            # host_alloc() buffers stay valid while any numpy view of them is alive: each is
+            # freed by its own finalizer (with a NULL handle once this context is gone)
+            state = getattr(self, "_pinned_state", None)
+            if state is not None:
+                state["handle"] = None
             self._L.ndt2d_matcher_destroy(self._m)
             self._m = None
 
     def host_alloc(self, shape):
         """float64 array in pinned, GPU-mapped host memory (ndt2d_host_alloc): the
         host-pointer entry points read / write such buffers in place over PCIe instead
-        of staging and copying them.  Owned by the matcher (freed by close())."""
+        of staging and copying them.  The memory is released when the last numpy view of
+        it is gone -- before or after close(), never under a live array."""
         shape = (shape,) if np.isscalar(shape) else tuple(shape)
         n = int(np.prod(shape))
         ptr = C.c_void_p()
         self._dev_check(self._L.ndt2d_host_alloc(self.device_handle, max(n, 1) * 8, C.byref(ptr)),
                         "ndt2d_host_alloc")
-        if not hasattr(self, "_pinned"):
-            self._pinned = []
-        self._pinned.append(ptr)
+        if not hasattr(self, "_pinned_state"):
+            self._pinned_state = {"handle": self.device_handle}
         buf = (C.c_double * max(n, 1)).from_address(ptr.value)
+        # every view of the array keeps `buf` alive (numpy's base chain); the block goes with it
+        weakref.finalize(buf, _free_pinned, self._L, self._pinned_state, ptr.value)
         return np.ctypeslib.as_array(buf)[:n].reshape(shape)
 
     def set_timing(self, enabled):

@@ -572,7 +572,8 @@ double orc_matcher_match_scan(const orc_matcher * m, const double * scan_pose_xy
 /* One (theta, dx) strip of the search: the dy loop of src/scan_matcher_ndt.cpp:119-142 for a
  * given rotated scan `outer`.  Work unit of the OpenMP variant below. */
 static void match_strip(const orc_matcher * m, size_t scan_points_to_use, double dth, double dx,
-                        uint64_t flat_base, const double * outer, double * inner, match_acc * acc)
+                        uint64_t flat_base, const double * outer, double * inner, match_acc * acc,
+                        double * all_scores, size_t all_scores_cap)
 {
   uint64_t flat = flat_base;
   for (double dy = -m->linear_size; dy < m->linear_size; dy += m->linear_res)
@@ -583,6 +584,7 @@ static void match_strip(const orc_matcher * m, size_t scan_points_to_use, double
       inner[2 * i + 1] = outer[2 * i + 1] + dy;
     }
     double score = -orc_ndt_likelihood_points(m->ndt, inner, scan_points_to_use);
+    if (all_scores && flat < all_scores_cap) all_scores[flat] = score;   /* each strip its own range */
     if (score < acc->best_score)
     {
       acc->best_score = score;
@@ -610,11 +612,12 @@ static void match_strip(const orc_matcher * m, size_t scan_points_to_use, double
  * the winner (score, pose, flat index) is the sequential loop's.  The covariance
  * accumulators are per-strip partial sums added in lattice order (the sequential loop
  * keeps one running sum: equal to rounding). */
-double orc_matcher_match_scan_omp_ex(const orc_matcher * m, const double * scan_pose_xyt,
-                                     const double * points_xy, size_t n_points,
-                                     double * pose_inout, double * covariance_out,
-                                     int n_threads, uint64_t * best_index_out,
-                                     int * threads_used_out)
+double orc_matcher_match_scan_omp_scores(const orc_matcher * m, const double * scan_pose_xyt,
+                                         const double * points_xy, size_t n_points,
+                                         double * pose_inout, double * covariance_out,
+                                         int n_threads, uint64_t * best_index_out,
+                                         int * threads_used_out, double * all_scores,
+                                         size_t all_scores_cap)
 {
   if (best_index_out) *best_index_out = UINT64_MAX;
   if (threads_used_out) *threads_used_out = 0;
@@ -668,7 +671,8 @@ double orc_matcher_match_scan_omp_ex(const orc_matcher * m, const double * scan_
       }
       accs[w].best_index = UINT64_MAX;
       match_strip(m, scan_points_to_use, dths[t], dlin[ix],
-                  ((uint64_t)t * n_lin + (uint64_t)ix) * n_lin, outer, inner, &accs[w]);
+                  ((uint64_t)t * n_lin + (uint64_t)ix) * n_lin, outer, inner, &accs[w],
+                  all_scores, all_scores_cap);
     }
     free(outer);
     free(inner);
@@ -697,6 +701,17 @@ double orc_matcher_match_scan_omp_ex(const orc_matcher * m, const double * scan_
   if (best_index_out) *best_index_out = acc.best_index;
   if (threads_used_out) *threads_used_out = threads_used;
   return acc.best_score / scan_points_to_use;
+}
+
+double orc_matcher_match_scan_omp_ex(const orc_matcher * m, const double * scan_pose_xyt,
+                                     const double * points_xy, size_t n_points,
+                                     double * pose_inout, double * covariance_out,
+                                     int n_threads, uint64_t * best_index_out,
+                                     int * threads_used_out)
+{
+  return orc_matcher_match_scan_omp_scores(m, scan_pose_xyt, points_xy, n_points, pose_inout,
+                                           covariance_out, n_threads, best_index_out,
+                                           threads_used_out, NULL, 0);
 }
 
 double orc_matcher_match_scan_omp(const orc_matcher * m, const double * scan_pose_xyt,

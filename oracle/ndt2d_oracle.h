@@ -122,6 +122,14 @@ double orc_matcher_match_scan(const orc_matcher * m, const double * scan_pose_xy
  * fixtures).  Strips are combined in lattice order: the winner (score, pose, flat
  * index) is the sequential loop's; the covariance accumulators are per-strip partial
  * sums added in lattice order.  *threads_used_out (optional) = threads of the team. */
+/* ... and every candidate's raw score (= -likelihood sum, src/scan_matcher_ndt.cpp:127)
+ * into all_scores[flat index] (each strip writes its own range). */
+double orc_matcher_match_scan_omp_scores(const orc_matcher * m, const double * scan_pose_xyt,
+                                         const double * points_xy, size_t n_points,
+                                         double * pose_inout, double * covariance_out,
+                                         int n_threads, uint64_t * best_index_out,
+                                         int * threads_used_out, double * all_scores,
+                                         size_t all_scores_cap);
 double orc_matcher_match_scan_omp_ex(const orc_matcher * m, const double * scan_pose_xyt,
                                      const double * points_xy, size_t n_points,
                                      double * pose_inout, double * covariance_out,

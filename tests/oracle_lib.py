@@ -85,6 +85,8 @@ def lib():
     sig("orc_matcher_match_scan_omp", d, [vp, _dp, _dp, sz, _dp, _dp, C.c_int])
     sig("orc_matcher_match_scan_omp_ex", d,
         [vp, _dp, _dp, sz, _dp, _dp, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_int)])
+    sig("orc_matcher_match_scan_omp_scores", d,
+        [vp, _dp, _dp, sz, _dp, _dp, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_int), _dp, sz])
     sig("orc_matcher_score_points", d, [vp, _dp, sz, _dp])
     sig("orc_matcher_score_scan", d, [vp, _dp, _dp, sz])
     sig("orc_matcher_reset", None, [vp])
@@ -267,10 +269,18 @@ class ScanMatcherNDT:
         if omp_threads is not None:
             best = C.c_uint64(0)
             used = C.c_int(0)
-            score = lib().orc_matcher_match_scan_omp_ex(
+            scores, sp_ptr, cap = None, None, 0
+            if want_scores:
+                p = self.params
+                n_th = len(search_offsets(p["search_angular_size"], p["search_angular_resolution"]))
+                n_lin = len(search_offsets(p["search_linear_size"], p["search_linear_resolution"]))
+                cap = n_th * n_lin * n_lin
+                scores = np.zeros(cap, dtype=np.float64)
+                sp_ptr = scores.ctypes.data_as(_dp)
+            score = lib().orc_matcher_match_scan_omp_scores(
                 self.m, spp, pp, len(pts), pose_io.ctypes.data_as(_dp),
-                cov.ctypes.data_as(_dp), int(omp_threads), C.byref(best), C.byref(used))
-            return dict(score=score, pose=pose_io, covariance=cov.reshape(3, 3),
+                cov.ctypes.data_as(_dp), int(omp_threads), C.byref(best), C.byref(used), sp_ptr, cap)
+            return dict(score=score, pose=pose_io, covariance=cov.reshape(3, 3), scores=scores,
                         best_index=best.value, threads_used=used.value)
         ncand = C.c_size_t(0)
         best = C.c_uint64(0)

@@ -507,9 +507,15 @@ def test_cfg2_full_size():
     assert got["n_candidates"] == 2000000
     # the headline configuration: compacted records in LDS, two blocks per CU
     assert "lane-per-candidate/lds-grid/compact-records" in gpu.last_variant(), gpu.last_variant()
-    exp = ref.matchScan(guess, pts, omp_threads=os.cpu_count())
+    exp = ref.matchScan(guess, pts, omp_threads=os.cpu_count(), want_scores=True)
     want = _big_winner(2)
     assert got["best_index"] == exp["best_index"] == want["best_index"]
+    # EVERY score against the CPU path (src/scan_matcher_ndt.cpp:127),
+    # raw sums and the returned /N scale, all 2,000,000 candidates
+    d_all = np.abs(got["scores"] - exp["scores"])
+    assert float(d_all.max()) < TOL_TIGHT, float(d_all.max())
+    assert float(d_all.max()) / 720 < 1e-5
+    assert int(np.argmin(exp["scores"])) == got["best_index"]
     assert [float(v).hex() for v in got["pose"]] == want["pose_hex"]
     assert abs(got["score"] - want["score"]) < TOL_TIGHT
     assert np.array_equal(got["pose"], exp["pose"])
