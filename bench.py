@@ -42,8 +42,12 @@ HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MAX_CLOCK_HZ = 2.4e9         # MI355X_MICROARCH.md chip table
 VALU_CYCLES_PER_INST = 4.0   # FP64 and VOP3 wave64 instructions issue in 4 cycles (experiments/ubench_f64.hip)
 FP64_PEAK_TFLOPS = 78.6      # vector FP64
-PMC_FILE = os.path.join(_ROOT, "profiles", "r02_pmc.json")
+PMC_CANDIDATES = ("r03_pmc.json", "r02_pmc.json")   # the newest committed counter passes win
+PMC_NAME = next((n for n in PMC_CANDIDATES if os.path.exists(os.path.join(_ROOT, "profiles", n))),
+                PMC_CANDIDATES[0])
+PMC_FILE = os.path.join(_ROOT, "profiles", PMC_NAME)
 CPU_BASELINE_FILE = os.path.join(_ROOT, "profiles", "r02_cpu_baselines.json")
+PREWARM_SECONDS = 0.5        # untimed launches before --warmup: the chip reaches its sustained clocks
 
 
 # --------------------------------------------------------------------------------------
@@ -149,12 +153,13 @@ def roofline(kernel, kernel_ms, units, n_cu, pmc, expected_dispatch_note):
 
     VALU issue: achieved = VALU wave-instructions per launch (SQ_INSTS_VALU, committed PMC
     pass of this same workload; the count is a property of the workload, not of the run)
-    / the kernel's average duration measured live with HIP events on the launch stream;
-    peak = SIMDs x clock / 4 cycles per FP64 / VOP3 wave-instruction, at the clock the
-    chip sustained in THIS run: the workload's busy cycles (SQ_BUSY_CU_CYCLES / CUs, same
-    pass) / the live duration.  So frac = SQ_INSTS_VALU x 4 / (4 x SQ_BUSY_CU_CYCLES), the
-    fraction of the kernel's SIMD cycles in which a VALU instruction issues, reproducible
-    from profiles/ alone (frac_pmc); frac_at_max_clock prices it against 2.4 GHz."""
+    / the kernel's average duration measured LIVE with HIP events on the launch stream;
+    peak = the chip's fixed issue peak: SIMDs x 2.4 GHz (MI355X_MICROARCH.md chip table)
+    / 4 cycles per FP64 / VOP3 wave-instruction = 614.4 G wave-instr/s for 256 CUs.  So
+    `frac` moves with the live kernel time.  `issue_slot_occupancy_pmc` = SQ_INSTS_VALU x 4
+    / (4 x SQ_BUSY_CU_CYCLES) is the run-invariant share of the kernel's own SIMD cycles
+    in which a VALU instruction issues (reproducible from profiles/ alone); the two differ
+    by sustained clock / 2.4 GHz."""
     t = kernel_ms * 1e-3
     alg_bytes = units * BYTES_PER_UNIT
     hbm = {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s", "achieved": None, "frac": None,
@@ -169,7 +174,7 @@ def roofline(kernel, kernel_ms, units, n_cu, pmc, expected_dispatch_note):
             "frac": None, "traffic": None, "kernel": kernel, "kernel_ms_avg": kernel_ms}
     k = (pmc or {}).get("kernels", {}).get(kernel)
     if not k or "SQ_INSTS_VALU" not in k:
-        roof["note"] = "profiles/r02_pmc.json has no counters for this kernel"
+        roof["note"] = "profiles/%s has no counters for this kernel" % PMC_NAME
         return roof, hbm
     n_simd = 4 * n_cu
     # cycles are the workload's (counted under the profiler), time is this run's: the clock
@@ -179,16 +184,17 @@ def roofline(kernel, kernel_ms, units, n_cu, pmc, expected_dispatch_note):
     clock = busy_cycles / t
     dur_pmc = k.get("avg_duration_ns", {}).get("sq1")
     achieved = k["SQ_INSTS_VALU"] / t / 1e9
-    peak = n_simd * clock / VALU_CYCLES_PER_INST / 1e9
+    peak = n_simd * MAX_CLOCK_HZ / VALU_CYCLES_PER_INST / 1e9
     roof.update(
         achieved=achieved, peak=peak, frac=achieved / peak,
-        frac_pmc=k["SQ_INSTS_VALU"] * VALU_CYCLES_PER_INST / (4.0 * k["SQ_BUSY_CU_CYCLES"]),
-        frac_at_max_clock=achieved / (n_simd * MAX_CLOCK_HZ / VALU_CYCLES_PER_INST / 1e9),
-        sustained_clock_GHz=clock / 1e9,
+        peak_note="%d SIMDs x %.1f GHz / %.0f cycles per wave-instruction" % (n_simd, MAX_CLOCK_HZ / 1e9,
+                                                                             VALU_CYCLES_PER_INST),
+        issue_slot_occupancy_pmc=k["SQ_INSTS_VALU"] * VALU_CYCLES_PER_INST / (4.0 * k["SQ_BUSY_CU_CYCLES"]),
+        sustained_clock_GHz_est=clock / 1e9,
         clock_in_pmc_pass_GHz=(busy_cycles / (dur_pmc * 1e-9) / 1e9) if dur_pmc else None,
         valu_insts_per_launch=k["SQ_INSTS_VALU"],
         valu_insts_per_unit=k["SQ_INSTS_VALU"] * 64.0 / units,
-        source="profiles/r02_pmc.json (experiments/profile_r02.sh) + live HIP-event kernel time; "
+        source="profiles/%s (experiments/profile_r03.sh) + live HIP-event kernel time; " % PMC_NAME
                + expected_dispatch_note)
     if "SQ_ACTIVE_INST_VALU" in k and "SQ_BUSY_CYCLES" in k:
         # SQ_ACTIVE_INST_VALU counts quad-cycles a SIMD spends issuing VALU work
@@ -208,7 +214,7 @@ def roofline(kernel, kernel_ms, units, n_cu, pmc, expected_dispatch_note):
         roof["traffic"] = traffic
         hbm.update(traffic=traffic, achieved=traffic / t / 1e9, frac=traffic / t / 1e9 / HBM_PEAK_GBPS,
                    traffic_bytes_per_unit=traffic / units,
-                   traffic_source="(2*FETCH_SIZE + WRITE_SIZE) KiB, separate --pmc passes, profiles/r02_pmc.json")
+                   traffic_source="(2*FETCH_SIZE + WRITE_SIZE) KiB, separate --pmc passes, profiles/%s" % PMC_NAME)
     return roof, hbm
 
 
@@ -325,7 +331,7 @@ def cfg1_search_bench(matcher_cls, synth, device_index, with_cpu):
     return out
 
 
-def default_search_bench(matcher_cls, synth, device_index, reps=300):
+def default_search_bench(matcher_cls, synth, device_index, reps=300, with_cpu=True):
     """The node's actual default workload (reference src/scan_matcher_ndt.cpp:37-44): 100 of
     720 beams, 21 x 21 x 80 = 35,280 candidates, per accepted scan the mapper runs
     reset + addScans + scoreScan + matchScan (src/ndt_mapper.cpp:508-515).  Host-call
@@ -386,6 +392,37 @@ def default_search_bench(matcher_cls, synth, device_index, reps=300):
             c_host = json.loads(r.stdout.strip().splitlines()[-1])
     out = default_search_record(units, match_ms, match_p99, kernel_ms, n_kernels, variant, score_ms,
                                 points_ms, add_ms, cycle_ms, cycle_p99, loop_ms, batch_ms)
+    if with_cpu:
+        # the reference's own execution of the same calls: the oracle, one thread, this box
+        sys.path.insert(0, os.path.join(_ROOT, "tests"))
+        import oracle_lib as O
+        ref = O.ScanMatcherNDT()
+        ref.initialize(**params)
+        ref.addScans(scans)
+
+        def med_cpu(fn, n):
+            ts = []
+            for i in range(n + 1):
+                t0 = time.perf_counter()
+                r = fn()
+                if i > 0:
+                    ts.append(time.perf_counter() - t0)
+            return statistics.median(ts) * 1e3, r
+        cpu_match_ms, exp = med_cpu(lambda: ref.matchScan(guess, pts), 5)
+        cpu_score_ms, _ = med_cpu(lambda: ref.scoreScan(guess, pts), 50)
+        cpu_add_ms, _ = med_cpu(lambda: (ref.reset(), ref.addScans(scans)), 20)
+        # ParticleFilter::measure's loop (src/particle_filter.cpp:81-87) incl. the reference's
+        # per-particle copy of the point vector (src/scan.cpp:67-70)
+        cpu_loop_ms, _ = med_cpu(lambda: O.pf_measure(ref, poses, pts, copy_points=True), 20)
+        out["cpu_single_thread"] = {
+            "match_scan_ms": cpu_match_ms, "score_scan_ms": cpu_score_ms, "add_scans_ms": cpu_add_ms,
+            "mapper_cycle_ms": cpu_match_ms + cpu_score_ms + cpu_add_ms,
+            "measure_500_particles_ms": cpu_loop_ms,
+            "kind": "port (oracle/ndt2d_oracle.c, 1 thread: the reference's execution model)",
+            "match_scan_best_index": exp["best_index"],
+            "note": "through the UNCHANGED per-particle loop the GPU plugin is slower than this CPU "
+                    "path (one launch per particle); the batched entry point needs the one-line node "
+                    "change of INTEGRATION.md section 4"}
     if c_host is not None:
         out["c_host"] = dict(c_host, what="ndt_2d_amd/tools/latency_probe.c: the same calls through the C-ABI "
                                           "from a C program, medians of 2000 (500 for addScans / the cycle)")
@@ -429,6 +466,81 @@ def in_grid_share(np, synth, params, guess, pts, grid, samples=2000000):
     return float(inside.mean())
 
 
+def self_launch(n_gpus, argv):
+    """`python bench.py --gpus N` without a launcher: the same job the driver starts with
+    torch.distributed.run, as a child process (one rank per GPU, rendezvous on 127.0.0.1,
+    a free port); its stdout -- the one JSON line of rank 0 -- is relayed, its return
+    code becomes ours."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    sys.stdout.write(proc.stdout.decode(errors="replace"))
+    sys.stdout.flush()
+    return proc.returncode
+
+
+def gpu_clock_mhz(torch, device_index=0):
+    """The shader clock the driver reports for THIS GPU right now (sysfs pp_dpm_sclk of its
+    PCI function, the level marked '*'), or None.  A host shows many cards: the device is
+    found by its PCI address."""
+    try:
+        pr = torch.cuda.get_device_properties(device_index)
+        addr = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        with open("/sys/bus/pci/devices/%s/pp_dpm_sclk" % addr) as f:
+            for ln in f:
+                if "*" in ln:
+                    return float(ln.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+    except (OSError, ValueError, IndexError, AttributeError, RuntimeError):
+        pass
+    return None
+
+
+def cfg4_single_gpu_bench(matcher_cls, synth, shard, np, torch, dev_index, steps=3):
+    """BASELINE.json configs[3] (cfg-4, the 8-GPU loop-closure lattice) on ONE GPU: the anchor
+    a 1 -> N curve of `--gpus N` lines is read against.  Whole lattice per step, `steps`
+    timed steps after one warm-up; the oracle's whole-lattice winner is asserted."""
+    params = synth.matcher_params(4)
+    guess, pts, _ = synth.query_scan(4)
+    m = matcher_cls(dev_index)
+    m.initialize("global_scan_matcher", **params)
+    m.addScans(synth.map_scans(4))
+    n_th, n_lin, n_beams = m.prepare_search(guess, pts)
+    units = n_th * n_lin * n_lin * n_beams
+    ms, kernel_ms = [], []
+    for i in range(steps + 1):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        m.match_launch(0, n_th)
+        rec = m.match_fetch()
+        if i > 0:
+            ms.append((time.perf_counter() - t0) * 1e3)
+            kernel_ms.append(m.last_launch_ms()[0])
+    res = m.finish_match(rec)
+    variant = m.last_variant()
+    best_index = int(rec[1])
+    expect = 80443810   # tests/golden/big_winners.json cfg4: the oracle over all 315,508,257 candidates
+    if best_index != expect:
+        raise SystemExit("bench.py: cfg-4 winner %d differs from the oracle's %d" % (best_index, expect))
+    share = in_grid_share(np, synth, params, guess, pts, m.grid())
+    m.close()
+    t = statistics.median(ms)
+    return {"workload": "cfg-4 (BASELINE.json configs[3]) on one GPU: 501 x 501 x 1257 = 315,508,257 candidates "
+                        "x 720 beams, the whole lattice per step",
+            "units_per_step": units, "steps": steps, "ms_per_step": t, "kernel_ms": statistics.median(kernel_ms),
+            "value": units / (t * 1e-3), "unit": "candidate-beams/s",
+            "in_grid_share_of_units": share, "value_in_grid_units": units * share / (t * 1e-3),
+            "best_index": best_index, "score": res["score"], "pose": [float(v) for v in res["pose"]],
+            "kernel_variant": variant,
+            "what": "the N = 1 point of the strong-scaling curve `bench.py --gpus N` (N > 1) reports"}
+
+
 # --------------------------------------------------------------------------------------
 
 def main():
@@ -440,7 +552,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-particles", action="store_true")
     ap.add_argument("--no-default-search", action="store_true")
+    ap.add_argument("--no-anchors", action="store_true",
+                    help="N = 1: skip the cfg-4 / cfg-5 single-GPU anchors of the 8-GPU workloads")
+    ap.add_argument("--prewarm", type=float, default=PREWARM_SECONDS,
+                    help="seconds of untimed launches before --warmup (profiler passes use 0)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # run directly (`python bench.py --gpus N`): start the N ranks as a CHILD job before
+        # anything here has touched the GPU (never exec: see gpurun's rules), relay its line
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
 
     # Native libraries write to stdout as well (RCCL flushes a version banner at
     # exit): keep the real stdout for the one JSON line, send the rest to stderr.
@@ -451,11 +572,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run "
-                             "--nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world
     cfg = {"auto": 2 if world == 1 else 4, "cfg2": 2, "cfg4": 4}[args.workload]
     if args.steps is None:
         args.steps = 200 if cfg == 2 else 20
@@ -563,6 +680,17 @@ def main():
                 pending[slot].wait()
                 pending[slot] = None
 
+    # untimed pre-warm: launches for --prewarm seconds, so that the timed region -- 10 ms
+    # under the driver's --steps 20 -- runs at the clocks the chip sustains, not at the
+    # ones it idles at
+    n_prewarm = 0
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < args.prewarm:
+        for _ in range(8):
+            step()
+        drain()
+        torch.cuda.synchronize()
+        n_prewarm += 8
     for _ in range(args.warmup):
         step()
     drain()
@@ -571,6 +699,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    clock_mhz = gpu_clock_mhz(torch, dev_index)   # sampled while the queued steps run
     drain()
     fence()
     elapsed = time.perf_counter() - t0
@@ -583,6 +712,12 @@ def main():
         all_reduce(t, dist.ReduceOp.MAX)
     elapsed = float(t[0])
     ms_per_step = elapsed / args.steps * 1e3
+    # every rank's average search-kernel time (slot per rank, summed = gathered)
+    rank_kernel = torch.zeros(world, dtype=torch.float64, device=dev)
+    rank_kernel[rank] = sum(kernel_ms) / max(len(kernel_ms), 1)
+    if collective:
+        all_reduce(rank_kernel, dist.ReduceOp.SUM)
+    rank_kernel_ms = [float(v) for v in rank_kernel.cpu()]
 
     # the result the search produced
     rec = tables[(n_steps_run[0] - 1) & 1].cpu().numpy()
@@ -645,13 +780,22 @@ def main():
             "roofline_hbm": hbm,
             "match_result": {"score": result["score"], "pose": [float(v) for v in result["pose"]],
                              "best_index": best_index},
+            "prewarm": {"seconds": args.prewarm, "steps": n_prewarm,
+                        "what": "untimed launches before --warmup (clocks reach their sustained level)"},
+            "shader_clock_MHz_sysfs": clock_mhz,
+            "rank_kernel_ms": {"max": max(rank_kernel_ms), "mean": sum(rank_kernel_ms) / len(rank_kernel_ms),
+                               "per_rank": rank_kernel_ms},
         }
+        if collective:
+            line["rccl_world_size"] = dist.get_world_size() if backend == "nccl" else None
+            line["collective_backend"] = backend
         if cfg == 4:
             share = in_grid_share(np, synth, params, guess, pts, grid)
             line["config"]["in_grid_share_of_units"] = share
             line["value_in_grid_units"] = line["value"] * share
             if single is not None:
                 line["single_gpu_same_workload"] = single
+                line["speedup_vs_single_gpu_same_workload"] = single["ms_per_step"] / ms_per_step
         if world == 1 and cfg == 2:
             # PCIe-inclusive figure (never `value`): the whole matchScan call with host
             # buffers in and out (subsample, tables, H2D, search, D2H of the 12-double record)
@@ -671,8 +815,17 @@ def main():
             line["particle_filter"] = particle_bench_1gpu(ScanMatcherNDT, synth, torch, dev_index, pmc, n_cu)
         if pf5 is not None:
             line["particle_filter_cfg5" if world == 1 else "particle_filter"] = pf5
+        if world == 1 and cfg == 2 and not args.no_anchors:
+            # the single-GPU points of the two 8-GPU workloads (BASELINE.json configs[3], [4])
+            m.set_stream(None)
+            line["cfg4_single_gpu"] = cfg4_single_gpu_bench(ScanMatcherNDT, synth, shard, np, torch, dev_index)
+            if pf5 is None and not args.no_particles:
+                line["cfg5_single_gpu"] = particle_bench_sharded(
+                    ScanMatcherNDT, synth, shard, torch, dist, dev, dev_index, 0, 1, backend, None,
+                    torch.cuda.synchronize)
         if world == 1 and not args.no_default_search:
-            line["default_search"] = default_search_bench(ScanMatcherNDT, synth, dev_index)
+            line["default_search"] = default_search_bench(ScanMatcherNDT, synth, dev_index,
+                                                          with_cpu=not args.no_cpu_baseline)
             line["cfg1_search"] = cfg1_search_bench(ScanMatcherNDT, synth, dev_index,
                                                     not args.no_cpu_baseline)
         os.write(json_fd, (json.dumps(line) + "\n").encode())
@@ -717,13 +870,15 @@ def particle_bench_sharded(matcher_cls, synth, shard, torch, dist, dev, dev_inde
         table.zero_()
         if n_local:
             m.score_poses_launch(d_parts.data_ptr(), n_local, d_w.data_ptr(), table[rank].data_ptr())
-        all_reduce(table, dist.ReduceOp.SUM)                   # total particle weight + moments
+        if all_reduce is not None:
+            all_reduce(table, dist.ReduceOp.SUM)               # total particle weight + moments
         torch.sum(table, dim=0, out=d_sum)                      # rank order, every rank the same
         if n_local:
             m.pf_finalize_launch(d_parts.data_ptr(), n_local, d_w.data_ptr(), d_sum.data_ptr(),
                                  d_out.data_ptr())
         d_var.copy_(d_out[7:8])
-        all_reduce(d_var, dist.ReduceOp.SUM)                    # theta variance, second pass
+        if all_reduce is not None:
+            all_reduce(d_var, dist.ReduceOp.SUM)                # theta variance, second pass
 
     for _ in range(warmup):
         step()
@@ -734,7 +889,8 @@ def particle_bench_sharded(matcher_cls, synth, shard, torch, dist, dev, dev_inde
     fence()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    all_reduce(t, dist.ReduceOp.MAX)
+    if all_reduce is not None:
+        all_reduce(t, dist.ReduceOp.MAX)
     ms = float(t[0]) / steps * 1e3
     out_h = d_out.cpu().numpy()
     units = n_total * n_beams
@@ -743,7 +899,8 @@ def particle_bench_sharded(matcher_cls, synth, shard, torch, dist, dev, dev_inde
            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": ms,
            "value": units / (ms * 1e-3), "unit": "candidate-beams/s", "scaling": "strong",
            "units_per_step": units, "variant": m.last_variant(),
-           "collectives_per_step": "all-reduce [N,8] moment sums + all-reduce [1] theta variance",
+           "collectives_per_step": ("all-reduce [N,8] moment sums + all-reduce [1] theta variance"
+                                    if all_reduce is not None else "none (one GPU, no process group)"),
            "result": {"sum_w": float(out_h[0]), "mean": [float(v) for v in out_h[1:4]],
                       "cov_xx_xy_yy": [float(v) for v in out_h[4:7]],
                       "theta_variance": float(d_var.cpu()[0])}}

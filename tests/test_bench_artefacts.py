@@ -59,3 +59,18 @@ def test_cpu_baseline_and_results(line):
     # BASELINE's CPU-runnable config beside its CPU timing
     c1 = line["cfg1_search"]
     assert c1["units"] == 17640 * 720 and c1["cpu_single_thread_ms"] > c1["gpu_match_scan_ms"] > 0
+
+
+def test_bench_gpus_n_run_directly_starts_its_ranks_as_a_child_job():
+    """`python bench.py --gpus 2` without a launcher starts torch.distributed.run as a child
+    process and hands its return code on: here (no GPU) the ranks refuse to run."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1",
+                        "--warmup", "0"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU box runs this for real (tests/test_gpu_dist_sharded.py)")
+    assert r.returncode != 0
+    assert "no GPU visible" in r.stderr and "torch.distributed" in r.stderr
