@@ -247,6 +247,10 @@ hipError_t launch_occupancy_render(const OccupancyArgs & args, double occ_thresh
 // receives one partial record per wave (*n_workers_out of them).
 size_t match_lane_outer_doubles(const MatchArgs & args);
 bool match_lane_supported(const MatchArgs & args, size_t lds_per_block);
+// How a launch's theta steps are cut into slabs of at most kLaneSlabItems work items (see
+// there): *slab_th theta steps per slab, *n_slabs slabs; false if no cut within the limits
+// exists.  Most searches are one slab.
+bool lane_slabs(const MatchArgs & args, uint32_t * slab_th, uint32_t * n_slabs);
 // no_skip: every beam of every candidate takes the exact path (no occupancy / bound
 // / negligible-term skipping) -- the bit-exactness control for the skipping logic.
 hipError_t launch_match_lane(const MatchArgs & args, double * outer, double * workspace,
@@ -318,8 +322,13 @@ enum { kVariantAuto = 0, kVariantLds = 1, kVariantGlobal = 2, kVariantGridMask =
 // a cache line of its own.
 constexpr uint32_t kItemShards = 8;
 constexpr uint32_t kItemShardStride = 64;   // in uint32: 256 bytes
-// The lane-per-candidate search leaves one record per work item (theta x 8x8 patch);
-// lattices with more items than this (1.5 GB of records) take the wave mapping.
+// The lane-per-candidate search leaves one record per work item (theta x 8x8 patch).  A
+// lattice of more than kLaneSlabItems items (192 MB of records) is searched in slabs of
+// whole theta steps, launch after launch on the stream, each slab's records reduced to 256
+// before the next one overwrites them; at most kMaxLaneSlabs slabs (larger ones if need
+// be), none beyond kMaxLaneItems items -- what neither allows takes the wave mapping.
+constexpr uint64_t kLaneSlabItems = 1ull << 21;
+constexpr uint32_t kMaxLaneSlabs = 32;
 constexpr uint64_t kMaxLaneItems = 1ull << 24;
 // launch_match: lattices with fewer (theta, 8x8 patch) items than this take the
 // small-lattice search (beams split across the waves of a block); it can hold

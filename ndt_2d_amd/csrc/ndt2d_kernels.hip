@@ -507,15 +507,17 @@ hipError_t dispatch_match_nbl(const MatchArgs & args, uint32_t blocks, size_t ld
 }  // namespace
 
 // Workspace layout: [work-item counters, 2 KB][256 records of the first reduction
-// stage][partial records: one per wave (wave mapping) or per work item (lane mapping)]
+// stage for each of up to kMaxLaneSlabs slabs][partial records: one per wave (wave
+// mapping) or per work item of a slab (lane mapping)]
 constexpr size_t kCounterDoubles = static_cast<size_t>(kItemShards) * kItemShardStride * sizeof(uint32_t) / sizeof(double);
-constexpr size_t kWorkspaceHead = kCounterDoubles + 256 * static_cast<size_t>(kRecord);
+constexpr size_t kWorkspaceHead = kCounterDoubles + 256 * static_cast<size_t>(kMaxLaneSlabs) * kRecord;
 
 size_t match_workspace_doubles(const MatchArgs & args)
 {
   const uint64_t p1 = (args.n_lin + 7) / 8;
-  uint64_t records = static_cast<uint64_t>(args.th_end - args.th_begin) * p1 * p1;
-  if (records > kMaxLaneItems) records = 0;   // the wave mapping will run
+  uint32_t slab_th = 0, n_slabs = 0;
+  uint64_t records = 0;   // (no cut into slabs: the wave mapping will run)
+  if (lane_slabs(args, &slab_th, &n_slabs)) records = static_cast<uint64_t>(slab_th) * p1 * p1;
   const uint64_t waves = static_cast<uint64_t>(kMaxMatchBlocks) * kMatchWaves;
   if (records < waves) records = waves;
   return kWorkspaceHead + static_cast<size_t>(records) * kRecord;
@@ -616,12 +618,56 @@ hipError_t launch_match(const MatchArgs & args_in, double * workspace, double * 
     }
     return hipSuccess;
   }
+  uint32_t n_staged = 0;   // records the slabs of a multi-slab lane search left in `staged`
+  uint32_t slabs_run = 1;
   if (use_lane)
   {
-    e = launch_match_lane(args, outer, workspace, kMaxMatchBlocks * kMatchWaves, lim.cus,
-                          lim.lds_per_block, (force_variant & kVariantNoSkip) != 0, stream,
-                          ev_main_start, &n_workers, &lane_records_mode);
-    if (e != hipSuccess) return e;
+    uint32_t slab_th = args.th_end - args.th_begin, n_slabs = 1;
+    if (!lane_slabs(args, &slab_th, &n_slabs)) return hipErrorInvalidValue;
+    if (n_slabs == 1)
+    {
+      e = launch_match_lane(args, outer, workspace, kMaxMatchBlocks * kMatchWaves, lim.cus,
+                            lim.lds_per_block, (force_variant & kVariantNoSkip) != 0, stream,
+                            ev_main_start, &n_workers, &lane_records_mode);
+      if (e != hipSuccess) return e;
+    }
+    else
+    {
+      // Slab after slab on the stream: table pre-kernel, search, first reduction stage into
+      // the slab's own 256 records -- the per-item records of a slab are dead before the
+      // next slab's search overwrites them.  Records carry whole-lattice flat indices, so
+      // the final stage below treats the slabs' records like any others.
+      const uint32_t th_total = args.th_end - args.th_begin;
+      for (uint32_t s = 0; s < n_slabs; ++s)
+      {
+        const uint32_t t0 = s * slab_th;
+        const uint32_t cnt = min(slab_th, th_total - t0);
+        MatchArgs sub = args;
+        sub.th_begin = args.th_begin + t0 * args.th_stride;
+        sub.th_end = sub.th_begin + cnt;
+        if (args.scores != nullptr) sub.scores = args.scores + static_cast<size_t>(t0) * args.n_lin * args.n_lin;
+        uint32_t n_slab_records = 0;
+        e = launch_match_lane(sub, outer, workspace, kMaxMatchBlocks * kMatchWaves, lim.cus,
+                              lim.lds_per_block, (force_variant & kVariantNoSkip) != 0, stream,
+                              s == 0 ? ev_main_start : nullptr, &n_slab_records, &lane_records_mode);
+        if (e != hipSuccess) return e;
+        if (s + 1 == n_slabs && ev_main_done != nullptr)
+        {
+          e = hipEventRecord(ev_main_done, stream);
+          if (e != hipSuccess) return e;
+          ev_main_done = nullptr;
+        }
+        const uint32_t per_block = (n_slab_records + 255) / 256;
+        const uint32_t stage_blocks = (n_slab_records + per_block - 1) / per_block;
+        hipLaunchKernelGGL(match_reduce_kernel, dim3(stage_blocks), dim3(256), 0, stream, workspace,
+                           n_slab_records, per_block, staged + static_cast<size_t>(n_staged) * kRecord,
+                           static_cast<double *>(nullptr), 0);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        n_staged += stage_blocks;
+      }
+      slabs_run = n_slabs;
+    }
   }
   else
   {
@@ -666,7 +712,12 @@ hipError_t launch_match(const MatchArgs & args_in, double * workspace, double * 
   // Up to 8,192 records: one block.  More (the lane mapping leaves one per work item):
   // 256 blocks first, each over a contiguous share.
   const double * records = workspace;
-  if (n_workers > kMaxMatchBlocks * kMatchWaves)
+  if (n_staged > 0)
+  {
+    records = staged;
+    n_workers = n_staged;
+  }
+  else if (n_workers > kMaxMatchBlocks * kMatchWaves)
   {
     const uint32_t per_block = (n_workers + 255) / 256;
     const uint32_t stage_blocks = (n_workers + per_block - 1) / per_block;
@@ -698,7 +749,7 @@ hipError_t launch_match(const MatchArgs & args_in, double * workspace, double * 
                                             : "match/lane-per-candidate/lds-map+global-records/block-map/div")
                                     : (pow2 ? "match/lane-per-candidate/lds-map+global-records/pow2"
                                             : "match/lane-per-candidate/lds-map+global-records/div"));
-      info->n_kernels = 3;
+      info->n_kernels = n_staged > 0 ? static_cast<int>(3 * slabs_run + 1) : 3;
     }
     else
     {

@@ -380,6 +380,17 @@ match_lane_compact_kernel(const MatchArgs a, const double4 * __restrict__ outer,
   match_lane_body<kLaneThreadsCompact, true, true, true, true>(a, outer, map_image, geo);
 }
 
+// Maps too large for LDS (records gathered from the 64-byte-stride HBM copy through L2):
+// the LDS image is the occupancy map alone, so two 768-thread blocks fit a CU as well --
+// six waves per SIMD to cover the gathers' latency instead of four.
+template <bool POW2>
+__global__ void __launch_bounds__(kLaneThreadsCompact) __attribute__((amdgpu_waves_per_eu(6)))
+match_lane_gather6_kernel(const MatchArgs a, const double4 * __restrict__ outer,
+                          const uint8_t * __restrict__ map_image, const LaneGeom geo)
+{
+  match_lane_body<kLaneThreadsCompact, POW2, false, true, false>(a, outer, map_image, geo);
+}
+
 bool pow2_grid(const MatchArgs & args) { return args.grid.pow2 != 0; }
 
 bool lane_records_in_lds(const MatchArgs & args, size_t map_bytes, size_t lds_per_block)
@@ -390,10 +401,35 @@ bool lane_records_in_lds(const MatchArgs & args, size_t map_bytes, size_t lds_pe
 
 }  // namespace
 
+bool lane_slabs(const MatchArgs & args, uint32_t * slab_th, uint32_t * n_slabs)
+{
+  const uint64_t p1 = (args.n_lin + kPatch - 1) / kPatch;
+  const uint64_t per_theta = p1 * p1;
+  const uint64_t th_total = args.th_end - args.th_begin;
+  if (per_theta == 0 || th_total == 0 || per_theta > kMaxLaneItems) return false;
+  uint64_t slab_items = kLaneSlabItems;
+  if (const char * env = std::getenv("NDT2D_LANE_SLAB_ITEMS"))   // tests: slabs on small lattices
+  {
+    const long long v = std::atoll(env);
+    if (v > 0 && static_cast<uint64_t>(v) <= kMaxLaneItems) slab_items = static_cast<uint64_t>(v);
+  }
+  uint64_t th = slab_items / per_theta;
+  if (th < 1) th = 1;
+  const uint64_t at_least = (th_total + kMaxLaneSlabs - 1) / kMaxLaneSlabs;
+  if (th < at_least) th = at_least;
+  if (th > th_total) th = th_total;
+  if (th * per_theta > kMaxLaneItems) return false;
+  *slab_th = static_cast<uint32_t>(th);
+  *n_slabs = static_cast<uint32_t>((th_total + th - 1) / th);
+  return true;
+}
+
 size_t match_lane_outer_doubles(const MatchArgs & args)
 {
-  // rotated-beam table + the occupancy-map image (at most 256 x 256 bytes)
-  return static_cast<size_t>(args.th_end - args.th_begin) * args.n_beams * 4 +
+  // rotated-beam table of one slab + the occupancy-map image (at most 256 x 256 bytes)
+  uint32_t slab_th = args.th_end - args.th_begin, n_slabs = 1;
+  (void)lane_slabs(args, &slab_th, &n_slabs);
+  return static_cast<size_t>(slab_th) * args.n_beams * 4 +
          static_cast<size_t>(kMapStride) * kMaxMapCells / sizeof(double);
 }
 
@@ -402,11 +438,10 @@ bool match_lane_supported(const MatchArgs & args, size_t lds_per_block)
   LaneGeom geo;
   size_t map_bytes = 0;
   if (args.grid.occ_bits == nullptr || !lane_geometry(args, lds_per_block, &geo, &map_bytes)) return false;
-  const uint64_t p1 = (args.n_lin + kPatch - 1) / kPatch;
-  const uint64_t items = static_cast<uint64_t>(args.th_end - args.th_begin) * p1 * p1;
+  uint32_t slab_th = 0, n_slabs = 0;
   // (24-bit multiplies index the grid rows and the LDS records)
-  return map_bytes <= lds_per_block && items <= kMaxLaneItems && args.grid.size_x < (1u << 24) &&
-         args.grid.ncell < (1u << 24);
+  return map_bytes <= lds_per_block && lane_slabs(args, &slab_th, &n_slabs) &&
+         args.grid.size_x < (1u << 24) && args.grid.ncell < (1u << 24);
 }
 
 hipError_t launch_match_lane(const MatchArgs & args_in, double * outer, double * workspace,
@@ -462,7 +497,11 @@ hipError_t launch_match_lane(const MatchArgs & args_in, double * outer, double *
   if (blocks > max_blocks) blocks = max_blocks;
   if (blocks == 0) blocks = 1;
 
-  const bool lds_records = lane_records_in_lds(args, map_bytes, lds_per_block);
+  // (NDT2D_LANE_RECORDS=global: gather the records from HBM although they would fit LDS --
+  // what a map too large for LDS costs, measured on a workload that has both forms)
+  const char * knob_rec = std::getenv("NDT2D_LANE_RECORDS");
+  const bool lds_records = lane_records_in_lds(args, map_bytes, lds_per_block) &&
+                           !(knob_rec != nullptr && knob_rec[0] == 'g');
   size_t lds_bytes =
     map_bytes +
     (lds_records ? static_cast<size_t>(args.grid.ncell + 1) * kCellDoubles * sizeof(double) : 0);
@@ -482,9 +521,14 @@ hipError_t launch_match_lane(const MatchArgs & args_in, double * outer, double *
   {
     *records_mode_out = (compact ? 2 : (lds_records ? 1 : 0)) | (geo.block_log2 > 0 ? 4 : 0);
   }
-  if (compact)
+  // records gathered from HBM: the same block geometry when two maps fit a CU
+  // (NDT2D_LANE_GATHER6=0: the one-block form, for A/B runs)
+  const char * knob6 = std::getenv("NDT2D_LANE_GATHER6");
+  const bool gather6 = !compact && !small && dynamic_items && !lds_records &&
+                       2 * map_bytes <= lds_per_block && !(knob6 != nullptr && knob6[0] == '0');
+  if (compact || gather6)
   {
-    lds_bytes = map_bytes + compact_bytes;
+    lds_bytes = compact ? map_bytes + compact_bytes : map_bytes;
     const uint32_t wpb = kLaneThreadsCompact / kWave;
     blocks = static_cast<uint32_t>((n_items + wpb - 1) / wpb);
     uint32_t cap = 2 * static_cast<uint32_t>(cus);
@@ -520,6 +564,11 @@ hipError_t launch_match_lane(const MatchArgs & args_in, double * outer, double *
   if (compact)
   {
     e = launch(match_lane_compact_kernel, kLaneThreadsCompact);
+  }
+  else if (gather6)
+  {
+    e = pow2 ? launch(match_lane_gather6_kernel<true>, kLaneThreadsCompact)
+             : launch(match_lane_gather6_kernel<false>, kLaneThreadsCompact);
   }
   else
   {

@@ -56,17 +56,18 @@ constexpr int kChunks = 8;
 constexpr int kPhaseA = 2;               // beams per dense step
 constexpr size_t kLdsBudget = 160 * 1024;
 
-template <int THREADS>
+template <int THREADS, bool SCREEN>
 struct CompactLayout
 {
   static constexpr int kWaves = THREADS / kWave;
   // occupancy bitmap (at LDS offset 0), then doubles: [stats kWaves*8][sums THREADS]
-  //          [q_px kWaves*cap][q_py kWaves*cap][q_meta (u32) kWaves*cap/2]; then beams
-  //          (f64), beams (f32, SCREEN only) and, when several waves share a group, the
-  //          chunk sums [groups][kChunks][64].  (SCREEN leaves q_px / q_py unused.)
+  //          [q_px kWaves*cap][q_py kWaves*cap] (unscreened kernel only: the screened one
+  //          queues {beam | lane} words)[q_meta (u32) kWaves*cap/2]; then beams (f64), beams
+  //          (f32, SCREEN only) and, when several waves share a group, the chunk sums
+  //          [groups][kChunks][64].
+  static constexpr size_t kPointDoubles = SCREEN ? 0 : static_cast<size_t>(kWaves) * kQueueCap;
   static constexpr size_t kFixedDoubles =
-    static_cast<size_t>(kWaves) * 8 + THREADS + 2 * static_cast<size_t>(kWaves) * kQueueCap +
-    static_cast<size_t>(kWaves) * kQueueCap / 2;
+    static_cast<size_t>(kWaves) * 8 + THREADS + 2 * kPointDoubles + static_cast<size_t>(kWaves) * kQueueCap / 2;
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -103,7 +104,7 @@ template <int THREADS, bool POW2, bool SCREEN>
 __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NDT2D_POSES_WAVES_PER_EU)))
 score_poses_compact_kernel(const PosesArgs a, const uint32_t split)
 {
-  using L = CompactLayout<THREADS>;
+  using L = CompactLayout<THREADS, SCREEN>;
   extern __shared__ __align__(16) double lds[];
   const GridDesc & g = a.grid;
   // The occupancy bitmap comes first: lds_word_at() addresses it absolutely, so it
@@ -114,8 +115,8 @@ score_poses_compact_kernel(const PosesArgs a, const uint32_t split)
   double * sh_stats = lds + ((n_words + 3) & ~3u) / 2;
   double * sh_sum = sh_stats + L::kWaves * 8;
   double * q_px_all = sh_sum + THREADS;
-  double * q_py_all = q_px_all + L::kWaves * kQueueCap;
-  uint32_t * q_meta_all = reinterpret_cast<uint32_t *>(q_py_all + L::kWaves * kQueueCap);
+  double * q_py_all = q_px_all + L::kPointDoubles;
+  uint32_t * q_meta_all = reinterpret_cast<uint32_t *>(q_py_all + L::kPointDoubles);
   double * lds_beams = reinterpret_cast<double *>(q_meta_all + L::kWaves * kQueueCap);
   float * lds_beams_f = reinterpret_cast<float *>(lds_beams + 2 * ((a.n_beams + 1) & ~1u));
   // chunk sums [group][chunk][lane], only used (and allocated) when split > 1
@@ -136,8 +137,8 @@ score_poses_compact_kernel(const PosesArgs a, const uint32_t split)
   const uint32_t group = wave / split;          // group of 64 poses inside the block
   const uint32_t part = wave - group * split;   // which share of the chunks
   const uint32_t groups_per_block = L::kWaves / split;
-  double * q_px = q_px_all + wave * kQueueCap;
-  double * q_py = q_py_all + wave * kQueueCap;
+  double * q_px = q_px_all + (SCREEN ? 0 : wave * kQueueCap);
+  double * q_py = q_py_all + (SCREEN ? 0 : wave * kQueueCap);
   uint32_t * q_meta = q_meta_all + wave * kQueueCap;
   double * my_sums = sh_sum + wave * kWave;
   double * my_chunks = sh_chunk + static_cast<size_t>(group) * kChunks * kWave;
@@ -145,9 +146,11 @@ score_poses_compact_kernel(const PosesArgs a, const uint32_t split)
   const uint32_t chunk_len = (a.n_beams + kChunks - 1) / kChunks;
   const uint32_t chunks_per_part = kChunks / split;
 
-  double st[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) st[k] = 0.0;
+  // The eight moment sums of updateStatistics are kept per WAVE in LDS (sh_stats), added to
+  // once per group of 64 poses after a wave-level reduction: carried in registers across the
+  // pose loop they cost 16 VGPRs of the hot loop's budget (and were spilled: 44 bytes of
+  // scratch per lane, 15 MB of HBM writes per cfg-3 launch).
+  if (lane < 8) sh_stats[wave * 8 + lane] = 0.0;
 
   // SCREEN: what a pose needs for the exact transform in phase B, read from its owner
   // lane with wave shuffles
@@ -420,19 +423,29 @@ score_poses_compact_kernel(const PosesArgs a, const uint32_t split)
       }
       // score = sum of (-likelihood) / n  ==  -(sum) / n (:175-177)
       const double score = -sum / static_cast<double>(a.n_beams);
-      if (valid)
+      if (valid) a.scores[i] = score;
+      if (a.partials != nullptr)
       {
-        a.scores[i] = score;
         // sums for ParticleFilter::updateStatistics (particle_filter.cpp:166-200)
-        const double w = score;
-        st[0] += w;
-        st[1] += w * x;
-        st[2] += w * y;
-        st[3] += w * c;
-        st[4] += w * s;
-        st[5] += w * x * x;
-        st[6] += w * x * y;
-        st[7] += w * y * y;
+        // (padding lanes hold a huge coordinate: they contribute exact zeros)
+        const double w = valid ? score : 0.0;
+        const double xv = valid ? x : 0.0, yv = valid ? y : 0.0;
+        double st[8];
+        st[0] = w;
+        st[1] = w * xv;
+        st[2] = w * yv;
+        st[3] = w * c;
+        st[4] = w * s;
+        st[5] = w * xv * xv;
+        st[6] = w * xv * yv;
+        st[7] = w * yv * yv;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) st[k] = wave_sum(st[k]);
+        if (lane == 0)
+        {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) sh_stats[wave * 8 + k] += st[k];
+        }
       }
     }
     if (split > 1) __syncthreads();
@@ -440,13 +453,6 @@ score_poses_compact_kernel(const PosesArgs a, const uint32_t split)
 
   if (a.partials != nullptr)
   {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) st[k] = wave_sum(st[k]);
-    if (lane == 0)
-    {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) sh_stats[wave * 8 + k] = st[k];
-    }
     __syncthreads();
     if (threadIdx.x < 8)
     {
@@ -671,10 +677,12 @@ __global__ void __launch_bounds__(kFewThreads) score_few_kernel(const PosesArgs 
   if (threadIdx.x == 0) raise_host_flag(reinterpret_cast<double *>(f.flag), f.seq);
 }
 
-size_t compact_lds_bytes(const PosesArgs & args, int threads, uint32_t split)
+size_t compact_lds_bytes(const PosesArgs & args, int threads, uint32_t split, bool screen)
 {
-  const size_t fixed = threads == 1024 ? CompactLayout<1024>::kFixedDoubles
-                                       : CompactLayout<256>::kFixedDoubles;
+  const size_t fixed = threads == 1024 ? (screen ? CompactLayout<1024, true>::kFixedDoubles
+                                                 : CompactLayout<1024, false>::kFixedDoubles)
+                                       : (screen ? CompactLayout<256, true>::kFixedDoubles
+                                                 : CompactLayout<256, false>::kFixedDoubles);
   // f64 beams + (screening) their f32 copy, 1.5 doubles per coordinate
   const size_t beams = static_cast<size_t>(3) * ((args.n_beams + 1) & ~1u) + kScreenPadFloats / 2;
   const size_t words = (static_cast<size_t>(args.grid.ncell) + 1 + 31) / 32;
@@ -768,7 +776,7 @@ hipError_t launch_score_few(const PosesArgs & args, const FewPoses * few, const 
 bool poses_compact_supported(const PosesArgs & args, size_t lds_per_block)
 {
   return args.grid.occ_bits != nullptr && args.grid.ncell < kCellMask &&
-         compact_lds_bytes(args, 1024, 1) <= lds_per_block;
+         compact_lds_bytes(args, 1024, 1, false) <= lds_per_block;
 }
 
 hipError_t launch_poses_compact(const PosesArgs & args_in, int cus, bool screen,
@@ -787,7 +795,7 @@ hipError_t launch_poses_compact(const PosesArgs & args_in, int cus, bool screen,
   // Small LDS image: 256-thread blocks, several per CU.  Large occupancy bitmap:
   // one 1024-thread block per CU shares it.
   uint32_t split = choose_split(args, cus, 4);
-  const size_t small = compact_lds_bytes(args, 256, split);
+  const size_t small = compact_lds_bytes(args, 256, split, screen);
   const bool use_small = small <= 48 * 1024;
   const int threads = use_small ? 256 : 1024;
   const uint32_t waves_per_block = static_cast<uint32_t>(threads / kWave);
@@ -795,11 +803,11 @@ hipError_t launch_poses_compact(const PosesArgs & args_in, int cus, bool screen,
   if (!use_small)
   {
     split = choose_split(args, cus, waves_per_block);
-    lds_bytes = compact_lds_bytes(args, 1024, split);
+    lds_bytes = compact_lds_bytes(args, 1024, split, screen);
     while (split > 1 && lds_bytes > kLdsBudget)
     {
       split /= 2;
-      lds_bytes = compact_lds_bytes(args, 1024, split);
+      lds_bytes = compact_lds_bytes(args, 1024, split, screen);
     }
   }
   const uint64_t groups = (args.n_poses + kWave - 1) / kWave;

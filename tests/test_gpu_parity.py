@@ -547,6 +547,86 @@ def test_cfg2_full_size():
     assert got["covariance"][2, 2] == pytest.approx(k22 / s_sum + (u2 / s_sum) ** 2, rel=1e-9)
 
 
+def test_theta_slabs_of_one_search_give_the_single_launch_result(monkeypatch):
+    """A lattice beyond kLaneSlabItems work items is searched slab after slab inside ONE
+    ndt2d_match_launch.  Forced here on the cfg-2 lattice (169 items per
+    theta step): every candidate score bitwise as from the single launch, same winner."""
+    gpu, ref, _, guess, pts = _pair(2)
+    one = gpu.matchScan(guess, pts, want_scores=True)
+    assert "lane-per-candidate" in gpu.last_variant()
+    for slab_items, n_slabs in ((5000, 7), (169, 29)):   # 29 / 1 -> clamped to 7 theta steps per slab
+        monkeypatch.setenv("NDT2D_LANE_SLAB_ITEMS", str(slab_items))
+        many = gpu.matchScan(guess, pts, want_scores=True)
+        assert "lane-per-candidate" in gpu.last_variant()
+        assert gpu.last_launch_ms()[1] == 3 * n_slabs + 1
+        assert np.array_equal(many["scores"], one["scores"])
+        assert many["best_index"] == one["best_index"] and many["score"] == one["score"]
+        assert np.array_equal(many["pose"], one["pose"])
+        assert np.allclose(many["covariance"], one["covariance"], rtol=1e-11, atol=0)
+        # ... and a rank's interleaved share of it
+        monkeypatch.delenv("NDT2D_LANE_SLAB_ITEMS")
+        n_th, n_lin, _ = gpu.prepare_search(guess, pts)
+        gpu.match_launch_strided(1, 3, (n_th - 1 + 2) // 3)
+        want = gpu.match_fetch()
+        monkeypatch.setenv("NDT2D_LANE_SLAB_ITEMS", str(slab_items))
+        gpu.match_launch_strided(1, 3, (n_th - 1 + 2) // 3)
+        got = gpu.match_fetch()
+        assert (got[0], got[1]) == (want[0], want[1])
+        assert np.allclose(got[2:], want[2:], rtol=1e-11, atol=0)
+    monkeypatch.delenv("NDT2D_LANE_SLAB_ITEMS")
+
+
+def test_lattice_beyond_two_to_the_24_work_items_keeps_the_lane_mapping():
+    """513 x 513 x 4189 = 1.1e9 candidates = 17.7 M (theta, patch) work items x 256 beams:
+    beyond the 2^24 items one launch can hold (it took the 4x slower wave mapping in
+    round 2), now nine slabs of the lane-per-candidate search.  The combined winner equals
+    the best of separate launches over theta ranges, its score the oracle's likelihood."""
+    gpu, ref, _, guess, pts = _pair(1, search_linear_size=2.56, search_linear_resolution=0.01,
+                                    search_angular_size=math.pi, search_angular_resolution=0.0015,
+                                    laser_max_beams=256)
+    n_th, n_lin, n_beams = gpu.prepare_search(guess, pts)
+    p1 = (n_lin + 7) // 8
+    assert n_th * p1 * p1 > 2 ** 24 and n_beams == 256
+    gpu.match_launch(0, n_th)
+    full = gpu.match_fetch()
+    assert "lane-per-candidate" in gpu.last_variant(), gpu.last_variant()
+    assert gpu.last_launch_ms()[1] > 4
+    recs = []
+    bounds = np.linspace(0, n_th, 12).astype(int)
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        gpu.match_launch(int(a), int(b))
+        recs.append(gpu.match_fetch())
+        assert gpu.last_launch_ms()[1] == 3          # each a single slab
+    s, i, acc = shard.combine_match_records(recs)
+    assert (s, i) == (full[0], int(full[1]))
+    assert np.allclose(acc, full[2:], rtol=1e-10, atol=0)
+    p = gpu.params
+    dth = O.search_offsets(p["search_angular_size"], p["search_angular_resolution"])
+    dlin = O.search_offsets(p["search_linear_size"], p["search_linear_resolution"])
+    assert (len(dth), len(dlin)) == (n_th, n_lin)
+    ith, ix, iy = shard.decode_index(i, n_lin)
+    use = pts[(np.arange(256) * (len(pts) / 256.0)).astype(int)]
+    c, sn = math.cos(guess[2] + dth[ith]), math.sin(guess[2] + dth[ith])
+    inner = np.stack([use[:, 0] * c - use[:, 1] * sn + guess[0] + dlin[ix],
+                      use[:, 0] * sn + use[:, 1] * c + guess[1] + dlin[iy]], axis=1)
+    assert abs(full[0] + ref.ndt.likelihood(inner)) < TOL_TIGHT
+    # one theta step of the last slab in full against the oracle
+    import torch
+    t = n_th - 3
+    d_scores = torch.zeros(n_lin * n_lin, dtype=torch.float64, device="cuda:0")
+    gpu.match_launch(t, t + 1, scores_ptr=d_scores.data_ptr())
+    gpu.synchronize()
+    slab = d_scores.cpu().numpy()
+    assert slab.min() >= full[0]
+    c, sn = math.cos(guess[2] + dth[t]), math.sin(guess[2] + dth[t])
+    ox = use[:, 0] * c - use[:, 1] * sn + guess[0]
+    oy = use[:, 0] * sn + use[:, 1] * c + guess[1]
+    rng = np.random.default_rng(12)
+    for f in rng.integers(0, n_lin * n_lin, 300):
+        inner = np.stack([ox + dlin[f // n_lin], oy + dlin[f % n_lin]], axis=1)
+        assert abs(slab[f] + ref.ndt.likelihood(inner)) < TOL_TIGHT
+
+
 def _big_winner(cfg):
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "big_winners.json")) as f:
         return json.load(f)["cfg%d" % cfg]
