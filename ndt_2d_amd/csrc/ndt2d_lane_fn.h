@@ -203,6 +203,10 @@ __host__ __device__ inline uint32_t compact_rank_bytes(uint32_t ncell)
   return kRankLead + (((ncell + 1u) * 2u + 15u) & ~15u);
 }
 
+#ifdef NDT2D_LANE_HIST
+__device__ double * g_lane_hist = nullptr;   // set by the kernel from MatchArgs::scores
+#endif
+
 struct LaneCtx
 {
   uint32_t rank_address;       // LDS byte address of entry 0 of the cell -> compact record table (COMPACT)
@@ -405,6 +409,23 @@ __device__ __forceinline__ void lane_beams(const GridDesc & g, const LaneCtx & c
           if (COMPACT) idx = lds_u16_at(c.rank_address + 2u * idx);
           const double e = LDS_RECORDS ? lds_record_exponent(c.lds_cells_address, idx, px, py)
                                        : indexed_exponent<false>(g, nullptr, idx, px, py);
+#ifdef NDT2D_LANE_HIST
+          // experiments/lane_useful_hist.py: how many lanes of an exact evaluation matter.
+          // hist[k]: evaluations with k lanes flagged (live and occupied or near a boundary);
+          // hist[70 + k]: with k lanes whose term can change their sum; [140] / [141]:
+          // evaluations that did / did not need exp()
+          if (g_lane_hist != nullptr)
+          {
+            const uint64_t flagged = occ_mask | near_mask;
+            const uint64_t needed = __builtin_amdgcn_ballot_w64(!(e < skip_below)) & flagged;
+            if ((threadIdx.x & 63u) == 0)
+            {
+              atomicAdd(g_lane_hist + __popcll(flagged), 1.0);
+              atomicAdd(g_lane_hist + 70 + __popcll(needed), 1.0);
+              atomicAdd(g_lane_hist + (needed != 0ull ? 140 : 141), 1.0);
+            }
+          }
+#endif
           // !(e < bound) also keeps NaN exponents (degenerate cells) on the exact path
           if (wave_any(!(e < skip_below)))
           {

@@ -163,6 +163,9 @@ __device__ __forceinline__ void match_lane_body(
   // the 64-byte-stride HBM copy (a patch touches 1-4 lines).
   extern __shared__ __align__(16) double lds[];
   const GridDesc & g = a.grid;
+#ifdef NDT2D_LANE_HIST
+  if (blockIdx.x == 0 && threadIdx.x == 0) g_lane_hist = a.scores;   // (set before any block uses it: see the experiment)
+#endif
   uint8_t * lds_map = reinterpret_cast<uint8_t *>(lds);
   // lds_byte_at() addresses the map absolutely: it must start at LDS offset 0
   if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();
@@ -307,7 +310,9 @@ __device__ __forceinline__ void match_lane_body(
       acc[7] += dy * score;
       acc[8] += dt * score;
       acc[9] += score;
+#ifndef NDT2D_LANE_HIST
       if (a.scores != nullptr) a.scores[local] = score;
+#endif
     }
 
     if (!DYNAMIC_ITEMS)
