@@ -81,6 +81,12 @@ struct MatchArgs
   // they have not been uploaded (then dth .. dlin above point at buffers the upload
   // would fill): a launch that passes them as kernel arguments needs no copy.
   const double * host_tables;
+  // Lane search of a mid-size lattice: a candidate's beams are cut into beam_parts runs of
+  // part_beams beams (a multiple of 64), each (theta, patch, part) a work item of its own
+  // that leaves the 64 lanes' partial sums in part_sums[(item * beam_parts + part) * 64 + lane];
+  // a second kernel adds a candidate's parts in order.  beam_parts <= 1: off.
+  uint32_t beam_parts, part_beams;
+  double * part_sums;
   double * partials;        // [n_workers][NDT2D_MATCH_RECORD_DOUBLES]
   uint32_t * next_item;     // work-item counters of the lane-per-candidate search (kItemShards, kItemShardStride apart)
   uint32_t chunk;           // candidates per work item
@@ -255,7 +261,8 @@ bool lane_slabs(const MatchArgs & args, uint32_t * slab_th, uint32_t * n_slabs);
 // / negligible-term skipping) -- the bit-exactness control for the skipping logic.
 hipError_t launch_match_lane(const MatchArgs & args, double * outer, double * workspace,
                              uint32_t max_workers, int cus, size_t lds_per_block, bool no_skip,
-                             hipStream_t stream, hipEvent_t ev_after_pre_kernel, uint32_t * n_workers_out, int * records_mode_out);
+                             hipStream_t stream, hipEvent_t ev_after_pre_kernel, uint32_t * n_workers_out,
+                             int * records_mode_out, uint32_t * parts_out = nullptr);
 
 // Small-lattice search (ndt2d_match_small.hip): a block per (theta, up to P tiles of 64
 // candidates), its waves split the beams; needs grid.cell_bytes.  The launch includes the
@@ -334,8 +341,16 @@ constexpr uint64_t kMaxLaneItems = 1ull << 24;
 // small-lattice search (beams split across the waves of a block); it can hold
 // kSmallMaxItems.  Above, the lane-per-candidate search; the wave-per-candidate mapping
 // serves what neither can (windows beyond 1,024 cells, > 2^24 items).
-constexpr uint64_t kSmallBelowItems = 4096;
+constexpr uint64_t kSmallBelowItems = 2560;
 constexpr uint64_t kSmallMaxItems = 8192;
+// Lane search: lattices (whole, not a launch's share) below these many work items have a
+// candidate's beams cut into four / two parts (MatchArgs::beam_parts): one expensive item
+// -- 720 exact evaluations in a dependent chain -- takes a wave 0.2 ms however few items
+// the launch has.
+// (experiments/mid_lattice_parts.py, 720 beams: 1,352 items 230 -> 93 us and 3,549 items 349 -> 155 us
+// with four parts, 13,520 items 311 -> 284 us with two, 23,660 items 377 us uncut against 411 us)
+constexpr uint64_t kPartsFourBelow = 10240;
+constexpr uint64_t kPartsTwoBelow = 18432;
 
 }  // namespace ndt2d
 

@@ -15,6 +15,8 @@
 // reference's x86-64 build keeps separate.  No MFMA: there is no dense
 // contraction on this path.
 #include <mutex>
+#include <string>
+#include <vector>
 
 #include "ndt2d_device_fn.h"
 
@@ -528,6 +530,30 @@ namespace
 
 enum class Mapping { kInvalid, kSmall, kLane, kWave };
 
+// Name of a lane-per-candidate launch: where the records live (0 gathered from HBM, 1 the
+// whole grid's in LDS, 2 compacted in LDS), whether the map is one byte per block of grid
+// cells (windows wider than 256 cells), whether a candidate's beams were cut into parts.
+const char * lane_variant_name(int records, bool block_map, bool pow2, bool parts)
+{
+  static const std::vector<std::string> names = [] {
+    std::vector<std::string> v;
+    for (int r = 0; r < 3; ++r)
+      for (int b = 0; b < 2; ++b)
+        for (int p2 = 0; p2 < 2; ++p2)
+          for (int pa = 0; pa < 2; ++pa)
+          {
+            std::string n = "match/lane-per-candidate/";
+            n += r == 2 ? "lds-grid/compact-records" : (r == 1 ? "lds-grid" : "lds-map+global-records");
+            if (b) n += "/block-map";
+            if (pa) n += "/beam-parts";
+            n += p2 ? "/pow2" : "/div";
+            v.push_back(n);
+          }
+    return v;
+  }();
+  return names[static_cast<size_t>(((records * 2 + (block_map ? 1 : 0)) * 2 + (pow2 ? 1 : 0)) * 2 + (parts ? 1 : 0))].c_str();
+}
+
 // Candidate mapping.  Lane-per-candidate (64 translations of one theta step per wave,
 // occupancy-map look-up, bit-exact skipping) whenever its LDS image fits: the
 // small-lattice form (a block per theta step and up to P tiles, beams split across its
@@ -620,6 +646,7 @@ hipError_t launch_match(const MatchArgs & args_in, double * workspace, double * 
   }
   uint32_t n_staged = 0;   // records the slabs of a multi-slab lane search left in `staged`
   uint32_t slabs_run = 1;
+  uint32_t lane_parts = 1;
   if (use_lane)
   {
     uint32_t slab_th = args.th_end - args.th_begin, n_slabs = 1;
@@ -628,7 +655,7 @@ hipError_t launch_match(const MatchArgs & args_in, double * workspace, double * 
     {
       e = launch_match_lane(args, outer, workspace, kMaxMatchBlocks * kMatchWaves, lim.cus,
                             lim.lds_per_block, (force_variant & kVariantNoSkip) != 0, stream,
-                            ev_main_start, &n_workers, &lane_records_mode);
+                            ev_main_start, &n_workers, &lane_records_mode, &lane_parts);
       if (e != hipSuccess) return e;
     }
     else
@@ -735,21 +762,8 @@ hipError_t launch_match(const MatchArgs & args_in, double * workspace, double * 
   {
     if (use_lane)
     {
-      // (bit 2 of the mode: the map is one byte per block of grid cells, a window wider
-      // than 256 cells)
-      const bool block_map = (lane_records_mode & 4) != 0;
-      const int records = lane_records_mode & 3;
-      info->variant =
-        records == 2   ? "match/lane-per-candidate/lds-grid/compact-records/pow2"
-        : records == 1 ? (block_map ? (pow2 ? "match/lane-per-candidate/lds-grid/block-map/pow2"
-                                            : "match/lane-per-candidate/lds-grid/block-map/div")
-                                    : (pow2 ? "match/lane-per-candidate/lds-grid/pow2"
-                                            : "match/lane-per-candidate/lds-grid/div"))
-                       : (block_map ? (pow2 ? "match/lane-per-candidate/lds-map+global-records/block-map/pow2"
-                                            : "match/lane-per-candidate/lds-map+global-records/block-map/div")
-                                    : (pow2 ? "match/lane-per-candidate/lds-map+global-records/pow2"
-                                            : "match/lane-per-candidate/lds-map+global-records/div"));
-      info->n_kernels = n_staged > 0 ? static_cast<int>(3 * slabs_run + 1) : 3;
+      info->variant = lane_variant_name(lane_records_mode & 3, (lane_records_mode & 4) != 0, pow2, lane_parts > 1);
+      info->n_kernels = n_staged > 0 ? static_cast<int>(3 * slabs_run + 1) : (lane_parts > 1 ? 4 : 3);
     }
     else
     {

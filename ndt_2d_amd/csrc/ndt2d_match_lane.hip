@@ -152,7 +152,7 @@ __device__ __forceinline__ double packed_offset(double dx, double dy, double inv
 // compacted records of the cells that can score and the cell -> record table
 // (GridDesc::compact_records / cell_rank): at cfg-2 15 KB instead of 81 KB, so that two
 // blocks share a CU (match_lane_compact_kernel below).
-template <int THREADS, bool POW2, bool LDS_RECORDS, bool DYNAMIC_ITEMS, bool COMPACT>
+template <int THREADS, bool POW2, bool LDS_RECORDS, bool DYNAMIC_ITEMS, bool COMPACT, bool PARTS = false>
 __device__ __forceinline__ void match_lane_body(
   const MatchArgs & a, const double4 * __restrict__ outer, const uint8_t * __restrict__ map_image,
   const LaneGeom & geo)
@@ -215,7 +215,9 @@ __device__ __forceinline__ void match_lane_body(
   const uint32_t n_lin = a.n_lin;
   const uint32_t patches_1d = (n_lin + kPatch - 1) / kPatch;
   const uint32_t patches = patches_1d * patches_1d;
-  const uint32_t n_items = (a.th_end - a.th_begin) * patches;
+  // PARTS: a work item is (theta, patch, part of the beams); item / beam_parts is the
+  // (theta, patch) item of the unsplit search
+  const uint32_t n_items = (a.th_end - a.th_begin) * patches * (PARTS ? a.beam_parts : 1u);
   constexpr uint32_t kLaneWaves = THREADS / kWave;
   const uint32_t n_workers = gridDim.x * kLaneWaves;
   const uint32_t worker = wave * gridDim.x + blockIdx.x;
@@ -235,7 +237,9 @@ __device__ __forceinline__ void match_lane_body(
   for (uint32_t item = worker; item < n_items;)
   {
     uint32_t t, pxi, pyi;
-    item_place(item, patches, patches_1d, th_mid, t, pxi, pyi);
+    const uint32_t whole_item = PARTS ? item / a.beam_parts : item;
+    const uint32_t part = PARTS ? item - whole_item * a.beam_parts : 0u;
+    item_place(whole_item, patches, patches_1d, th_mid, t, pxi, pyi);
     const uint32_t ix = pxi * kPatch + lx;
     const uint32_t iy = pyi * kPatch + ly;
     const bool valid = (ix < n_lin) & (iy < n_lin);
@@ -255,7 +259,9 @@ __device__ __forceinline__ void match_lane_body(
     // beam order, so a lane's sum is built exactly as before.
     const double dxy_corner = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(dxy)),
                                                __builtin_amdgcn_readfirstlane(__double2loint(dxy)));
-    for (uint32_t b0 = 0; b0 < a.n_beams; b0 += kWave)
+    const uint32_t beams_begin = PARTS ? part * a.part_beams : 0u;
+    const uint32_t beams_end = PARTS ? min(beams_begin + a.part_beams, a.n_beams) : a.n_beams;
+    for (uint32_t b0 = beams_begin; b0 < beams_end; b0 += kWave)
     {
       uint64_t can_score = ~0ull;
       if (geo.box_span >= 0)
@@ -263,7 +269,7 @@ __device__ __forceinline__ void match_lane_body(
         const double k = row[min(b0 + lane, a.n_beams - 1u)].z;
         can_score = __builtin_amdgcn_ballot_w64(patch_can_score(k + dxy_corner, geo.box_span));
       }
-      const uint32_t chunk_end = min(b0 + static_cast<uint32_t>(kWave), a.n_beams);
+      const uint32_t chunk_end = min(b0 + static_cast<uint32_t>(kWave), beams_end);
       uint32_t b = b0;
       for (; b + kUnroll <= chunk_end; b += kUnroll, can_score >>= kUnroll)
       {
@@ -287,6 +293,25 @@ __device__ __forceinline__ void match_lane_body(
       }
     }
 
+    if (PARTS)
+    {
+      // the part's 64 partial sums, one coalesced store; match_lane_combine_kernel adds a
+      // candidate's parts in order and does everything that follows from its score
+      a.part_sums[static_cast<size_t>(item) * kWave + lane] = sum;
+      uint32_t next = n_items;
+      if (lane == kWave - 1)
+      {
+        for (uint32_t tried = 0; tried < kItemShards && next >= n_items; ++tried)
+        {
+          const uint32_t shard = (home_shard + tried) % kItemShards;
+          const uint32_t k = atomicAdd(a.next_item + shard * kItemShardStride, 1u);
+          const uint64_t candidate = static_cast<uint64_t>(n_workers) + static_cast<uint64_t>(k) * kItemShards + shard;
+          if (candidate < n_items) next = static_cast<uint32_t>(candidate);
+        }
+      }
+      item = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(next), kWave - 1));
+      continue;
+    }
     if (valid)
     {
       const double score = -sum;  // (:127)
@@ -396,7 +421,109 @@ match_lane_gather6_kernel(const MatchArgs a, const double4 * __restrict__ outer,
   match_lane_body<kLaneThreadsCompact, POW2, false, true, false>(a, outer, map_image, geo);
 }
 
+// The beam-part forms of the two six-wave kernels (mid-size lattices, MatchArgs::beam_parts).
+__global__ void __launch_bounds__(kLaneThreadsCompact) __attribute__((amdgpu_waves_per_eu(6)))
+match_lane_compact_parts_kernel(const MatchArgs a, const double4 * __restrict__ outer,
+                                const uint8_t * __restrict__ map_image, const LaneGeom geo)
+{
+  match_lane_body<kLaneThreadsCompact, true, true, true, true, true>(a, outer, map_image, geo);
+}
+
+template <bool POW2>
+__global__ void __launch_bounds__(kLaneThreadsCompact) __attribute__((amdgpu_waves_per_eu(6)))
+match_lane_gather6_parts_kernel(const MatchArgs a, const double4 * __restrict__ outer,
+                                const uint8_t * __restrict__ map_image, const LaneGeom geo)
+{
+  match_lane_body<kLaneThreadsCompact, POW2, false, true, false, true>(a, outer, map_image, geo);
+}
+
+// Second kernel of the beam-part form: a wave per (theta, patch) item, lane = candidate.
+// The candidate's score is the in-order sum of its parts' in-order sums,
+// ((p_0 + p_1) + p_2) + p_3; then the reference's strict-< best (:128-134) and the
+// covariance accumulators (:137-140) exactly as the unsplit search's epilogue has them,
+// one 12-double record per item.
+__global__ void __launch_bounds__(256) match_lane_combine_kernel(const MatchArgs a)
+{
+  const uint32_t lane = threadIdx.x & (kWave - 1);
+  const uint32_t n_lin = a.n_lin;
+  const uint32_t patches_1d = (n_lin + kPatch - 1) / kPatch;
+  const uint32_t patches = patches_1d * patches_1d;
+  const uint32_t n_items = (a.th_end - a.th_begin) * patches;
+  const uint32_t item = blockIdx.x * 4u + (threadIdx.x >> 6);
+  if (item >= n_items) return;
+  const uint32_t th_mid = (a.th_end - a.th_begin - 1u) / 2u;
+  uint32_t t, pxi, pyi;
+  item_place(item, patches, patches_1d, th_mid, t, pxi, pyi);
+  const uint32_t ix = pxi * kPatch + (lane >> 3);
+  const uint32_t iy = pyi * kPatch + (lane & 7);
+  const bool valid = (ix < n_lin) & (iy < n_lin);
+  const double * p = a.part_sums + static_cast<size_t>(item) * a.beam_parts * kWave + lane;
+  double sum = p[0];
+  for (uint32_t j = 1; j < a.beam_parts; ++j) sum += p[static_cast<size_t>(j) * kWave];
+  double best_s = 0.0;       // `double best_score = 0;` (:83)
+  double best_i = kNoIndex;
+  double acc[10];
+#pragma unroll
+  for (int k = 0; k < 10; ++k) acc[k] = 0.0;
+  if (valid)
+  {
+    const double dx = a.dlin[ix];
+    const double dy = a.dlin[iy];
+    const double score = -sum;  // (:127)
+    const uint64_t per_theta = static_cast<uint64_t>(n_lin) * n_lin;
+    const uint64_t in_theta = static_cast<uint64_t>(ix) * n_lin + iy;
+    const uint32_t ith = a.th_begin + t * a.th_stride;
+    if (score < 0.0)
+    {
+      best_s = score;
+      best_i = static_cast<double>(static_cast<uint64_t>(ith) * per_theta + in_theta);
+    }
+    const double dt = a.dth[ith];
+    acc[0] = (dx * dx) * score;
+    acc[1] = (dx * dy) * score;
+    acc[2] = (dx * dt) * score;
+    acc[3] = (dy * dy) * score;
+    acc[4] = (dy * dt) * score;
+    acc[5] = (dt * dt) * score;
+    acc[6] = dx * score;
+    acc[7] = dy * score;
+    acc[8] = dt * score;
+    acc[9] = score;
+    if (a.scores != nullptr) a.scores[static_cast<uint64_t>(t) * per_theta + in_theta] = score;
+  }
+  wave_best_to_last_lane(best_s, best_i);
+#pragma unroll
+  for (int k = 0; k < 10; ++k) acc[k] = wave_sum_to_last_lane(acc[k]);
+  if (lane == kWave - 1)
+  {
+    double * out = a.partials + static_cast<size_t>(item) * kRecord;
+    out[0] = best_s;
+    out[1] = best_i;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) out[2 + k] = acc[k];
+  }
+}
+
 bool pow2_grid(const MatchArgs & args) { return args.grid.pow2 != 0; }
+
+// Beam parts of a lattice (see MatchArgs::beam_parts): by the WHOLE lattice's work items, so
+// that every shard of a search cuts a candidate's beams alike.
+uint32_t lane_beam_parts(const MatchArgs & args, uint32_t * part_beams)
+{
+  const uint64_t p1 = (args.n_lin + kPatch - 1) / kPatch;
+  const uint64_t whole = static_cast<uint64_t>(args.n_th) * p1 * p1;
+  uint32_t parts = whole < kPartsFourBelow ? 4u : (whole < kPartsTwoBelow ? 2u : 1u);
+  if (const char * env = std::getenv("NDT2D_LANE_PARTS"))   // A/B knob (1: never cut)
+  {
+    const int v = std::atoi(env);
+    if (v == 1 || v == 2 || v == 4 || v == 8) parts = static_cast<uint32_t>(v);
+  }
+  const uint32_t chunks = (args.n_beams + kWave - 1) / kWave;
+  if (args.n_beams < kDynamicItemsFromBeams || parts > chunks) parts = 1;
+  const uint32_t per_part = (chunks + parts - 1) / parts;
+  *part_beams = per_part * kWave;
+  return (chunks + per_part - 1) / per_part;
+}
 
 bool lane_records_in_lds(const MatchArgs & args, size_t map_bytes, size_t lds_per_block)
 {
@@ -434,8 +561,12 @@ size_t match_lane_outer_doubles(const MatchArgs & args)
   // rotated-beam table of one slab + the occupancy-map image (at most 256 x 256 bytes)
   uint32_t slab_th = args.th_end - args.th_begin, n_slabs = 1;
   (void)lane_slabs(args, &slab_th, &n_slabs);
+  uint32_t part_beams = 0;
+  const uint32_t parts = lane_beam_parts(args, &part_beams);
+  const uint64_t p1 = (args.n_lin + kPatch - 1) / kPatch;
+  const size_t part_sums = parts > 1 ? static_cast<size_t>(slab_th) * p1 * p1 * parts * kWave : 0;
   return static_cast<size_t>(slab_th) * args.n_beams * 4 +
-         static_cast<size_t>(kMapStride) * kMaxMapCells / sizeof(double);
+         static_cast<size_t>(kMapStride) * kMaxMapCells / sizeof(double) + part_sums;
 }
 
 bool match_lane_supported(const MatchArgs & args, size_t lds_per_block)
@@ -452,7 +583,7 @@ bool match_lane_supported(const MatchArgs & args, size_t lds_per_block)
 hipError_t launch_match_lane(const MatchArgs & args_in, double * outer, double * workspace,
                              uint32_t max_workers, int cus, size_t lds_per_block, bool no_skip,
                              hipStream_t stream, hipEvent_t ev_after_pre_kernel,
-                             uint32_t * n_workers_out, int * records_mode_out)
+                             uint32_t * n_workers_out, int * records_mode_out, uint32_t * parts_out)
 {
   MatchArgs args = args_in;
   args.partials = workspace;
@@ -480,6 +611,10 @@ hipError_t launch_match_lane(const MatchArgs & args_in, double * outer, double *
   if (oblocks > 4096) oblocks = 4096;
   if (oblocks < 64) oblocks = 64;  // the map build wants a few thousand threads as well
   uint8_t * map_image = reinterpret_cast<uint8_t *>(outer + n_outer * 4);
+  // mid-size lattices: a candidate's beams in parts (decided below, once the kernel form is known)
+  uint32_t part_beams = 0;
+  uint32_t beam_parts = dynamic_items ? lane_beam_parts(args, &part_beams) : 1u;
+  args.part_sums = outer + n_outer * 4 + static_cast<size_t>(kMapStride) * kMaxMapCells / sizeof(double);
   hipLaunchKernelGGL(outer_table_kernel, dim3(oblocks), dim3(256), 0, stream, args,
                      reinterpret_cast<double4 *>(outer), map_image, geo);
   hipError_t e = hipGetLastError();
@@ -526,16 +661,22 @@ hipError_t launch_match_lane(const MatchArgs & args_in, double * outer, double *
   {
     *records_mode_out = (compact ? 2 : (lds_records ? 1 : 0)) | (geo.block_log2 > 0 ? 4 : 0);
   }
+  if (parts_out != nullptr) *parts_out = 1;
   // records gathered from HBM: the same block geometry when two maps fit a CU
   // (NDT2D_LANE_GATHER6=0: the one-block form, for A/B runs)
   const char * knob6 = std::getenv("NDT2D_LANE_GATHER6");
   const bool gather6 = !compact && !small && dynamic_items && !lds_records &&
                        2 * map_bytes <= lds_per_block && !(knob6 != nullptr && knob6[0] == '0');
+  // (the beam-part form exists for the two six-wave kernels)
+  if (!(compact || gather6)) beam_parts = 1;
+  args.beam_parts = beam_parts;
+  args.part_beams = part_beams;
+  const uint64_t n_sub_items = n_items * beam_parts;
   if (compact || gather6)
   {
     lds_bytes = compact ? map_bytes + compact_bytes : map_bytes;
     const uint32_t wpb = kLaneThreadsCompact / kWave;
-    blocks = static_cast<uint32_t>((n_items + wpb - 1) / wpb);
+    blocks = static_cast<uint32_t>((n_sub_items + wpb - 1) / wpb);
     uint32_t cap = 2 * static_cast<uint32_t>(cus);
     if (cap * wpb > max_workers) cap = max_workers / wpb;
     if (blocks > cap) blocks = cap;
@@ -566,7 +707,19 @@ hipError_t launch_match_lane(const MatchArgs & args_in, double * outer, double *
     };
     return dynamic_items ? with_items(std::true_type{}) : with_items(std::false_type{});
   };
-  if (compact)
+  if (beam_parts > 1)
+  {
+    e = compact ? launch(match_lane_compact_parts_kernel, kLaneThreadsCompact)
+                : (pow2 ? launch(match_lane_gather6_parts_kernel<true>, kLaneThreadsCompact)
+                        : launch(match_lane_gather6_parts_kernel<false>, kLaneThreadsCompact));
+    if (e == hipSuccess)
+    {
+      hipLaunchKernelGGL(match_lane_combine_kernel, dim3(static_cast<uint32_t>((n_items + 3) / 4)), dim3(256),
+                         0, stream, args);
+      e = hipGetLastError();
+    }
+  }
+  else if (compact)
   {
     e = launch(match_lane_compact_kernel, kLaneThreadsCompact);
   }
@@ -580,6 +733,7 @@ hipError_t launch_match_lane(const MatchArgs & args_in, double * outer, double *
     e = small ? pick(std::integral_constant<int, kLaneThreadsSmall>{})
               : pick(std::integral_constant<int, kLaneThreads>{});
   }
+  if (parts_out != nullptr) *parts_out = beam_parts;
   if (n_workers_out != nullptr)
   {
     *n_workers_out = dynamic_items ? static_cast<uint32_t>(n_items) : blocks * waves_per_block;

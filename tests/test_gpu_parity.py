@@ -627,6 +627,61 @@ def test_lattice_beyond_two_to_the_24_work_items_keeps_the_lane_mapping():
         assert abs(slab[f] + ref.ndt.likelihood(inner)) < TOL_TIGHT
 
 
+def test_mid_size_lattices_cut_a_candidates_beams_into_parts(monkeypatch):
+    """Lattices of a few thousand (theta, patch) work items with many beams: one item of the
+    large search is a chain of up to 720 exact evaluations, 0.2 ms for a wave however few
+    items there are.  The beams are therefore cut into 4 (or 2) parts, each a work item of
+    its own, and a second kernel adds a candidate's part sums in order.  Skipping stays
+    bit-exact, the cut follows the WHOLE lattice (so score bits do not depend on the
+    sharding), and the scores are within a few ulps of the uncut search's."""
+    gpu, ref, _, guess, pts = _pair(2, search_linear_size=1.0, search_linear_resolution=0.02,
+                                    search_angular_size=0.1, search_angular_resolution=0.005)
+    exp = ref.matchScan(guess, pts, want_scores=True)
+    got = gpu.matchScan(guess, pts, want_scores=True)           # 40 x 169 = 6,760 items
+    assert "compact-records/beam-parts" in gpu.last_variant(), gpu.last_variant()
+    assert gpu.last_launch_ms()[1] == 4
+    _check_match(got, exp, 720)
+    gpu.set_variant("lane-noskip")
+    full = gpu.matchScan(guess, pts, want_scores=True)
+    gpu.set_variant("auto")
+    assert "beam-parts" in gpu.last_variant()
+    assert np.array_equal(got["scores"], full["scores"])
+    assert got["best_index"] == full["best_index"] and np.array_equal(got["covariance"], full["covariance"])
+    # theta shards of the same lattice: the same bits for every candidate
+    import torch
+    n_th, n_lin, _ = gpu.prepare_search(guess, pts)
+    per = n_lin * n_lin
+    for a, b in ((0, 7), (7, 29), (29, n_th)):
+        d = torch.zeros((b - a) * per, dtype=torch.float64, device="cuda:0")
+        gpu.match_launch(a, b, scores_ptr=d.data_ptr())
+        gpu.synchronize()
+        assert "beam-parts" in gpu.last_variant()
+        assert np.array_equal(d.cpu().numpy(), got["scores"][a * per:b * per])
+    # the uncut search (one running sum per candidate, the reference's order)
+    monkeypatch.setenv("NDT2D_LANE_PARTS", "1")
+    uncut = gpu.matchScan(guess, pts, want_scores=True)
+    monkeypatch.delenv("NDT2D_LANE_PARTS")
+    assert "beam-parts" not in gpu.last_variant()
+    assert uncut["best_index"] == got["best_index"]
+    assert np.max(np.abs(uncut["scores"] - got["scores"])) < 1e-12
+    # two parts, and a map whose records are gathered from HBM
+    gpu2, ref2, _, guess2, pts2 = _pair(2, search_linear_size=1.0, search_linear_resolution=0.02,
+                                        search_angular_size=0.2, search_angular_resolution=0.005)
+    got2 = gpu2.matchScan(guess2, pts2, want_scores=True)        # 80 x 169 = 13,520 items
+    assert "beam-parts" in gpu2.last_variant()
+    _check_match(got2, ref2.matchScan(guess2, pts2, want_scores=True), 720)
+    gpu3, ref3, _, guess3, pts3 = _pair(3, search_linear_size=0.5, search_linear_resolution=0.02,
+                                        search_angular_size=0.1, search_angular_resolution=0.005)
+    got3 = gpu3.matchScan(guess3, pts3, want_scores=True)        # 40 x 49 = 1,960 ... small; force the lane form
+    gpu3.set_variant("lane")
+    lane3 = gpu3.matchScan(guess3, pts3, want_scores=True)
+    assert "lds-map+global-records/beam-parts" in gpu3.last_variant(), gpu3.last_variant()
+    gpu3.set_variant("auto")
+    exp3 = ref3.matchScan(guess3, pts3, want_scores=True)
+    _check_match(got3, exp3, 720)
+    _check_match(lane3, exp3, 720)
+
+
 def _big_winner(cfg):
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "big_winners.json")) as f:
         return json.load(f)["cfg%d" % cfg]
