@@ -683,14 +683,29 @@ def main():
     # untimed pre-warm: launches for --prewarm seconds, so that the timed region -- 10 ms
     # under the driver's --steps 20 -- runs at the clocks the chip sustains, not at the
     # ones it idles at
+    # (every rank must run the SAME number of steps -- each carries a collective -- so the
+    # count comes from a short calibration whose slowest rank's time all ranks share)
     n_prewarm = 0
-    t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < args.prewarm:
-        for _ in range(8):
+    if args.prewarm > 0:
+        for _ in range(2):
             step()
         drain()
-        torch.cuda.synchronize()
-        n_prewarm += 8
+        fence()
+        t_cal = time.perf_counter()
+        for _ in range(4):
+            step()
+        drain()
+        fence()
+        cal = torch.tensor([(time.perf_counter() - t_cal) / 4.0], dtype=torch.float64, device=dev)
+        if collective:
+            all_reduce(cal, dist.ReduceOp.MAX)
+        n_prewarm = int(min(max(args.prewarm / max(float(cal[0]), 1e-6), 1.0), 20000.0))
+        for i in range(n_prewarm):
+            step()
+            if (i & 63) == 63:
+                drain()
+                torch.cuda.synchronize()
+        n_prewarm += 6
     for _ in range(args.warmup):
         step()
     drain()
