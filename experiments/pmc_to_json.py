@@ -12,7 +12,8 @@ import json
 import os
 import sys
 
-KERNELS = ("match_lane_compact_kernel", "match_lane_kernel", "match_kernel", "match_small_kernel", "score_poses_compact_kernel",
+KERNELS = ("match_lane_compact_parts_kernel", "match_lane_gather6_parts_kernel", "match_lane_gather6_kernel",
+           "match_lane_combine_kernel", "match_lane_compact_kernel", "match_lane_kernel", "match_kernel", "match_small_kernel", "score_poses_compact_kernel",
            "outer_table_kernel", "match_reduce_kernel", "score_one_kernel")
 
 
@@ -49,9 +50,9 @@ def main(root):
                     dur[k].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
             for k, vals in dur.items():
                 out[k].setdefault("avg_duration_ns", {})[pname] = sum(vals) / len(vals)
-    doc = {"source": "experiments/profile_r02.sh: rocprofv3 --kernel-trace [--pmc ...] on "
-                     "`python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-default-search` "
-                     "(kt: --stats pass, --steps 20 --warmup 3), one MI355X; counters are averages "
+    doc = {"source": "experiments/profile_r0N.sh: rocprofv3 --kernel-trace [--pmc ...] on "
+                     "`python3 bench.py --steps 4 --warmup 2 --prewarm 0 --no-cpu-baseline --no-default-search --no-anchors` "
+                     "(kt: --stats pass, --steps 200 --warmup 10 behind the 0.5 s pre-warm), one MI355X; counters are averages "
                      "per dispatch; FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them",
            "kernels": out}
     with open(os.path.join(root, "pmc.json"), "w") as f:

@@ -378,7 +378,12 @@ __device__ __forceinline__ void lane_beams(const GridDesc & g, const LaneCtx & c
           (near_boundary(lo[u]) | near_boundary(fy) | ((no_skip | c.exact_index) != 0 ? ~0ull : 0ull)) & live_mask;
         const uint64_t occ_lanes = __builtin_amdgcn_ballot_w64(occ);
         const uint64_t occ_mask = occ_lanes & live_mask;
+#ifdef NDT2D_LANE_NO_EXACT
+        // (experiment: what the search costs WITHOUT its exact evaluations -- results are wrong)
+        if ((occ_mask | near_mask) == 0x1234567ull)
+#else
         if ((occ_mask | near_mask) != 0ull)
+#endif
         {
           // points_inner (:121-125) and Cell::score, exact
           const double px = o[u].x + dx;

@@ -1,4 +1,4 @@
-"""The committed bench line (profiles/r02_bench.json, written by `python bench.py` on an
+"""The committed bench line (profiles/r03_bench.json, written by `python bench.py` on an
 MI355X) keeps the driver's contract and agrees with the committed counters and golden
 results.  No GPU needed."""
 import json
@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.fixture(scope="module")
 def line():
-    with open(os.path.join(ROOT, "profiles", "r02_bench.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r03_bench.json")) as f:
         return json.load(f)
 
 
@@ -35,16 +35,49 @@ def test_roofline_is_a_fraction_of_something_that_binds(line):
     r = line["roofline"]
     assert r["bound"] == "valu_issue" and 0.0 < r["frac"] <= 1.0
     assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-9)
-    # reproducible from the committed counters: SQ_INSTS_VALU * 4 / (4 * SQ_BUSY_CU_CYCLES)
-    with open(os.path.join(ROOT, "profiles", "r02_pmc.json")) as f:
+    # the peak is the chip's fixed issue peak (1,024 SIMDs x 2.4 GHz / 4 cycles), the time is
+    # the run's own: achieved = committed SQ_INSTS_VALU / live kernel time
+    assert r["peak"] == pytest.approx(1024 * 2.4e9 / 4.0 / 1e9, rel=1e-9)
+    with open(os.path.join(ROOT, "profiles", "r03_pmc.json")) as f:
         pmc = json.load(f)
     k = pmc["kernels"][r["kernel"]]
-    assert r["frac"] == pytest.approx(k["SQ_INSTS_VALU"] * 4.0 / (4.0 * k["SQ_BUSY_CU_CYCLES"]), rel=1e-6)
+    assert r["achieved"] == pytest.approx(k["SQ_INSTS_VALU"] / (r["kernel_ms_avg"] * 1e-3) / 1e9, rel=1e-9)
     assert r["valu_insts_per_launch"] == pytest.approx(k["SQ_INSTS_VALU"], rel=1e-9)
+    # the run-invariant share of the kernel's own issue slots, reproducible from the counters alone
+    assert r["issue_slot_occupancy_pmc"] == pytest.approx(
+        k["SQ_INSTS_VALU"] * 4.0 / (4.0 * k["SQ_BUSY_CU_CYCLES"]), rel=1e-6)
+    assert r["frac"] < r["issue_slot_occupancy_pmc"]          # the chip sustains less than 2.4 GHz
+    # ... and it does move with the run: the same command with the driver's flags
+    with open(os.path.join(ROOT, "profiles", "r03_bench_driver_flags.json")) as f:
+        other = json.load(f)
+    assert other["steps"] == 20 and other["warmup"] == 5
+    assert other["roofline"]["frac"] != r["frac"]
+    assert other["roofline"]["frac"] * other["roofline"]["kernel_ms_avg"] == pytest.approx(
+        r["frac"] * r["kernel_ms_avg"], rel=1e-9)
+    assert other["value"] == pytest.approx(line["value"], rel=0.03)   # the pre-warm: within 3 %
+    # the kernel's average duration under rocprofv3 (--kernel-trace --stats) agrees with the HIP events
+    with open(os.path.join(ROOT, "profiles", "r03_kernel_stats.csv")) as f:
+        row = next(ln for ln in f if "match_lane_compact_kernel" in ln)
+    avg_ns = float(row.rsplit('"', 1)[1].split(",")[3])
+    assert avg_ns * 1e-6 == pytest.approx(r["kernel_ms_avg"], rel=0.03)
     # the measured HBM side stays a small fraction of the peak; the declared 64 B/unit does not fit under it
     h = line["roofline_hbm"]
     assert 0.0 < h["frac"] < 0.1 and h["algorithmic_over_peak"] > 1.0
     assert h["traffic"] == pytest.approx((2 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024, rel=1e-6)
+
+
+def test_single_gpu_anchors_of_the_eight_gpu_workloads(line):
+    c4 = line["cfg4_single_gpu"]
+    assert c4["units_per_step"] == 315508257 * 720 and c4["best_index"] == 80443810
+    assert c4["value"] == pytest.approx(c4["units_per_step"] / (c4["ms_per_step"] * 1e-3), rel=1e-6)
+    assert 0.5 < c4["in_grid_share_of_units"] < 0.6
+    c5 = line["cfg5_single_gpu"]
+    assert c5["units_per_step"] == 1000000 * 720 and c5["n_gpus"] == 1
+    d = line["default_search"]["cpu_single_thread"]
+    assert d["match_scan_ms"] > line["default_search"]["match_scan_ms"] > 0
+    # the honest comparison: through the unchanged per-particle loop the plugin is slower than the CPU
+    assert d["measure_500_particles_ms"] * 1e3 < line["default_search"]["c_host"]["measure_500_particles_unchanged_loop_us"]
+    assert d["measure_500_particles_ms"] * 1e3 > line["default_search"]["c_host"]["pf_measure_500_particles_us"]
 
 
 def test_cpu_baseline_and_results(line):
