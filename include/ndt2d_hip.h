@@ -75,6 +75,17 @@ int ndt2d_device_id(ndt2d_handle h);
  * (include/ndt_2d/ndt_model.hpp:128-131). */
 int ndt2d_set_grid(ndt2d_handle h, const double * cells6, uint32_t size_x, uint32_t size_y,
                    double cell_size, double origin_x, double origin_y);
+
+/* The same grid given as the LIST of its cells that received points: cells6[k] (layout as
+ * above) belongs to cell cell_index[k] = grid_y * size_x + grid_x, every cell not listed is
+ * an empty one (n = 0, as NDT::NDT leaves it, src/ndt_model.cpp:118-126).  The mapper
+ * rebuilds its local NDT for every scan (src/ndt_mapper.cpp:508-509); with a real lidar
+ * that grid has tens of thousands of cells (scan poses +- range_max,
+ * src/scan_matcher_ndt.cpp:52-66) of which the scans touch a thousand or two: the cost of
+ * this call follows the list, not the grid. */
+int ndt2d_set_grid_sparse(ndt2d_handle h, const uint32_t * cell_index, const double * cells6,
+                          size_t n_listed, uint32_t size_x, uint32_t size_y, double cell_size,
+                          double origin_x, double origin_y);
 /* Build the NDT on the device from the scans themselves and install it: the
  * whole of ScanMatcherNDT::addScans (src/scan_matcher_ndt.cpp:49-74) --
  * bounding box of the scan poses +- range_max, NDT::addScan for every scan in

@@ -75,6 +75,7 @@ SIGNATURES = {
     "ndt2d_get_stream": (_vp, [_vp]),
     "ndt2d_device_id": (C.c_int, [_vp]),
     "ndt2d_set_grid": (C.c_int, [_vp, _dp, _u32, _u32, _d, _d, _d]),
+    "ndt2d_set_grid_sparse": (C.c_int, [_vp, C.POINTER(C.c_uint32), _dp, _sz, _u32, _u32, _d, _d, _d]),
     "ndt2d_build_grid": (C.c_int, [_vp, _d, _d, _dp, _dp, _szp, _sz]),
     "ndt2d_get_grid": (C.c_int, [_vp, _dp, _sz, C.POINTER(_u32), C.POINTER(_u32), _dp, _dp, _dp]),
     "ndt2d_clear_grid": (C.c_int, [_vp]),

@@ -305,6 +305,103 @@ __global__ void __launch_bounds__(256) pack_grid_kernel(const GridDesc g, const 
   write_scorer_record(g.ncell, cell, rec, cells_lds_image, cells_global, occ_bits);
 }
 
+// ---- a grid given as the LIST of its cells that hold points (ndt2d_set_grid_sparse) ----
+//
+// The mapper installs a new local NDT for every scan (reference src/ndt_mapper.cpp:508-509),
+// and with a real lidar that grid is tens of thousands of cells (scan poses +- range_max,
+// src/scan_matcher_ndt.cpp:52-66: 245 x 245 at 30 m / 0.25 m) of which the scans' points touch
+// one or two thousand.  Dense, every install moved and packed all of them (2.9 MB over PCIe);
+// here the host sends the touched cells only and three small kernels produce the layouts the
+// scorers read: fill (every cell the "cannot score" sentinel, no occupancy), scatter (the
+// listed cells), bytes (the map bytes of the cells around the listed ones).
+
+// Every record the sentinel, every bit and byte zero, every rank `n_occ` (= the sentinel's).
+__global__ void __launch_bounds__(256) grid_fill_kernel(const GridDesc g, double * cells_lds_image,
+                                                        double * cells_global, uint32_t * occ_bits,
+                                                        uint8_t * bytes, uint16_t * ranks, uint32_t n_occ)
+{
+  const uint32_t n_words = (g.ncell + 1 + 31) / 32;
+  const uint32_t n_bytes = (g.size_x + 2) * (g.size_y + 2);
+  const uint32_t stride = gridDim.x * 256;
+  for (uint32_t cell = blockIdx.x * 256 + threadIdx.x; cell <= g.ncell; cell += stride)
+  {
+    double2 * l = reinterpret_cast<double2 *>(cells_lds_image + static_cast<size_t>(cell) * kCellDoubles);
+    double2 * gl = reinterpret_cast<double2 *>(cells_global + static_cast<size_t>(cell) * kCellStrideGlobal);
+    const double2 a = {1.0e300, 0.0}, b = {-1.0, 0.0}, c = {-1.0, 0.0}, z = {0.0, 0.0};
+    l[0] = a;
+    l[1] = b;
+    l[2] = c;
+    gl[0] = a;
+    gl[1] = b;
+    gl[2] = c;
+    gl[3] = z;
+    if (ranks != nullptr) ranks[cell] = static_cast<uint16_t>(n_occ);
+  }
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_words; i += stride) occ_bits[i] = 0u;
+  // (whole words; the byte array is allocated in doubles)
+  uint32_t * b32 = reinterpret_cast<uint32_t *>(bytes);
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < (n_bytes + 3) / 4; i += stride) b32[i] = 0u;
+}
+
+// The listed cells: packed records h = -0.5 * information in both strides, occupancy bit,
+// rank (host-assigned: the cell's record among the compacted ones, 0xffff if it cannot score).
+__global__ void __launch_bounds__(256) grid_scatter_kernel(const GridDesc g, const uint32_t * cell_index,
+                                                           const double * cells6, const uint16_t * rank_of,
+                                                           uint32_t n, double * cells_lds_image,
+                                                           double * cells_global, uint32_t * occ_bits,
+                                                           uint16_t * ranks)
+{
+  const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  const uint32_t cell = cell_index[k];
+  const double * c = cells6 + static_cast<size_t>(k) * 6;
+  if (cell >= g.ncell || c[5] < 5.0) return;    // cannot score (n < 5, src/ndt_model.cpp:107): stays the sentinel
+  const double rec[kCellDoubles] = {c[0], c[1], -0.5 * c[2], -0.5 * c[3], -0.5 * c[4], 1.0};
+  double * l = cells_lds_image + static_cast<size_t>(cell) * kCellDoubles;
+  double * gl = cells_global + static_cast<size_t>(cell) * kCellStrideGlobal;
+#pragma unroll
+  for (int j = 0; j < kCellDoubles; ++j)
+  {
+    l[j] = rec[j];
+    gl[j] = rec[j];
+  }
+  atomicOr(occ_bits + (cell >> 5), 1u << (cell & 31u));
+  if (ranks != nullptr && rank_of != nullptr) ranks[cell] = rank_of[k];
+}
+
+// Map bytes: a byte depends on the 3 x 3 cells around it, so the bytes that are not zero lie
+// in the 3 x 3 blocks around the listed cells that can score.  Row = (listed cell, neighbour
+// position); neighbouring listed cells compute the same byte twice and store the same value.
+__global__ void __launch_bounds__(256) grid_bytes_sparse_kernel(const GridDesc g, const uint32_t * cell_index,
+                                                                const double * cells6, uint32_t n,
+                                                                uint8_t * bytes)
+{
+  const uint32_t row = (blockIdx.x * 256 + threadIdx.x) >> 4;
+  const uint32_t k = row / 9, pos = row - k * 9;
+  uint32_t target = 0xffffffffu;   // (cell_byte_row treats an index past the array as "no cell")
+  if (k < n)
+  {
+    const uint32_t cell = cell_index[k];
+    if (cell < g.ncell && !(cells6[static_cast<size_t>(k) * 6 + 5] < 5.0))
+    {
+      const uint32_t cx = cell % g.size_x, cy = cell / g.size_x;
+      // extended-grid coordinates of the neighbour: (cx + 1 + dx, cy + 1 + dy), dx, dy in -1..1
+      target = (cy + pos / 3) * (g.size_x + 2) + cx + pos % 3;
+    }
+  }
+  cell_byte_row<false>(g, nullptr, target, threadIdx.x & 15u, bytes);
+}
+
+// Dense raw records of a sparse grid (ndt2d_get_grid): zeroed by the caller, the listed cells here.
+__global__ void __launch_bounds__(256) grid_scatter_raw_kernel(const uint32_t * cell_index, const double * cells6,
+                                                               uint32_t n, uint32_t ncell, double * dense6)
+{
+  const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= n || cell_index[k] >= ncell) return;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) dense6[static_cast<size_t>(cell_index[k]) * 6 + j] = cells6[static_cast<size_t>(k) * 6 + j];
+}
+
 int key_bits(uint32_t ncell)
 {
   int b = 1;
@@ -373,6 +470,39 @@ hipError_t launch_pack_grid(const GridDesc & geometry, const double * cells6,
   const uint32_t byte_blocks = (n_bytes + 15) / 16;
   hipLaunchKernelGGL(pack_grid_kernel, dim3(pack_blocks + byte_blocks), dim3(256), 0, stream, geometry,
                      cells6, pack_blocks, cells_lds_image, cells_global, occ_bits, cell_bytes);
+  return hipGetLastError();
+}
+
+hipError_t launch_grid_sparse(const GridDesc & geometry, const uint32_t * cell_index, const double * cells6,
+                              const uint16_t * rank_of, uint32_t n, double * cells_lds_image,
+                              double * cells_global, uint32_t * occ_bits, uint8_t * cell_bytes,
+                              uint16_t * ranks, uint32_t n_occ, hipStream_t stream)
+{
+  const uint32_t fill_blocks = (geometry.ncell + 1 + 255) / 256 < 2048 ? (geometry.ncell + 1 + 255) / 256 : 2048;
+  hipLaunchKernelGGL(grid_fill_kernel, dim3(fill_blocks), dim3(256), 0, stream, geometry, cells_lds_image,
+                     cells_global, occ_bits, cell_bytes, ranks, n_occ);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess || n == 0) return e;
+  hipLaunchKernelGGL(grid_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, geometry, cell_index,
+                     cells6, rank_of, n, cells_lds_image, cells_global, occ_bits, ranks);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  GridDesc g = geometry;
+  g.cells_lds_image = cells_lds_image;
+  g.occ_bits = occ_bits;
+  const uint64_t rows = static_cast<uint64_t>(n) * 9;
+  hipLaunchKernelGGL(grid_bytes_sparse_kernel, dim3(static_cast<uint32_t>((rows + 15) / 16)), dim3(256), 0,
+                     stream, g, cell_index, cells6, n, cell_bytes);
+  return hipGetLastError();
+}
+
+hipError_t launch_grid_sparse_to_dense(const uint32_t * cell_index, const double * cells6, uint32_t n,
+                                       uint32_t ncell, double * dense6, hipStream_t stream)
+{
+  hipError_t e = hipMemsetAsync(dense6, 0, static_cast<size_t>(ncell) * 6 * sizeof(double), stream);
+  if (e != hipSuccess || n == 0) return e;
+  hipLaunchKernelGGL(grid_scatter_raw_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, cell_index, cells6,
+                     n, ncell, dense6);
   return hipGetLastError();
 }
 

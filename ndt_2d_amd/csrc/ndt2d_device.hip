@@ -53,6 +53,12 @@ struct ndt2d_context
   DeviceBuffer compact;     // [cells6 | compact records | cell ranks]: ndt2d_set_grid's upload
   DeviceBuffer cells6;    // raw {mean, information, n} records of a device-built grid
   const double * cells6_ptr = nullptr;  // ... of the installed grid, wherever they live
+  // a grid installed as the list of its touched cells (ndt2d_set_grid_sparse): the list on the
+  // device (inside `compact`), from which ndt2d_get_grid makes the dense records on demand
+  DeviceBuffer ranks;       // cell -> compact record table of such a grid (uint16 per cell)
+  uint32_t sparse_n = 0;
+  const uint32_t * sparse_index = nullptr;
+  const double * sparse_cells6 = nullptr;
   // device NDT build scratch + host staging that must outlive the async copies
   DeviceBuffer b_points, b_scans, b_offsets, b_world, b_keys, b_vals, b_temp, b_seg;
   std::vector<double> stage_scans;
@@ -433,6 +439,7 @@ int ndt2d_destroy(ndt2d_handle h)
   release(h->cell_bytes);
   release(h->compact);
   release(h->cells6);
+  release(h->ranks);
   release(h->call_dev);
   release(h->stage_grid);
   release(h->stage_call);
@@ -572,6 +579,9 @@ int ndt2d_set_grid(ndt2d_handle h, const double * cells6, uint32_t size_x, uint3
   g.origin_x = origin_x;
   g.origin_y = origin_y;
   h->cells6_ptr = h->compact.ptr;
+  h->sparse_n = 0;
+  h->sparse_index = nullptr;
+  h->sparse_cells6 = nullptr;
   hipError_t e = ndt2d::launch_pack_grid(g, h->cells6_ptr, h->cells_lds_image.ptr, h->cells_global.ptr,
                                          reinterpret_cast<uint32_t *>(h->occ_bits.ptr),
                                          reinterpret_cast<uint8_t *>(h->cell_bytes.ptr), h->stream);
@@ -715,6 +725,129 @@ int ndt2d_build_grid(ndt2d_handle h, double ndt_resolution, double range_max,
   g.occ_bits = reinterpret_cast<const uint32_t *>(h->occ_bits.ptr);
   g.cell_bytes = reinterpret_cast<const uint8_t *>(h->cell_bytes.ptr);
   h->cells6_ptr = h->cells6.ptr;
+  h->sparse_n = 0;
+  h->sparse_index = nullptr;
+  h->sparse_cells6 = nullptr;
+  h->grid = g;
+  h->has_grid = true;
+  return NDT2D_OK;
+}
+
+// Largest [rank table | compacted records] image any search kernel would keep in LDS
+// (ndt2d_match_small.hip: 72 KB together with its map and rows; ndt2d_match_lane.hip: half a
+// CU's LDS minus its map): beyond it the compacted form is not prepared.
+static constexpr size_t kCompactImageBudget = 80 * 1024;
+
+int ndt2d_set_grid_sparse(ndt2d_handle h, const uint32_t * cell_index, const double * cells6,
+                          size_t n_listed, uint32_t size_x, uint32_t size_y, double cell_size,
+                          double origin_x, double origin_y)
+{
+  if (h == nullptr) return NDT2D_ERR_INVALID;
+  if ((n_listed > 0 && (cell_index == nullptr || cells6 == nullptr)) || size_x == 0 || size_y == 0 ||
+      !(cell_size > 0.0) || n_listed >= (1ull << 31))
+  {
+    return fail(h, NDT2D_ERR_INVALID, "ndt2d_set_grid_sparse: bad argument");
+  }
+  const uint64_t ncell64 = static_cast<uint64_t>(size_x) * size_y;
+  if (ncell64 >= (1ull << 31)) return fail(h, NDT2D_ERR_INVALID, "ndt2d_set_grid_sparse: grid too large");
+  const uint32_t ncell = static_cast<uint32_t>(ncell64);
+  const uint32_t n = static_cast<uint32_t>(n_listed);
+  for (uint32_t k = 0; k < n; ++k)
+  {
+    if (cell_index[k] >= ncell) return fail(h, NDT2D_ERR_INVALID, "ndt2d_set_grid_sparse: cell index out of range");
+  }
+  NDT2D_HIP(h, hipSetDevice(h->device));
+  h->has_grid = false;   // (see ndt2d_set_grid)
+
+  uint32_t n_occ = 0;
+  for (uint32_t k = 0; k < n; ++k) n_occ += !(cells6[6 * static_cast<size_t>(k) + 5] < 5.0) ? 1u : 0u;
+  const size_t rank_table_bytes = (static_cast<size_t>(ncell) + 1 + 7) / 8 * 16;
+  const bool compactable = n_occ > 0 && n_occ < 65535u &&
+                           rank_table_bytes + (static_cast<size_t>(n_occ) + 1) * kCellDoubles * sizeof(double) <=
+                             kCompactImageBudget;
+  // one staged copy: [cells6: 6 n][cell indices: n u32][ranks of the listed cells: n u16][compact records]
+  const size_t n6 = static_cast<size_t>(n) * 6;
+  const size_t n_idx = (static_cast<size_t>(n) + 1) / 2;
+  size_t n_rk = (static_cast<size_t>(n) + 3) / 4;
+  if ((n6 + n_idx + n_rk) & 1) ++n_rk;   // the compact records are read with 16-byte loads
+  const size_t n_compact = compactable ? static_cast<size_t>(n_occ + 1) * kCellDoubles : 0;
+  const size_t n_upload = n6 + n_idx + n_rk + n_compact + 2;
+  int rc;
+  if ((rc = ensure(h, h->compact, n_upload)) != NDT2D_OK) return rc;
+  if ((rc = ensure(h, h->cells_lds_image, static_cast<size_t>(ncell + 1) * kCellDoubles)) != NDT2D_OK) return rc;
+  if ((rc = ensure(h, h->cells_global, static_cast<size_t>(ncell + 1) * kCellStrideGlobal)) != NDT2D_OK) return rc;
+  if ((rc = ensure(h, h->occ_bits, ((static_cast<size_t>(ncell) + 1 + 31) / 32 + 2) / 2)) != NDT2D_OK) return rc;
+  if ((rc = ensure(h, h->cell_bytes, (static_cast<size_t>(size_x) + 2) * (size_y + 2) / 8 + 1)) != NDT2D_OK) return rc;
+  if (compactable && (rc = ensure(h, h->ranks, rank_table_bytes / sizeof(double) + 2)) != NDT2D_OK) return rc;
+  if ((rc = stage_acquire(h, h->stage_grid, n_upload)) != NDT2D_OK) return rc;
+  double * st = h->stage_grid.ptr;
+  if (n > 0) std::memcpy(st, cells6, n6 * sizeof(double));
+  uint32_t * st_idx = reinterpret_cast<uint32_t *>(st + n6);
+  if (n > 0) std::memcpy(st_idx, cell_index, static_cast<size_t>(n) * sizeof(uint32_t));
+  uint16_t * st_rk = reinterpret_cast<uint16_t *>(st + n6 + n_idx);
+  double * st_rec = st + n6 + n_idx + n_rk;
+  uint32_t k_occ = 0;
+  for (uint32_t k = 0; k < n; ++k)
+  {
+    const double * c = cells6 + 6 * static_cast<size_t>(k);
+    if (!(c[5] < 5.0))
+    {
+      if (compactable)
+      {
+        double * r = st_rec + static_cast<size_t>(k_occ) * kCellDoubles;
+        r[0] = c[0];
+        r[1] = c[1];
+        r[2] = -0.5 * c[2];
+        r[3] = -0.5 * c[3];
+        r[4] = -0.5 * c[4];
+        r[5] = 1.0;
+      }
+      st_rk[k] = static_cast<uint16_t>(k_occ++);
+    }
+    else
+    {
+      st_rk[k] = static_cast<uint16_t>(n_occ);
+    }
+  }
+  if (compactable)
+  {
+    static const double sentinel[kCellDoubles] = {1.0e300, 0.0, -1.0, 0.0, -1.0, 0.0};
+    std::memcpy(st_rec + static_cast<size_t>(n_occ) * kCellDoubles, sentinel, sizeof(sentinel));
+  }
+  if ((rc = stage_copy(h, h->stage_grid, h->compact.ptr, n_upload)) != NDT2D_OK) return rc;
+
+  GridDesc g{};
+  g.size_x = size_x;
+  g.size_y = size_y;
+  g.ncell = ncell;
+  g.cell_size = cell_size;
+  g.pow2 = is_pow2(cell_size) ? 1 : 0;
+  g.inv_cell_size = 1.0 / cell_size;
+  g.origin_x = origin_x;
+  g.origin_y = origin_y;
+  const double * d_cells6 = h->compact.ptr;
+  const uint32_t * d_idx = reinterpret_cast<const uint32_t *>(h->compact.ptr + n6);
+  const uint16_t * d_rk = reinterpret_cast<const uint16_t *>(h->compact.ptr + n6 + n_idx);
+  hipError_t e = ndt2d::launch_grid_sparse(
+    g, d_idx, d_cells6, compactable ? d_rk : nullptr, n, h->cells_lds_image.ptr, h->cells_global.ptr,
+    reinterpret_cast<uint32_t *>(h->occ_bits.ptr), reinterpret_cast<uint8_t *>(h->cell_bytes.ptr),
+    compactable ? reinterpret_cast<uint16_t *>(h->ranks.ptr) : nullptr, n_occ, h->stream);
+  if (e != hipSuccess) return fail_hip(h, e, "launch_grid_sparse");
+  if ((rc = stage_mark(h, h->stage_grid)) != NDT2D_OK) return rc;
+  g.cells_lds_image = h->cells_lds_image.ptr;
+  g.cells_global = h->cells_global.ptr;
+  g.occ_bits = reinterpret_cast<const uint32_t *>(h->occ_bits.ptr);
+  g.cell_bytes = reinterpret_cast<const uint8_t *>(h->cell_bytes.ptr);
+  if (compactable)
+  {
+    g.compact_records = h->compact.ptr + n6 + n_idx + n_rk;
+    g.cell_rank = reinterpret_cast<const uint16_t *>(h->ranks.ptr);
+    g.n_occ = n_occ;
+  }
+  h->cells6_ptr = nullptr;          // made from the list when ndt2d_get_grid asks for them
+  h->sparse_n = n;
+  h->sparse_index = d_idx;
+  h->sparse_cells6 = d_cells6;
   h->grid = g;
   h->has_grid = true;
   return NDT2D_OK;
@@ -734,6 +867,16 @@ int ndt2d_get_grid(ndt2d_handle h, double * cells6_out, size_t capacity_cells, u
   {
     if (capacity_cells < h->grid.ncell) return fail(h, NDT2D_ERR_INVALID, "ndt2d_get_grid: capacity");
     NDT2D_HIP(h, hipSetDevice(h->device));
+    if (h->cells6_ptr == nullptr)
+    {
+      // a grid installed as a list: the dense records from the list, once
+      int rc = ensure(h, h->cells6, static_cast<size_t>(h->grid.ncell) * 6);
+      if (rc != NDT2D_OK) return rc;
+      hipError_t e = ndt2d::launch_grid_sparse_to_dense(h->sparse_index, h->sparse_cells6, h->sparse_n,
+                                                        h->grid.ncell, h->cells6.ptr, h->stream);
+      if (e != hipSuccess) return fail_hip(h, e, "launch_grid_sparse_to_dense");
+      h->cells6_ptr = h->cells6.ptr;
+    }
     NDT2D_HIP(h, hipMemcpyAsync(cells6_out, h->cells6_ptr,
                                 static_cast<size_t>(h->grid.ncell) * 6 * sizeof(double),
                                 hipMemcpyDeviceToHost, h->stream));

@@ -133,6 +133,15 @@ hipError_t launch_build_grid(const BuildArgs & args, hipStream_t stream);
 hipError_t launch_pack_grid(const GridDesc & geometry, const double * cells6,
                             double * cells_lds_image, double * cells_global, uint32_t * occ_bits,
                             uint8_t * cell_bytes, hipStream_t stream);
+// A grid given as the list of its n cells that hold points (cells6[k] belongs to cell
+// cell_index[k]; all others are empty): fill + scatter + the map bytes around the listed
+// cells.  ranks (optional): the cell -> compact record table, rank_of[k] the listed cell's.
+hipError_t launch_grid_sparse(const GridDesc & geometry, const uint32_t * cell_index, const double * cells6,
+                              const uint16_t * rank_of, uint32_t n, double * cells_lds_image,
+                              double * cells_global, uint32_t * occ_bits, uint8_t * cell_bytes,
+                              uint16_t * ranks, uint32_t n_occ, hipStream_t stream);
+hipError_t launch_grid_sparse_to_dense(const uint32_t * cell_index, const double * cells6, uint32_t n,
+                                       uint32_t ncell, double * dense6, hipStream_t stream);
 hipError_t launch_grid_tail(const GridDesc & geometry, const double * cells_lds_image,
                             uint32_t * occ_bits, uint8_t * cell_bytes, hipStream_t stream);
 

@@ -682,6 +682,71 @@ def test_mid_size_lattices_cut_a_candidates_beams_into_parts(monkeypatch):
     _check_match(lane3, exp3, 720)
 
 
+@pytest.mark.parametrize("cfg,search", [
+    (1, dict(search_linear_size=0.5, search_linear_resolution=0.05, search_angular_size=0.2,
+             search_angular_resolution=0.01)),
+    (3, dict(search_linear_size=0.3, search_linear_resolution=0.05, search_angular_size=0.05,
+             search_angular_resolution=0.01)),
+])
+def test_grid_installed_as_a_list_of_cells_equals_the_dense_install(cfg, search):
+    """ndt2d_set_grid_sparse (the cells that hold points, in any order; what addScans sends
+    since round 3) against ndt2d_set_grid (every cell): the same device state -- every
+    candidate score of a search bitwise, with and without skipping, and the same records
+    back through ndt2d_get_grid."""
+    from ndt_2d_amd import host_build_grid
+    scans = synth.map_scans(cfg)
+    params = synth.matcher_params(cfg)
+    cells, sx, sy, ox, oy = host_build_grid(params["ndt_resolution"], params["range_max"], scans)
+    listed = np.flatnonzero(cells[:, 5] > 0).astype(np.uint32)
+    assert 0 < len(listed) < len(cells) and np.any(cells[listed, 5] < 5)    # also cells that cannot score
+    rng = np.random.default_rng(3)
+    rng.shuffle(listed)
+    sparse6 = np.ascontiguousarray(cells[listed])
+    guess, pts, _ = synth.query_scan(cfg)
+    pose = guess + np.array([0.03, -0.02, 0.01])
+    dth = O.search_offsets(search["search_angular_size"], search["search_angular_resolution"])
+    dlin = O.search_offsets(search["search_linear_size"], search["search_linear_resolution"])
+    cos_t = np.array([math.cos(pose[2] + d) for d in dth])
+    sin_t = np.array([math.sin(pose[2] + d) for d in dth])
+    L = _capi.lib()
+    out = {}
+    for how in ("dense", "sparse"):
+        h = C.c_void_p()
+        assert L.ndt2d_create(C.byref(h), 0) == 0
+        try:
+            if how == "dense":
+                assert L.ndt2d_set_grid(h, _capi.dptr(cells), sx, sy, 0.25, ox, oy) == 0
+            else:
+                assert L.ndt2d_set_grid_sparse(h, listed.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                               _capi.dptr(sparse6), len(listed), sx, sy, 0.25, ox, oy) == 0
+            assert L.ndt2d_set_beams(h, _capi.dptr(pts), len(pts)) == 0
+            assert L.ndt2d_set_search(h, pose[0], pose[1], _capi.dptr(dth), _capi.dptr(cos_t),
+                                      _capi.dptr(sin_t), len(dth), _capi.dptr(dlin), len(dlin)) == 0
+            got = {}
+            for variant in (b"auto", b"lane", b"lane-noskip", b"small", b"wave"):
+                if L.ndt2d_set_variant(h, variant) != 0:
+                    continue
+                res = _capi.MatchResult()
+                sc = np.zeros(len(dth) * len(dlin) ** 2)
+                rc = L.ndt2d_match(h, 0, len(dth), _capi.dptr(sc), C.byref(res))
+                if rc != 0:
+                    continue          # (a variant this lattice / map does not support)
+                got[variant] = (sc, res.best_index, res.best_score, L.ndt2d_last_variant(h))
+            back = np.zeros_like(cells)
+            assert L.ndt2d_get_grid(h, _capi.dptr(back), len(back), None, None, None, None, None) == 0
+            out[how] = (got, back)
+        finally:
+            L.ndt2d_destroy(h)
+    assert set(out["dense"][0]) == set(out["sparse"][0]) and b"auto" in out["dense"][0]
+    for variant, (sc, bi, bs, name) in out["dense"][0].items():
+        sc2, bi2, bs2, name2 = out["sparse"][0][variant]
+        assert np.array_equal(sc, sc2), variant
+        assert (bi, bs) == (bi2, bs2)
+    assert np.array_equal(out["dense"][1], cells) and np.array_equal(out["sparse"][1], cells)
+    assert np.array_equal(out["sparse"][0][b"lane"][0], out["sparse"][0][b"lane-noskip"][0])
+    assert (out["dense"][0][b"auto"][0] < 0).sum() > 100
+
+
 def _big_winner(cfg):
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "big_winners.json")) as f:
         return json.load(f)["cfg%d" % cfg]
