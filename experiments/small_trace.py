@@ -17,15 +17,30 @@ import torch  # noqa: E402
 from ndt_2d_amd import ScanMatcherNDT, synth  # noqa: E402
 
 which = sys.argv[1] if len(sys.argv) > 1 else "defaults"
-over = {"defaults": dict(search_linear_size=0.05, search_linear_resolution=0.005, search_angular_size=0.1,
-                         search_angular_resolution=0.0025, laser_max_beams=100),
+DEFAULTS = dict(search_linear_size=0.05, search_linear_resolution=0.005, search_angular_size=0.1,
+                search_angular_resolution=0.0025, laser_max_beams=100)
+over = {"defaults": DEFAULTS, "real30": DEFAULTS,
         "d720": dict(search_linear_size=0.05, search_linear_resolution=0.005, search_angular_size=0.1,
                      search_angular_resolution=0.0025),
         "cfg1": {}}[which]
 m = ScanMatcherNDT(0)
-m.initialize("m", **synth.matcher_params(1, **over))
-m.addScans(synth.map_scans(1))
-guess, pts, _ = synth.query_scan(1)
+if which == "real30":
+    # a 30 m lidar's local map (245 x 245 cells): nine scans around the pose in cfg-5's world
+    w = synth.world_of(5)
+    guess, pts, true = synth.query_scan(5)
+    scans = []
+    for j in range(3):
+        for i in range(3):
+            x, y = true[0] + (i - 1) * 0.5, true[1] + (j - 1) * 0.5
+            if not synth.pose_blocked(w, x, y):
+                scans.append(((x, y, 0.0), synth.scan(w, (x, y, 0.0), 77 + 10 * j + i)))
+    m.initialize("m", **dict(synth.matcher_params(5, **over), range_max=30.0))
+    m.addScans(scans)
+    guess = true + np.array([0.02, -0.02, 0.01])
+else:
+    m.initialize("m", **synth.matcher_params(1, **over))
+    m.addScans(synth.map_scans(1))
+    guess, pts, _ = synth.query_scan(1)
 n_th, n_lin, n_b = m.prepare_search(guess, pts)
 buf = torch.zeros(8192 * 16 * 8, dtype=torch.float64, device="cuda:0")
 for _ in range(5):

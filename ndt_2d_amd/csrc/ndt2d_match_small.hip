@@ -140,20 +140,78 @@ match_small_kernel(const MatchArgs a,
   const uint32_t ith = a.th_begin + t_local * a.th_stride;
 
   // map window: one byte per grid cell, copied from the grid's extended byte image;
-  // cells further than one cell outside the grid cannot be reached by anything: 0
-  // (a wave per map row, a lane per column)
+  // cells further than one cell outside the grid cannot be reached by anything: 0.
+  // A real lidar's window is most of a 245 x 245 grid: 60 KB per block, and byte by byte
+  // (a wave per row, a lane per column) the copy was 12 of such a block's 17 us
+  // (experiments/small_trace.py real30).  Now: 16-column pieces -- the global side read
+  // unaligned, the LDS row stride is 256 -- with all of a thread's loads in flight before
+  // its first store; the (at most two) pieces of a row that straddle the image's edge are
+  // left to a second, byte-wise pass over just those pieces.
   {
     const int32_t ew = static_cast<int32_t>(g.size_x) + 2, eh = static_cast<int32_t>(g.size_y) + 2;
-    const uint32_t n_waves = n_threads >> 6;
-    for (uint32_t my = threadIdx.x >> 6; my < static_cast<uint32_t>(geo.map_h); my += n_waves)
+    const int32_t x_shift = geo.win_x0 + 1 - geo.pad;    // image column of map column 0
+    const int32_t y_shift = geo.win_y0 + 1 - geo.pad;
+    const uint32_t pieces = (plan.need_w + 15u) / 16u;   // per row, <= 16
+    const uint32_t n_vec = static_cast<uint32_t>(geo.map_h) * 16u;
+    typedef uint32_t unaligned_u32 __attribute__((aligned(1)));
+    constexpr int kCopyUnroll = 8;
+    for (uint32_t base = threadIdx.x; base < n_vec; base += n_threads * kCopyUnroll)
     {
-      const int32_t ey = static_cast<int32_t>(my) - geo.pad + geo.win_y0 + 1;
-      for (uint32_t mx = threadIdx.x & 63u; mx < plan.need_w; mx += 64u)
+      uint4 v[kCopyUnroll];
+#pragma unroll
+      for (int u = 0; u < kCopyUnroll; ++u)
       {
-        const int32_t ex = static_cast<int32_t>(mx) - geo.pad + geo.win_x0 + 1;
-        uint8_t v = 0;
-        if (ex >= 0 && ex < ew && ey >= 0 && ey < eh) v = g.cell_bytes[ey * ew + ex];
-        lds_map[my * kMapStride + mx] = v;
+        const uint32_t w = base + static_cast<uint32_t>(u) * n_threads;
+        const int32_t ey = static_cast<int32_t>(w >> 4) + y_shift;
+        const int32_t ex = static_cast<int32_t>((w & 15u) * 16u) + x_shift;
+        v[u] = uint4{0u, 0u, 0u, 0u};
+        if (w < n_vec && (w & 15u) < pieces && ey >= 0 && ey < eh && ex >= 0 && ex + 16 <= ew)
+        {
+          const unaligned_u32 * s32 =
+            reinterpret_cast<const unaligned_u32 *>(g.cell_bytes + static_cast<size_t>(ey) * ew + ex);
+          v[u] = uint4{s32[0], s32[1], s32[2], s32[3]};
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kCopyUnroll; ++u)
+      {
+        const uint32_t w = base + static_cast<uint32_t>(u) * n_threads;
+        if (w < n_vec && (w & 15u) < pieces)
+        {
+          *reinterpret_cast<uint4 *>(lds_map + (w >> 4) * kMapStride + (w & 15u) * 16u) = v[u];
+        }
+      }
+    }
+    // the pieces that hold column 0 / column ew - 1 of the image (those the pass above left
+    // at zero although some of their columns are inside): piece index, or none
+    const int32_t left = x_shift < 0 && (-x_shift) % 16 != 0 ? (-x_shift) / 16 : -1;
+    const int32_t right = (ew - x_shift) % 16 != 0 ? (ew - x_shift) / 16 : -1;
+    __syncthreads();
+    const uint32_t n_edge = static_cast<uint32_t>(geo.map_h) * 32u;
+    constexpr int kEdgeUnroll = 4;   // (loads of four trips in flight together)
+    for (uint32_t base = threadIdx.x; base < n_edge; base += n_threads * kEdgeUnroll)
+    {
+      uint8_t bv[kEdgeUnroll];
+      uint32_t at[kEdgeUnroll];
+#pragma unroll
+      for (int u = 0; u < kEdgeUnroll; ++u)
+      {
+        const uint32_t e = base + static_cast<uint32_t>(u) * n_threads;
+        const uint32_t my = e >> 5;
+        const int32_t piece = (e & 16u) ? right : left;
+        const bool listed = e < n_edge && piece >= 0 && piece < static_cast<int32_t>(pieces) &&
+                            !((e & 16u) && right == left);
+        const uint32_t mx = static_cast<uint32_t>(listed ? piece : 0) * 16u + (e & 15u);
+        const int32_t ey = static_cast<int32_t>(my) + y_shift;
+        const int32_t ex = static_cast<int32_t>(mx) + x_shift;
+        const bool inside = listed && ex >= 0 && ex < ew && ey >= 0 && ey < eh;
+        at[u] = inside ? my * kMapStride + mx : 0xffffffffu;
+        bv[u] = inside ? g.cell_bytes[ey * ew + ex] : static_cast<uint8_t>(0);
+      }
+#pragma unroll
+      for (int u = 0; u < kEdgeUnroll; ++u)
+      {
+        if (at[u] != 0xffffffffu) lds_map[at[u]] = bv[u];
       }
     }
   }
