@@ -423,6 +423,31 @@ def default_search_bench(matcher_cls, synth, device_index, reps=300, with_cpu=Tr
             "note": "through the UNCHANGED per-particle loop the GPU plugin is slower than this CPU "
                     "path (one launch per particle); the batched entry point needs the one-line node "
                     "change of INTEGRATION.md section 4"}
+    if with_cpu and c_host is not None and "real_lidar_map" in c_host:
+        # the probe's second scenario -- a 30 m lidar's 245 x 245 local map -- on the CPU oracle
+        import numpy as np
+        w5 = synth.world_of(5)
+        g5, pts5, true5 = synth.query_scan(5)
+        scans5 = []
+        for j in range(3):
+            for i in range(3):
+                x, y = true5[0] + 0.5 * (i - 1), true5[1] + 0.5 * (j - 1)
+                if not synth.pose_blocked(w5, x, y):
+                    scans5.append(((x, y, 0.0), synth.scan(w5, (x, y, 0.0), 77 + 10 * j + i)))
+        p5 = dict(params, range_max=30.0)
+        ref5 = O.ScanMatcherNDT()
+        ref5.initialize(**p5)
+        ref5.addScans(scans5)
+        pose5 = true5 + np.array([0.02, -0.02, 0.01])
+        cm, exp5 = med_cpu(lambda: ref5.matchScan(pose5, pts5), 3)
+        cs, _ = med_cpu(lambda: ref5.scoreScan(pose5, pts5), 20)
+        ca, _ = med_cpu(lambda: (ref5.reset(), ref5.addScans(scans5)), 10)
+        out["cpu_single_thread"]["real_lidar_map"] = {
+            "match_scan_ms": cm, "score_scan_ms": cs, "add_scans_ms": ca, "mapper_cycle_ms": cm + cs + ca,
+            "match_scan_pose": [float(v) for v in exp5["pose"]], "match_scan_score": exp5["score"]}
+        got5 = c_host["real_lidar_map"]
+        if [float(v) for v in exp5["pose"]] != got5["check_pose"] or abs(exp5["score"] - got5["check_score"]) > 1e-9:
+            raise SystemExit("bench.py: the real-lidar-map search differs from the oracle's")
     if c_host is not None:
         out["c_host"] = dict(c_host, what="ndt_2d_amd/tools/latency_probe.c: the same calls through the C-ABI "
                                           "from a C program, medians of 2000 (500 for addScans / the cycle)")

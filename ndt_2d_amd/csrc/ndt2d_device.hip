@@ -149,7 +149,9 @@ int ensure(ndt2d_context * h, DeviceBuffer & b, size_t doubles)
     b.ptr = nullptr;
     b.cap = 0;
   }
-  size_t cap = doubles < 64 ? 64 : doubles;
+  // (an eighth of headroom: the mapper's grid follows the scan poses and grows by a row or
+  // a column of cells now and then -- not a free + malloc + stream synchronisation each time)
+  size_t cap = doubles < 64 ? 64 : doubles + doubles / 8;
   NDT2D_HIP(h, hipMalloc(reinterpret_cast<void **>(&b.ptr), cap * sizeof(double)));
   b.cap = cap;
   return NDT2D_OK;

@@ -6,7 +6,8 @@
  * 8 x 8 m room (SURVEY.md 8d, cfg-1's map).  Per accepted scan the mapper runs
  * reset + addScans + scoreScan + matchScan (src/ndt_mapper.cpp:508-515); the unchanged
  * ParticleFilter::measure calls scorePoints once per particle (src/particle_filter.cpp:
- * 81-87).  Prints one JSON object with medians in microseconds.
+ * 81-87).  Then the mapper's calls once more on a grid of a real lidar's size (245 x 245
+ * cells).  Prints one JSON object with medians in microseconds.
  *
  *   gcc -O2 -std=c99 -I include ndt_2d_amd/tools/latency_probe.c -L ndt_2d_amd -lndt2d_hip -lm
  */
@@ -39,8 +40,9 @@ static int cmp(const void * a, const void * b)
 static ndt2d_matcher * m;
 static double map_poses[3 * N_SCANS], map_pts[2 * N_BEAMS * N_SCANS];
 static size_t map_off[N_SCANS + 1];
+static size_t n_map_scans = N_SCANS;
 static double scan_pts[2 * N_BEAMS];
-static const double guess[3] = {0.11, -0.05, 0.02};
+static double guess[3] = {0.11, -0.05, 0.02};
 static double pf_poses[3 * 500];
 
 static void op_match(void)
@@ -56,7 +58,7 @@ static void op_score_scan(void)
 static void op_add(void)
 {
   if (ndt2d_matcher_reset(m) != NDT2D_OK) exit(5);
-  if (ndt2d_matcher_add_scans(m, map_poses, map_pts, map_off, N_SCANS) != NDT2D_OK) exit(6);
+  if (ndt2d_matcher_add_scans(m, map_poses, map_pts, map_off, n_map_scans) != NDT2D_OK) exit(6);
 }
 static void op_cycle(void)
 {
@@ -152,14 +154,69 @@ int main(void)
   measure(op_pf_measure, REPS / 4, &med[6], &p99[6]);
   double pose[3] = {0, 0, 0}, cov[9], score;
   ndt2d_matcher_match_scan(m, guess, scan_pts, N_BEAMS, pose, cov, &score);
+  char variant[128];
+  snprintf(variant, sizeof(variant), "%s", ndt2d_last_variant(ndt2d_matcher_device(m)));
+  ndt2d_matcher_destroy(m);
+
+  /* The same calls on a grid of a real lidar's size: the local NDT spans the scan poses
+   * +- range_max (reference src/scan_matcher_ndt.cpp:52-66), 245 x 245 cells for 30 m at
+   * 0.25 m.  cfg-5's world (190 x 190 m room, pillars every 5 m), nine scans on a 3 x 3
+   * lattice of pitch 0.5 m around the query pose (1.0, 0.5, 0.3). */
+  const ndt2d_world big = {95.0, 5.0, 0.25};
+  const double truth5[3] = {1.0, 0.5, 0.3};
+  n_map_scans = 0;
+  for (int j = -1; j <= 1; ++j)
+  {
+    for (int i = -1; i <= 1; ++i)
+    {
+      double * p = map_poses + 3 * n_map_scans;
+      p[0] = truth5[0] + 0.5 * i;
+      p[1] = truth5[1] + 0.5 * j;
+      p[2] = 0.0;
+      if (ndt2d_synth_pose_blocked(&big, p[0], p[1], 0.25)) continue;
+      if (ndt2d_synth_scan(&big, p, N_BEAMS, 0.01, 77u + (unsigned)(10 * (j + 1) + (i + 1)),
+                           map_pts + 2 * N_BEAMS * n_map_scans) != NDT2D_OK)
+        return 1;
+      map_off[n_map_scans] = (size_t)N_BEAMS * n_map_scans;
+      ++n_map_scans;
+    }
+  }
+  map_off[n_map_scans] = (size_t)N_BEAMS * n_map_scans;
+  if (ndt2d_synth_scan(&big, truth5, N_BEAMS, 0.01, 501u, scan_pts) != NDT2D_OK) return 1;
+  guess[0] = truth5[0] + 0.02;
+  guess[1] = truth5[1] - 0.02;
+  guess[2] = truth5[2] + 0.01;
+  if (ndt2d_matcher_create(&m, 0) != NDT2D_OK) return 2;
+  ndt2d_matcher_initialize(m, 0.25, 0.0025, 0.1, 0.005, 0.05, 100, 30.0);
+  ndt2d_set_timing(ndt2d_matcher_device(m), 0);
+  op_add();
+  double rmed[4], rp99[4];
+  measure(op_match, REPS, &rmed[0], &rp99[0]);
+  measure(op_score_scan, REPS, &rmed[1], &rp99[1]);
+  measure(op_add, REPS / 4, &rmed[2], &rp99[2]);
+  measure(op_cycle, REPS / 4, &rmed[3], &rp99[3]);
+  uint32_t gsx = 0, gsy = 0;
+  ndt2d_matcher_grid_info(m, &gsx, &gsy, NULL, NULL, NULL);
+  double rpose[3] = {0, 0, 0}, rscore;
+  ndt2d_matcher_match_scan(m, guess, scan_pts, N_BEAMS, rpose, cov, &rscore);
+  char rvariant[128];
+  snprintf(rvariant, sizeof(rvariant), "%s", ndt2d_last_variant(ndt2d_matcher_device(m)));
+  char real[640];
+  snprintf(real, sizeof(real),
+           "{\"grid\": [%u, %u], \"map_scans\": %zu, \"range_max_m\": 30.0, \"match_scan_us\": %.2f, "
+           "\"match_scan_p99_us\": %.2f, \"score_scan_us\": %.2f, \"add_scans_us\": %.2f, "
+           "\"mapper_cycle_us\": %.2f, \"mapper_cycle_p99_us\": %.2f, \"variant\": \"%s\", "
+           "\"check_pose\": [%.17g, %.17g, %.17g], \"check_score\": %.17g}",
+           gsx, gsy, n_map_scans, rmed[0], rp99[0], rmed[1], rmed[2], rmed[3], rp99[3], rvariant, rpose[0],
+           rpose[1], rpose[2], rscore);
   printf("{\"match_scan_us\": %.2f, \"match_scan_p99_us\": %.2f, \"score_scan_us\": %.2f, "
          "\"add_scans_us\": %.2f, \"mapper_cycle_us\": %.2f, \"mapper_cycle_p99_us\": %.2f, "
          "\"measure_500_particles_unchanged_loop_us\": %.1f, \"score_points_call_us\": %.2f, "
          "\"measure_500_particles_batched_us\": %.2f, \"pf_measure_500_particles_us\": %.2f, "
          "\"variant\": \"%s\", "
-         "\"check_pose\": [%.17g, %.17g, %.17g], \"check_score\": %.17g}\n",
+         "\"check_pose\": [%.17g, %.17g, %.17g], \"check_score\": %.17g, \"real_lidar_map\": %s}\n",
          med[0], p99[0], med[1], med[2], med[3], p99[3], med[4], med[4] / 500.0, med[5], med[6],
-         ndt2d_last_variant(ndt2d_matcher_device(m)), pose[0], pose[1], pose[2], score);
+         variant, pose[0], pose[1], pose[2], score, real);
   ndt2d_matcher_destroy(m);
   return 0;
 }
