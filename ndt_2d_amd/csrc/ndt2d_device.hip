@@ -56,6 +56,10 @@ struct ndt2d_context
   // a grid installed as the list of its touched cells (ndt2d_set_grid_sparse): the list on the
   // device (inside `compact`), from which ndt2d_get_grid makes the dense records on demand
   DeviceBuffer ranks;       // cell -> compact record table of such a grid (uint16 per cell)
+  // particle scoring on a grid whose occupancy bitmap does not fit LDS: one bit per block of
+  // cells, made from the bitmap on the first launch that needs it (-1: not made for this grid)
+  DeviceBuffer coarse_bits;
+  int coarse_log2 = -1;
   uint32_t sparse_n = 0;
   const uint32_t * sparse_index = nullptr;
   const double * sparse_cells6 = nullptr;
@@ -442,6 +446,7 @@ int ndt2d_destroy(ndt2d_handle h)
   release(h->compact);
   release(h->cells6);
   release(h->ranks);
+  release(h->coarse_bits);
   release(h->call_dev);
   release(h->stage_grid);
   release(h->stage_call);
@@ -600,6 +605,7 @@ int ndt2d_set_grid(ndt2d_handle h, const double * cells6, uint32_t size_x, uint3
     g.n_occ = n_occ;
   }
   h->grid = g;
+  h->coarse_log2 = -1;
   h->has_grid = true;
   return NDT2D_OK;
 }
@@ -731,6 +737,7 @@ int ndt2d_build_grid(ndt2d_handle h, double ndt_resolution, double range_max,
   h->sparse_index = nullptr;
   h->sparse_cells6 = nullptr;
   h->grid = g;
+  h->coarse_log2 = -1;
   h->has_grid = true;
   return NDT2D_OK;
 }
@@ -851,6 +858,7 @@ int ndt2d_set_grid_sparse(ndt2d_handle h, const uint32_t * cell_index, const dou
   h->sparse_index = d_idx;
   h->sparse_cells6 = d_cells6;
   h->grid = g;
+  h->coarse_log2 = -1;
   h->has_grid = true;
   return NDT2D_OK;
 }
@@ -1167,6 +1175,24 @@ int ndt2d_score_poses_launch(ndt2d_handle h, const double * d_poses_xyt, size_t 
   a.n_poses = n_poses;
   a.scores = d_scores;
   a.beam_rmax = h->beam_rmax;
+  {
+    // an occupancy bitmap too large for LDS: screen with one bit per block of cells
+    const int k = ndt2d::poses_coarse_log2(a, ndt2d::poses_lds_per_block());
+    if (k > 0)
+    {
+      if (h->coarse_log2 != k)
+      {
+        rc = ensure(h, h->coarse_bits, ndt2d::poses_coarse_words(h->grid, static_cast<uint32_t>(k)) / 2 + 2);
+        if (rc != NDT2D_OK) return rc;
+        hipError_t ce = ndt2d::poses_coarse_bits_launch(h->grid, static_cast<uint32_t>(k),
+                                                        reinterpret_cast<uint32_t *>(h->coarse_bits.ptr), h->stream);
+        if (ce != hipSuccess) return fail_hip(h, ce, "poses_coarse_bits_launch");
+        h->coarse_log2 = k;
+      }
+      a.coarse_bits = reinterpret_cast<const uint32_t *>(h->coarse_bits.ptr);
+      a.coarse_log2 = static_cast<uint32_t>(k);
+    }
+  }
 
   ndt2d::LaunchInfo info{"", 0};
   if (h->timing)

@@ -103,6 +103,12 @@ struct PosesArgs
   double * partials;         // [n_blocks][8]  (may be null)
   double beam_rmax;          // max |beam| (host side copy of the scan's reach)
   float screen_guard;        // set by launch_poses_compact: FP32 screening error bound, cells
+  // Grids whose occupancy bitmap does not fit LDS are screened with one bit per block of
+  // 2^coarse_log2 x 2^coarse_log2 cells (bit = some cell of the block holds a distribution;
+  // the last bit, index coarse_sx * coarse_sy, stands for "outside" and is never set):
+  // coarse_bits from poses_coarse_bits_launch, null / 0 for the cell-level bitmap grid.occ_bits.
+  const uint32_t * coarse_bits;
+  uint32_t coarse_log2;
 };
 
 // NDT build on the device (ndt2d_build.hip).  `grid` carries the geometry only.
@@ -287,6 +293,12 @@ hipError_t launch_match_small(const MatchArgs & args, double * workspace, uint32
 // Particle scoring with per-wave compaction of the occupied (pose, beam) pairs
 // (ndt2d_poses_compact.hip).
 bool poses_compact_supported(const PosesArgs & args, size_t lds_per_block);
+// Smallest coarse_log2 (0 = the cell-level bitmap) with which the kernel's LDS image fits;
+// -1 if none up to 4 does.
+int poses_coarse_log2(const PosesArgs & args, size_t lds_per_block);
+size_t poses_coarse_words(const GridDesc & g, uint32_t coarse_log2);
+size_t poses_lds_per_block();   // the LDS a block of the particle kernels may use on this device
+hipError_t poses_coarse_bits_launch(const GridDesc & g, uint32_t coarse_log2, uint32_t * out, hipStream_t stream);
 // screen: phase A decides in FP32 which pairs can contribute (exact FP64 follows for
 // those); false = the exact phase A ("compact-exact", the control).
 hipError_t launch_poses_compact(const PosesArgs & args, int cus, bool screen, hipStream_t stream,

@@ -881,6 +881,8 @@ hipError_t launch_poses_variant(const PosesArgs & args, uint32_t blocks, size_t 
 
 }  // namespace
 
+size_t poses_lds_per_block() { return device_limits().lds_per_block; }
+
 hipError_t launch_score_poses(const PosesArgs & args_in, double * workspace, double * stats_out,
                               int force_variant, hipStream_t stream, hipEvent_t ev_main_done,
                               LaunchInfo * info)
@@ -944,8 +946,11 @@ hipError_t launch_score_poses(const PosesArgs & args_in, double * workspace, dou
   }
   if (info != nullptr)
   {
-    info->variant = use_compact ? (pow2 ? "poses/lane-per-pose/compact/pow2"
-                                        : "poses/lane-per-pose/compact/div")
+    info->variant = use_compact ? (args.coarse_log2 > 0
+                                     ? (pow2 ? "poses/lane-per-pose/compact/coarse-bitmap/pow2"
+                                             : "poses/lane-per-pose/compact/coarse-bitmap/div")
+                                     : (pow2 ? "poses/lane-per-pose/compact/pow2"
+                                             : "poses/lane-per-pose/compact/div"))
                     : use_lds   ? (pow2 ? "poses/lane-per-pose/lds-grid/pow2"
                                         : "poses/lane-per-pose/lds-grid/div")
                                 : (pow2 ? "poses/lane-per-pose/global-grid/pow2"

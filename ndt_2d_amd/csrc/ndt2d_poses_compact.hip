@@ -94,7 +94,7 @@ __host__ __device__ inline float screen_guard(float magnitude)
 }
 
 // SPLIT waves share the 64 poses of a group; each takes kChunks / SPLIT chunks.
-template <int THREADS, bool POW2, bool SCREEN>
+template <int THREADS, bool POW2, bool SCREEN, bool COARSE = false>
 // (4 waves per SIMD = at most 128 VGPRs, also for the 256-thread geometry: the
 // accumulators that no longer fit are spilled on the once-per-pose path, and a CU
 // holds four blocks instead of three)
@@ -111,7 +111,13 @@ score_poses_compact_kernel(const PosesArgs a, const uint32_t split)
   // must start at LDS offset 0.
   if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();
   uint32_t * lds_bits = reinterpret_cast<uint32_t *>(lds);
-  const uint32_t n_words = (g.ncell + 1 + 31) / 32;
+  // COARSE: one bit per block of 2^k x 2^k cells (PosesArgs::coarse_bits) instead of one per cell
+  const uint32_t k_log2 = COARSE ? a.coarse_log2 : 0u;
+  const uint32_t bits_sx = COARSE ? (g.size_x + (1u << k_log2) - 1u) >> k_log2 : g.size_x;
+  const uint32_t bits_sy = COARSE ? (g.size_y + (1u << k_log2) - 1u) >> k_log2 : g.size_y;
+  const uint32_t bits_outside = COARSE ? bits_sx * bits_sy : g.ncell;   // a bit that is never set
+  const uint32_t n_words = (bits_outside + 1 + 31) / 32;
+  const uint32_t * bits_src = COARSE ? a.coarse_bits : g.occ_bits;
   double * sh_stats = lds + ((n_words + 3) & ~3u) / 2;
   double * sh_sum = sh_stats + L::kWaves * 8;
   double * q_px_all = sh_sum + THREADS;
@@ -129,7 +135,7 @@ score_poses_compact_kernel(const PosesArgs a, const uint32_t split)
     lds_beams[i] = v;
     if (SCREEN) lds_beams_f[i] = static_cast<float>(v);
   }
-  for (uint32_t i = threadIdx.x; i < n_words; i += THREADS) lds_bits[i] = g.occ_bits[i];
+  for (uint32_t i = threadIdx.x; i < n_words; i += THREADS) lds_bits[i] = bits_src[i];
   __syncthreads();
 
   const uint32_t lane = threadIdx.x & (kWave - 1);
@@ -233,6 +239,14 @@ score_poses_compact_kernel(const PosesArgs a, const uint32_t split)
       rot_y = f32x2{-si, ci};
     }
 
+    // (unscreened control path) the bitmap bit of an exact cell index; ncell = outside
+    auto bit_of_cell = [&](uint32_t cell) -> uint32_t {
+      if (!COARSE) return cell;
+      if (cell >= g.ncell) return bits_outside;
+      const uint32_t cy = cell / g.size_x, cx = cell - cy * g.size_x;
+      return (cy >> k_log2) * bits_sx + (cx >> k_log2);
+    };
+    (void)bit_of_cell;
     double total = 0.0;
     for (uint32_t cj = 0; cj < chunks_per_part; ++cj)
     {
@@ -285,7 +299,8 @@ score_poses_compact_kernel(const PosesArgs a, const uint32_t split)
         asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(iv) : "v"(uv.y));
         const bool inside = (static_cast<uint32_t>(iu) < g.size_x) & (static_cast<uint32_t>(iv) < g.size_y);
         Screen r;
-        r.idx = inside ? __umul24(static_cast<uint32_t>(iv), g.size_x) + static_cast<uint32_t>(iu) : g.ncell;
+        r.idx = inside ? __umul24(static_cast<uint32_t>(iv) >> k_log2, bits_sx) + (static_cast<uint32_t>(iu) >> k_log2)
+                       : bits_outside;
         // The coordinate carries +guard, so "within guard of a cell boundary" reads
         // fract < 2 guard, and where that is false floor() is the exact point's cell.
         // (Far outside the grid it also fires now and then: a harmless false candidate.)
@@ -372,7 +387,7 @@ score_poses_compact_kernel(const PosesArgs a, const uint32_t split)
       for (; k + kPhaseA <= k1; k += kPhaseA)
       {
         double px[kPhaseA], py[kPhaseA];
-        uint32_t idx[kPhaseA], word[kPhaseA];
+        uint32_t idx[kPhaseA], word[kPhaseA], bit[kPhaseA];
 #pragma unroll
         for (int u = 0; u < kPhaseA; ++u)
         {
@@ -381,12 +396,13 @@ score_poses_compact_kernel(const PosesArgs a, const uint32_t split)
           px[u] = x + (c * p.x - s * p.y);
           py[u] = y + (s * p.x + c * p.y);
           idx[u] = cell_index<POW2>(g, px[u], py[u]);
-          word[u] = lds_bits[idx[u] >> 5];
+          bit[u] = bit_of_cell(idx[u]);
+          word[u] = lds_bits[bit[u] >> 5];
         }
 #pragma unroll
         for (int u = 0; u < kPhaseA; ++u)
         {
-          push(px[u], py[u], idx[u], ((word[u] >> (idx[u] & 31u)) & 1u) != 0);
+          push(px[u], py[u], idx[u], ((word[u] >> (bit[u] & 31u)) & 1u) != 0);
         }
       }
       for (; k < k1; ++k)
@@ -395,7 +411,8 @@ score_poses_compact_kernel(const PosesArgs a, const uint32_t split)
         const double px = x + (c * p.x - s * p.y);
         const double py = y + (s * p.x + c * p.y);
         const uint32_t idx = cell_index<POW2>(g, px, py);
-        push(px, py, idx, ((lds_bits[idx >> 5] >> (idx & 31u)) & 1u) != 0);
+        const uint32_t bit = bit_of_cell(idx);
+        push(px, py, idx, ((lds_bits[bit >> 5] >> (bit & 31u)) & 1u) != 0);
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       drain(head, count);
@@ -685,7 +702,8 @@ size_t compact_lds_bytes(const PosesArgs & args, int threads, uint32_t split, bo
                                                  : CompactLayout<256, false>::kFixedDoubles);
   // f64 beams + (screening) their f32 copy, 1.5 doubles per coordinate
   const size_t beams = static_cast<size_t>(3) * ((args.n_beams + 1) & ~1u) + kScreenPadFloats / 2;
-  const size_t words = (static_cast<size_t>(args.grid.ncell) + 1 + 31) / 32;
+  const size_t words = args.coarse_log2 > 0 ? poses_coarse_words(args.grid, args.coarse_log2)
+                                            : (static_cast<size_t>(args.grid.ncell) + 1 + 31) / 32;
   const size_t chunk_sums =
     split > 1 ? static_cast<size_t>(threads / kWave / split) * kChunks * kWave : 0;
   return (fixed + beams + chunk_sums) * sizeof(double) + ((words + 3) & ~size_t(3)) * 4;
@@ -721,6 +739,18 @@ hipError_t launch_compact(const PosesArgs & args, uint32_t blocks, uint32_t spli
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(THREADS), lds_bytes, stream, args, split);
     return hipGetLastError();
   };
+  if (args.coarse_log2 > 0)
+  {
+    // (one bit per block of cells: large grids only, i.e. the 1024-thread geometry)
+    if (THREADS != 1024 || args.coarse_bits == nullptr) return hipErrorInvalidValue;
+    if (screen)
+    {
+      return args.grid.pow2 ? launch(score_poses_compact_kernel<1024, true, true, true>)
+                            : launch(score_poses_compact_kernel<1024, false, true, true>);
+    }
+    return args.grid.pow2 ? launch(score_poses_compact_kernel<1024, true, false, true>)
+                          : launch(score_poses_compact_kernel<1024, false, false, true>);
+  }
   if (screen)
   {
     return args.grid.pow2 ? launch(score_poses_compact_kernel<THREADS, true, true>)
@@ -773,10 +803,75 @@ hipError_t launch_score_few(const PosesArgs & args, const FewPoses * few, const 
   return args.grid.pow2 ? launch(score_few_kernel<true, false>) : launch(score_few_kernel<false, false>);
 }
 
+size_t poses_coarse_words(const GridDesc & g, uint32_t coarse_log2)
+{
+  const size_t sx = (static_cast<size_t>(g.size_x) + (1u << coarse_log2) - 1) >> coarse_log2;
+  const size_t sy = (static_cast<size_t>(g.size_y) + (1u << coarse_log2) - 1) >> coarse_log2;
+  return (sx * sy + 1 + 31) / 32;
+}
+
+int poses_coarse_log2(const PosesArgs & args_in, size_t lds_per_block)
+{
+  if (args_in.grid.occ_bits == nullptr || args_in.grid.ncell >= kCellMask) return -1;
+  PosesArgs args = args_in;
+  for (uint32_t k = 0; k <= 4; ++k)
+  {
+    args.coarse_log2 = k;
+    if (compact_lds_bytes(args, 1024, 1, false) <= lds_per_block) return static_cast<int>(k);
+  }
+  return -1;
+}
+
 bool poses_compact_supported(const PosesArgs & args, size_t lds_per_block)
 {
-  return args.grid.occ_bits != nullptr && args.grid.ncell < kCellMask &&
-         compact_lds_bytes(args, 1024, 1, false) <= lds_per_block;
+  const int k = poses_coarse_log2(args, lds_per_block);
+  return k >= 0 && static_cast<uint32_t>(k) == args.coarse_log2 && (k == 0 || args.coarse_bits != nullptr);
+}
+
+namespace
+{
+
+// bit (by, bx) = some cell of the block of 2^k x 2^k cells at (bx << k, by << k) holds a
+// distribution; bit sx * sy ("outside") and the padding of the last word stay zero
+__global__ void __launch_bounds__(256) coarse_bits_kernel(const GridDesc g, uint32_t k, uint32_t sx, uint32_t sy,
+                                                          uint32_t * out)
+{
+  const uint32_t word = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t n_bits = sx * sy;
+  if (word >= (n_bits + 1 + 31) / 32) return;
+  uint32_t v = 0;
+  for (uint32_t j = 0; j < 32; ++j)
+  {
+    const uint32_t b = word * 32 + j;
+    if (b >= n_bits) break;
+    const uint32_t by = b / sx, bx = b - by * sx;
+    bool any = false;
+    for (uint32_t cy = by << k; cy < min((by + 1) << k, g.size_y) && !any; ++cy)
+    {
+      for (uint32_t cx = bx << k; cx < min((bx + 1) << k, g.size_x); ++cx)
+      {
+        const uint32_t cell = cy * g.size_x + cx;
+        if ((g.occ_bits[cell >> 5] >> (cell & 31u)) & 1u)
+        {
+          any = true;
+          break;
+        }
+      }
+    }
+    v |= any ? (1u << j) : 0u;
+  }
+  out[word] = v;
+}
+
+}  // namespace
+
+hipError_t poses_coarse_bits_launch(const GridDesc & g, uint32_t coarse_log2, uint32_t * out, hipStream_t stream)
+{
+  const uint32_t sx = (g.size_x + (1u << coarse_log2) - 1) >> coarse_log2;
+  const uint32_t sy = (g.size_y + (1u << coarse_log2) - 1) >> coarse_log2;
+  const uint32_t words = static_cast<uint32_t>(poses_coarse_words(g, coarse_log2));
+  hipLaunchKernelGGL(coarse_bits_kernel, dim3((words + 255) / 256), dim3(256), 0, stream, g, coarse_log2, sx, sy, out);
+  return hipGetLastError();
 }
 
 hipError_t launch_poses_compact(const PosesArgs & args_in, int cus, bool screen,

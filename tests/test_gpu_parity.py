@@ -747,6 +747,40 @@ def test_grid_installed_as_a_list_of_cells_equals_the_dense_install(cfg, search)
     assert (out["dense"][0][b"auto"][0] < 0).sum() > 100
 
 
+@pytest.mark.parametrize("resolution", [0.125, 0.1])
+def test_particles_on_a_grid_whose_bitmap_does_not_fit_lds(resolution):
+    """cfg-5's 200 x 200 m map at 0.125 m (1601 x 1601 cells, a 320 KB occupancy bitmap) and at
+    0.1 m (2001 x 2001, true division): the batched scorePoints kernel screens with one bit per
+    block of 2 x 2 (4 x 4) cells instead of falling back to the dense kernel.  Weights against
+    the oracle, the screen against its exact control bit for bit, and against the dense kernel."""
+    gpu, ref, _, guess, pts = _pair(5, ndt_resolution=resolution)
+    parts = synth.particles(5, 20000)
+    parts[:4000, :2] = guess[:2] + (parts[:4000, :2] / 95.0) * 3.0      # a cluster around the true pose
+    got = gpu.scorePoses(pts, parts)
+    assert "compact/coarse-bitmap" in gpu.last_variant(), gpu.last_variant()
+    exp = O.pf_measure(ref, parts, pts, omp_threads=os.cpu_count())
+    assert np.max(np.abs(got - exp)) < TOL_TIGHT
+    assert (exp < -1e-3).sum() > 500
+    gpu.set_variant("compact-exact")
+    exact = gpu.scorePoses(pts, parts)
+    assert "compact/coarse-bitmap" in gpu.last_variant(), gpu.last_variant()
+    gpu.set_variant("dense")
+    dense = gpu.scorePoses(pts, parts)
+    assert "compact" not in gpu.last_variant()
+    gpu.set_variant("auto")
+    assert np.array_equal(got, exact)
+    assert np.max(np.abs(got - dense)) < 1e-12
+    # a new grid invalidates the block bitmap: the same matcher on the cfg-3 map
+    gpu.reset()
+    gpu.addScans(synth.map_scans(3))
+    p3 = synth.particles(3, 5000)
+    w3 = gpu.scorePoses(pts, p3)
+    ref3 = O.ScanMatcherNDT()
+    ref3.initialize(**dict(synth.matcher_params(5, ndt_resolution=resolution)))
+    ref3.addScans(synth.map_scans(3))
+    assert np.max(np.abs(w3 - O.pf_measure(ref3, p3, pts))) < TOL_TIGHT
+
+
 def _big_winner(cfg):
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "big_winners.json")) as f:
         return json.load(f)["cfg%d" % cfg]
