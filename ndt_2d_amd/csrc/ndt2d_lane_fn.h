@@ -63,7 +63,7 @@ struct LaneGeom
 };
 
 constexpr int kMaxBoxSpan = 3;   // the pre-test reads a 4 x 4 sub-cell box
-constexpr int kMaxBlockLog2 = 2; // coarsest map: one byte per 4 x 4 grid cells (windows up to 1,024 cells)
+constexpr int kMaxBlockLog2 = 3; // coarsest map: one byte per 8 x 8 grid cells (windows up to 2,048 cells)
 
 // Upper bound of Cell::score's exponent e(p) = q^T h q, q = p - mean (h = -0.5 *
 // information, packed record rec) over the box [x0, x1] x [y0, y1].  For a

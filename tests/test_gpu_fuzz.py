@@ -156,7 +156,7 @@ def test_random_large_lattice(seed):
         "small-lattice" in gpu.last_variant()
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(10))
 def test_random_wide_window(seed):
     """Fine NDT cells under a scan that reaches several metres: the search window is wider
     than 256 cells, the lane mapping's map goes to one byte per 2 x 2 or 4 x 4 block of grid
@@ -165,6 +165,9 @@ def test_random_wide_window(seed):
     rng = np.random.default_rng(9000 + seed)
     params, scans, scan_pose, _, _ = _random_case(rng)
     params["ndt_resolution"] = float([0.05, 0.03125, 0.04, 0.03][seed % 4])
+    if seed >= 8:
+        # windows beyond 1,024 cells: one map byte per 8 x 8 block of grid cells
+        params["ndt_resolution"] = float([0.015625, 0.0125][seed % 2])
     params["range_max"] = float(rng.uniform(5.0, 7.0))
     params["search_linear_resolution"] = float(rng.choice([0.01, 0.02]))
     params["search_linear_size"] = params["search_linear_resolution"] * float(rng.uniform(6, 20))
@@ -176,7 +179,7 @@ def test_random_wide_window(seed):
                             np.stack([rng.uniform(1, 6, n_q - n_q // 2),
                                       rng.uniform(-5, 5, n_q - n_q // 2)], axis=1)])
     reach = np.max(np.hypot(query[:, 0], query[:, 1]))
-    assert 2 * reach / params["ndt_resolution"] > 256
+    assert 2 * reach / params["ndt_resolution"] > (1024 if seed >= 8 else 256)
     ref = O.ScanMatcherNDT()
     ref.initialize(**params)
     ref.addScans(scans)
