@@ -60,6 +60,9 @@ struct ndt2d_context
   // cells, made from the bitmap on the first launch that needs it (-1: not made for this grid)
   DeviceBuffer coarse_bits;
   int coarse_log2 = -1;
+  // ... and the small-lattice search on a window wider than 256 cells: map bytes per block of cells
+  DeviceBuffer block_bytes;
+  int block_bytes_log2 = -1;
   uint32_t sparse_n = 0;
   const uint32_t * sparse_index = nullptr;
   const double * sparse_cells6 = nullptr;
@@ -447,6 +450,7 @@ int ndt2d_destroy(ndt2d_handle h)
   release(h->cells6);
   release(h->ranks);
   release(h->coarse_bits);
+  release(h->block_bytes);
   release(h->call_dev);
   release(h->stage_grid);
   release(h->stage_call);
@@ -606,6 +610,7 @@ int ndt2d_set_grid(ndt2d_handle h, const double * cells6, uint32_t size_x, uint3
   }
   h->grid = g;
   h->coarse_log2 = -1;
+  h->block_bytes_log2 = -1;
   h->has_grid = true;
   return NDT2D_OK;
 }
@@ -738,6 +743,7 @@ int ndt2d_build_grid(ndt2d_handle h, double ndt_resolution, double range_max,
   h->sparse_cells6 = nullptr;
   h->grid = g;
   h->coarse_log2 = -1;
+  h->block_bytes_log2 = -1;
   h->has_grid = true;
   return NDT2D_OK;
 }
@@ -859,6 +865,7 @@ int ndt2d_set_grid_sparse(ndt2d_handle h, const uint32_t * cell_index, const dou
   h->sparse_cells6 = d_cells6;
   h->grid = g;
   h->coarse_log2 = -1;
+  h->block_bytes_log2 = -1;
   h->has_grid = true;
   return NDT2D_OK;
 }
@@ -1057,6 +1064,26 @@ int ndt2d_match_launch_strided(ndt2d_handle h, size_t th_first, size_t th_stride
   a.pose_x = h->pose_x;
   a.pose_y = h->pose_y;
   a.scores = d_scores;
+  if (!(h->force_variant & (ndt2d::kVariantWave | ndt2d::kVariantLane)))
+  {
+    // a small lattice on a window wider than 256 cells: the small-lattice search wants the
+    // grid's map bytes per block of cells (made once per grid and block size)
+    const int k = ndt2d::match_small_block_log2(a, ndt2d::poses_lds_per_block());
+    if (k > 0)
+    {
+      if (h->block_bytes_log2 != k)
+      {
+        rc = ensure(h, h->block_bytes, ndt2d::grid_block_bytes_size(h->grid, static_cast<uint32_t>(k)) / 8 + 2);
+        if (rc != NDT2D_OK) return rc;
+        hipError_t be = ndt2d::grid_block_bytes_launch(h->grid, static_cast<uint32_t>(k),
+                                                       reinterpret_cast<uint8_t *>(h->block_bytes.ptr), h->stream);
+        if (be != hipSuccess) return fail_hip(h, be, "grid_block_bytes_launch");
+        h->block_bytes_log2 = k;
+      }
+      a.grid.block_bytes = reinterpret_cast<const uint8_t *>(h->block_bytes.ptr);
+      a.grid.block_bytes_log2 = static_cast<uint32_t>(k);
+    }
+  }
   if (!h->tables_uploaded)
   {
     a.host_tables = h->stage_tables.ptr;

@@ -49,6 +49,12 @@ struct GridDesc
   const double * compact_records;
   const uint16_t * cell_rank;
   uint32_t n_occ;
+  // Map bytes at one byte per block of 2^block_bytes_log2 x 2^block_bytes_log2 cells, blocks
+  // aligned to the grid's origin, extended by one block on every side:
+  // [ceil(size_y / B) + 2][ceil(size_x / B) + 2] (grid_block_bytes_launch; the small-lattice
+  // search on windows wider than 256 cells).  Null / 0: not made.
+  const uint8_t * block_bytes;
+  uint32_t block_bytes_log2;
   uint32_t size_x, size_y, ncell;
   double cell_size;
   double inv_cell_size;  // exact iff pow2
@@ -284,6 +290,12 @@ hipError_t launch_match_lane(const MatchArgs & args, double * outer, double * wo
 // final reduction: workspace takes one record per (theta, tile), the block that finishes
 // last (tickets: one zeroed uint32) writes the result record(s) as launch_match does.
 bool match_small_supported(const MatchArgs & args, size_t lds_per_block);
+// The block size (log2) of the map the small-lattice search of `args` needs: 0 = the
+// per-cell bytes, k > 0 = GridDesc::block_bytes at 2^k cells per byte (to be made with
+// grid_block_bytes_launch before the launch), -1 = the small-lattice search cannot serve it.
+int match_small_block_log2(const MatchArgs & args, size_t lds_per_block);
+size_t grid_block_bytes_size(const GridDesc & g, uint32_t block_log2);
+hipError_t grid_block_bytes_launch(const GridDesc & g, uint32_t block_log2, uint8_t * out, hipStream_t stream);
 bool match_small_takes_arg_tables(const MatchArgs & args);
 hipError_t launch_match_small(const MatchArgs & args, double * workspace, uint32_t * tickets,
                               int cus, size_t lds_per_block, bool no_skip, double * record_out,

@@ -465,8 +465,11 @@ inline bool axis_window(double pose, double reach, double origin, double inv_cel
 
 // Map geometry for a search; false if the byte-per-axis cell coordinate cannot
 // hold the padded window even at one map cell per 4 x 4 grid cells.
-// coarse_map: one map cell per grid cell whatever the lattice (the small search copies
-// the per-cell bytes prepared when the grid was installed).
+// coarse_map: the small search, which copies its map from a per-grid image -- one map cell per
+// grid cell whatever the lattice (the bytes prepared when the grid was installed), or, for a
+// window wider than 256 cells, per block of 2^block_log2 cells from the image of
+// grid_block_bytes (blocks aligned to the grid's origin: the window's origin is moved down to
+// a block boundary).
 inline bool lane_geometry(const MatchArgs & args, size_t lds_per_block, LaneGeom * geo,
                           size_t * map_bytes, bool coarse_map = false)
 {
@@ -491,11 +494,22 @@ inline bool lane_geometry(const MatchArgs & args, size_t lds_per_block, LaneGeom
   while (need_w > (static_cast<uint64_t>(kMaxMapCells) << block_log2) ||
          need_h > (static_cast<uint64_t>(kMaxMapCells) << block_log2))
   {
-    if (++block_log2 > kMaxBlockLog2 || coarse_map) return false;
+    if (++block_log2 > kMaxBlockLog2) return false;
     const int32_t cells = 1 << block_log2;
     pad = (static_cast<int32_t>(2.0 * lin_cells) + 3 + cells - 1) / cells * cells;
-    need_w = (static_cast<uint64_t>(geo->win_w) + 2 * pad + cells - 1) / cells * cells;
-    need_h = (static_cast<uint64_t>(geo->win_h) + 2 * pad + cells - 1) / cells * cells;
+    // (coarse_map: the window as it grows when its origin moves to a block boundary)
+    const int32_t grow_x = coarse_map ? (geo->win_x0 & (cells - 1)) : 0;
+    const int32_t grow_y = coarse_map ? (geo->win_y0 & (cells - 1)) : 0;
+    need_w = (static_cast<uint64_t>(geo->win_w + grow_x) + 2 * pad + cells - 1) / cells * cells;
+    need_h = (static_cast<uint64_t>(geo->win_h + grow_y) + 2 * pad + cells - 1) / cells * cells;
+  }
+  if (coarse_map && block_log2 > 0)
+  {
+    const int32_t cells = 1 << block_log2;
+    geo->win_w += geo->win_x0 & (cells - 1);
+    geo->win_h += geo->win_y0 & (cells - 1);
+    geo->win_x0 &= ~(cells - 1);
+    geo->win_y0 &= ~(cells - 1);
   }
   geo->pad = pad;
   geo->block_log2 = block_log2;

@@ -148,9 +148,14 @@ match_small_kernel(const MatchArgs a,
   // its first store; the (at most two) pieces of a row that straddle the image's edge are
   // left to a second, byte-wise pass over just those pieces.
   {
-    const int32_t ew = static_cast<int32_t>(g.size_x) + 2, eh = static_cast<int32_t>(g.size_y) + 2;
-    const int32_t x_shift = geo.win_x0 + 1 - geo.pad;    // image column of map column 0
-    const int32_t y_shift = geo.win_y0 + 1 - geo.pad;
+    // (a window wider than 256 cells: the image at one byte per block of cells; win_x0 - pad is
+    // a multiple of the block size there, so the shift below is exact)
+    const int32_t bl = geo.block_log2;
+    const uint8_t * const image = bl > 0 ? g.block_bytes : g.cell_bytes;
+    const int32_t ew = static_cast<int32_t>((g.size_x + (1u << bl) - 1u) >> bl) + 2;
+    const int32_t eh = static_cast<int32_t>((g.size_y + (1u << bl) - 1u) >> bl) + 2;
+    const int32_t x_shift = ((geo.win_x0 - geo.pad) >> bl) + 1;    // image column of map column 0
+    const int32_t y_shift = ((geo.win_y0 - geo.pad) >> bl) + 1;
     const uint32_t pieces = (plan.need_w + 15u) / 16u;   // per row, <= 16
     const uint32_t n_vec = static_cast<uint32_t>(geo.map_h) * 16u;
     typedef uint32_t unaligned_u32 __attribute__((aligned(1)));
@@ -168,7 +173,7 @@ match_small_kernel(const MatchArgs a,
         if (w < n_vec && (w & 15u) < pieces && ey >= 0 && ey < eh && ex >= 0 && ex + 16 <= ew)
         {
           const unaligned_u32 * s32 =
-            reinterpret_cast<const unaligned_u32 *>(g.cell_bytes + static_cast<size_t>(ey) * ew + ex);
+            reinterpret_cast<const unaligned_u32 *>(image + static_cast<size_t>(ey) * ew + ex);
           v[u] = uint4{s32[0], s32[1], s32[2], s32[3]};
         }
       }
@@ -206,7 +211,7 @@ match_small_kernel(const MatchArgs a,
         const int32_t ex = static_cast<int32_t>(mx) + x_shift;
         const bool inside = listed && ex >= 0 && ex < ew && ey >= 0 && ey < eh;
         at[u] = inside ? my * kMapStride + mx : 0xffffffffu;
-        bv[u] = inside ? g.cell_bytes[ey * ew + ex] : static_cast<uint8_t>(0);
+        bv[u] = inside ? image[ey * ew + ex] : static_cast<uint8_t>(0);
       }
 #pragma unroll
       for (int u = 0; u < kEdgeUnroll; ++u)
@@ -257,7 +262,7 @@ match_small_kernel(const MatchArgs a,
   c.rank_address = map_bytes + (COMPACT ? kRankLead : 0u);
   c.lds_cells_address = map_bytes + rank_bytes;   // (not COMPACT: records are gathered from HBM)
   c.sub_log2 = 0;
-  c.exact_index = 0;
+  c.exact_index = geo.block_log2 > 0 ? 1u : 0u;   // a byte per block: the cell comes from the reference's own arithmetic
   c.idx_bias = static_cast<uint32_t>(geo.pad - geo.win_y0) * g.size_x +
                static_cast<uint32_t>(geo.pad - geo.win_x0);
   c.size_x = g.size_x;
@@ -540,7 +545,7 @@ SmallPlan small_plan(const MatchArgs & args, const LaneGeom & geo, int cus)
   SmallPlan plan{};
   plan.linear = args.n_lin <= kSmallLinearBelow ? 1u : 0u;
   plan.tiles = small_tiles(args.n_lin);
-  plan.need_w = static_cast<uint32_t>(geo.win_w + 2 * geo.pad);
+  plan.need_w = static_cast<uint32_t>((geo.win_w + 2 * geo.pad + (1 << geo.block_log2) - 1) >> geo.block_log2);
   plan.no_tail = std::getenv("NDT2D_SMALL_NOTAIL") != nullptr ? 1u : 0u;
   const uint32_t groups = (args.n_beams + kSmallUnroll - 1) / kSmallUnroll;
   // (C beam chunks per tile, P tiles per block), P * C <= 16 waves.  Measured over the
@@ -592,6 +597,48 @@ bool match_small_takes_arg_tables(const MatchArgs & args)
          3 * static_cast<uint64_t>(args.n_th) + args.n_lin <= kArgTableDoubles;
 }
 
+int match_small_block_log2(const MatchArgs & args, size_t lds_per_block)
+{
+  LaneGeom geo;
+  size_t map_bytes = 0;
+  if (args.grid.cell_bytes == nullptr || args.n_beams == 0 || args.n_beams > kSmallMaxBeams) return -1;
+  if (!lane_geometry(args, lds_per_block, &geo, &map_bytes, true) || geo.sub_log2 != 0) return -1;
+  const uint64_t p1 = (args.n_lin + kPatch - 1) / kPatch;
+  if (static_cast<uint64_t>(args.n_th) * p1 * p1 > kSmallMaxItems) return -1;
+  return geo.block_log2;
+}
+
+namespace
+{
+
+__global__ void __launch_bounds__(256) grid_block_bytes_kernel(const GridDesc g, uint32_t k, uint32_t bw,
+                                                               uint32_t bh, uint8_t * out)
+{
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= bw * bh) return;
+  const int32_t cells = 1 << k;
+  const int32_t bx = static_cast<int32_t>(i % bw) - 1, by = static_cast<int32_t>(i / bw) - 1;
+  out[i] = block_byte(g, bx * cells, by * cells, cells);
+}
+
+}  // namespace
+
+size_t grid_block_bytes_size(const GridDesc & g, uint32_t block_log2)
+{
+  const size_t bw = ((static_cast<size_t>(g.size_x) + (1u << block_log2) - 1) >> block_log2) + 2;
+  const size_t bh = ((static_cast<size_t>(g.size_y) + (1u << block_log2) - 1) >> block_log2) + 2;
+  return bw * bh;
+}
+
+hipError_t grid_block_bytes_launch(const GridDesc & g, uint32_t block_log2, uint8_t * out, hipStream_t stream)
+{
+  const uint32_t bw = ((g.size_x + (1u << block_log2) - 1) >> block_log2) + 2;
+  const uint32_t bh = ((g.size_y + (1u << block_log2) - 1) >> block_log2) + 2;
+  hipLaunchKernelGGL(grid_block_bytes_kernel, dim3((bw * bh + 255) / 256), dim3(256), 0, stream, g, block_log2,
+                     bw, bh, out);
+  return hipGetLastError();
+}
+
 bool match_small_supported(const MatchArgs & args, size_t lds_per_block)
 {
   LaneGeom geo;
@@ -599,6 +646,12 @@ bool match_small_supported(const MatchArgs & args, size_t lds_per_block)
   if (args.grid.cell_bytes == nullptr || args.n_beams == 0 || args.n_beams > kSmallMaxBeams) return false;
   if (!lane_geometry(args, lds_per_block, &geo, &map_bytes, true)) return false;
   if (geo.sub_log2 != 0) return false;
+  // a window wider than 256 cells needs the grid's block bytes at the geometry's block size
+  if (geo.block_log2 > 0 && (args.grid.block_bytes == nullptr ||
+                             args.grid.block_bytes_log2 != static_cast<uint32_t>(geo.block_log2)))
+  {
+    return false;
+  }
   const uint64_t p1 = (args.n_lin + kPatch - 1) / kPatch;
   // the WHOLE lattice's work items (as choose_mapping counts them): every shard of a search
   // must make the same choice, or a candidate's bits would depend on the sharding; a
@@ -617,7 +670,9 @@ hipError_t launch_match_small(const MatchArgs & args_in, double * workspace, uin
   args.partials = workspace;
   LaneGeom geo;
   size_t map_bytes = 0;
-  if (!lane_geometry(args, lds_per_block, &geo, &map_bytes, true) || geo.sub_log2 != 0)
+  if (!lane_geometry(args, lds_per_block, &geo, &map_bytes, true) || geo.sub_log2 != 0 ||
+      (geo.block_log2 > 0 && (args.grid.block_bytes == nullptr ||
+                              args.grid.block_bytes_log2 != static_cast<uint32_t>(geo.block_log2))))
   {
     return hipErrorInvalidValue;
   }

@@ -160,8 +160,9 @@ def test_random_large_lattice(seed):
 def test_random_wide_window(seed):
     """Fine NDT cells under a scan that reaches several metres: the search window is wider
     than 256 cells, the lane mapping's map goes to one byte per 2 x 2 or 4 x 4 block of grid
-    cells (every live lane then takes the reference's own index).  Against the oracle, the
-    skipping against its control bit for bit, and the wave mapping."""
+    cells (every live lane then takes the reference's own index); the small-lattice search
+    copies its map from the grid's block bytes.  Against the oracle, the skipping against its
+    controls bit for bit, and the wave mapping."""
     rng = np.random.default_rng(9000 + seed)
     params, scans, scan_pose, _, _ = _random_case(rng)
     params["ndt_resolution"] = float([0.05, 0.03125, 0.04, 0.03][seed % 4])
@@ -192,8 +193,11 @@ def test_random_wide_window(seed):
         gpu.set_variant(variant)
         got[variant] = r = gpu.matchScan(scan_pose, query, want_scores=True)
         if variant == "auto":
-            # (lattices this small are left to the wave mapping)
-            assert "wave-per-candidate" in gpu.last_variant(), (seed, gpu.last_variant())
+            # (lattices this small take the small-lattice search, on the grid's block bytes;
+            # seeds whose lattice is beyond its 8,192 items the wave mapping)
+            assert "small-lattice" in gpu.last_variant() or "wave-per-candidate" in gpu.last_variant(), \
+                (seed, gpu.last_variant())
+            small_lattice = "small-lattice" in gpu.last_variant()
         if variant.startswith("lane"):
             assert "lane-per-candidate/lds-" in gpu.last_variant() and "block-map" in gpu.last_variant(), \
                 (seed, gpu.last_variant())
@@ -202,5 +206,10 @@ def test_random_wide_window(seed):
         finite = exp["scores"][~np.isnan(exp["scores"])]
         if finite.size > 1 and np.sort(finite)[1] - finite.min() > 1e-9:
             assert r["best_index"] == exp["best_index"], (seed, variant)
+    if small_lattice:
+        gpu.set_variant("small-noskip")
+        control = gpu.matchScan(scan_pose, query, want_scores=True)
+        assert "small-lattice" in gpu.last_variant()
+        assert np.array_equal(got["auto"]["scores"], control["scores"], equal_nan=True), seed
     gpu.set_variant("auto")
     assert np.array_equal(got["lane"]["scores"], got["lane-noskip"]["scores"], equal_nan=True), seed

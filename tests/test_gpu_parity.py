@@ -899,7 +899,16 @@ def test_wide_windows_keep_the_lane_mapping():
     assert 2 * reach / 0.25 > 256
     wrong = guess + np.array([0.16, -0.12, 0.03])
     exp = ref.matchScan(wrong, pts, want_scores=True)
-    # (a lattice this small is left to the wave mapping; the lane mapping on request)
+    # (a lattice this small takes the small-lattice search, its map copied from the grid's bytes
+    # per 2 x 2 block of cells -- round 2 left it to the wave mapping; the others on request)
+    small = gpu.matchScan(wrong, pts, want_scores=True)
+    assert "small-lattice" in gpu.last_variant(), gpu.last_variant()
+    _check_match(small, exp, 720)
+    gpu.set_variant("small-noskip")
+    control_small = gpu.matchScan(wrong, pts, want_scores=True)
+    assert "small-lattice" in gpu.last_variant(), gpu.last_variant()
+    assert np.array_equal(small["scores"], control_small["scores"])
+    gpu.set_variant("wave")
     wave = gpu.matchScan(wrong, pts, want_scores=True)
     assert "wave-per-candidate" in gpu.last_variant(), gpu.last_variant()
     _check_match(wave, exp, 720)
