@@ -676,7 +676,8 @@ hipError_t launch_match(const MatchArgs & args_in, double * workspace, double * 
         uint32_t n_slab_records = 0;
         e = launch_match_lane(sub, outer, workspace, kMaxMatchBlocks * kMatchWaves, lim.cus,
                               lim.lds_per_block, (force_variant & kVariantNoSkip) != 0, stream,
-                              s == 0 ? ev_main_start : nullptr, &n_slab_records, &lane_records_mode);
+                              s == 0 ? ev_main_start : nullptr, &n_slab_records, &lane_records_mode,
+                              &lane_parts);
         if (e != hipSuccess) return e;
         if (s + 1 == n_slabs && ev_main_done != nullptr)
         {
@@ -763,7 +764,9 @@ hipError_t launch_match(const MatchArgs & args_in, double * workspace, double * 
     if (use_lane)
     {
       info->variant = lane_variant_name(lane_records_mode & 3, (lane_records_mode & 4) != 0, pow2, lane_parts > 1);
-      info->n_kernels = n_staged > 0 ? static_cast<int>(3 * slabs_run + 1) : (lane_parts > 1 ? 4 : 3);
+      // per slab: table pre-kernel, search, (combine,) first reduction stage; then the final stage
+      info->n_kernels = n_staged > 0 ? static_cast<int>((lane_parts > 1 ? 4 : 3) * slabs_run + 1)
+                                     : (lane_parts > 1 ? 4 : 3);
     }
     else
     {

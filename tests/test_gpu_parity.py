@@ -574,6 +574,18 @@ def test_theta_slabs_of_one_search_give_the_single_launch_result(monkeypatch):
         assert (got[0], got[1]) == (want[0], want[1])
         assert np.allclose(got[2:], want[2:], rtol=1e-11, atol=0)
     monkeypatch.delenv("NDT2D_LANE_SLAB_ITEMS")
+    # slabs of a lattice whose beams are cut into parts (6,760 items)
+    mid, ref_mid, _, guess, pts = _pair(2, search_angular_size=0.1)
+    one = mid.matchScan(guess, pts, want_scores=True)
+    assert "beam-parts" in mid.last_variant()
+    monkeypatch.setenv("NDT2D_LANE_SLAB_ITEMS", "2000")
+    many = mid.matchScan(guess, pts, want_scores=True)
+    monkeypatch.delenv("NDT2D_LANE_SLAB_ITEMS")
+    assert "beam-parts" in mid.last_variant() and mid.last_launch_ms()[1] > 4
+    assert np.array_equal(many["scores"], one["scores"])
+    assert many["best_index"] == one["best_index"] and many["score"] == one["score"]
+    assert np.allclose(many["covariance"], one["covariance"], rtol=1e-11, atol=0)
+    _check_match(many, ref_mid.matchScan(guess, pts, want_scores=True), 720)
 
 
 def test_lattice_beyond_two_to_the_24_work_items_keeps_the_lane_mapping():
