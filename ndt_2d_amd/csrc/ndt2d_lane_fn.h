@@ -519,7 +519,9 @@ inline bool lane_geometry(const MatchArgs & args, size_t lds_per_block, LaneGeom
   const bool records_fit = grid_bytes + kMapStride * need_h <= lds_per_block;
   // (a small search does not repay copying a 16x larger map into every block)
   const uint64_t p1 = (args.n_lin + kPatch - 1) / kPatch;
-  const bool small_search = static_cast<uint64_t>(args.th_end - args.th_begin) * p1 * p1 < 4096;
+  // (the WHOLE lattice's items, not the launch's share: the map's resolution decides which
+  // kernel forms fit LDS, and with them whether a mid-size lattice's beams are cut into parts)
+  const bool small_search = static_cast<uint64_t>(args.n_th) * p1 * p1 < 4096;
   int sub_log2 = (small_search || coarse_map || block_log2 > 0) ? 0 : 2;
   for (; sub_log2 > 0; --sub_log2)
   {

@@ -631,18 +631,6 @@ hipError_t launch_match_lane(const MatchArgs & args_in, double * outer, double *
     if (e != hipSuccess) return e;
   }
 
-  // Few work items (the plugin's default lattice is 720 of them): 256-thread blocks
-  // put them on four times as many CUs -- as long as every wave still gets at most
-  // one item; the LDS image allows one block per CU, so beyond that the larger block
-  // is what puts more waves on a CU.
-  const bool small = n_items <= static_cast<uint64_t>(cus) * (kLaneThreadsSmall / kWave);
-  const uint32_t waves_per_block = (small ? kLaneThreadsSmall : kLaneThreads) / kWave;
-  uint32_t blocks = static_cast<uint32_t>((n_items + waves_per_block - 1) / waves_per_block);
-  uint32_t max_blocks = static_cast<uint32_t>(cus);
-  if (max_blocks * waves_per_block > max_workers) max_blocks = max_workers / waves_per_block;
-  if (blocks > max_blocks) blocks = max_blocks;
-  if (blocks == 0) blocks = 1;
-
   // (NDT2D_LANE_RECORDS=global: gather the records from HBM although they would fit LDS --
   // what a map too large for LDS costs, measured on a workload that has both forms)
   const char * knob_rec = std::getenv("NDT2D_LANE_RECORDS");
@@ -657,27 +645,44 @@ hipError_t launch_match_lane(const MatchArgs & args_in, double * outer, double *
     compact_rank_bytes(args.grid.ncell) +
     (static_cast<size_t>(args.grid.n_occ) + 1) * kCellDoubles * sizeof(double);
   const char * knob = std::getenv("NDT2D_LANE_COMPACT");
-  const bool compact = !small && dynamic_items && pow2_grid(args) && lds_records && args.grid.n_occ > 0 &&
-                       args.grid.compact_records != nullptr &&
-                       2 * (map_bytes + compact_bytes) <= lds_per_block &&
-                       !(knob != nullptr && knob[0] == '0');
+  const bool compact_possible = dynamic_items && pow2_grid(args) && lds_records && args.grid.n_occ > 0 &&
+                                args.grid.compact_records != nullptr &&
+                                2 * (map_bytes + compact_bytes) <= lds_per_block &&
+                                !(knob != nullptr && knob[0] == '0');
+  // records gathered from HBM: the same block geometry when two maps fit a CU
+  // (NDT2D_LANE_GATHER6=0: the one-block form, for A/B runs)
+  const char * knob6 = std::getenv("NDT2D_LANE_GATHER6");
+  const bool gather6_possible = dynamic_items && !lds_records && 2 * map_bytes <= lds_per_block &&
+                                !(knob6 != nullptr && knob6[0] == '0');
+  // The beam-part form exists for the two six-wave kernels.  Whether a candidate's beams are
+  // cut decides the bits of its score, so it must not depend on THIS launch's share of the
+  // lattice: everything above follows from the grid, the scan and the whole lattice (the map
+  // geometry included, lane_geometry), and a cut search takes a six-wave kernel however
+  // few items the launch holds.
+  if (!(compact_possible || gather6_possible)) beam_parts = 1;
+  args.beam_parts = beam_parts;
+  args.part_beams = part_beams;
+  const uint64_t n_sub_items = n_items * beam_parts;
+
+  // Few work items (the plugin's default lattice is 720 of them): 256-thread blocks
+  // put them on four times as many CUs -- as long as every wave still gets at most
+  // one item; the LDS image allows one block per CU, so beyond that the larger block
+  // is what puts more waves on a CU.
+  const bool small = beam_parts == 1 && n_items <= static_cast<uint64_t>(cus) * (kLaneThreadsSmall / kWave);
+  const uint32_t waves_per_block = (small ? kLaneThreadsSmall : kLaneThreads) / kWave;
+  uint32_t blocks = static_cast<uint32_t>((n_items + waves_per_block - 1) / waves_per_block);
+  uint32_t max_blocks = static_cast<uint32_t>(cus);
+  if (max_blocks * waves_per_block > max_workers) max_blocks = max_workers / waves_per_block;
+  if (blocks > max_blocks) blocks = max_blocks;
+  if (blocks == 0) blocks = 1;
+  const bool compact = !small && compact_possible;
+  const bool gather6 = !compact && !small && gather6_possible;
   // 0: records gathered from HBM, 1: the whole grid's records in LDS, 2: compacted records in LDS
   // (+4: the map is one byte per block of grid cells)
   if (records_mode_out != nullptr)
   {
     *records_mode_out = (compact ? 2 : (lds_records ? 1 : 0)) | (geo.block_log2 > 0 ? 4 : 0);
   }
-  if (parts_out != nullptr) *parts_out = 1;
-  // records gathered from HBM: the same block geometry when two maps fit a CU
-  // (NDT2D_LANE_GATHER6=0: the one-block form, for A/B runs)
-  const char * knob6 = std::getenv("NDT2D_LANE_GATHER6");
-  const bool gather6 = !compact && !small && dynamic_items && !lds_records &&
-                       2 * map_bytes <= lds_per_block && !(knob6 != nullptr && knob6[0] == '0');
-  // (the beam-part form exists for the two six-wave kernels)
-  if (!(compact || gather6)) beam_parts = 1;
-  args.beam_parts = beam_parts;
-  args.part_beams = part_beams;
-  const uint64_t n_sub_items = n_items * beam_parts;
   if (compact || gather6)
   {
     lds_bytes = compact ? map_bytes + compact_bytes : map_bytes;

@@ -669,6 +669,16 @@ def test_mid_size_lattices_cut_a_candidates_beams_into_parts(monkeypatch):
         gpu.synchronize()
         assert "beam-parts" in gpu.last_variant()
         assert np.array_equal(d.cpu().numpy(), got["scores"][a * per:b * per])
+    # ... also for shares of fewer than a CU-load of items each (8 interleaved shares of 5 theta
+    # steps = 845 items: a launch this small on its own would take the uncut 256-thread form)
+    for r in range(8):
+        first, stride, count = shard.shard_strided(n_th, r, 8)
+        d = torch.zeros(count * per, dtype=torch.float64, device="cuda:0")
+        gpu.match_launch_strided(first, stride, count, scores_ptr=d.data_ptr())
+        gpu.synchronize()
+        assert "beam-parts" in gpu.last_variant(), gpu.last_variant()
+        mine = np.concatenate([got["scores"][t * per:(t + 1) * per] for t in range(first, n_th, stride)])
+        assert np.array_equal(d.cpu().numpy(), mine)
     # the uncut search (one running sum per candidate, the reference's order)
     monkeypatch.setenv("NDT2D_LANE_PARTS", "1")
     uncut = gpu.matchScan(guess, pts, want_scores=True)
