@@ -3,7 +3,9 @@ set -e
 R=$(cd $(dirname $0)/.. && pwd)
 mkdir -p $R/experiments/bin/trace_obj
 for f in ndt2d_kernels ndt2d_match_lane ndt2d_match_small ndt2d_poses_compact ndt2d_build ndt2d_motion ndt2d_scan ndt2d_occupancy ndt2d_device; do
-  if [ $f = ndt2d_match_small ] || [ ! -f $R/experiments/bin/trace_obj/$f.o ] || [ $R/ndt_2d_amd/csrc/$f.hip -nt $R/experiments/bin/trace_obj/$f.o ]; then
+  # (every unit every time: a header change -- a struct that gained a field -- otherwise leaves
+  # stale objects behind, and a library of mixed layouts runs, wrongly, and measures nonsense)
+  if true; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -DNDT2D_SMALL_TRACE -I $R/include -I $R/ndt_2d_amd/csrc -c $R/ndt_2d_amd/csrc/$f.hip -o $R/experiments/bin/trace_obj/$f.o &
   fi
 done

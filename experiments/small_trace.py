@@ -43,15 +43,24 @@ else:
     guess, pts, _ = synth.query_scan(1)
 n_th, n_lin, n_b = m.prepare_search(guess, pts)
 buf = torch.zeros(8192 * 16 * 8, dtype=torch.float64, device="cuda:0")
+isolated = len(sys.argv) > 2 and sys.argv[2] == "isolated"
 for _ in range(5):
     m.match_launch(0, n_th, scores_ptr=buf.data_ptr())
+    if isolated:
+        # as the node calls it: one launch, the host waits for it, does something else, calls again
+        m.synchronize()
+        import time
+        time.sleep(0.002)
 m.synchronize()
-t = buf.cpu().numpy().reshape(-1, 16, 8)
+raw = buf.cpu().numpy()
+tail = raw[-8:].copy()      # the last block's stamp after its final reduction and host publish
+raw[-8:] = 0
+t = raw.reshape(-1, 16, 8)
 used = t[:, :, 0].max(axis=1) > 0
 t = t[used]
 act = t[:, :, 6] > 0
 clk = 2.1e9   # shader clock (s_memtime ticks; MI355X_MICROARCH.md), per-XCD time bases
-print("%s: %d blocks, %d active waves per block (max)" % (which, len(t), int(act.sum(axis=1).max())))
+print("%s%s: %d blocks, %d active waves per block (max)" % (which, " (isolated launches)" if isolated else "", len(t), int(act.sum(axis=1).max())))
 # block start / end on the chip-wide 100 MHz clock (the shader clock counters above have
 # a time base per CU)
 starts = np.array([t[b, :, 5][act[b]].min() for b in range(len(t))]) / 100.0
@@ -62,6 +71,8 @@ print("  block start after the launch's first block: median %.2f  p90 %.2f  max 
       % (np.median(late), np.percentile(late, 90), late.max(), int((late > 5.0).sum())))
 print("  first block start -> last record written: %.1f us; block duration median %.1f  max %.1f us"
       % (ends.max() - t0, np.median(ends - starts), (ends - starts).max()))
+print("  first block start -> the last block's flag has left (final reduction + publish done): %.1f us (block %d)"
+      % (tail[0] / 100.0 - t0, int(tail[1])))
 d_setup = (t[:, :, 1] - t[:, :, 0])[act] / clk * 1e6
 d_main = (t[:, :, 2] - t[:, :, 1])[act] / clk * 1e6
 d_wait = (t[:, :, 3] - t[:, :, 2])[act] / clk * 1e6

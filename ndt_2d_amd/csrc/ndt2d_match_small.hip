@@ -159,7 +159,7 @@ match_small_kernel(const MatchArgs a,
     const uint32_t pieces = (plan.need_w + 15u) / 16u;   // per row, <= 16
     const uint32_t n_vec = static_cast<uint32_t>(geo.map_h) * 16u;
     typedef uint32_t unaligned_u32 __attribute__((aligned(1)));
-    constexpr int kCopyUnroll = 8;
+    constexpr int kCopyUnroll = 4;   // (eight in flight cost the gather forms of the kernel spilled registers)
     for (uint32_t base = threadIdx.x; base < n_vec; base += n_threads * kCopyUnroll)
     {
       uint4 v[kCopyUnroll];
@@ -193,7 +193,7 @@ match_small_kernel(const MatchArgs a,
     const int32_t right = (ew - x_shift) % 16 != 0 ? (ew - x_shift) / 16 : -1;
     __syncthreads();
     const uint32_t n_edge = static_cast<uint32_t>(geo.map_h) * 32u;
-    constexpr int kEdgeUnroll = 4;   // (loads of four trips in flight together)
+    constexpr int kEdgeUnroll = 2;   // (loads of two trips in flight together; four spill in the gather forms)
     for (uint32_t base = threadIdx.x; base < n_edge; base += n_threads * kEdgeUnroll)
     {
       uint8_t bv[kEdgeUnroll];
@@ -502,6 +502,16 @@ match_small_kernel(const MatchArgs a,
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) raise_host_flag(fin.host_out + kHostFlagSlot, fin.seq);
   }
+#ifdef NDT2D_SMALL_TRACE
+  // the launch's last block: when the flag had left (final reduction and publish done)
+  if (a.scores != nullptr && threadIdx.x == 0)
+  {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    double * tr = a.scores + static_cast<size_t>(8192) * kSmallMaxWaves * 8 - 8;
+    tr[0] = static_cast<double>(wall_clock64());
+    tr[1] = static_cast<double>(blockIdx.x);
+  }
+#endif
 }
 
 size_t small_compact_bytes(const MatchArgs & args)
