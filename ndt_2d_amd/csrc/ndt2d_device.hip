@@ -1101,7 +1101,15 @@ int ndt2d_match_launch_strided(ndt2d_handle h, size_t th_first, size_t th_stride
     const size_t cap_before = h->ws_match.cap;
     rc = ensure(h, h->ws_match, ndt2d::match_workspace_doubles(a));
     if (rc != NDT2D_OK) return rc;
-    if (h->ws_match.cap != cap_before) NDT2D_HIP(h, hipMemsetAsync(h->ws_match.ptr, 0, 4096, h->stream));
+    // (a fresh allocation is cleared once: the counters at its head, and the `done` words of the
+    // small-lattice search behind its record table)
+    if (h->ws_match.cap != cap_before)
+    {
+      const size_t head_and_small = (ndt2d::match_workspace_head_doubles() +
+                                     ndt2d::kSmallMaxItems * (NDT2D_MATCH_RECORD_DOUBLES + 1)) * sizeof(double);
+      const size_t all = h->ws_match.cap * sizeof(double);
+      NDT2D_HIP(h, hipMemsetAsync(h->ws_match.ptr, 0, head_and_small < all ? head_and_small : all, h->stream));
+    }
   }
 
   // scratch for the rotated-beam table of the lane-per-candidate mapping

@@ -167,6 +167,7 @@ struct LaunchInfo
 // 12 doubles.  workspace: device scratch for per-wave partials, at least
 // match_workspace_doubles() doubles.
 size_t match_workspace_doubles(const MatchArgs & args);
+size_t match_workspace_head_doubles();   // counters + first-stage records in front of the record table
 // ev_main_done (optional) is recorded right after the search kernel, before the
 // tiny final reduction, so the caller can time the dominant kernel alone.
 // outer (optional): scratch of match_lane_outer_doubles() doubles; without it the
@@ -287,8 +288,9 @@ hipError_t launch_match_lane(const MatchArgs & args, double * outer, double * wo
 
 // Small-lattice search (ndt2d_match_small.hip): a block per (theta, up to P tiles of 64
 // candidates), its waves split the beams; needs grid.cell_bytes.  The launch includes the
-// final reduction: workspace takes one record per (theta, tile), the block that finishes
-// last (tickets: one zeroed uint32) writes the result record(s) as launch_match does.
+// final reduction: workspace takes one record per (theta, tile), `done` one word per record
+// (kSmallMaxItems of them, zero when allocated); the launch's extra, last block writes the
+// result record(s) as launch_match does.
 bool match_small_supported(const MatchArgs & args, size_t lds_per_block);
 // The block size (log2) of the map the small-lattice search of `args` needs: 0 = the
 // per-cell bytes, k > 0 = GridDesc::block_bytes at 2^k cells per byte (to be made with
@@ -297,7 +299,7 @@ int match_small_block_log2(const MatchArgs & args, size_t lds_per_block);
 size_t grid_block_bytes_size(const GridDesc & g, uint32_t block_log2);
 hipError_t grid_block_bytes_launch(const GridDesc & g, uint32_t block_log2, uint8_t * out, hipStream_t stream);
 bool match_small_takes_arg_tables(const MatchArgs & args);
-hipError_t launch_match_small(const MatchArgs & args, double * workspace, uint32_t * tickets,
+hipError_t launch_match_small(const MatchArgs & args, double * workspace, unsigned long long * done,
                               int cus, size_t lds_per_block, bool no_skip, double * record_out,
                               double * record_out2, double * host_record, unsigned long long seq,
                               hipStream_t stream);

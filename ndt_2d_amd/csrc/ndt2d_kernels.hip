@@ -514,6 +514,8 @@ hipError_t dispatch_match_nbl(const MatchArgs & args, uint32_t blocks, size_t ld
 constexpr size_t kCounterDoubles = static_cast<size_t>(kItemShards) * kItemShardStride * sizeof(uint32_t) / sizeof(double);
 constexpr size_t kWorkspaceHead = kCounterDoubles + 256 * static_cast<size_t>(kMaxLaneSlabs) * kRecord;
 
+size_t match_workspace_head_doubles() { return kWorkspaceHead; }
+
 size_t match_workspace_doubles(const MatchArgs & args)
 {
   const uint64_t p1 = (args.n_lin + 7) / 8;
@@ -522,7 +524,10 @@ size_t match_workspace_doubles(const MatchArgs & args)
   if (lane_slabs(args, &slab_th, &n_slabs)) records = static_cast<uint64_t>(slab_th) * p1 * p1;
   const uint64_t waves = static_cast<uint64_t>(kMaxMatchBlocks) * kMatchWaves;
   if (records < waves) records = waves;
-  return kWorkspaceHead + static_cast<size_t>(records) * kRecord;
+  // (the small-lattice search: kSmallMaxItems records and, behind them, as many `done` words)
+  const uint64_t small_doubles = kSmallMaxItems * (static_cast<uint64_t>(kRecord) + 1);
+  const uint64_t doubles = records * kRecord < small_doubles ? small_doubles : records * kRecord;
+  return kWorkspaceHead + static_cast<size_t>(doubles);
 }
 
 namespace
@@ -624,10 +629,11 @@ hipError_t launch_match(const MatchArgs & args_in, double * workspace, double * 
   }
   if (use_small)
   {
-    // search and final reduction in one launch; the ticket counter sits beside the lane
-    // search's first work-item counter (a word that search never touches): zero when the
-    // workspace is allocated, left at zero by every launch
-    e = launch_match_small(args, workspace, args.next_item + 1, lim.cus,
+    // search and final reduction in one launch; the records' `done` words sit behind the
+    // largest record table the small-lattice search can have (zero when the workspace is
+    // allocated; a launch stores its own sequence number there)
+    e = launch_match_small(args, workspace,
+                           reinterpret_cast<unsigned long long *>(workspace + kSmallMaxItems * kRecord), lim.cus,
                            lim.lds_per_block, (force_variant & kVariantNoSkip) != 0, record_out,
                            record_out2, host_record, seq, stream);
     if (e != hipSuccess) return e;

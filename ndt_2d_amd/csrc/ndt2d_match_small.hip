@@ -35,12 +35,16 @@
 //
 // Final reduction in the same launch.  The search ends every matchScan call, and a second
 // launch for a few hundred records costs more than the records do (launch gap + 8 us on
-// its own).  Records are stored with agent-scope 8-byte atomics; the block that draws the
-// last ticket of the launch reads them back the same way (the valid both-sides form of
-// MI355X_MICROARCH.md: no L2 write-back, no stale L1/L2 line) and reduces them in a fixed
-// order -- which block that is leaves no trace in the result -- applying "no candidate
-// scored below 0 -> no index" and writing the result record to HBM and, behind a flag,
-// to host-coherent memory.
+// its own).  The launch carries ONE MORE BLOCK than the search needs -- the last one, so
+// every other block has been dispatched before it -- which does nothing but reduce: every
+// record is stored with agent-scope 8-byte atomics, then (its stores acknowledged) the
+// launch's sequence number into the record's `done` word; thread r of the reducing block
+// polls done[r], reads record r back the same way (the valid both-sides form of
+// MI355X_MICROARCH.md: no L2 write-back, no stale L1/L2 line) and the block reduces them in
+// a fixed order, applying "no candidate scored below 0 -> no index" and writing the
+// result record to HBM and, behind a flag, to host-coherent memory.  (Round 2 had the block
+// that drew the launch's last ticket do this: an atomic's round trip and two barriers on
+// the critical path of every block, and the reduction started only after the last one.)
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -71,12 +75,15 @@ struct SmallPlan
   uint32_t tiles;               // tiles of one theta step
   uint32_t linear;              // tiles are runs of 64 consecutive candidates, not 8 x 8 patches
   uint32_t no_tail;             // (experiments) leave out the final reduction
+  uint32_t search_blocks;       // blocks of the search proper; block search_blocks (if launched) reduces
 };
 
 // What the launch's last block needs for the final reduction.
 struct SmallFinal
 {
-  uint32_t * tickets;           // one counter, zero between launches
+  // one word per record: the sequence number of the launch whose record is in place (zero when
+  // the workspace is allocated; sequence numbers start at 1 and only rise)
+  unsigned long long * done;
   double * record_out;          // device, 12 doubles
   double * record_out2;         // device, optional
   double * host_out;            // host-coherent, optional; flag at host_out[kHostFlagSlot]
@@ -96,6 +103,97 @@ __device__ __forceinline__ void store_agent(double * p, double v)
 __device__ __forceinline__ double load_agent(const double * p)
 {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The reducing block of a launch (see the header): waits for the n_records records of the
+// launch `fin.seq`, reduces them, publishes the result.  scratch: LDS for one record per wave.
+__device__ __forceinline__ void small_final_reduction(const MatchArgs & a, const SmallFinal & fin,
+                                                      uint32_t n_records, double * scratch)
+{
+  const uint32_t n_threads = blockDim.x;
+  const uint32_t lane = threadIdx.x & (kWave - 1);
+  const uint32_t wave = threadIdx.x >> 6;
+  const uint32_t n_waves = n_threads >> 6;
+  // Every lane takes whole records (r = thread, thread + n_threads, ...; the 12 loads of a
+  // record in flight together), each wave reduces its lanes over the DPP network, the waves'
+  // results meet in LDS and one thread per column adds them in wave order.  Fixed order throughout.
+  double bs = 0.0, bi = kNoIndex;
+  double acc[10];
+#pragma unroll
+  for (int k = 0; k < 10; ++k) acc[k] = 0.0;
+  for (uint32_t r = threadIdx.x; r < n_records; r += n_threads)
+  {
+    while (__hip_atomic_load(fin.done + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != fin.seq)
+    {
+      __builtin_amdgcn_s_sleep(2);
+    }
+    const double * p = a.partials + static_cast<size_t>(r) * kRecord;
+    double v[kRecord];
+#pragma unroll
+    for (int k = 0; k < kRecord; ++k) v[k] = load_agent(p + k);
+    if (better(v[0], v[1], bs, bi))
+    {
+      bs = v[0];
+      bi = v[1];
+    }
+#pragma unroll
+    for (int k = 0; k < 10; ++k) acc[k] += v[2 + k];
+  }
+  wave_best_to_last_lane(bs, bi);
+#pragma unroll
+  for (int k = 0; k < 10; ++k) acc[k] = wave_sum_to_last_lane(acc[k]);
+  if (lane == kWave - 1)
+  {
+    scratch[wave * kRecord + 0] = bs;
+    scratch[wave * kRecord + 1] = bi;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) scratch[wave * kRecord + 2 + k] = acc[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < kRecord)
+  {
+    const uint32_t k = threadIdx.x;
+    double val;
+    if (k < 2)
+    {
+      double s0 = scratch[0], i0 = scratch[1];
+      for (uint32_t w = 1; w < n_waves; ++w)
+      {
+        const double sw = scratch[w * kRecord], iw = scratch[w * kRecord + 1];
+        if (better(sw, iw, s0, i0))
+        {
+          s0 = sw;
+          i0 = iw;
+        }
+      }
+      val = k == 0 ? s0 : (s0 < 0.0 ? i0 : -1.0);   // no candidate scored below 0: no index
+    }
+    else
+    {
+      val = scratch[k];
+      for (uint32_t w = 1; w < n_waves; ++w) val += scratch[w * kRecord + k];
+    }
+    fin.record_out[k] = val;
+    if (fin.record_out2 != nullptr) fin.record_out2[k] = val;
+    if (fin.host_out != nullptr) store_host(fin.host_out + k, val);
+  }
+  if (fin.host_out != nullptr && wave == 0)
+  {
+    // the record (lanes 0..11 of this wave) has been acknowledged before the flag leaves
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) raise_host_flag(fin.host_out + kHostFlagSlot, fin.seq);
+  }
+#ifdef NDT2D_SMALL_TRACE
+  // when the flag had left (final reduction and publish done)
+  if (a.scores != nullptr && threadIdx.x == 0)
+  {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    double * tr = a.scores + static_cast<size_t>(8192) * kSmallMaxWaves * 8 - 8;
+    tr[0] = static_cast<double>(wall_clock64());
+    tr[1] = static_cast<double>(blockIdx.x);
+  }
+#endif
 }
 
 // COMPACT: the grid came with compacted records (GridDesc::compact_records, small maps
@@ -126,6 +224,12 @@ match_small_kernel(const MatchArgs a,
 #endif
   const GridDesc & g = a.grid;
   if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();
+  if (blockIdx.x == plan.search_blocks)
+  {
+    // the launch's last block reduces (every search block has been dispatched before it)
+    small_final_reduction(a, fin, plan.search_blocks / plan.blocks_per_theta * plan.tiles, lds);
+    return;
+  }
   uint8_t * lds_map = reinterpret_cast<uint8_t *>(lds);
   const uint32_t map_bytes = static_cast<uint32_t>(geo.map_h) * kMapStride;
   const uint32_t rank_bytes = COMPACT ? compact_rank_bytes(g.ncell) : 0u;
@@ -391,17 +495,14 @@ match_small_kernel(const MatchArgs a,
 #pragma unroll
       for (int k = 0; k < 10; ++k) store_agent(out + 2 + k, acc[k]);
     }
-    // The record must be in L2 before this block's ticket is drawn: the barrier below
-    // is a workgroup-scope release only (it waits on lgkmcnt, not on vmcnt), so the
-    // storing wave itself waits for its stores' acknowledgements first.
+    // the record is in L2 (its stores acknowledged) before its `done` word says so
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == kWave - 1)
+    {
+      __hip_atomic_store(fin.done + (static_cast<size_t>(t_local) * plan.tiles + tile), fin.seq, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
-
-  // ---- final reduction by the block that draws the launch's last ticket ----
-  // (every wave's record stores have been acknowledged before it passes the barrier)
-  // (the ticket travels through the partial-sum area, free again after the barrier: a
-  // static __shared__ variable would push the map off LDS offset 0)
-  uint32_t * ticket_slot = reinterpret_cast<uint32_t *>(partials);
 #ifdef NDT2D_SMALL_TRACE
   // experiments/small_trace.py: per wave {block start, setup done, beams done, barrier
   // passed, records written} in shader clocks, into the (otherwise unused) scores array
@@ -416,100 +517,6 @@ match_small_kernel(const MatchArgs a,
     tr[5] = static_cast<double>(w_start);
     tr[6] = active ? 1.0 : 0.0;
     tr[7] = static_cast<double>(wall_clock64());
-  }
-#endif
-  __syncthreads();
-  if (threadIdx.x == 0)
-  {
-    *ticket_slot = __hip_atomic_fetch_add(fin.tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __syncthreads();
-  if (*ticket_slot != gridDim.x - 1) return;
-  if (plan.no_tail)   // experiments/small_plan_sweep.py: the search without its reduction
-  {
-    if (threadIdx.x == 0) __hip_atomic_store(fin.tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return;
-  }
-
-  // Every lane takes whole records (r = thread, thread + n_threads, ...; the 12 loads of a
-  // record in flight together: one trip to memory for a few hundred records), each wave
-  // reduces its lanes over the DPP network, the waves' results meet in LDS and thread 0
-  // adds them in wave order.  Fixed order throughout.
-  const uint32_t n_records = gridDim.x / plan.blocks_per_theta * plan.tiles;
-  const uint32_t n_waves = n_threads >> 6;
-  double bs = 0.0, bi = kNoIndex;
-  double acc[10];
-#pragma unroll
-  for (int k = 0; k < 10; ++k) acc[k] = 0.0;
-  for (uint32_t r = threadIdx.x; r < n_records; r += n_threads)
-  {
-    const double * p = a.partials + static_cast<size_t>(r) * kRecord;
-    double v[kRecord];
-#pragma unroll
-    for (int k = 0; k < kRecord; ++k) v[k] = load_agent(p + k);
-    if (better(v[0], v[1], bs, bi))
-    {
-      bs = v[0];
-      bi = v[1];
-    }
-#pragma unroll
-    for (int k = 0; k < 10; ++k) acc[k] += v[2 + k];
-  }
-  wave_best_to_last_lane(bs, bi);
-#pragma unroll
-  for (int k = 0; k < 10; ++k) acc[k] = wave_sum_to_last_lane(acc[k]);
-  double * wave_out = rows;   // [n_waves][kRecord], the rotated-beam rows are done with
-  if (lane == kWave - 1)
-  {
-    wave_out[wave * kRecord + 0] = bs;
-    wave_out[wave * kRecord + 1] = bi;
-#pragma unroll
-    for (int k = 0; k < 10; ++k) wave_out[wave * kRecord + 2 + k] = acc[k];
-  }
-  __syncthreads();
-  if (threadIdx.x < kRecord)
-  {
-    const uint32_t k = threadIdx.x;
-    double val;
-    if (k < 2)
-    {
-      double s0 = wave_out[0], i0 = wave_out[1];
-      for (uint32_t w = 1; w < n_waves; ++w)
-      {
-        const double sw = wave_out[w * kRecord], iw = wave_out[w * kRecord + 1];
-        if (better(sw, iw, s0, i0))
-        {
-          s0 = sw;
-          i0 = iw;
-        }
-      }
-      val = k == 0 ? s0 : (s0 < 0.0 ? i0 : -1.0);   // no candidate scored below 0: no index
-    }
-    else
-    {
-      val = wave_out[k];
-      for (uint32_t w = 1; w < n_waves; ++w) val += wave_out[w * kRecord + k];
-    }
-    fin.record_out[k] = val;
-    if (fin.record_out2 != nullptr) fin.record_out2[k] = val;
-    if (fin.host_out != nullptr) store_host(fin.host_out + k, val);
-  }
-  if (threadIdx.x == 0) __hip_atomic_store(fin.tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (fin.host_out != nullptr && wave == 0)
-  {
-    // the record (lanes 0..11 of this wave) has been acknowledged before the flag leaves
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    if (lane == 0) raise_host_flag(fin.host_out + kHostFlagSlot, fin.seq);
-  }
-#ifdef NDT2D_SMALL_TRACE
-  // the launch's last block: when the flag had left (final reduction and publish done)
-  if (a.scores != nullptr && threadIdx.x == 0)
-  {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    double * tr = a.scores + static_cast<size_t>(8192) * kSmallMaxWaves * 8 - 8;
-    tr[0] = static_cast<double>(wall_clock64());
-    tr[1] = static_cast<double>(blockIdx.x);
   }
 #endif
 }
@@ -671,7 +678,7 @@ bool match_small_supported(const MatchArgs & args, size_t lds_per_block)
          small_lds_bytes(args, geo, kSmallMaxWaves, false) <= lds_per_block;
 }
 
-hipError_t launch_match_small(const MatchArgs & args_in, double * workspace, uint32_t * tickets,
+hipError_t launch_match_small(const MatchArgs & args_in, double * workspace, unsigned long long * done,
                               int cus, size_t lds_per_block, bool no_skip, double * record_out,
                               double * record_out2, double * host_record, unsigned long long seq,
                               hipStream_t stream)
@@ -687,11 +694,13 @@ hipError_t launch_match_small(const MatchArgs & args_in, double * workspace, uin
     return hipErrorInvalidValue;
   }
   geo.no_skip = no_skip ? 1 : 0;
-  const SmallPlan plan = small_plan(args, geo, cus);
+  SmallPlan plan = small_plan(args, geo, cus);
   const uint32_t waves = plan.patches_per_block * plan.chunks;
-  const uint32_t blocks = (args.th_end - args.th_begin) * plan.blocks_per_theta;
+  plan.search_blocks = (args.th_end - args.th_begin) * plan.blocks_per_theta;
+  // (+ the reducing block, see the file header)
+  const uint32_t blocks = plan.search_blocks + (plan.no_tail ? 0u : 1u);
   SmallFinal fin;
-  fin.tickets = tickets;
+  fin.done = done;
   fin.record_out = record_out;
   fin.record_out2 = record_out2;
   fin.host_out = host_record;
