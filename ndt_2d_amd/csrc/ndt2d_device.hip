@@ -88,7 +88,7 @@ struct ndt2d_context
   double * host_res_dev = nullptr;  // the same memory as the GPU addresses it
   unsigned long long seq = 0;       // last sequence number handed out
   unsigned long long match_seq = 0; // ... to the pending match launch
-  uint32_t * done_counter = nullptr;
+  unsigned long long * done_words = nullptr;   // score_few launches: one word per pose
 
   DeviceBuffer tables;  // dth | cos | sin | dlin
   // ndt2d_set_search keeps the tables in its pinned staging buffer and leaves the upload
@@ -281,13 +281,14 @@ int ensure_host_res(ndt2d_context * h)
     return fail_hip(h, e, "hipHostGetDevicePointer");
   }
   void * counter = nullptr;
-  e = hipMalloc(&counter, 256);
+  const size_t done_bytes = (static_cast<size_t>(ndt2d::kFewPosesMax) + 8) * sizeof(unsigned long long);
+  e = hipMalloc(&counter, done_bytes);
   if (e != hipSuccess)
   {
     (void)hipHostFree(p);
     return fail_hip(h, e, "hipMalloc");
   }
-  e = hipMemsetAsync(counter, 0, 256, h->stream);
+  e = hipMemsetAsync(counter, 0, done_bytes, h->stream);
   if (e != hipSuccess)
   {
     (void)hipHostFree(p);
@@ -296,7 +297,7 @@ int ensure_host_res(ndt2d_context * h)
   }
   h->host_res = static_cast<double *>(p);
   h->host_res_dev = static_cast<double *>(d);
-  h->done_counter = static_cast<uint32_t *>(counter);
+  h->done_words = static_cast<unsigned long long *>(counter);
   return NDT2D_OK;
 }
 
@@ -455,7 +456,7 @@ int ndt2d_destroy(ndt2d_handle h)
   release(h->stage_grid);
   release(h->stage_call);
   if (h->host_res != nullptr) (void)hipHostFree(h->host_res);
-  if (h->done_counter != nullptr) (void)hipFree(h->done_counter);
+  if (h->done_words != nullptr) (void)hipFree(h->done_words);
   release(h->b_points);
   release(h->b_scans);
   release(h->b_offsets);
@@ -1584,7 +1585,7 @@ int run_few(ndt2d_context * h, const double * arg_beams, size_t n_beams, const d
   ndt2d::FewOut out{};
   out.flag = reinterpret_cast<unsigned long long *>(h->host_res_dev + kScoreFlagSlot);
   out.seq = ++h->seq;
-  out.done_counter = h->done_counter;
+  out.done = h->done_words;
   out.beams_out = arg_beams != nullptr ? h->beams.ptr : nullptr;
   out.stats = stats ? 1 : 0;
   if (stats)

@@ -339,7 +339,10 @@ struct FewOut
 {
   unsigned long long * flag;
   unsigned long long seq;
-  uint32_t * done_counter;      // one zeroed uint32 (needed with flag != nullptr)
+  // one word per pose (kFewPosesMax of them, zero when allocated; needed with flag != nullptr):
+  // a pose's block stores the launch's `seq` there once its score is in place, and the
+  // launch's extra last block polls them (instead of a ticket that every block would draw)
+  unsigned long long * done;
   double * beams_out;           // device: the beams, when they came as kernel arguments
   int stats;                    // run ParticleFilter::updateStatistics in the launch's last block
   double * dev_scores;          // device scratch [n_poses] (stats)

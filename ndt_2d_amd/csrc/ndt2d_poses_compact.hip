@@ -511,6 +511,29 @@ __global__ void __launch_bounds__(kFewThreads) score_few_kernel(const PosesArgs 
   double * chunk_sums = lds + a.n_beams;        // [kChunks + 8]: chunk sums, then a scratch row
   const GridDesc & g = a.grid;
   const uint32_t i = blockIdx.x;
+  const uint32_t n = static_cast<uint32_t>(a.n_poses);
+  // With a completion flag and more than one pose the launch has one more block than poses:
+  // the last one, dispatched after all the others, waits for their `done` words and raises
+  // the flag (or runs updateStatistics first).  A ticket drawn by every block put an atomic's
+  // round trip on the path of the block that happened to finish last.
+  if (i == n)
+  {
+    for (uint32_t k = threadIdx.x; k < n; k += kFewThreads)
+    {
+      while (__hip_atomic_load(f.done + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != f.seq)
+      {
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+    __syncthreads();
+    if (!f.stats)
+    {
+      if (threadIdx.x == 0) raise_host_flag(reinterpret_cast<double *>(f.flag), f.seq);
+      return;
+    }
+  }
+  else
+  {
   if (ARG_BEAMS && i == 0)
   {
     for (uint32_t k = threadIdx.x; k < 2 * a.n_beams; k += kFewThreads) f.beams_out[k] = arg_beams.xy[k];
@@ -549,7 +572,6 @@ __global__ void __launch_bounds__(kFewThreads) score_few_kernel(const PosesArgs 
     chunk_sums[threadIdx.x] = csum;
   }
   __syncthreads();
-  uint32_t * last_slot = reinterpret_cast<uint32_t *>(chunk_sums + kChunks);
   if (threadIdx.x == 0)
   {
     double sum = chunk_sums[0];
@@ -557,16 +579,14 @@ __global__ void __launch_bounds__(kFewThreads) score_few_kernel(const PosesArgs 
     for (int j = 1; j < kChunks; ++j) sum += chunk_sums[j];
     // score = sum of (-likelihood) / n  ==  -(sum) / n (:175-177)
     const double score = -sum / static_cast<double>(a.n_beams);
-    uint32_t is_last = 0;
     if (f.flag == nullptr)
     {
       a.scores[i] = score;
     }
     else
     {
-      // scores go to host-coherent memory (or, with f.stats, to the device array the last
-      // block reads); the block that finishes last goes on, after every block's store has
-      // been acknowledged
+      // scores go to host-coherent memory (or, with f.stats, to the device array the
+      // statistics read); once the store has been acknowledged the pose's `done` word says so
       if (f.stats)
       {
         __hip_atomic_store(f.dev_scores + i, score, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -582,26 +602,22 @@ __global__ void __launch_bounds__(kFewThreads) score_few_kernel(const PosesArgs 
         store_host(a.scores + i, score);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      uint32_t arrived = gridDim.x;
-      if (gridDim.x > 1)
+      if (n > 1)
       {
-        arrived = __hip_atomic_fetch_add(f.done_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        __hip_atomic_store(f.done + i, f.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      if (arrived == gridDim.x)
+      else if (!f.stats)
       {
-        if (gridDim.x > 1) __hip_atomic_store(f.done_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        is_last = 1;
-        if (!f.stats) raise_host_flag(reinterpret_cast<double *>(f.flag), f.seq);
+        raise_host_flag(reinterpret_cast<double *>(f.flag), f.seq);   // a single pose signals for itself
       }
     }
-    *last_slot = is_last;
   }
-  if (!f.stats) return;
+  // (a single pose with statistics goes on by itself; every other pose block is done)
+  if (!(f.flag != nullptr && f.stats && n == 1)) return;
   __syncthreads();
-  if (*last_slot == 0) return;
+  }
 
-  // ---- updateStatistics by the last block (src/particle_filter.cpp:163-218) ----
-  const uint32_t n = gridDim.x;
+  // ---- updateStatistics by the launch's last block (src/particle_filter.cpp:163-218) ----
   const uint32_t lane = threadIdx.x & (kWave - 1);
   const uint32_t wave = threadIdx.x >> 6;
   double * row = chunk_sums + kChunks;          // 8 doubles of scratch
@@ -792,7 +808,9 @@ hipError_t launch_score_few(const PosesArgs & args, const FewPoses * few, const 
                                          static_cast<int>(lds_bytes));
       if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kernel, dim3(static_cast<uint32_t>(args.n_poses)), dim3(kFewThreads),
+    // (+ the block that waits for the others, see the kernel)
+    const uint32_t extra = (out.flag != nullptr && args.n_poses > 1) ? 1u : 0u;
+    hipLaunchKernelGGL(kernel, dim3(static_cast<uint32_t>(args.n_poses) + extra), dim3(kFewThreads),
                        lds_bytes, stream, args, few != nullptr ? *few : none, out, fb);
     return hipGetLastError();
   };
