@@ -311,62 +311,129 @@ __global__ void __launch_bounds__(256) pack_grid_kernel(const GridDesc g, const 
 // and with a real lidar that grid is tens of thousands of cells (scan poses +- range_max,
 // src/scan_matcher_ndt.cpp:52-66: 245 x 245 at 30 m / 0.25 m) of which the scans' points touch
 // one or two thousand.  Dense, every install moved and packed all of them (2.9 MB over PCIe);
-// here the host sends the touched cells only and three small kernels produce the layouts the
-// scorers read: fill (every cell the "cannot score" sentinel, no occupancy), scatter (the
-// listed cells), bytes (the map bytes of the cells around the listed ones).
+// here the host sends the touched cells only and two small kernels produce the layouts the
+// scorers read: install (every listed cell its packed record, every other cell the "cannot
+// score" sentinel) and bytes (the map bytes of the cells around the listed ones).
 
-// Every record the sentinel, every bit and byte zero, every rank `n_occ` (= the sentinel's).
-__global__ void __launch_bounds__(256) grid_fill_kernel(const GridDesc g, double * cells_lds_image,
-                                                        double * cells_global, uint32_t * occ_bits,
-                                                        uint8_t * bytes, uint16_t * ranks, uint32_t n_occ)
+// fill + scatter in ONE launch that reads the host's staged image in place (over PCIe, each
+// byte once) and leaves its device copy behind: no copy command in front of it -- the copy
+// and the dependency behind it were a third of what the mapper's per-scan install kept the
+// stream busy for.  Nothing here is ordered against anything else in the launch: the host's
+// occupancy words say which cells the list will write, and the fill leaves those alone.
+//   listed cells, 256 per step: their records through LDS with 16-byte loads (a lane reading
+//   its own 48 bytes would fetch every line three times), packed into both strides;
+//   all other cells, 1024 per step: the sentinel, rank n_occ; the occupancy words copied;
+//   the compacted records copied; the map bytes zeroed (grid_bytes_sparse_kernel follows).
+__global__ void __launch_bounds__(256) grid_install_kernel(const GridDesc g, const SparseImage im,
+                                                           double * cells_lds_image, double * cells_global,
+                                                           uint32_t * occ_bits, uint8_t * bytes,
+                                                           uint16_t * ranks, uint32_t n_occ)
 {
-  const uint32_t n_words = (g.ncell + 1 + 31) / 32;
-  const uint32_t n_bytes = (g.size_x + 2) * (g.size_y + 2);
-  const uint32_t stride = gridDim.x * 256;
-  for (uint32_t cell = blockIdx.x * 256 + threadIdx.x; cell <= g.ncell; cell += stride)
+  __shared__ __align__(16) double sh_rec[256 * 6];
+  __shared__ uint32_t sh_words[32];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t * src_idx = reinterpret_cast<const uint32_t *>(im.src + im.off_idx);
+  const uint16_t * src_rk = reinterpret_cast<const uint16_t *>(im.src + im.off_rk);
+  const uint32_t * src_occ = reinterpret_cast<const uint32_t *>(im.src + im.off_occ);
+  uint32_t * dst_idx = im.dst != nullptr ? reinterpret_cast<uint32_t *>(im.dst + im.off_idx) : nullptr;
+  uint16_t * dst_rk = im.dst != nullptr ? reinterpret_cast<uint16_t *>(im.dst + im.off_rk) : nullptr;
+
+  const uint32_t list_chunks = (im.n + 255) / 256;
+  const size_t d_end = static_cast<size_t>(im.n) * 6;
+  for (uint32_t chunk = blockIdx.x; chunk < list_chunks; chunk += gridDim.x)
   {
-    double2 * l = reinterpret_cast<double2 *>(cells_lds_image + static_cast<size_t>(cell) * kCellDoubles);
-    double2 * gl = reinterpret_cast<double2 *>(cells_global + static_cast<size_t>(cell) * kCellStrideGlobal);
-    const double2 a = {1.0e300, 0.0}, b = {-1.0, 0.0}, c = {-1.0, 0.0}, z = {0.0, 0.0};
-    l[0] = a;
-    l[1] = b;
-    l[2] = c;
-    gl[0] = a;
-    gl[1] = b;
-    gl[2] = c;
-    gl[3] = z;
-    if (ranks != nullptr) ranks[cell] = static_cast<uint16_t>(n_occ);
-  }
-  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_words; i += stride) occ_bits[i] = 0u;
-  // (whole words; the byte array is allocated in doubles)
-  uint32_t * b32 = reinterpret_cast<uint32_t *>(bytes);
-  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < (n_bytes + 3) / 4; i += stride) b32[i] = 0u;
-}
-
-// The listed cells: packed records h = -0.5 * information in both strides, occupancy bit,
-// rank (host-assigned: the cell's record among the compacted ones, 0xffff if it cannot score).
-__global__ void __launch_bounds__(256) grid_scatter_kernel(const GridDesc g, const uint32_t * cell_index,
-                                                           const double * cells6, const uint16_t * rank_of,
-                                                           uint32_t n, double * cells_lds_image,
-                                                           double * cells_global, uint32_t * occ_bits,
-                                                           uint16_t * ranks)
-{
-  const uint32_t k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= n) return;
-  const uint32_t cell = cell_index[k];
-  const double * c = cells6 + static_cast<size_t>(k) * 6;
-  if (cell >= g.ncell || c[5] < 5.0) return;    // cannot score (n < 5, src/ndt_model.cpp:107): stays the sentinel
-  const double rec[kCellDoubles] = {c[0], c[1], -0.5 * c[2], -0.5 * c[3], -0.5 * c[4], 1.0};
-  double * l = cells_lds_image + static_cast<size_t>(cell) * kCellDoubles;
-  double * gl = cells_global + static_cast<size_t>(cell) * kCellStrideGlobal;
+    const size_t d0 = static_cast<size_t>(chunk) * (256 * 6);
 #pragma unroll
-  for (int j = 0; j < kCellDoubles; ++j)
-  {
-    l[j] = rec[j];
-    gl[j] = rec[j];
+    for (uint32_t p = 0; p < 3; ++p)
+    {
+      const uint32_t piece = p * 256 + tid;
+      const size_t d = d0 + 2 * static_cast<size_t>(piece);
+      if (d < d_end)
+      {
+        const double2 v = *reinterpret_cast<const double2 *>(im.src + d);
+        *reinterpret_cast<double2 *>(sh_rec + 2 * piece) = v;
+        if (im.dst != nullptr) *reinterpret_cast<double2 *>(im.dst + d) = v;
+      }
+    }
+    __syncthreads();
+    const uint32_t k = chunk * 256 + tid;
+    if (k < im.n)
+    {
+      const uint32_t cell = src_idx[k];
+      const uint16_t rk = src_rk[k];
+      if (im.dst != nullptr)
+      {
+        dst_idx[k] = cell;
+        dst_rk[k] = rk;
+      }
+      const double * c = sh_rec + tid * 6;
+      // (a listed cell that cannot score -- n < 5, src/ndt_model.cpp:107 -- has no occupancy
+      // bit: the fill below writes its sentinel)
+      if (cell < g.ncell && !(c[5] < 5.0))
+      {
+        const double2 r0 = {c[0], c[1]}, r1 = {-0.5 * c[2], -0.5 * c[3]}, r2 = {-0.5 * c[4], 1.0};
+        double2 * l = reinterpret_cast<double2 *>(cells_lds_image + static_cast<size_t>(cell) * kCellDoubles);
+        double2 * gl = reinterpret_cast<double2 *>(cells_global + static_cast<size_t>(cell) * kCellStrideGlobal);
+        l[0] = r0;
+        l[1] = r1;
+        l[2] = r2;
+        gl[0] = r0;
+        gl[1] = r1;
+        gl[2] = r2;
+        if (ranks != nullptr) ranks[cell] = rk;
+      }
+    }
+    __syncthreads();
   }
-  atomicOr(occ_bits + (cell >> 5), 1u << (cell & 31u));
-  if (ranks != nullptr && rank_of != nullptr) ranks[cell] = rank_of[k];
+
+  const uint32_t n_words = (g.ncell + 1 + 31) / 32;
+  const uint32_t fill_chunks = (n_words + 31) / 32;
+  for (uint32_t chunk = blockIdx.x; chunk < fill_chunks; chunk += gridDim.x)
+  {
+    if (tid < 32)
+    {
+      const uint32_t w = chunk * 32 + tid;
+      const uint32_t v = w < n_words ? src_occ[w] : 0u;
+      sh_words[tid] = v;
+      if (w < n_words) occ_bits[w] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j)
+    {
+      const uint32_t local = j * 256 + tid;
+      const uint32_t cell = chunk * 1024 + local;
+      if (cell <= g.ncell && !((sh_words[local >> 5] >> (local & 31u)) & 1u))
+      {
+        double2 * l = reinterpret_cast<double2 *>(cells_lds_image + static_cast<size_t>(cell) * kCellDoubles);
+        double2 * gl = reinterpret_cast<double2 *>(cells_global + static_cast<size_t>(cell) * kCellStrideGlobal);
+        const double2 a = {1.0e300, 0.0}, b = {-1.0, 0.0}, z = {0.0, 0.0};
+        l[0] = a;
+        l[1] = b;
+        l[2] = b;
+        gl[0] = a;
+        gl[1] = b;
+        gl[2] = b;
+        gl[3] = z;
+        if (ranks != nullptr) ranks[cell] = static_cast<uint16_t>(n_occ);
+      }
+    }
+    __syncthreads();
+  }
+
+  const uint32_t stride = gridDim.x * 256;
+  if (im.dst != nullptr)
+  {
+    for (size_t p = blockIdx.x * 256 + tid; p < im.n_compact / 2; p += stride)
+    {
+      reinterpret_cast<double2 *>(im.dst + im.off_compact)[p] =
+        reinterpret_cast<const double2 *>(im.src + im.off_compact)[p];
+    }
+  }
+  // (whole words; the byte array is allocated in doubles)
+  const uint32_t n_bytes = (g.size_x + 2) * (g.size_y + 2);
+  uint32_t * b32 = reinterpret_cast<uint32_t *>(bytes);
+  for (uint32_t i = blockIdx.x * 256 + tid; i < (n_bytes + 3) / 4; i += stride) b32[i] = 0u;
 }
 
 // Map bytes: a byte depends on the 3 x 3 cells around it, so the bytes that are not zero lie
@@ -473,26 +540,27 @@ hipError_t launch_pack_grid(const GridDesc & geometry, const double * cells6,
   return hipGetLastError();
 }
 
-hipError_t launch_grid_sparse(const GridDesc & geometry, const uint32_t * cell_index, const double * cells6,
-                              const uint16_t * rank_of, uint32_t n, double * cells_lds_image,
-                              double * cells_global, uint32_t * occ_bits, uint8_t * cell_bytes,
-                              uint16_t * ranks, uint32_t n_occ, hipStream_t stream)
+hipError_t launch_grid_install(const GridDesc & geometry, const SparseImage & image, double * cells_lds_image,
+                               double * cells_global, uint32_t * occ_bits, uint8_t * cell_bytes,
+                               uint16_t * ranks, uint32_t n_occ, hipStream_t stream)
 {
-  const uint32_t fill_blocks = (geometry.ncell + 1 + 255) / 256 < 2048 ? (geometry.ncell + 1 + 255) / 256 : 2048;
-  hipLaunchKernelGGL(grid_fill_kernel, dim3(fill_blocks), dim3(256), 0, stream, geometry, cells_lds_image,
+  const uint32_t n_words = (geometry.ncell + 1 + 31) / 32;
+  const uint32_t fill_chunks = (n_words + 31) / 32;
+  const uint32_t list_chunks = (image.n + 255) / 256;
+  uint32_t blocks = fill_chunks < 2048 ? fill_chunks : 2048;
+  if (list_chunks > blocks) blocks = list_chunks < 4096 ? list_chunks : 4096;
+  hipLaunchKernelGGL(grid_install_kernel, dim3(blocks), dim3(256), 0, stream, geometry, image, cells_lds_image,
                      cells_global, occ_bits, cell_bytes, ranks, n_occ);
   hipError_t e = hipGetLastError();
-  if (e != hipSuccess || n == 0) return e;
-  hipLaunchKernelGGL(grid_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, geometry, cell_index,
-                     cells6, rank_of, n, cells_lds_image, cells_global, occ_bits, ranks);
-  e = hipGetLastError();
-  if (e != hipSuccess) return e;
+  if (e != hipSuccess || image.n == 0) return e;
+  // the map bytes around the listed cells, from the device copy the launch above left
+  const double * img = image.dst != nullptr ? image.dst : image.src;
   GridDesc g = geometry;
   g.cells_lds_image = cells_lds_image;
   g.occ_bits = occ_bits;
-  const uint64_t rows = static_cast<uint64_t>(n) * 9;
+  const uint64_t rows = static_cast<uint64_t>(image.n) * 9;
   hipLaunchKernelGGL(grid_bytes_sparse_kernel, dim3(static_cast<uint32_t>((rows + 15) / 16)), dim3(256), 0,
-                     stream, g, cell_index, cells6, n, cell_bytes);
+                     stream, g, reinterpret_cast<const uint32_t *>(img + image.off_idx), img, image.n, cell_bytes);
   return hipGetLastError();
 }
 

@@ -787,7 +787,11 @@ int ndt2d_set_grid_sparse(ndt2d_handle h, const uint32_t * cell_index, const dou
   size_t n_rk = (static_cast<size_t>(n) + 3) / 4;
   if ((n6 + n_idx + n_rk) & 1) ++n_rk;   // the compact records are read with 16-byte loads
   const size_t n_compact = compactable ? static_cast<size_t>(n_occ + 1) * kCellDoubles : 0;
-  const size_t n_upload = n6 + n_idx + n_rk + n_compact + 2;
+  // (occupancy words of the cells that can score: they tell the install kernel which cells
+  // the list will write, ndt2d_build.hip)
+  const size_t n_words = (static_cast<size_t>(ncell) + 1 + 31) / 32;
+  const size_t off_occ = n6 + n_idx + n_rk + n_compact;
+  const size_t n_upload = off_occ + (n_words + 1) / 2 + 2;
   int rc;
   if ((rc = ensure(h, h->compact, n_upload)) != NDT2D_OK) return rc;
   if ((rc = ensure(h, h->cells_lds_image, static_cast<size_t>(ncell + 1) * kCellDoubles)) != NDT2D_OK) return rc;
@@ -802,12 +806,15 @@ int ndt2d_set_grid_sparse(ndt2d_handle h, const uint32_t * cell_index, const dou
   if (n > 0) std::memcpy(st_idx, cell_index, static_cast<size_t>(n) * sizeof(uint32_t));
   uint16_t * st_rk = reinterpret_cast<uint16_t *>(st + n6 + n_idx);
   double * st_rec = st + n6 + n_idx + n_rk;
+  uint32_t * st_occ = reinterpret_cast<uint32_t *>(st + off_occ);
+  std::memset(st_occ, 0, (n_words + 1) / 2 * sizeof(double));
   uint32_t k_occ = 0;
   for (uint32_t k = 0; k < n; ++k)
   {
     const double * c = cells6 + 6 * static_cast<size_t>(k);
     if (!(c[5] < 5.0))
     {
+      st_occ[cell_index[k] >> 5] |= 1u << (cell_index[k] & 31u);
       if (compactable)
       {
         double * r = st_rec + static_cast<size_t>(k_occ) * kCellDoubles;
@@ -830,7 +837,26 @@ int ndt2d_set_grid_sparse(ndt2d_handle h, const uint32_t * cell_index, const dou
     static const double sentinel[kCellDoubles] = {1.0e300, 0.0, -1.0, 0.0, -1.0, 0.0};
     std::memcpy(st_rec + static_cast<size_t>(n_occ) * kCellDoubles, sentinel, sizeof(sentinel));
   }
-  if ((rc = stage_copy(h, h->stage_grid, h->compact.ptr, n_upload)) != NDT2D_OK) return rc;
+  // the install kernel reads the staged image in place and leaves the device copy behind; a
+  // staging buffer the device cannot address is copied first
+  ndt2d::SparseImage image{};
+  image.n = n;
+  image.off_idx = n6;
+  image.off_rk = n6 + n_idx;
+  image.off_compact = n6 + n_idx + n_rk;
+  image.n_compact = n_compact;
+  image.off_occ = off_occ;
+  if (h->stage_grid.dev != nullptr)
+  {
+    image.src = h->stage_grid.dev;
+    image.dst = h->compact.ptr;
+  }
+  else
+  {
+    if ((rc = stage_copy(h, h->stage_grid, h->compact.ptr, n_upload)) != NDT2D_OK) return rc;
+    image.src = h->compact.ptr;
+    image.dst = nullptr;
+  }
 
   GridDesc g{};
   g.size_x = size_x;
@@ -843,12 +869,11 @@ int ndt2d_set_grid_sparse(ndt2d_handle h, const uint32_t * cell_index, const dou
   g.origin_y = origin_y;
   const double * d_cells6 = h->compact.ptr;
   const uint32_t * d_idx = reinterpret_cast<const uint32_t *>(h->compact.ptr + n6);
-  const uint16_t * d_rk = reinterpret_cast<const uint16_t *>(h->compact.ptr + n6 + n_idx);
-  hipError_t e = ndt2d::launch_grid_sparse(
-    g, d_idx, d_cells6, compactable ? d_rk : nullptr, n, h->cells_lds_image.ptr, h->cells_global.ptr,
-    reinterpret_cast<uint32_t *>(h->occ_bits.ptr), reinterpret_cast<uint8_t *>(h->cell_bytes.ptr),
+  hipError_t e = ndt2d::launch_grid_install(
+    g, image, h->cells_lds_image.ptr, h->cells_global.ptr, reinterpret_cast<uint32_t *>(h->occ_bits.ptr),
+    reinterpret_cast<uint8_t *>(h->cell_bytes.ptr),
     compactable ? reinterpret_cast<uint16_t *>(h->ranks.ptr) : nullptr, n_occ, h->stream);
-  if (e != hipSuccess) return fail_hip(h, e, "launch_grid_sparse");
+  if (e != hipSuccess) return fail_hip(h, e, "launch_grid_install");
   if ((rc = stage_mark(h, h->stage_grid)) != NDT2D_OK) return rc;
   g.cells_lds_image = h->cells_lds_image.ptr;
   g.cells_global = h->cells_global.ptr;

@@ -146,12 +146,22 @@ hipError_t launch_pack_grid(const GridDesc & geometry, const double * cells6,
                             double * cells_lds_image, double * cells_global, uint32_t * occ_bits,
                             uint8_t * cell_bytes, hipStream_t stream);
 // A grid given as the list of its n cells that hold points (cells6[k] belongs to cell
-// cell_index[k]; all others are empty): fill + scatter + the map bytes around the listed
-// cells.  ranks (optional): the cell -> compact record table, rank_of[k] the listed cell's.
-hipError_t launch_grid_sparse(const GridDesc & geometry, const uint32_t * cell_index, const double * cells6,
-                              const uint16_t * rank_of, uint32_t n, double * cells_lds_image,
-                              double * cells_global, uint32_t * occ_bits, uint8_t * cell_bytes,
-                              uint16_t * ranks, uint32_t n_occ, hipStream_t stream);
+// cell_index[k]; all others are empty; rank_of[k]: the listed cell's record among the compacted
+// ones, the cell -> record table `ranks` is optional), as the host staged it:
+// [cells6: 6 n doubles | cell indices: n u32 | ranks of the listed cells: n u16 | compacted
+// records | occupancy words of the cells that can score], offsets in doubles.
+// src: the image as the kernel addresses it -- the pinned staging buffer in place, or
+// its device copy (then dst == nullptr); dst: where to leave the device copy.  Two launches.
+struct SparseImage
+{
+  const double * src;
+  double * dst;
+  uint32_t n;            // listed cells
+  size_t off_idx, off_rk, off_compact, n_compact, off_occ;
+};
+hipError_t launch_grid_install(const GridDesc & geometry, const SparseImage & image, double * cells_lds_image,
+                               double * cells_global, uint32_t * occ_bits, uint8_t * cell_bytes,
+                               uint16_t * ranks, uint32_t n_occ, hipStream_t stream);
 hipError_t launch_grid_sparse_to_dense(const uint32_t * cell_index, const double * cells6, uint32_t n,
                                        uint32_t ncell, double * dense6, hipStream_t stream);
 hipError_t launch_grid_tail(const GridDesc & geometry, const double * cells_lds_image,

@@ -909,7 +909,9 @@ hipError_t launch_poses_compact(const PosesArgs & args_in, int cus, bool screen,
   // one 1024-thread block per CU shares it.
   uint32_t split = choose_split(args, cus, 4);
   const size_t small = compact_lds_bytes(args, 256, split, screen);
-  const bool use_small = small <= 48 * 1024;
+  // (the coarse-bitmap kernels exist in the 1024-thread geometry only -- also when the coarse
+  // bitmap itself is small: a grid of a million cells screens with 33 KB of bits)
+  const bool use_small = small <= 48 * 1024 && args.coarse_log2 == 0;
   const int threads = use_small ? 256 : 1024;
   const uint32_t waves_per_block = static_cast<uint32_t>(threads / kWave);
   size_t lds_bytes = small;

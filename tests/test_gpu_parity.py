@@ -1384,3 +1384,90 @@ def test_two_instances_on_two_threads(cfg1):
     assert not errors, errors
     for r in results.values():
         assert np.array_equal(r["pose"], exp["pose"]) and abs(r["score"] - exp["score"]) < TOL_TIGHT
+
+
+@pytest.mark.parametrize("sx,sy,n_listed", [
+    (1, 1, 0), (1, 1, 1), (33, 31, 0), (33, 31, 256), (33, 31, 257), (257, 129, 5000),
+    (1023, 1025, 3000), (3000, 2000, 70000),
+])
+def test_list_install_shapes(sx, sy, n_listed):
+    """The install kernel of ndt2d_set_grid_sparse (ndt2d_build.hip: the listed cells 256 per
+    step, all others 1024 per step behind the host's occupancy words, grid-stride beyond 2048
+    blocks): an empty list, a single cell, lists that end on and just past a step, grids whose
+    cell count is not a multiple of anything, cells that cannot score (n < 5) in the list.
+    Against the dense install of the same cells: the records back (ndt2d_get_grid), a search's
+    candidate scores and the particle weights, all bitwise."""
+    rng = np.random.default_rng(sx * 7919 + sy * 31 + n_listed)
+    ncell = sx * sy
+    listed = rng.choice(ncell, size=n_listed, replace=False).astype(np.uint32)
+    if n_listed > 2:
+        listed[0], listed[1] = 0, ncell - 1                       # the corners of the grid
+        listed = np.unique(listed).astype(np.uint32)
+        rng.shuffle(listed)
+    n = len(listed)
+    res = 0.25
+    cx = (listed % sx + 0.5) * res
+    cy = (listed // sx + 0.5) * res
+    rec = np.zeros((n, 6))
+    rec[:, 0] = cx + rng.uniform(-0.1, 0.1, n)
+    rec[:, 1] = cy + rng.uniform(-0.1, 0.1, n)
+    a, b, t = rng.uniform(20, 400, n), rng.uniform(20, 400, n), rng.uniform(0, math.pi, n)
+    rec[:, 2] = a * np.cos(t) ** 2 + b * np.sin(t) ** 2
+    rec[:, 3] = (a - b) * np.cos(t) * np.sin(t)
+    rec[:, 4] = a * np.sin(t) ** 2 + b * np.cos(t) ** 2
+    rec[:, 5] = rng.integers(1, 40, n)                            # some below 5: listed, cannot score
+    dense = np.zeros((ncell, 6))
+    dense[listed] = rec
+    # beams around a listed cell that can score, if there is one
+    scoring = np.flatnonzero(rec[:, 5] >= 5)
+    centre = rec[scoring[0], :2] if len(scoring) else np.array([0.1, 0.1])
+    pts = rng.uniform(-1.0, 1.0, (64, 2))
+    pose = np.array([centre[0], centre[1], 0.3])
+    dth = np.linspace(-0.05, 0.05, 5)
+    dlin = np.linspace(-0.25, 0.25, 11)
+    cos_t, sin_t = np.cos(pose[2] + dth), np.sin(pose[2] + dth)
+    poses = np.column_stack([rng.uniform(0, sx * res, 3000), rng.uniform(0, sy * res, 3000),
+                             rng.uniform(-3, 3, 3000)])
+    if len(scoring):
+        poses[:1000, :2] = rec[rng.choice(scoring, 1000), :2] + rng.uniform(-0.5, 0.5, (1000, 2))
+    L = _capi.lib()
+    out = {}
+    for how in ("dense", "sparse"):
+        h = C.c_void_p()
+        assert L.ndt2d_create(C.byref(h), 0) == 0
+        try:
+            for _ in range(2):        # (twice: the second install finds the buffers of the first)
+                if how == "dense":
+                    assert L.ndt2d_set_grid(h, _capi.dptr(dense), sx, sy, res, 0.0, 0.0) == 0
+                else:
+                    idx = listed if n else np.zeros(1, np.uint32)
+                    assert L.ndt2d_set_grid_sparse(h, idx.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                   _capi.dptr(rec if n else np.zeros((1, 6))), n,
+                                                   sx, sy, res, 0.0, 0.0) == 0
+            assert L.ndt2d_set_beams(h, _capi.dptr(pts), len(pts)) == 0
+            assert L.ndt2d_set_search(h, pose[0], pose[1], _capi.dptr(dth), _capi.dptr(cos_t),
+                                      _capi.dptr(sin_t), len(dth), _capi.dptr(dlin), len(dlin)) == 0
+            got = {}
+            for variant in (b"auto", b"lane", b"lane-noskip"):
+                assert L.ndt2d_set_variant(h, variant) == 0
+                r = _capi.MatchResult()
+                sc = np.zeros(len(dth) * len(dlin) ** 2)
+                assert L.ndt2d_match(h, 0, len(dth), _capi.dptr(sc), C.byref(r)) == 0, variant
+                got[variant] = (sc, r.best_index, r.best_score)
+            assert L.ndt2d_set_variant(h, b"auto") == 0
+            w = np.zeros(len(poses))
+            assert L.ndt2d_score_poses(h, _capi.dptr(poses), len(poses), _capi.dptr(w), None) == 0, (how, L.ndt2d_last_error(h))
+            back = np.full_like(dense, -1.0)
+            assert L.ndt2d_get_grid(h, _capi.dptr(back), len(back), None, None, None, None, None) == 0
+            out[how] = (got, w, back)
+        finally:
+            L.ndt2d_destroy(h)
+    assert np.array_equal(out["sparse"][2], dense) and np.array_equal(out["dense"][2], dense)
+    for variant, (sc, bi, bs) in out["dense"][0].items():
+        sc2, bi2, bs2 = out["sparse"][0][variant]
+        assert np.array_equal(sc, sc2), variant
+        assert (bi, bs) == (bi2, bs2), variant
+    assert np.array_equal(out["sparse"][0][b"lane"][0], out["sparse"][0][b"lane-noskip"][0])
+    assert np.array_equal(out["dense"][1], out["sparse"][1])
+    if len(scoring) > 10:
+        assert (out["sparse"][0][b"auto"][0] < 0).any() and (out["sparse"][1] < 0).any()
