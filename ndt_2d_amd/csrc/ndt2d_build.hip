@@ -203,68 +203,6 @@ __global__ void __launch_bounds__(256) cells_kernel(const BuildArgs a, const uin
   write_scorer_record(a.grid.ncell, cell, rec, a.cells_lds_image, a.cells_global, a.occ_bits);
 }
 
-// One occupancy-map byte per grid cell, for the grid extended by one cell on every
-// side ([size_y + 2][size_x + 2], cell (cx, cy) at (cy + 1) * (size_x + 2) + cx + 1):
-// the byte the lane-per-candidate search's map holds at one map cell per grid cell
-// (ndt2d_lane_fn.h, sub_cell_byte with sub_log2 = 0).  It depends on the grid only, so
-// it is prepared once here and the small-lattice search copies its window from it.
-// FROM_CELLS6: occupancy and records come from the cells6 records themselves (the fused
-// kernel of a host-installed grid, which has no packed records yet); else from the packed
-// records and the bitmap (device build).  lane16 = this thread's lane in its 16-lane row,
-// i = the extended-grid cell the row works on.
-template <bool FROM_CELLS6>
-__device__ __forceinline__ void cell_byte_row(const GridDesc & g, const double * cells6, uint32_t i,
-                                              uint32_t j, uint8_t * bytes)
-{
-  // 16 lanes (one DPP row) per cell, lane j < 9 takes neighbour j of the 3 x 3 block: the
-  // bound is a maximum over the neighbours that can score, each a closed form with a few
-  // divisions -- nine of them one after the other in one lane was the whole kernel's time
-  const uint32_t w = g.size_x + 2, h = g.size_y + 2;
-  const bool live = i < w * h;
-  const int32_t cx = static_cast<int32_t>(live ? i % w : 0) - 1, cy = static_cast<int32_t>(live ? i / w : 0) - 1;
-  // the sub-cell box of sub_cell_byte() at one sub-cell per cell
-  const double x0 = g.origin_x + (static_cast<double>(cx) - kBoxMargin) * g.cell_size;
-  const double y0 = g.origin_y + (static_cast<double>(cy) - kBoxMargin) * g.cell_size;
-  const double x1 = x0 + (1.0 + 2.0 * kBoxMargin) * g.cell_size;
-  const double y1 = y0 + (1.0 + 2.0 * kBoxMargin) * g.cell_size;
-  double bound = -HUGE_VAL;
-  uint32_t self = 0;
-  if (live && j < 9)
-  {
-    const int32_t nx = cx + static_cast<int32_t>(j % 3) - 1, ny = cy + static_cast<int32_t>(j / 3) - 1;
-    if (nx >= 0 && nx < static_cast<int32_t>(g.size_x) && ny >= 0 && ny < static_cast<int32_t>(g.size_y))
-    {
-      const uint32_t cell = static_cast<uint32_t>(ny) * g.size_x + static_cast<uint32_t>(nx);
-      if (FROM_CELLS6)
-      {
-        const double * c = cells6 + static_cast<size_t>(cell) * 6;
-        if (!(c[5] < 5.0))
-        {
-          const double rec[5] = {c[0], c[1], -0.5 * c[2], -0.5 * c[3], -0.5 * c[4]};
-          if (j == 4) self = 1;
-          bound = exponent_upper_bound(rec, x0, x1, y0, y1);
-        }
-      }
-      else if ((g.occ_bits[cell >> 5] >> (cell & 31u)) & 1u)
-      {
-        if (j == 4) self = 1;
-        bound = exponent_upper_bound(g.cells_lds_image + static_cast<size_t>(cell) * kCellDoubles, x0, x1, y0, y1);
-      }
-    }
-  }
-  // NaN-propagating maximum over the row (a NaN bound means "no claim")
-  uint32_t nan_any = bound != bound ? 1u : 0u;
-  double m = bound != bound ? -HUGE_VAL : bound;
-#pragma unroll
-  for (int off = 8; off > 0; off >>= 1)
-  {
-    m = fmax(m, __shfl_xor(m, off, 16));
-    nan_any |= static_cast<uint32_t>(__shfl_xor(static_cast<int>(nan_any), off, 16));
-    self |= static_cast<uint32_t>(__shfl_xor(static_cast<int>(self), off, 16));
-  }
-  if (live && j == 0) bytes[i] = map_byte(self, nan_any ? NAN : m);
-}
-
 __global__ void __launch_bounds__(256) cell_bytes_kernel(const GridDesc g, uint8_t * bytes)
 {
   cell_byte_row<false>(g, nullptr, (blockIdx.x * 256 + threadIdx.x) >> 4, threadIdx.x & 15u, bytes);
@@ -338,29 +276,43 @@ __global__ void __launch_bounds__(256) grid_install_kernel(const GridDesc g, con
   uint32_t * dst_idx = im.dst != nullptr ? reinterpret_cast<uint32_t *>(im.dst + im.off_idx) : nullptr;
   uint16_t * dst_rk = im.dst != nullptr ? reinterpret_cast<uint16_t *>(im.dst + im.off_rk) : nullptr;
 
+  // Reads of the staged image cross PCIe (a couple of microseconds each way): everything a
+  // step needs is requested before anything is waited for -- the records' pieces, the cell
+  // index and rank, and, ahead of the first step, the block's first occupancy word.
+  const uint32_t n_words = (g.ncell + 1 + 31) / 32;
+  const uint32_t fill_chunks = (n_words + 31) / 32;
+  uint32_t first_word = 0;
+  if (blockIdx.x < fill_chunks && tid < 32 && blockIdx.x * 32 + tid < n_words)
+  {
+    first_word = src_occ[blockIdx.x * 32 + tid];
+  }
+
   const uint32_t list_chunks = (im.n + 255) / 256;
   const size_t d_end = static_cast<size_t>(im.n) * 6;
   for (uint32_t chunk = blockIdx.x; chunk < list_chunks; chunk += gridDim.x)
   {
     const size_t d0 = static_cast<size_t>(chunk) * (256 * 6);
+    const uint32_t k = chunk * 256 + tid;
+    double2 v[3];
+#pragma unroll
+    for (uint32_t p = 0; p < 3; ++p)
+    {
+      const size_t d = d0 + 2 * static_cast<size_t>(p * 256 + tid);
+      v[p] = d < d_end ? *reinterpret_cast<const double2 *>(im.src + d) : double2{0.0, 0.0};
+    }
+    const uint32_t cell = k < im.n ? src_idx[k] : 0u;
+    const uint16_t rk = k < im.n ? src_rk[k] : static_cast<uint16_t>(0);
 #pragma unroll
     for (uint32_t p = 0; p < 3; ++p)
     {
       const uint32_t piece = p * 256 + tid;
       const size_t d = d0 + 2 * static_cast<size_t>(piece);
-      if (d < d_end)
-      {
-        const double2 v = *reinterpret_cast<const double2 *>(im.src + d);
-        *reinterpret_cast<double2 *>(sh_rec + 2 * piece) = v;
-        if (im.dst != nullptr) *reinterpret_cast<double2 *>(im.dst + d) = v;
-      }
+      *reinterpret_cast<double2 *>(sh_rec + 2 * piece) = v[p];
+      if (im.dst != nullptr && d < d_end) *reinterpret_cast<double2 *>(im.dst + d) = v[p];
     }
     __syncthreads();
-    const uint32_t k = chunk * 256 + tid;
     if (k < im.n)
     {
-      const uint32_t cell = src_idx[k];
-      const uint16_t rk = src_rk[k];
       if (im.dst != nullptr)
       {
         dst_idx[k] = cell;
@@ -386,14 +338,12 @@ __global__ void __launch_bounds__(256) grid_install_kernel(const GridDesc g, con
     __syncthreads();
   }
 
-  const uint32_t n_words = (g.ncell + 1 + 31) / 32;
-  const uint32_t fill_chunks = (n_words + 31) / 32;
   for (uint32_t chunk = blockIdx.x; chunk < fill_chunks; chunk += gridDim.x)
   {
     if (tid < 32)
     {
       const uint32_t w = chunk * 32 + tid;
-      const uint32_t v = w < n_words ? src_occ[w] : 0u;
+      const uint32_t v = chunk == blockIdx.x ? first_word : (w < n_words ? src_occ[w] : 0u);
       sh_words[tid] = v;
       if (w < n_words) occ_bits[w] = v;
     }
@@ -436,27 +386,10 @@ __global__ void __launch_bounds__(256) grid_install_kernel(const GridDesc g, con
   for (uint32_t i = blockIdx.x * 256 + tid; i < (n_bytes + 3) / 4; i += stride) b32[i] = 0u;
 }
 
-// Map bytes: a byte depends on the 3 x 3 cells around it, so the bytes that are not zero lie
-// in the 3 x 3 blocks around the listed cells that can score.  Row = (listed cell, neighbour
-// position); neighbouring listed cells compute the same byte twice and store the same value.
-__global__ void __launch_bounds__(256) grid_bytes_sparse_kernel(const GridDesc g, const uint32_t * cell_index,
-                                                                const double * cells6, uint32_t n,
-                                                                uint8_t * bytes)
+// The map bytes around the listed cells (sparse_byte_rows, ndt2d_lane_fn.h) as a launch of its own.
+__global__ void __launch_bounds__(256) grid_bytes_sparse_kernel(const GridDesc g, const SparseBytesJob job)
 {
-  const uint32_t row = (blockIdx.x * 256 + threadIdx.x) >> 4;
-  const uint32_t k = row / 9, pos = row - k * 9;
-  uint32_t target = 0xffffffffu;   // (cell_byte_row treats an index past the array as "no cell")
-  if (k < n)
-  {
-    const uint32_t cell = cell_index[k];
-    if (cell < g.ncell && !(cells6[static_cast<size_t>(k) * 6 + 5] < 5.0))
-    {
-      const uint32_t cx = cell % g.size_x, cy = cell / g.size_x;
-      // extended-grid coordinates of the neighbour: (cx + 1 + dx, cy + 1 + dy), dx, dy in -1..1
-      target = (cy + pos / 3) * (g.size_x + 2) + cx + pos % 3;
-    }
-  }
-  cell_byte_row<false>(g, nullptr, target, threadIdx.x & 15u, bytes);
+  sparse_byte_rows(g, job, blockIdx.x * 256 + threadIdx.x);
 }
 
 // Dense raw records of a sparse grid (ndt2d_get_grid): zeroed by the caller, the listed cells here.
@@ -551,16 +484,13 @@ hipError_t launch_grid_install(const GridDesc & geometry, const SparseImage & im
   if (list_chunks > blocks) blocks = list_chunks < 4096 ? list_chunks : 4096;
   hipLaunchKernelGGL(grid_install_kernel, dim3(blocks), dim3(256), 0, stream, geometry, image, cells_lds_image,
                      cells_global, occ_bits, cell_bytes, ranks, n_occ);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess || image.n == 0) return e;
-  // the map bytes around the listed cells, from the device copy the launch above left
-  const double * img = image.dst != nullptr ? image.dst : image.src;
-  GridDesc g = geometry;
-  g.cells_lds_image = cells_lds_image;
-  g.occ_bits = occ_bits;
-  const uint64_t rows = static_cast<uint64_t>(image.n) * 9;
-  hipLaunchKernelGGL(grid_bytes_sparse_kernel, dim3(static_cast<uint32_t>((rows + 15) / 16)), dim3(256), 0,
-                     stream, g, reinterpret_cast<const uint32_t *>(img + image.off_idx), img, image.n, cell_bytes);
+  return hipGetLastError();
+}
+
+hipError_t launch_sparse_bytes(const GridDesc & geometry, const SparseBytesJob & job, hipStream_t stream)
+{
+  if (job.n == 0) return hipSuccess;
+  hipLaunchKernelGGL(grid_bytes_sparse_kernel, dim3(sparse_bytes_blocks(job)), dim3(256), 0, stream, geometry, job);
   return hipGetLastError();
 }
 

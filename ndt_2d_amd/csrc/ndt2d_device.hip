@@ -50,6 +50,10 @@ struct ndt2d_context
   DeviceBuffer cells_global;
   DeviceBuffer occ_bits;  // uint32 words stored in a double buffer
   DeviceBuffer cell_bytes;  // per-cell occupancy-map bytes of the extended grid
+  // what a list install left to do (bytes_job.n > 0): the map bytes around the listed cells.
+  // Only the small-lattice search reads them: the job rides along in the next few-pose launch
+  // (the mapper's scoreScan) or runs ahead of the next search, whichever comes first.
+  ndt2d::SparseBytesJob bytes_job{};
   DeviceBuffer compact;     // [cells6 | compact records | cell ranks]: ndt2d_set_grid's upload
   DeviceBuffer cells6;    // raw {mean, information, n} records of a device-built grid
   const double * cells6_ptr = nullptr;  // ... of the installed grid, wherever they live
@@ -523,6 +527,7 @@ int ndt2d_set_grid(ndt2d_handle h, const double * cells6, uint32_t size_x, uint3
   // The old grid is gone from here on (ensure() may free its buffers): a failure
   // below leaves the context without a grid, never with dangling pointers.
   h->has_grid = false;
+  h->bytes_job.n = 0;
 
   // The cells6 records travel once, through pinned staging (the caller's buffer is
   // free on return); the device derives the layouts the scorers read -- packed records
@@ -655,6 +660,7 @@ int ndt2d_build_grid(ndt2d_handle h, double ndt_resolution, double range_max,
   NDT2D_HIP(h, hipSetDevice(h->device));
   // as in ndt2d_set_grid: no grid until the new one is complete
   h->has_grid = false;
+  h->bytes_job.n = 0;
 
   // staging that must stay alive until the copies are done: kept in the context
   NDT2D_HIP(h, hipStreamSynchronize(h->stream));
@@ -774,6 +780,7 @@ int ndt2d_set_grid_sparse(ndt2d_handle h, const uint32_t * cell_index, const dou
   }
   NDT2D_HIP(h, hipSetDevice(h->device));
   h->has_grid = false;   // (see ndt2d_set_grid)
+  h->bytes_job.n = 0;
 
   uint32_t n_occ = 0;
   for (uint32_t k = 0; k < n; ++k) n_occ += !(cells6[6 * static_cast<size_t>(k) + 5] < 5.0) ? 1u : 0u;
@@ -874,6 +881,10 @@ int ndt2d_set_grid_sparse(ndt2d_handle h, const uint32_t * cell_index, const dou
     reinterpret_cast<uint8_t *>(h->cell_bytes.ptr),
     compactable ? reinterpret_cast<uint16_t *>(h->ranks.ptr) : nullptr, n_occ, h->stream);
   if (e != hipSuccess) return fail_hip(h, e, "launch_grid_install");
+  h->bytes_job.cell_index = d_idx;
+  h->bytes_job.cells6 = d_cells6;
+  h->bytes_job.n = n;
+  h->bytes_job.bytes = reinterpret_cast<uint8_t *>(h->cell_bytes.ptr);
   if ((rc = stage_mark(h, h->stage_grid)) != NDT2D_OK) return rc;
   g.cells_lds_image = h->cells_lds_image.ptr;
   g.cells_global = h->cells_global.ptr;
@@ -932,6 +943,7 @@ int ndt2d_clear_grid(ndt2d_handle h)
 {
   if (h == nullptr) return NDT2D_ERR_INVALID;
   h->has_grid = false;
+  h->bytes_job.n = 0;
   return NDT2D_OK;
 }
 
@@ -1070,6 +1082,13 @@ int ndt2d_match_launch_strided(ndt2d_handle h, size_t th_first, size_t th_stride
   NDT2D_HIP(h, hipSetDevice(h->device));
   int rc = ensure(h, h->record, NDT2D_MATCH_RECORD_DOUBLES);
   if (rc != NDT2D_OK) return rc;
+  if (h->bytes_job.n > 0)
+  {
+    // the map bytes of a list install that no scoreScan has carried yet
+    hipError_t be = ndt2d::launch_sparse_bytes(h->grid, h->bytes_job, h->stream);
+    if (be != hipSuccess) return fail_hip(h, be, "launch_sparse_bytes");
+    h->bytes_job.n = 0;
+  }
 
   ndt2d::MatchArgs a{};
   a.grid = h->grid;
@@ -1620,8 +1639,10 @@ int run_few(ndt2d_context * h, const double * arg_beams, size_t n_beams, const d
     out.host_out = h->host_res_dev + kPfOutSlot;
     out.dev_poses = poses_in_place ? h->tmp_poses.ptr : nullptr;
   }
+  out.side = h->bytes_job;   // (n == 0: none)
   hipError_t e = ndt2d::launch_score_few(a, &few, out, arg_beams, h->stream);
   if (e != hipSuccess) return fail_hip(h, e, "launch_score_few");
+  h->bytes_job.n = 0;
   h->timed = false;
   h->last_kernels = 1;
   h->last_variant = h->grid.pow2 ? "poses/block-per-pose/pow2" : "poses/block-per-pose/div";

@@ -151,7 +151,8 @@ hipError_t launch_pack_grid(const GridDesc & geometry, const double * cells6,
 // [cells6: 6 n doubles | cell indices: n u32 | ranks of the listed cells: n u16 | compacted
 // records | occupancy words of the cells that can score], offsets in doubles.
 // src: the image as the kernel addresses it -- the pinned staging buffer in place, or
-// its device copy (then dst == nullptr); dst: where to leave the device copy.  Two launches.
+// its device copy (then dst == nullptr); dst: where to leave the device copy.  The map bytes
+// are left zeroed: launch_sparse_bytes.
 struct SparseImage
 {
   const double * src;
@@ -162,6 +163,22 @@ struct SparseImage
 hipError_t launch_grid_install(const GridDesc & geometry, const SparseImage & image, double * cells_lds_image,
                                double * cells_global, uint32_t * occ_bits, uint8_t * cell_bytes,
                                uint16_t * ranks, uint32_t n_occ, hipStream_t stream);
+// What is left of a list install afterwards: the map bytes around the n listed cells (device
+// copies of the list; the geometry's cells_lds_image / occ_bits as the install left them).
+// Only the small-lattice search reads the bytes, so the job need not run before a scoreScan:
+// it rides along in that launch's spare blocks (FewOut::side) or runs ahead of the search.
+struct SparseBytesJob
+{
+  const uint32_t * cell_index;
+  const double * cells6;
+  uint32_t n;
+  uint8_t * bytes;
+};
+inline uint32_t sparse_bytes_blocks(const SparseBytesJob & job)
+{
+  return static_cast<uint32_t>((static_cast<uint64_t>(job.n) * 9 + 15) / 16);   // 16 lanes per (cell, neighbour)
+}
+hipError_t launch_sparse_bytes(const GridDesc & geometry, const SparseBytesJob & job, hipStream_t stream);
 hipError_t launch_grid_sparse_to_dense(const uint32_t * cell_index, const double * cells6, uint32_t n,
                                        uint32_t ncell, double * dense6, hipStream_t stream);
 hipError_t launch_grid_tail(const GridDesc & geometry, const double * cells_lds_image,
@@ -360,6 +377,9 @@ struct FewOut
   // device scratch [n_poses][3] (stats, optional): every block leaves its pose here, so that
   // the statistics pass does not read args.poses_xyt -- pinned host memory, over PCIe -- again
   double * dev_poses;
+  // (optional, side.n > 0) the map bytes of a list install, computed by blocks of this launch
+  // behind the poses' -- nobody waits for them here, the search that reads them is queued later
+  SparseBytesJob side;
 };
 bool score_few_supported(const PosesArgs & args, size_t lds_per_block);
 // args.poses_xyt == nullptr: the (<= kFewPoses) poses are few->xyt.  host_beams (optional,

@@ -193,6 +193,91 @@ __device__ __forceinline__ uint8_t block_byte(const GridDesc & g, int32_t cx0, i
   return map_byte(self, bound);
 }
 
+// One occupancy-map byte per grid cell, for the grid extended by one cell on every
+// side ([size_y + 2][size_x + 2], cell (cx, cy) at (cy + 1) * (size_x + 2) + cx + 1):
+// the byte the lane-per-candidate search's map holds at one map cell per grid cell
+// (ndt2d_lane_fn.h, sub_cell_byte with sub_log2 = 0).  It depends on the grid only, so
+// it is prepared once here and the small-lattice search copies its window from it.
+// FROM_CELLS6: occupancy and records come from the cells6 records themselves (the fused
+// kernel of a host-installed grid, which has no packed records yet); else from the packed
+// records and the bitmap (device build).  lane16 = this thread's lane in its 16-lane row,
+// i = the extended-grid cell the row works on.
+template <bool FROM_CELLS6>
+__device__ __forceinline__ void cell_byte_row(const GridDesc & g, const double * cells6, uint32_t i,
+                                              uint32_t j, uint8_t * bytes)
+{
+  // 16 lanes (one DPP row) per cell, lane j < 9 takes neighbour j of the 3 x 3 block: the
+  // bound is a maximum over the neighbours that can score, each a closed form with a few
+  // divisions -- nine of them one after the other in one lane was the whole kernel's time
+  const uint32_t w = g.size_x + 2, h = g.size_y + 2;
+  const bool live = i < w * h;
+  const int32_t cx = static_cast<int32_t>(live ? i % w : 0) - 1, cy = static_cast<int32_t>(live ? i / w : 0) - 1;
+  // the sub-cell box of sub_cell_byte() at one sub-cell per cell
+  const double x0 = g.origin_x + (static_cast<double>(cx) - kBoxMargin) * g.cell_size;
+  const double y0 = g.origin_y + (static_cast<double>(cy) - kBoxMargin) * g.cell_size;
+  const double x1 = x0 + (1.0 + 2.0 * kBoxMargin) * g.cell_size;
+  const double y1 = y0 + (1.0 + 2.0 * kBoxMargin) * g.cell_size;
+  double bound = -HUGE_VAL;
+  uint32_t self = 0;
+  if (live && j < 9)
+  {
+    const int32_t nx = cx + static_cast<int32_t>(j % 3) - 1, ny = cy + static_cast<int32_t>(j / 3) - 1;
+    if (nx >= 0 && nx < static_cast<int32_t>(g.size_x) && ny >= 0 && ny < static_cast<int32_t>(g.size_y))
+    {
+      const uint32_t cell = static_cast<uint32_t>(ny) * g.size_x + static_cast<uint32_t>(nx);
+      if (FROM_CELLS6)
+      {
+        const double * c = cells6 + static_cast<size_t>(cell) * 6;
+        if (!(c[5] < 5.0))
+        {
+          const double rec[5] = {c[0], c[1], -0.5 * c[2], -0.5 * c[3], -0.5 * c[4]};
+          if (j == 4) self = 1;
+          bound = exponent_upper_bound(rec, x0, x1, y0, y1);
+        }
+      }
+      else if ((g.occ_bits[cell >> 5] >> (cell & 31u)) & 1u)
+      {
+        if (j == 4) self = 1;
+        bound = exponent_upper_bound(g.cells_lds_image + static_cast<size_t>(cell) * kCellDoubles, x0, x1, y0, y1);
+      }
+    }
+  }
+  // NaN-propagating maximum over the row (a NaN bound means "no claim")
+  uint32_t nan_any = bound != bound ? 1u : 0u;
+  double m = bound != bound ? -HUGE_VAL : bound;
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1)
+  {
+    m = fmax(m, __shfl_xor(m, off, 16));
+    nan_any |= static_cast<uint32_t>(__shfl_xor(static_cast<int>(nan_any), off, 16));
+    self |= static_cast<uint32_t>(__shfl_xor(static_cast<int>(self), off, 16));
+  }
+  if (live && j == 0) bytes[i] = map_byte(self, nan_any ? NAN : m);
+}
+
+// Map bytes of a grid installed as a list (ndt2d_build.hip): a byte depends on the 3 x 3 cells
+// around it, so the bytes that are not zero lie in the 3 x 3 blocks around the listed cells that
+// can score.  Row = (listed cell, neighbour position), 16 lanes per row; neighbouring listed
+// cells compute the same byte twice and store the same value.  thread: the launch-wide index
+// of this lane among the job's lanes.
+__device__ __forceinline__ void sparse_byte_rows(const GridDesc & g, const SparseBytesJob & job, uint32_t thread)
+{
+  const uint32_t row = thread >> 4;
+  const uint32_t k = row / 9, pos = row - k * 9;
+  uint32_t target = 0xffffffffu;   // (cell_byte_row treats an index past the array as "no cell")
+  if (k < job.n)
+  {
+    const uint32_t cell = job.cell_index[k];
+    if (cell < g.ncell && !(job.cells6[static_cast<size_t>(k) * 6 + 5] < 5.0))
+    {
+      const uint32_t cx = cell % g.size_x, cy = cell / g.size_x;
+      // extended-grid coordinates of the neighbour: (cx + 1 + dx, cy + 1 + dy), dx, dy in -1..1
+      target = (cy + pos / 3) * (g.size_x + 2) + cx + pos % 3;
+    }
+  }
+  cell_byte_row<false>(g, nullptr, target, thread & 15u, job.bytes);
+}
+
 // LDS bytes of the cell -> compact record table: kRankLead bytes whose last two hold the
 // sentinel's rank -- entry -1, what a lane outside every occupied cell selects with one
 // v_cndmask_b32 and the inline constant -1 -- then a u16 per grid cell and entry ncell

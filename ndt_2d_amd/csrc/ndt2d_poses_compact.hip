@@ -37,6 +37,7 @@
 #include <cstring>
 
 #include "ndt2d_device_fn.h"
+#include "ndt2d_lane_fn.h"
 
 namespace ndt2d
 {
@@ -512,11 +513,19 @@ __global__ void __launch_bounds__(kFewThreads) score_few_kernel(const PosesArgs 
   const GridDesc & g = a.grid;
   const uint32_t i = blockIdx.x;
   const uint32_t n = static_cast<uint32_t>(a.n_poses);
+  // Blocks behind the poses' (and the waiting block's): the map bytes a list install left to
+  // do (FewOut::side).  Nothing in this launch reads them or waits for them.
+  const uint32_t first_side = n + ((f.flag != nullptr && n > 1) ? 1u : 0u);
+  if (i >= first_side)
+  {
+    sparse_byte_rows(g, f.side, (i - first_side) * kFewThreads + threadIdx.x);
+    return;
+  }
   // With a completion flag and more than one pose the launch has one more block than poses:
   // the last one, dispatched after all the others, waits for their `done` words and raises
   // the flag (or runs updateStatistics first).  A ticket drawn by every block put an atomic's
   // round trip on the path of the block that happened to finish last.
-  if (i == n)
+  if (i == n)   // (n > 1 and a flag: see first_side)
   {
     for (uint32_t k = threadIdx.x; k < n; k += kFewThreads)
     {
@@ -810,7 +819,11 @@ hipError_t launch_score_few(const PosesArgs & args, const FewPoses * few, const 
     }
     // (+ the block that waits for the others, see the kernel)
     const uint32_t extra = (out.flag != nullptr && args.n_poses > 1) ? 1u : 0u;
-    hipLaunchKernelGGL(kernel, dim3(static_cast<uint32_t>(args.n_poses) + extra), dim3(kFewThreads),
+    static_assert(kFewThreads == 256, "sparse_bytes_blocks counts blocks of 256 lanes");
+    static_assert(sizeof(PosesArgs) + sizeof(FewPoses) + sizeof(FewOut) + sizeof(FewBeams) <= 4096,
+                  "kernel arguments of score_few_kernel");
+    const uint32_t side = out.side.n > 0 ? sparse_bytes_blocks(out.side) : 0u;
+    hipLaunchKernelGGL(kernel, dim3(static_cast<uint32_t>(args.n_poses) + extra + side), dim3(kFewThreads),
                        lds_bytes, stream, args, few != nullptr ? *few : none, out, fb);
     return hipGetLastError();
   };

@@ -1471,3 +1471,50 @@ def test_list_install_shapes(sx, sy, n_listed):
     assert np.array_equal(out["dense"][1], out["sparse"][1])
     if len(scoring) > 10:
         assert (out["sparse"][0][b"auto"][0] < 0).any() and (out["sparse"][1] < 0).any()
+
+
+@pytest.mark.parametrize("cfg,override", [
+    (1, dict(search_angular_size=0.1, search_angular_resolution=0.0025, search_linear_size=0.05,
+             search_linear_resolution=0.005, laser_max_beams=100)),
+    (5, dict(search_angular_size=0.1, search_angular_resolution=0.0025, search_linear_size=0.05,
+             search_linear_resolution=0.005, laser_max_beams=100)),
+])
+def test_map_bytes_of_an_install_arrive_whichever_call_comes_first(cfg, override):
+    """After addScans the map bytes around the listed cells are still to do (only the
+    small-lattice search reads them): the next few-pose launch -- the mapper's scoreScan,
+    reference src/ndt_mapper.cpp:514 -- carries the job in spare blocks, else the search runs it
+    first.  Every order of calls gives the same search, bit for bit, and the oracle's."""
+    scans = synth.map_scans(cfg)
+    params = synth.matcher_params(cfg, **override)
+    ref = O.ScanMatcherNDT()
+    ref.initialize(**params)
+    ref.addScans(scans)
+    guess, pts, _ = synth.query_scan(cfg)
+    exp = ref.matchScan(guess, pts, want_scores=True)
+    poses = np.tile(guess, (300, 1)) + np.random.default_rng(5).uniform(-0.3, 0.3, (300, 3))
+    results = {}
+    for order in ("match", "scoreScan", "scorePoints", "measure", "twice"):
+        gpu = ScanMatcherNDT(0)
+        gpu.initialize("test", **params)
+        gpu.addScans(scans)
+        if order == "scoreScan":
+            assert abs(gpu.scoreScan(guess, pts) - ref.scoreScan(guess, pts)) < TOL_TIGHT
+        elif order == "scorePoints":
+            gpu.scorePoints(pts, guess)
+        elif order == "measure":
+            w = gpu.scorePoses(pts, poses)           # 300 poses: the block-per-pose launch
+            assert "block-per-pose" in gpu.last_variant()
+            assert np.all(np.isfinite(w))
+        elif order == "twice":
+            gpu.reset()
+            gpu.addScans(scans)                      # an install whose job was never run, then another
+            gpu.scoreScan(guess, pts)
+        got = gpu.matchScan(guess, pts, want_scores=True)
+        assert "small-lattice" in gpu.last_variant(), gpu.last_variant()
+        _check_match(got, exp, params["laser_max_beams"])
+        results[order] = got
+    first = results["match"]
+    for order, got in results.items():
+        assert np.array_equal(got["scores"], first["scores"]), order
+        assert got["best_index"] == first["best_index"] and got["score"] == first["score"], order
+        assert np.array_equal(got["covariance"], first["covariance"], equal_nan=True), order
