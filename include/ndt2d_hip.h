@@ -79,7 +79,7 @@ int ndt2d_set_grid(ndt2d_handle h, const double * cells6, uint32_t size_x, uint3
 /* The same grid given as the LIST of its cells that received points: cells6[k] (layout as
  * above) belongs to cell cell_index[k] = grid_y * size_x + grid_x, every cell not listed is
  * an empty one (n = 0, as NDT::NDT leaves it, src/ndt_model.cpp:118-126); a cell may be
- * listed once, in any order.  The mapper
+ * listed once, in any order (a cell with n >= 5 listed twice: NDT2D_ERR_INVALID).  The mapper
  * rebuilds its local NDT for every scan (src/ndt_mapper.cpp:508-509); with a real lidar
  * that grid has tens of thousands of cells (scan poses +- range_max,
  * src/scan_matcher_ndt.cpp:52-66) of which the scans touch a thousand or two: the cost of

@@ -821,7 +821,13 @@ int ndt2d_set_grid_sparse(ndt2d_handle h, const uint32_t * cell_index, const dou
     const double * c = cells6 + 6 * static_cast<size_t>(k);
     if (!(c[5] < 5.0))
     {
-      st_occ[cell_index[k] >> 5] |= 1u << (cell_index[k] & 31u);
+      const uint32_t bit = 1u << (cell_index[k] & 31u);
+      if (st_occ[cell_index[k] >> 5] & bit)
+      {
+        // two records for one cell: whichever thread stored last would win
+        return fail(h, NDT2D_ERR_INVALID, "ndt2d_set_grid_sparse: a cell is listed twice");
+      }
+      st_occ[cell_index[k] >> 5] |= bit;
       if (compactable)
       {
         double * r = st_rec + static_cast<size_t>(k_occ) * kCellDoubles;

@@ -1518,3 +1518,24 @@ def test_map_bytes_of_an_install_arrive_whichever_call_comes_first(cfg, override
         assert np.array_equal(got["scores"], first["scores"]), order
         assert got["best_index"] == first["best_index"] and got["score"] == first["score"], order
         assert np.array_equal(got["covariance"], first["covariance"], equal_nan=True), order
+
+
+def test_list_install_rejects_a_cell_listed_twice():
+    """ndt2d_set_grid_sparse: two records for one cell that can score would race in the
+    install kernel -- refused (NDT2D_ERR_INVALID), and the context is left without a grid."""
+    L = _capi.lib()
+    h = C.c_void_p()
+    assert L.ndt2d_create(C.byref(h), 0) == 0
+    try:
+        idx = np.array([5, 9, 5], np.uint32)
+        rec = np.tile(np.array([0.3, 0.3, 100.0, 0.0, 100.0, 9.0]), (3, 1))
+        rc = L.ndt2d_set_grid_sparse(h, idx.ctypes.data_as(C.POINTER(C.c_uint32)), _capi.dptr(rec), 3,
+                                     8, 8, 0.25, 0.0, 0.0)
+        assert rc == 1 and b"listed twice" in L.ndt2d_last_error(h)
+        assert L.ndt2d_has_grid(h) == 0
+        idx[2] = 6
+        assert L.ndt2d_set_grid_sparse(h, idx.ctypes.data_as(C.POINTER(C.c_uint32)), _capi.dptr(rec), 3,
+                                       8, 8, 0.25, 0.0, 0.0) == 0
+        assert L.ndt2d_has_grid(h) == 1
+    finally:
+        L.ndt2d_destroy(h)
