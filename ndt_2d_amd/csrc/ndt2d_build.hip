@@ -281,11 +281,15 @@ __global__ void __launch_bounds__(256) grid_install_kernel(const GridDesc g, con
   // index and rank, and, ahead of the first step, the block's first occupancy word.
   const uint32_t n_words = (g.ncell + 1 + 31) / 32;
   const uint32_t fill_chunks = (n_words + 31) / 32;
-  uint32_t first_word = 0;
-  if (blockIdx.x < fill_chunks && tid < 32 && blockIdx.x * 32 + tid < n_words)
-  {
-    first_word = src_occ[blockIdx.x * 32 + tid];
-  }
+  // (unconditional loads from clamped addresses: behind a branch the compiler waits for the
+  // value where the branches join, i.e. before the next request goes out)
+  const uint32_t word_index = blockIdx.x * 32 + (tid & 31u);
+  const uint32_t first_word = src_occ[word_index < n_words ? word_index : n_words - 1];
+  const uint32_t stride = gridDim.x * 256;
+  const size_t first_piece = blockIdx.x * 256 + tid;     // of the compacted records' copy (the last step)
+  const size_t n_pieces = im.n_compact / 2;
+  const double2 first_compact =
+    reinterpret_cast<const double2 *>(im.src + im.off_compact)[first_piece < n_pieces ? first_piece : 0];
 
   const uint32_t list_chunks = (im.n + 255) / 256;
   const size_t d_end = static_cast<size_t>(im.n) * 6;
@@ -343,7 +347,7 @@ __global__ void __launch_bounds__(256) grid_install_kernel(const GridDesc g, con
     if (tid < 32)
     {
       const uint32_t w = chunk * 32 + tid;
-      const uint32_t v = chunk == blockIdx.x ? first_word : (w < n_words ? src_occ[w] : 0u);
+      const uint32_t v = w >= n_words ? 0u : (chunk == blockIdx.x ? first_word : src_occ[w]);
       sh_words[tid] = v;
       if (w < n_words) occ_bits[w] = v;
     }
@@ -371,10 +375,11 @@ __global__ void __launch_bounds__(256) grid_install_kernel(const GridDesc g, con
     __syncthreads();
   }
 
-  const uint32_t stride = gridDim.x * 256;
   if (im.dst != nullptr)
   {
-    for (size_t p = blockIdx.x * 256 + tid; p < im.n_compact / 2; p += stride)
+    // (the launch has a block per 256 pieces, so the loop behind the first piece is idle)
+    if (first_piece < n_pieces) reinterpret_cast<double2 *>(im.dst + im.off_compact)[first_piece] = first_compact;
+    for (size_t p = first_piece + stride; p < n_pieces; p += stride)
     {
       reinterpret_cast<double2 *>(im.dst + im.off_compact)[p] =
         reinterpret_cast<const double2 *>(im.src + im.off_compact)[p];
@@ -482,6 +487,10 @@ hipError_t launch_grid_install(const GridDesc & geometry, const SparseImage & im
   const uint32_t list_chunks = (image.n + 255) / 256;
   uint32_t blocks = fill_chunks < 2048 ? fill_chunks : 2048;
   if (list_chunks > blocks) blocks = list_chunks < 4096 ? list_chunks : 4096;
+  // (every thread's first piece of the compacted records is requested up front: a block per 256 pieces)
+  const uint32_t copy_blocks = image.dst != nullptr ? static_cast<uint32_t>((image.n_compact / 2 + 255) / 256) : 0u;
+  if (copy_blocks > blocks) blocks = copy_blocks < 4096 ? copy_blocks : 4096;
+  if (blocks == 0) blocks = 1;
   hipLaunchKernelGGL(grid_install_kernel, dim3(blocks), dim3(256), 0, stream, geometry, image, cells_lds_image,
                      cells_global, occ_bits, cell_bytes, ranks, n_occ);
   return hipGetLastError();
