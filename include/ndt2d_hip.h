@@ -196,6 +196,17 @@ int ndt2d_score_poses(ndt2d_handle h, const double * h_poses_xyt, size_t n_poses
 int ndt2d_score_poses_beams(ndt2d_handle h, const double * beams_xy, size_t n_beams,
                             const double * h_poses_xyt, size_t n_poses, double * h_scores);
 
+/* The kernel-argument launch of ndt2d_score_poses_beams without the wait (<= 8 poses; beams_xy
+ * with <= 208 beams, or NULL: the beams the context holds), and the wait.  Between the two the
+ * caller may queue the search of the same scan -- the mapper calls scoreScan(scan) and then
+ * matchScan(scan, ...) (reference src/ndt_mapper.cpp:514-515, 552-553), and a search queued
+ * behind the scoring kernel starts when that ends instead of a host round trip later
+ * (ndt2d_matcher_score_scan does this once it has seen the pair).  NDT2D_ERR_STATE when the
+ * request is not a kernel-argument launch.  One launch may be pending per context. */
+int ndt2d_score_poses_beams_launch(ndt2d_handle h, const double * beams_xy, size_t n_beams,
+                                   const double * h_poses_xyt, size_t n_poses);
+int ndt2d_score_fetch(ndt2d_handle h, double * h_scores);
+
 /* ParticleFilter::updateStatistics (src/particle_filter.cpp:163-218) on the
  * device, from the (all-reduced) moment sums d_stats of ndt2d_score_poses_launch:
  * d_weights[n] are divided by the total weight in place (:171-174) and d_out
@@ -440,9 +451,20 @@ int ndt2d_matcher_finish_match(ndt2d_matcher * m, const double * record, double 
  * ndt2d_score_poses_launch on ndt2d_matcher_device(m)). */
 int ndt2d_matcher_prepare_beams(ndt2d_matcher * m, const double * points_xy, size_t n_points,
                                 size_t * n_beams_out);
-/* ScanMatcherNDT::scoreScan (:151-154) and scorePoints (:156-178). */
+/* ScanMatcherNDT::scoreScan (:151-154) and scorePoints (:156-178).
+ * The mapper calls scoreScan(scan) and then matchScan(scan, ...) (src/ndt_mapper.cpp:514-515,
+ * 552-553).  Once a matcher has seen that pair -- a matchScan of the scan and pose of the
+ * scoreScan just before it -- its scoreScan queues the scan's search behind the scoring kernel
+ * before it waits for the score, and the matchScan that follows collects that search (same
+ * kernels, same results; the search starts when the scoring kernel ends instead of a host
+ * round trip later).  Any other call waits such a search out, drops it, and the matcher stops
+ * launching ahead until it sees the pair again.  ndt2d_matcher_set_search_ahead(m, 0) turns
+ * it off (default: on). */
 int ndt2d_matcher_score_scan(ndt2d_matcher * m, const double * scan_pose_xyt,
                              const double * points_xy, size_t n_points, double * score_out);
+int ndt2d_matcher_set_search_ahead(ndt2d_matcher * m, int enabled);
+/* Searches launched ahead by scoreScan, and how many of them a matchScan collected. */
+int ndt2d_matcher_search_ahead_stats(ndt2d_matcher * m, uint64_t * launched, uint64_t * collected);
 int ndt2d_matcher_score_points(ndt2d_matcher * m, const double * points_xy, size_t n_points,
                                const double * pose_xyt, double * score_out);
 /* ScanMatcherNDT::reset (:180-183). */

@@ -90,6 +90,8 @@ SIGNATURES = {
     "ndt2d_score_poses_launch": (C.c_int, [_vp, _vp, _sz, _vp, _vp]),
     "ndt2d_score_poses": (C.c_int, [_vp, _dp, _sz, _dp, _dp]),
     "ndt2d_score_poses_beams": (C.c_int, [_vp, _dp, _sz, _dp, _sz, _dp]),
+    "ndt2d_score_poses_beams_launch": (C.c_int, [_vp, _dp, _sz, _dp, _sz]),
+    "ndt2d_score_fetch": (C.c_int, [_vp, _dp]),
     "ndt2d_pf_finalize_launch": (C.c_int, [_vp, _vp, _sz, _vp, _vp, _vp]),
     "ndt2d_pf_measure": (C.c_int, [_vp, _dp, _sz, _dp, _dp]),
     "ndt2d_pf_noise_launch": (C.c_int, [_vp, _u64, _u64, _u64, _sz, _vp]),
@@ -135,6 +137,8 @@ SIGNATURES = {
     "ndt2d_matcher_finish_match": (C.c_int, [_vp, _dp, _dp, _dp, _dp]),
     "ndt2d_matcher_prepare_beams": (C.c_int, [_vp, _dp, _sz, _szp]),
     "ndt2d_matcher_score_scan": (C.c_int, [_vp, _dp, _dp, _sz, _dp]),
+    "ndt2d_matcher_set_search_ahead": (C.c_int, [_vp, C.c_int]),
+    "ndt2d_matcher_search_ahead_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "ndt2d_matcher_score_points": (C.c_int, [_vp, _dp, _sz, _dp, _dp]),
     "ndt2d_matcher_reset": (C.c_int, [_vp]),
     "ndt2d_matcher_has_ndt": (C.c_int, [_vp]),

@@ -124,6 +124,11 @@ struct ndt2d_context
   bool batched_only = false;   // "batched": small pose batches stay on the batched kernels
 
   bool match_pending = false;
+  // a few-pose launch whose results have not been collected (ndt2d_score_poses_beams_launch)
+  bool few_pending = false;
+  unsigned long long few_seq = 0;
+  size_t few_n_poses = 0;
+  bool few_stats = false;
   uint64_t last_candidates = 0;
 };
 
@@ -360,6 +365,10 @@ void lattice_extent(ndt2d_context * h, const double * dlin, size_t n_lin)
 // NDT2D_PF_RESULT_DOUBLES into h_out).
 int run_few(ndt2d_context * h, const double * arg_beams, size_t n_beams, const double * h_poses,
             size_t n_poses, bool stats, double * h_scores, double * h_out);
+// ... and in two steps: the launch, and the wait for its results (one launch may be pending)
+int run_few_launch(ndt2d_context * h, const double * arg_beams, size_t n_beams, const double * h_poses,
+                   size_t n_poses, bool stats);
+int run_few_fetch(ndt2d_context * h, double * h_scores, double * h_out);
 
 // Take the next pair of timing events (created on first use) as h->ev0 / h->ev1.
 int next_timing_slot(ndt2d_context * h)
@@ -1343,6 +1352,61 @@ int ndt2d_score_poses_beams(ndt2d_handle h, const double * beams_xy, size_t n_be
   return ndt2d_score_poses(h, h_poses_xyt, n_poses, h_scores, nullptr);
 }
 
+int ndt2d_score_poses_beams_launch(ndt2d_handle h, const double * beams_xy, size_t n_beams,
+                                   const double * h_poses_xyt, size_t n_poses)
+{
+  if (h == nullptr) return NDT2D_ERR_INVALID;
+  if (h_poses_xyt == nullptr || n_poses == 0 || (beams_xy != nullptr && n_beams == 0))
+  {
+    return fail(h, NDT2D_ERR_INVALID, "ndt2d_score_poses_beams_launch: bad argument");
+  }
+  if (!h->has_grid) return fail(h, NDT2D_ERR_NO_GRID, "ndt2d_score_poses_beams_launch: no grid");
+  if (beams_xy == nullptr) n_beams = h->n_beams;
+  ndt2d::PosesArgs probe{};
+  probe.n_beams = static_cast<uint32_t>(n_beams);
+  probe.n_poses = n_poses;
+  // only what travels as kernel arguments: nothing of the caller's is read after the return
+  if (n_poses > ndt2d::kFewPoses || n_beams == 0 || (beams_xy != nullptr && n_beams > ndt2d::kArgBeams) ||
+      h->force_variant != ndt2d::kVariantAuto || h->batched_only || !ndt2d::score_few_supported(probe, 64 * 1024))
+  {
+    return fail(h, NDT2D_ERR_STATE, "ndt2d_score_poses_beams_launch: not a kernel-argument launch (use ndt2d_score_poses_beams)");
+  }
+  NDT2D_HIP(h, hipSetDevice(h->device));
+  if (beams_xy == nullptr) return run_few_launch(h, nullptr, n_beams, h_poses_xyt, n_poses, false);
+  int rc = ensure(h, h->beams, 2 * n_beams + 2);
+  if (rc != NDT2D_OK) return rc;
+  if (h->stage_beams.pending)   // the buffer may still be the target of a staged upload
+  {
+    NDT2D_HIP(h, hipEventSynchronize(h->stage_beams.done));
+    h->stage_beams.pending = false;
+  }
+  h->n_beams = 0;
+  h->beams_ptr = nullptr;
+  h->has_search = false;
+  rc = run_few_launch(h, beams_xy, n_beams, h_poses_xyt, n_poses, false);
+  if (rc != NDT2D_OK) return rc;
+  // (the kernel is queued: what follows on the stream finds the beams in place; a failed
+  // ndt2d_score_fetch takes them away again)
+  h->n_beams = n_beams;
+  h->beams_ptr = h->beams.ptr;
+  h->beam_rmax = beam_reach(beams_xy, n_beams);
+  return NDT2D_OK;
+}
+
+int ndt2d_score_fetch(ndt2d_handle h, double * h_scores)
+{
+  if (h == nullptr) return NDT2D_ERR_INVALID;
+  if (h_scores == nullptr) return fail(h, NDT2D_ERR_INVALID, "ndt2d_score_fetch: bad argument");
+  const int rc = run_few_fetch(h, h_scores, nullptr);
+  if (rc != NDT2D_OK && rc != NDT2D_ERR_STATE)
+  {
+    h->n_beams = 0;
+    h->beams_ptr = nullptr;
+    h->has_search = false;
+  }
+  return rc;
+}
+
 int ndt2d_score_poses(ndt2d_handle h, const double * h_poses_xyt, size_t n_poses,
                       double * h_scores, double * h_stats)
 {
@@ -1595,9 +1659,31 @@ int ndt2d_pf_update(ndt2d_handle h, double * h_poses_xyt, size_t n, double dx, d
 namespace
 {
 
-int run_few(ndt2d_context * h, const double * arg_beams, size_t n_beams, const double * h_poses,
-            size_t n_poses, bool stats, double * h_scores, double * h_out)
+// The results of the pending few-pose launch: wait for its flag, copy them out.
+int run_few_fetch(ndt2d_context * h, double * h_scores, double * h_out)
 {
+  if (!h->few_pending) return fail(h, NDT2D_ERR_STATE, "no few-pose launch is pending");
+  h->few_pending = false;
+  const int rc = wait_host_flag(h, kScoreFlagSlot, h->few_seq);
+  if (rc != NDT2D_OK) return rc;
+  if (h_scores != nullptr) std::memcpy(h_scores, h->host_res + kScoreSlot, h->few_n_poses * sizeof(double));
+  if (h->few_stats && h_out != nullptr)
+  {
+    for (int k = 0; k < NDT2D_PF_RESULT_DOUBLES; ++k) h_out[k] = h->host_res[kPfOutSlot + k];
+  }
+  return NDT2D_OK;
+}
+
+int run_few_launch(ndt2d_context * h, const double * arg_beams, size_t n_beams, const double * h_poses,
+                   size_t n_poses, bool stats)
+{
+  if (h->few_pending)
+  {
+    // (results nobody collected: the slots are about to be written again)
+    const int drc = run_few_fetch(h, nullptr, nullptr);
+    if (drc != NDT2D_OK) return drc;
+  }
+
   int rc = ensure_host_res(h);
   if (rc != NDT2D_OK) return rc;
   ndt2d::PosesArgs a{};
@@ -1652,13 +1738,18 @@ int run_few(ndt2d_context * h, const double * arg_beams, size_t n_beams, const d
   h->timed = false;
   h->last_kernels = 1;
   h->last_variant = h->grid.pow2 ? "poses/block-per-pose/pow2" : "poses/block-per-pose/div";
-  if ((rc = wait_host_flag(h, kScoreFlagSlot, out.seq)) != NDT2D_OK) return rc;
-  std::memcpy(h_scores, h->host_res + kScoreSlot, n_poses * sizeof(double));
-  if (stats)
-  {
-    for (int k = 0; k < NDT2D_PF_RESULT_DOUBLES; ++k) h_out[k] = h->host_res[kPfOutSlot + k];
-  }
+  h->few_pending = true;
+  h->few_seq = out.seq;
+  h->few_n_poses = n_poses;
+  h->few_stats = stats;
   return NDT2D_OK;
+}
+
+int run_few(ndt2d_context * h, const double * arg_beams, size_t n_beams, const double * h_poses,
+            size_t n_poses, bool stats, double * h_scores, double * h_out)
+{
+  const int rc = run_few_launch(h, arg_beams, n_beams, h_poses, n_poses, stats);
+  return rc != NDT2D_OK ? rc : run_few_fetch(h, h_scores, h_out);
 }
 
 ndt2d::ScanDesc scan_desc(const ndt2d_laser_scan & s)

@@ -360,6 +360,20 @@ struct ndt2d_matcher
   // skips the upload.  The matcher must be the only writer of its context's beams.
   bool beams_on_device = false;
   std::vector<double> scratch_beams, cos_th, sin_th;
+  // The mapper calls scoreScan(scan) and then matchScan(scan, ...) (reference
+  // src/ndt_mapper.cpp:514-515, 552-553).  Once that pair has been seen, scoreScan queues the
+  // scan's search behind its own kernel before it waits for the score (`ahead`): the search
+  // then starts when the scoring kernel ends, not a host round trip later, and the matchScan
+  // that follows only collects it.  A call that is not that matchScan waits the search out,
+  // discards it, and scoreScan stops doing it until the pair is seen again.
+  bool pair_seen = false;         // the last matchScan was of the scan and pose of the scoreScan before it
+  bool score_scan_last = false;   // the previous device call was a scoreScan ...
+  double score_scan_pose[3] = {0.0, 0.0, 0.0};   // ... from this pose (its beams are `beams`)
+  bool ahead = false;             // a search launched by scoreScan has not been collected
+  double ahead_pose[3] = {0.0, 0.0, 0.0};
+  size_t ahead_n_th = 0;
+  int ahead_enabled = 1;          // ndt2d_matcher_set_search_ahead
+  uint64_t ahead_launched = 0, ahead_collected = 0;
 };
 
 namespace
@@ -450,6 +464,18 @@ int stage_beams(ndt2d_matcher * m, const double * points_xy, size_t n_points, si
   return NDT2D_OK;
 }
 
+// A search launched ahead that the call now arriving cannot use: wait it out (its record is
+// dropped), and do not launch ahead again until the scoreScan / matchScan pair reappears.
+void discard_ahead(ndt2d_matcher * m)
+{
+  m->score_scan_last = false;
+  if (!m->ahead) return;
+  ndt2d_match_result res;
+  (void)ndt2d_match_fetch(m->dev, &res);
+  m->ahead = false;
+  m->pair_seen = false;
+}
+
 }  // namespace
 
 extern "C" {
@@ -477,6 +503,7 @@ int ndt2d_matcher_create(ndt2d_matcher ** out, int device_id)
 int ndt2d_matcher_destroy(ndt2d_matcher * m)
 {
   if (m == nullptr) return NDT2D_ERR_INVALID;
+  discard_ahead(m);
   ndt2d_destroy(m->dev);
   delete m;
   return NDT2D_OK;
@@ -496,6 +523,8 @@ int ndt2d_matcher_initialize(ndt2d_matcher * m, double ndt_resolution,
 {
   if (m == nullptr) return NDT2D_ERR_INVALID;
   if (!(ndt_resolution > 0.0)) return mfail(m, NDT2D_ERR_INVALID, "ndt_resolution must be > 0");
+  discard_ahead(m);
+  m->pair_seen = false;
   m->resolution = ndt_resolution;
   m->angular_res = search_angular_resolution;
   m->angular_size = search_angular_size;
@@ -517,6 +546,7 @@ int ndt2d_matcher_add_scans(ndt2d_matcher * m, const double * poses_xyt,
   {
     return mfail(m, NDT2D_ERR_INVALID, "add_scans: null input");
   }
+  discard_ahead(m);
   static const double no_points[2] = {0.0, 0.0};
   if (points_xy == nullptr) points_xy = no_points;
   static const size_t no_offsets[1] = {0};
@@ -583,6 +613,7 @@ int ndt2d_matcher_set_build_mode(ndt2d_matcher * m, const char * mode)
 int ndt2d_matcher_reset(ndt2d_matcher * m)
 {
   if (m == nullptr) return NDT2D_ERR_INVALID;
+  discard_ahead(m);
   if (m->ndt) m->spare = std::move(m->ndt);   // `ndt_.reset()`; the storage serves the next addScans
   m->have_ndt = false;
   return ndt2d_clear_grid(m->dev);
@@ -590,10 +621,11 @@ int ndt2d_matcher_reset(ndt2d_matcher * m)
 
 int ndt2d_matcher_has_ndt(ndt2d_matcher * m) { return (m != nullptr && m->have_ndt) ? 1 : 0; }
 
-int ndt2d_matcher_prepare_search(ndt2d_matcher * m, const double * scan_pose_xyt,
-                                 const double * points_xy, size_t n_points, size_t * n_th_out,
-                                 size_t * n_lin_out, size_t * n_beams_out)
+static int prepare_search_impl(ndt2d_matcher * m, const double * scan_pose_xyt,
+                               const double * points_xy, size_t n_points, size_t * n_th_out,
+                               size_t * n_lin_out, size_t * n_beams_out, bool * same_out)
 {
+  if (same_out != nullptr) *same_out = false;
   if (m == nullptr || scan_pose_xyt == nullptr) return NDT2D_ERR_INVALID;
   if (n_points > 0 && points_xy == nullptr) return mfail(m, NDT2D_ERR_INVALID, "null points");
   subsample_into(m->scratch_beams, points_xy, n_points, m->laser_max_beams);
@@ -606,6 +638,7 @@ int ndt2d_matcher_prepare_search(ndt2d_matcher * m, const double * scan_pose_xyt
   const bool same = m->beams_on_device && use > 0 && m->beams.size() == m->scratch_beams.size() &&
                     std::memcmp(m->beams.data(), m->scratch_beams.data(),
                                 m->beams.size() * sizeof(double)) == 0;
+  if (same_out != nullptr) *same_out = same;
   if (!same)
   {
     m->beams.swap(m->scratch_beams);
@@ -613,6 +646,15 @@ int ndt2d_matcher_prepare_search(ndt2d_matcher * m, const double * scan_pose_xyt
   }
   return prepare_tables(m, scan_pose_xyt, use, same ? nullptr : m->beams.data(), same, n_th_out,
                         n_lin_out);
+}
+
+int ndt2d_matcher_prepare_search(ndt2d_matcher * m, const double * scan_pose_xyt,
+                                 const double * points_xy, size_t n_points, size_t * n_th_out,
+                                 size_t * n_lin_out, size_t * n_beams_out)
+{
+  if (m != nullptr) discard_ahead(m);
+  return prepare_search_impl(m, scan_pose_xyt, points_xy, n_points, n_th_out, n_lin_out, n_beams_out,
+                             nullptr);
 }
 
 int ndt2d_matcher_finish_match(ndt2d_matcher * m, const double * record, double * pose_inout,
@@ -678,9 +720,46 @@ int ndt2d_matcher_match_scan_ex(ndt2d_matcher * m, const double * scan_pose_xyt,
     *score_out = 0.0;
     return NDT2D_OK;
   }
+  if (m->ahead)
+  {
+    // scoreScan launched a search ahead: is this the matchScan it was launched for -- the same
+    // pose, the same subsampled beams, no per-candidate scores wanted?
+    bool hit = all_scores == nullptr && (n_points == 0 || points_xy != nullptr) &&
+               std::memcmp(m->ahead_pose, scan_pose_xyt, sizeof(m->ahead_pose)) == 0;
+    if (hit)
+    {
+      subsample_into(m->scratch_beams, points_xy, n_points, m->laser_max_beams);
+      hit = m->scratch_beams.size() == m->beams.size() && !m->beams.empty() &&
+            std::memcmp(m->beams.data(), m->scratch_beams.data(), m->beams.size() * sizeof(double)) == 0;
+    }
+    if (hit)
+    {
+      m->ahead = false;
+      ++m->ahead_collected;
+      m->score_scan_last = false;
+      const size_t n_lin_a = m->dlin.size();
+      if (n_candidates_out != nullptr) *n_candidates_out = m->ahead_n_th * n_lin_a * n_lin_a;
+      ndt2d_match_result res;
+      const int frc = ndt2d_match_fetch(m->dev, &res);
+      if (frc != NDT2D_OK) return dev_fail(m, frc, "ndt2d_match_fetch");
+      double rec[NDT2D_MATCH_RECORD_DOUBLES];
+      rec[0] = res.best_score;
+      rec[1] = res.best_index == NDT2D_NO_INDEX ? -1.0 : static_cast<double>(res.best_index);
+      for (int i = 0; i < 10; ++i) rec[2 + i] = res.acc[i];
+      if (best_index_out != nullptr) *best_index_out = res.best_index;
+      return ndt2d_matcher_finish_match(m, rec, pose_inout, covariance_out, score_out);
+    }
+    discard_ahead(m);
+  }
+  // (the pair: this matchScan is of the scan and pose the scoreScan just before it scored)
+  const bool after_score_scan =
+    m->score_scan_last && std::memcmp(m->score_scan_pose, scan_pose_xyt, sizeof(m->score_scan_pose)) == 0;
+  m->score_scan_last = false;
   size_t n_th = 0, n_lin = 0, use = 0;
-  int rc = ndt2d_matcher_prepare_search(m, scan_pose_xyt, points_xy, n_points, &n_th, &n_lin, &use);
+  bool same_scan = false;
+  int rc = prepare_search_impl(m, scan_pose_xyt, points_xy, n_points, &n_th, &n_lin, &use, &same_scan);
   if (rc != NDT2D_OK) return rc;
+  if (after_score_scan && same_scan) m->pair_seen = true;
   const size_t n_cand = n_th * n_lin * n_lin;
   if (n_candidates_out != nullptr) *n_candidates_out = n_cand;
 
@@ -749,6 +828,7 @@ int ndt2d_matcher_match_laser_scan(ndt2d_matcher * m, const double * scan_pose_x
     *score_out = 0.0;
     return NDT2D_OK;
   }
+  discard_ahead(m);
   size_t n_points = 0, use = 0;
   int rc = ndt2d_set_beams_from_ranges(m->dev, ranges, n_ranges, scan, m->laser_max_beams,
                                        &n_points, &use);
@@ -781,6 +861,7 @@ int ndt2d_matcher_score_poses(ndt2d_matcher * m, const double * points_xy, size_
     return NDT2D_ERR_INVALID;
   }
   if (n_poses == 0) return NDT2D_OK;
+  discard_ahead(m);
   // `if (!ndt_) return 0.0;` (reference src/scan_matcher_ndt.cpp:159)
   if (!m->have_ndt)
   {
@@ -816,6 +897,7 @@ int ndt2d_matcher_prepare_beams(ndt2d_matcher * m, const double * points_xy, siz
 {
   if (m == nullptr) return NDT2D_ERR_INVALID;
   if (n_points > 0 && points_xy == nullptr) return mfail(m, NDT2D_ERR_INVALID, "null points");
+  discard_ahead(m);
   size_t use = 0;
   int rc = stage_beams(m, points_xy, n_points, &use);
   if (n_beams_out != nullptr) *n_beams_out = use;
@@ -833,7 +915,73 @@ int ndt2d_matcher_score_scan(ndt2d_matcher * m, const double * scan_pose_xyt,
                              const double * points_xy, size_t n_points, double * score_out)
 {
   // scoreScan(scan) = scorePoints(scan->getPoints(), scan->getPose()) (:151-154)
-  return ndt2d_matcher_score_points(m, points_xy, n_points, scan_pose_xyt, score_out);
+  if (m == nullptr || scan_pose_xyt == nullptr || score_out == nullptr) return NDT2D_ERR_INVALID;
+  discard_ahead(m);
+  if (m->ahead_enabled && m->pair_seen && m->have_ndt && (n_points == 0 || points_xy != nullptr) &&
+      !m->dth.empty() && !m->dlin.empty())
+  {
+    // The matchScan of this scan is coming (see `ahead`): its search goes onto the stream
+    // behind the scoring kernel, then the score is waited for.
+    size_t use = 0;
+    bool pending = false;
+    int rc = stage_beams(m, points_xy, n_points, &use, &pending);
+    if (rc != NDT2D_OK) return rc;
+    if (use > 0)
+    {
+      rc = ndt2d_score_poses_beams_launch(m->dev, pending ? m->beams.data() : nullptr, use, scan_pose_xyt, 1);
+      if (rc == NDT2D_OK)
+      {
+        m->beams_on_device = true;
+        size_t n_th = 0, n_lin = 0;
+        // (a search that cannot be launched ahead is not scoreScan's failure: matchScan will say)
+        if (prepare_tables(m, scan_pose_xyt, use, nullptr, true, &n_th, &n_lin) == NDT2D_OK && m->search_ready &&
+            ndt2d_match_launch(m->dev, 0, n_th, nullptr, nullptr) == NDT2D_OK)
+        {
+          m->ahead = true;
+          ++m->ahead_launched;
+          std::memcpy(m->ahead_pose, scan_pose_xyt, sizeof(m->ahead_pose));
+          m->ahead_n_th = n_th;
+          m->n_use = use;
+        }
+        rc = ndt2d_score_fetch(m->dev, score_out);
+        if (rc != NDT2D_OK)
+        {
+          discard_ahead(m);
+          m->beams_on_device = false;
+          return dev_fail(m, rc, "ndt2d_score_fetch");
+        }
+        m->score_scan_last = true;
+        std::memcpy(m->score_scan_pose, scan_pose_xyt, sizeof(m->score_scan_pose));
+        return NDT2D_OK;
+      }
+      if (rc != NDT2D_ERR_STATE) return dev_fail(m, rc, "ndt2d_score_poses_beams_launch");
+      // (not a kernel-argument launch -- more beams than travel as arguments: the ordinary call)
+    }
+  }
+  const int rc = ndt2d_matcher_score_poses(m, points_xy, n_points, scan_pose_xyt, 1, score_out);
+  if (rc == NDT2D_OK && m->have_ndt)
+  {
+    m->score_scan_last = true;
+    std::memcpy(m->score_scan_pose, scan_pose_xyt, sizeof(m->score_scan_pose));
+  }
+  return rc;
+}
+
+int ndt2d_matcher_search_ahead_stats(ndt2d_matcher * m, uint64_t * launched, uint64_t * collected)
+{
+  if (m == nullptr) return NDT2D_ERR_INVALID;
+  if (launched != nullptr) *launched = m->ahead_launched;
+  if (collected != nullptr) *collected = m->ahead_collected;
+  return NDT2D_OK;
+}
+
+int ndt2d_matcher_set_search_ahead(ndt2d_matcher * m, int enabled)
+{
+  if (m == nullptr) return NDT2D_ERR_INVALID;
+  discard_ahead(m);
+  m->ahead_enabled = enabled != 0 ? 1 : 0;
+  m->pair_seen = false;
+  return NDT2D_OK;
 }
 
 int ndt2d_matcher_pf_measure(ndt2d_matcher * m, const double * particles_xyt,
@@ -845,6 +993,7 @@ int ndt2d_matcher_pf_measure(ndt2d_matcher * m, const double * particles_xyt,
   {
     return NDT2D_ERR_INVALID;
   }
+  discard_ahead(m);
   if (n_particles > 0 && m->have_ndt && n_points > 0 && m->laser_max_beams > 0)
   {
     // weights_[i] = scorePoints(points, particle_i) (particle_filter.cpp:81-87), then
@@ -923,6 +1072,7 @@ int ndt2d_matcher_grid_cells6(ndt2d_matcher * m, double * cells6_out, size_t cap
 {
   if (m == nullptr || cells6_out == nullptr) return NDT2D_ERR_INVALID;
   if (!m->have_ndt) return mfail(m, NDT2D_ERR_NO_GRID, "no NDT");
+  discard_ahead(m);
   if (m->ndt)
   {
     if (capacity_cells < m->ndt->ncell()) return mfail(m, NDT2D_ERR_INVALID, "capacity too small");

@@ -243,6 +243,17 @@ class ScanMatcherNDT:
     def reset(self):
         self._check(self._L.ndt2d_matcher_reset(self._m), "reset")
 
+    def set_search_ahead(self, enabled):
+        """scoreScan launching the scan's search behind itself once the mapper's scoreScan /
+        matchScan pair has been seen (include/ndt2d_hip.h, ndt2d_matcher_score_scan): on by default."""
+        self._check(self._L.ndt2d_matcher_set_search_ahead(self._m, 1 if enabled else 0), "set_search_ahead")
+
+    def search_ahead_stats(self):
+        """(searches scoreScan launched ahead, how many a matchScan collected)."""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self._check(self._L.ndt2d_matcher_search_ahead_stats(self._m, C.byref(a), C.byref(b)), "search_ahead_stats")
+        return a.value, b.value
+
     def set_build_mode(self, mode):
         """Where addScans builds the NDT: "host", "device" or "auto" (bit-identical grids)."""
         self._check(self._L.ndt2d_matcher_set_build_mode(self._m, mode.encode()), "set_build_mode")

@@ -1539,3 +1539,80 @@ def test_list_install_rejects_a_cell_listed_twice():
         assert L.ndt2d_has_grid(h) == 1
     finally:
         L.ndt2d_destroy(h)
+
+
+def test_score_scan_launches_the_search_of_its_scan_ahead():
+    """The mapper's pair scoreScan(scan), matchScan(scan, ...) (reference src/ndt_mapper.cpp:
+    514-515): once a matcher has seen it, scoreScan queues the search behind its own kernel and
+    matchScan collects it.  Same bits as a matcher that never launches ahead, and the oracle's;
+    calls that break the pattern (another pose, another scan, per-candidate scores wanted, a
+    scorePoints or a reset in between) drop the search and still get their own results."""
+    over = dict(search_angular_size=0.1, search_angular_resolution=0.0025, search_linear_size=0.05,
+                search_linear_resolution=0.005, laser_max_beams=100)
+    scans = synth.map_scans(1)
+    params = synth.matcher_params(1, **over)
+    ref = O.ScanMatcherNDT()
+    ref.initialize(**params)
+    ref.addScans(scans)
+    guess, pts, _ = synth.query_scan(1)
+    other = guess + np.array([0.02, 0.01, -0.004])
+    pts2 = pts[::-1].copy()
+    exp = {k: ref.matchScan(g, p, want_scores=True) for k, (g, p) in
+           dict(a=(guess, pts), b=(other, pts), c=(guess, pts2)).items()}
+    exp_score = ref.scoreScan(guess, pts)
+
+    def blob(r):
+        return (r["score"], r["best_index"], r["pose"].tobytes(), r["covariance"].tobytes())
+
+    plain = ScanMatcherNDT(0)
+    plain.initialize("plain", **params)
+    plain.set_search_ahead(False)
+    plain.addScans(scans)
+    want = {k: plain.matchScan(g, p) for k, (g, p) in dict(a=(guess, pts), b=(other, pts), c=(guess, pts2)).items()}
+    for k in want:
+        _check_match(want[k], exp[k], 100)
+    assert plain.search_ahead_stats() == (0, 0)
+
+    gpu = ScanMatcherNDT(0)
+    gpu.initialize("ahead", **params)
+    for cycle in range(4):
+        gpu.reset()
+        gpu.addScans(scans)
+        assert abs(gpu.scoreScan(guess, pts) - exp_score) < TOL_TIGHT
+        assert blob(gpu.matchScan(guess, pts)) == blob(want["a"]), cycle
+    assert gpu.search_ahead_stats() == (3, 3)          # the first cycle shows the pair, the others use it
+    # the pattern breaks: every call still gets its own result, the search launched ahead is dropped
+    launched = 3
+    for breaker in ("pose", "scan", "scores", "scorePoints", "reset", "measure", "grid"):
+        gpu.scoreScan(guess, pts)                       # pair seen: launches ahead
+        launched += 1
+        assert gpu.search_ahead_stats() == (launched, 3), breaker
+        if breaker == "pose":
+            assert blob(gpu.matchScan(other, pts)) == blob(want["b"])
+        elif breaker == "scan":
+            assert blob(gpu.matchScan(guess, pts2)) == blob(want["c"])
+        elif breaker == "scores":
+            got = gpu.matchScan(guess, pts, want_scores=True)
+            _check_match(got, exp["a"], 100)
+            assert blob(got) == blob(want["a"])
+        elif breaker == "scorePoints":
+            assert abs(gpu.scorePoints(pts, guess) - exp_score) < TOL_TIGHT
+            assert blob(gpu.matchScan(guess, pts)) == blob(want["a"])
+        elif breaker == "reset":
+            gpu.reset()
+            gpu.addScans(scans)
+            assert blob(gpu.matchScan(guess, pts)) == blob(want["a"])
+        elif breaker == "measure":
+            w = gpu.scorePoses(pts, np.tile(guess, (40, 1)))
+            assert np.all(np.abs(w - exp_score) < TOL_TIGHT)
+            assert blob(gpu.matchScan(guess, pts)) == blob(want["a"])
+        else:
+            assert np.array_equal(gpu.grid()[0], ref.ndt.cells6(), equal_nan=True)
+            assert blob(gpu.matchScan(guess, pts)) == blob(want["a"])
+        # dropped: the next scoreScan does not launch ahead until the pair has been seen again
+        gpu.scoreScan(guess, pts)
+        assert gpu.search_ahead_stats() == (launched, 3), breaker
+        assert blob(gpu.matchScan(guess, pts)) == blob(want["a"])     # ... which this is
+    gpu.scoreScan(guess, pts)
+    assert blob(gpu.matchScan(guess, pts)) == blob(want["a"])
+    assert gpu.search_ahead_stats() == (launched + 1, 4)
