@@ -112,7 +112,22 @@ double ScanMatcherNDTHip::matchScan(const ndt_2d::ScanPtr & scan, ndt_2d::Pose2d
 
 double ScanMatcherNDTHip::scoreScan(const ndt_2d::ScanPtr & scan) const
 {
-  return scorePoints(scan->getPoints(), scan->getPose());
+  // scorePoints(scan->getPoints(), scan->getPose()) (reference src/scan_matcher_ndt.cpp:151-154)
+  // through its own entry point: the mapper's next call is matchScan(scan, ...)
+  // (src/ndt_mapper.cpp:514-515), and the library queues that search behind this call's kernel
+  // once it has seen the pair (include/ndt2d_hip.h, ndt2d_matcher_score_scan)
+  if (!matcher_) return 0.0;
+  const ndt_2d::Pose2d scan_pose = scan->getPose();
+  const std::vector<ndt_2d::Point> points = scan->getPoints();
+  const double p[3] = {scan_pose.x, scan_pose.y, scan_pose.theta};
+  double score = 0.0;
+  if (!ok(ndt2d_matcher_score_scan(matcher_, p, reinterpret_cast<const double *>(points.data()),
+                                   points.size(), &score),
+          "ndt2d_matcher_score_scan"))
+  {
+    return 0.0;
+  }
+  return score;
 }
 
 double ScanMatcherNDTHip::scorePoints(const std::vector<ndt_2d::Point> & points,
