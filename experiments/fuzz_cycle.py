@@ -41,7 +41,7 @@ for c in range(cycles):
     ref.addScans(scans)
     gpu.reset()
     gpu.addScans(scans)
-    calls = [k for k in ("grid", "scoreScan", "scorePoints", "measure", "matchScan", "matchScan2")
+    calls = [k for k in ("grid", "scoreScan", "scorePoints", "measure", "matchScan", "matchScan2", "pair", "pair")
              if rng.random() < 0.6]
     rng.shuffle(calls)
     try:
@@ -55,6 +55,21 @@ for c in range(cycles):
             elif call == "scorePoints":
                 g, e = gpu.scorePoints(query, scan_pose), ref.scorePoints(query, scan_pose)
                 assert (np.isnan(g) and np.isnan(e)) or abs(g - e) < 1e-9, ("scorePoints", g, e)
+            elif call == "pair":
+                # the mapper's pair: scoreScan(scan), matchScan(scan, ...) -- after the first one a
+                # matcher launches the search ahead; no per-candidate scores here, so it is collected
+                g, e = gpu.scoreScan(scan_pose, query), ref.scoreScan(scan_pose, query)
+                assert (np.isnan(g) and np.isnan(e)) or abs(g - e) < 1e-9, ("pair scoreScan", g, e)
+                got = gpu.matchScan(scan_pose, query)
+                exp = ref.matchScan(scan_pose, query, want_scores=True)
+                assert got["n_candidates"] == exp["n_candidates"]
+                assert (np.isnan(got["score"]) and np.isnan(exp["score"])) or abs(got["score"] - exp["score"]) < 1e-9, "pair score"
+                finite = exp["scores"][~np.isnan(exp["scores"])]
+                if finite.size > 1 and np.sort(finite)[1] - finite.min() > 1e-9:
+                    assert got["best_index"] == exp["best_index"], "pair index"
+                    assert np.array_equal(got["pose"], exp["pose"])
+                if abs(np.nansum(exp["scores"])) > 1e-6:
+                    assert np.allclose(got["covariance"], exp["covariance"], rtol=1e-7, atol=1e-12, equal_nan=True), "pair cov"
             elif call == "measure":
                 w = gpu.scorePoses(query, poses)
                 w_exp = O.pf_measure(ref, poses, query)
@@ -84,3 +99,5 @@ print("cycles %d (seed %d): %d failures" % (cycles, first, len(bad)))
 for b in bad[:10]:
     print(b)
 print(sorted(counts.items(), key=lambda kv: -kv[1]))
+if gpu is not None:
+    print("search ahead (launched, collected) of the last matcher:", gpu.search_ahead_stats())
