@@ -33,8 +33,13 @@ struct PinnedStage
   double * ptr = nullptr;
   double * dev = nullptr;   // the same memory as the device addresses it (kernels may read it in place)
   size_t cap = 0;  // doubles
-  hipEvent_t done = nullptr;
+  // the stream position (ndt2d_context::queued) behind the buffer's last queued reader: the
+  // buffer may be written again once the stream is known to have passed it
   bool pending = false;
+  uint64_t needed = 0;
+  // (optional) a host-coherent word the buffer's reader raises to `needed` when it is done
+  // reading: what a host that refills the buffer before any later result is back spins on
+  volatile unsigned long long * consumed = nullptr;
 };
 
 struct ndt2d_context
@@ -88,6 +93,11 @@ struct ndt2d_context
   // sequence number the host spins on (a stream synchronisation costs ~4 us more):
   //   [0..11] match record   [16] match flag   [24] score flag   [32..2079] scores / weights
   //   [2080..2087] particle statistics
+  // Stream positions: `queued` counts the marks handed out behind queued work
+  // (stage_mark), `reached` is the newest mark the in-order stream is known to have
+  // passed -- a result flag seen by the host proves everything queued before that kernel done.
+  uint64_t queued = 0, reached = 0;
+  uint64_t match_pos = 0, few_pos = 0;   // `queued` when the pending search / few-pose launch went out
   double * host_res = nullptr;      // host address
   double * host_res_dev = nullptr;  // the same memory as the GPU addresses it
   unsigned long long seq = 0;       // last sequence number handed out
@@ -155,12 +165,20 @@ int fail_hip(ndt2d_context * h, hipError_t e, const char * what)
     if (e__ != hipSuccess) return fail_hip(h, e__, #call); \
   } while (0)
 
+// hipStreamSynchronize, noting how far the stream has come (see ndt2d_context::reached)
+#define NDT2D_SYNC(h)                                          \
+  do {                                                         \
+    const uint64_t q_ = (h)->queued;                           \
+    NDT2D_HIP(h, hipStreamSynchronize((h)->stream));           \
+    if ((h)->reached < q_) (h)->reached = q_;                  \
+  } while (0)
+
 int ensure(ndt2d_context * h, DeviceBuffer & b, size_t doubles)
 {
   if (doubles <= b.cap && b.ptr != nullptr) return NDT2D_OK;
   if (b.ptr != nullptr)
   {
-    NDT2D_HIP(h, hipStreamSynchronize(h->stream));
+    NDT2D_SYNC(h);
     NDT2D_HIP(h, hipFree(b.ptr));
     b.ptr = nullptr;
     b.cap = 0;
@@ -173,15 +191,34 @@ int ensure(ndt2d_context * h, DeviceBuffer & b, size_t doubles)
   return NDT2D_OK;
 }
 
+// Wait until nothing queued reads `st` any more.  After a sequence of synchronous calls the
+// stream is already known to be past the buffer's mark (the call that used it ended with a result
+// flag); only a caller that queues launch upon launch without fetching waits here.
+int stage_wait(ndt2d_context * h, PinnedStage & st)
+{
+  if (st.pending)
+  {
+    if (h->reached < st.needed && st.consumed != nullptr)
+    {
+      for (int i = 0; i < (1 << 18) && *st.consumed < st.needed; ++i) __builtin_ia32_pause();
+      if (*st.consumed >= st.needed)
+      {
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        st.pending = false;
+        return NDT2D_OK;
+      }
+    }
+    if (h->reached < st.needed) NDT2D_SYNC(h);
+    st.pending = false;
+  }
+  return NDT2D_OK;
+}
+
 // Make `st` ready to take `doubles` values: wait for the previous copy out of it.
 int stage_acquire(ndt2d_context * h, PinnedStage & st, size_t doubles)
 {
-  if (st.done == nullptr) NDT2D_HIP(h, hipEventCreateWithFlags(&st.done, hipEventDisableTiming));
-  if (st.pending)
-  {
-    NDT2D_HIP(h, hipEventSynchronize(st.done));
-    st.pending = false;
-  }
+  const int wrc = stage_wait(h, st);
+  if (wrc != NDT2D_OK) return wrc;
   if (doubles > st.cap || st.ptr == nullptr)
   {
     if (st.ptr != nullptr) NDT2D_HIP(h, hipHostFree(st.ptr));
@@ -200,11 +237,13 @@ int stage_acquire(ndt2d_context * h, PinnedStage & st, size_t doubles)
   return NDT2D_OK;
 }
 
-// The copy out of a staging buffer, and the event that tells when the buffer may be written
-// again.  A recorded event holds the stream up for ~5 us (experiments/kernel_gaps.py), so a
-// caller that launches the copy's consumer right away copies first, launches, and marks
-// afterwards (stage_copy + stage_mark): the hold-up then falls behind the call's last
-// kernel, where the host is busy anyway.
+// The copy out of a staging buffer, and the mark that tells when the buffer may be written
+// again: a POSITION in the in-order stream, not an event.  A recorded event holds the stream
+// up for ~5 us in front of whatever is queued next (experiments/kernel_gaps.py; in the mapper's
+// cycle 5.8 us between the install kernel and the scoreScan behind it,
+// experiments/r03_cycle.sh), and the question it answers is already answered: every
+// synchronous call ends with a result flag (or a stream synchronisation) seen by the host,
+// which proves everything queued before that kernel done (ndt2d_context::reached).
 int stage_copy(ndt2d_context * h, PinnedStage & st, double * dst, size_t doubles)
 {
   NDT2D_HIP(h, hipMemcpyAsync(dst, st.ptr, doubles * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -213,7 +252,7 @@ int stage_copy(ndt2d_context * h, PinnedStage & st, double * dst, size_t doubles
 
 int stage_mark(ndt2d_context * h, PinnedStage & st)
 {
-  NDT2D_HIP(h, hipEventRecord(st.done, h->stream));
+  st.needed = ++h->queued;
   st.pending = true;
   return NDT2D_OK;
 }
@@ -227,7 +266,6 @@ int stage_submit(ndt2d_context * h, PinnedStage & st, double * dst, size_t doubl
 void release(PinnedStage & st)
 {
   if (st.ptr != nullptr) (void)hipHostFree(st.ptr);
-  if (st.done != nullptr) (void)hipEventDestroy(st.done);
   st = PinnedStage{};
 }
 
@@ -271,6 +309,7 @@ ndt2d::MotionParams motion_params(double dx, double dy, double dth, const double
 }
 
 constexpr int kScoreFlagSlot = 24;
+constexpr int kGridConsumedSlot = 20;   // raised by the install kernel: the grid's staging buffer has been read
 constexpr int kScoreSlot = 32;                                             // scores / weights of a small batch
 constexpr int kPfOutSlot = kScoreSlot + static_cast<int>(ndt2d::kFewPosesMax);   // its statistics
 constexpr int kHostResDoubles = kPfOutSlot + 32;
@@ -313,7 +352,7 @@ int ensure_host_res(ndt2d_context * h)
 // Wait until the kernel that was given `seq` has published its results at `slot`:
 // spin on the flag for a while (the GPU writes it over PCIe into coherent host memory;
 // ~4 us sooner than a stream synchronisation returns), then fall back to the stream.
-int wait_host_flag(ndt2d_context * h, int slot, unsigned long long seq)
+int wait_host_flag(ndt2d_context * h, int slot, unsigned long long seq, uint64_t position)
 {
   volatile unsigned long long * flag =
     reinterpret_cast<volatile unsigned long long *>(h->host_res + slot);
@@ -324,6 +363,7 @@ int wait_host_flag(ndt2d_context * h, int slot, unsigned long long seq)
       if (*flag == seq)
       {
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        if (h->reached < position) h->reached = position;   // the stream is in order
         return NDT2D_OK;
       }
       __builtin_ia32_pause();
@@ -332,9 +372,10 @@ int wait_host_flag(ndt2d_context * h, int slot, unsigned long long seq)
     const hipError_t q = hipStreamQuery(h->stream);
     if (q != hipErrorNotReady && q != hipSuccess) return fail_hip(h, q, "hipStreamQuery");
   }
-  NDT2D_HIP(h, hipStreamSynchronize(h->stream));
+  NDT2D_SYNC(h);
   if (*flag != seq) return fail(h, NDT2D_ERR_HIP, "result flag was not raised");
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  if (h->reached < position) h->reached = position;
   return NDT2D_OK;
 }
 
@@ -612,6 +653,7 @@ int ndt2d_set_grid(ndt2d_handle h, const double * cells6, uint32_t size_x, uint3
                                          reinterpret_cast<uint32_t *>(h->occ_bits.ptr),
                                          reinterpret_cast<uint8_t *>(h->cell_bytes.ptr), h->stream);
   if (e != hipSuccess) return fail_hip(h, e, "launch_pack_grid");
+  h->stage_grid.consumed = nullptr;   // (no kernel of this path says when the buffer has been read)
   if ((rc = stage_mark(h, h->stage_grid)) != NDT2D_OK) return rc;   // (behind the kernel, see stage_copy)
   g.cells_lds_image = h->cells_lds_image.ptr;
   g.cells_global = h->cells_global.ptr;
@@ -672,7 +714,7 @@ int ndt2d_build_grid(ndt2d_handle h, double ndt_resolution, double range_max,
   h->bytes_job.n = 0;
 
   // staging that must stay alive until the copies are done: kept in the context
-  NDT2D_HIP(h, hipStreamSynchronize(h->stream));
+  NDT2D_SYNC(h);
   h->stage_scans.resize(4 * n_scans);
   h->stage_offsets.resize(((n_scans + 1) + 1) & ~size_t(1));
   for (size_t k = 0; k < n_scans; ++k)
@@ -872,12 +914,18 @@ int ndt2d_set_grid_sparse(ndt2d_handle h, const uint32_t * cell_index, const dou
   {
     image.src = h->stage_grid.dev;
     image.dst = h->compact.ptr;
+    if ((rc = ensure_host_res(h)) != NDT2D_OK) return rc;
+    image.consumed_flag = reinterpret_cast<unsigned long long *>(h->host_res_dev + kGridConsumedSlot);
+    image.consumed_seq = h->queued + 1;   // = the mark stage_mark hands out below
+    image.ticket = reinterpret_cast<uint32_t *>(h->done_words + ndt2d::kFewPosesMax);
+    h->stage_grid.consumed = reinterpret_cast<volatile unsigned long long *>(h->host_res + kGridConsumedSlot);
   }
   else
   {
     if ((rc = stage_copy(h, h->stage_grid, h->compact.ptr, n_upload)) != NDT2D_OK) return rc;
     image.src = h->compact.ptr;
     image.dst = nullptr;
+    h->stage_grid.consumed = nullptr;
   }
 
   GridDesc g{};
@@ -900,6 +948,7 @@ int ndt2d_set_grid_sparse(ndt2d_handle h, const uint32_t * cell_index, const dou
   h->bytes_job.cells6 = d_cells6;
   h->bytes_job.n = n;
   h->bytes_job.bytes = reinterpret_cast<uint8_t *>(h->cell_bytes.ptr);
+  // (behind the install kernel, which reads the buffer in place)
   if ((rc = stage_mark(h, h->stage_grid)) != NDT2D_OK) return rc;
   g.cells_lds_image = h->cells_lds_image.ptr;
   g.cells_global = h->cells_global.ptr;
@@ -949,7 +998,7 @@ int ndt2d_get_grid(ndt2d_handle h, double * cells6_out, size_t capacity_cells, u
     NDT2D_HIP(h, hipMemcpyAsync(cells6_out, h->cells6_ptr,
                                 static_cast<size_t>(h->grid.ncell) * 6 * sizeof(double),
                                 hipMemcpyDeviceToHost, h->stream));
-    NDT2D_HIP(h, hipStreamSynchronize(h->stream));
+    NDT2D_SYNC(h);
   }
   return NDT2D_OK;
 }
@@ -1189,6 +1238,7 @@ int ndt2d_match_launch_strided(ndt2d_handle h, size_t th_first, size_t th_stride
     if (int trc = next_timing_slot(h); trc != NDT2D_OK) return trc;
   }
   h->match_seq = ++h->seq;
+  h->match_pos = h->queued;   // (every mark so far is behind work queued before this search)
   // (the event pair brackets the search kernel itself)
   hipError_t e = ndt2d::launch_match(a, h->ws_match.ptr, outer, h->record.ptr, d_record,
                                      h->host_res_dev, h->match_seq, h->force_variant, h->stream,
@@ -1208,7 +1258,7 @@ int ndt2d_match_fetch(ndt2d_handle h, ndt2d_match_result * out)
   if (!h->match_pending) return fail(h, NDT2D_ERR_STATE, "ndt2d_match_fetch: nothing launched");
   NDT2D_HIP(h, hipSetDevice(h->device));
   // the final reduction wrote the record into host-coherent memory, then its flag
-  int rc = wait_host_flag(h, ndt2d::kHostFlagSlot, h->match_seq);
+  int rc = wait_host_flag(h, ndt2d::kHostFlagSlot, h->match_seq, h->match_pos);
   if (rc != NDT2D_OK) return rc;
   double rec[NDT2D_MATCH_RECORD_DOUBLES];
   for (int k = 0; k < NDT2D_MATCH_RECORD_DOUBLES; ++k) rec[k] = h->host_res[k];
@@ -1243,7 +1293,7 @@ int ndt2d_match(ndt2d_handle h, size_t th_begin, size_t th_end, double * h_score
   {
     NDT2D_HIP(h, hipMemcpyAsync(h_scores, d_scores, n_scores * sizeof(double),
                                 hipMemcpyDeviceToHost, h->stream));
-    NDT2D_HIP(h, hipStreamSynchronize(h->stream));
+    NDT2D_SYNC(h);
   }
   return ndt2d_match_fetch(h, out);
 }
@@ -1322,11 +1372,6 @@ int ndt2d_score_poses_beams(ndt2d_handle h, const double * beams_xy, size_t n_be
     // in the context's beam buffer for the calls that follow on this scan
     int rc = ensure(h, h->beams, 2 * n_beams + 2);
     if (rc != NDT2D_OK) return rc;
-    if (h->stage_beams.pending)   // the buffer may still be the target of a staged upload
-    {
-      NDT2D_HIP(h, hipEventSynchronize(h->stage_beams.done));
-      h->stage_beams.pending = false;
-    }
     ndt2d::PosesArgs probe{};
     probe.n_beams = static_cast<uint32_t>(n_beams);
     probe.n_poses = n_poses;
@@ -1375,11 +1420,6 @@ int ndt2d_score_poses_beams_launch(ndt2d_handle h, const double * beams_xy, size
   if (beams_xy == nullptr) return run_few_launch(h, nullptr, n_beams, h_poses_xyt, n_poses, false);
   int rc = ensure(h, h->beams, 2 * n_beams + 2);
   if (rc != NDT2D_OK) return rc;
-  if (h->stage_beams.pending)   // the buffer may still be the target of a staged upload
-  {
-    NDT2D_HIP(h, hipEventSynchronize(h->stage_beams.done));
-    h->stage_beams.pending = false;
-  }
   h->n_beams = 0;
   h->beams_ptr = nullptr;
   h->has_search = false;
@@ -1469,7 +1509,7 @@ int ndt2d_score_poses(ndt2d_handle h, const double * h_poses_xyt, size_t n_poses
     NDT2D_HIP(h, hipMemcpyAsync(h_stats, h->stats.ptr, NDT2D_POSE_STATS_DOUBLES * sizeof(double),
                                 hipMemcpyDeviceToHost, h->stream));
   }
-  NDT2D_HIP(h, hipStreamSynchronize(h->stream));
+  NDT2D_SYNC(h);
   return NDT2D_OK;
 }
 
@@ -1531,7 +1571,7 @@ int ndt2d_pf_measure(ndt2d_handle h, const double * h_poses_xyt, size_t n_poses,
                               hipMemcpyDeviceToHost, h->stream));
   NDT2D_HIP(h, hipMemcpyAsync(h_out, d_out, NDT2D_PF_RESULT_DOUBLES * sizeof(double),
                               hipMemcpyDeviceToHost, h->stream));
-  NDT2D_HIP(h, hipStreamSynchronize(h->stream));
+  NDT2D_SYNC(h);
   return NDT2D_OK;
 }
 
@@ -1650,7 +1690,7 @@ int ndt2d_pf_update(ndt2d_handle h, double * h_poses_xyt, size_t n, double dx, d
                               hipMemcpyDeviceToHost, h->stream));
   NDT2D_HIP(h, hipMemcpyAsync(h_out, d_out, NDT2D_PF_RESULT_DOUBLES * sizeof(double),
                               hipMemcpyDeviceToHost, h->stream));
-  NDT2D_HIP(h, hipStreamSynchronize(h->stream));
+  NDT2D_SYNC(h);
   return NDT2D_OK;
 }
 
@@ -1664,7 +1704,7 @@ int run_few_fetch(ndt2d_context * h, double * h_scores, double * h_out)
 {
   if (!h->few_pending) return fail(h, NDT2D_ERR_STATE, "no few-pose launch is pending");
   h->few_pending = false;
-  const int rc = wait_host_flag(h, kScoreFlagSlot, h->few_seq);
+  const int rc = wait_host_flag(h, kScoreFlagSlot, h->few_seq, h->few_pos);
   if (rc != NDT2D_OK) return rc;
   if (h_scores != nullptr) std::memcpy(h_scores, h->host_res + kScoreSlot, h->few_n_poses * sizeof(double));
   if (h->few_stats && h_out != nullptr)
@@ -1732,6 +1772,7 @@ int run_few_launch(ndt2d_context * h, const double * arg_beams, size_t n_beams, 
     out.dev_poses = poses_in_place ? h->tmp_poses.ptr : nullptr;
   }
   out.side = h->bytes_job;   // (n == 0: none)
+  const uint64_t flag_pos = h->queued;   // (every mark so far is behind work queued before this kernel)
   hipError_t e = ndt2d::launch_score_few(a, &few, out, arg_beams, h->stream);
   if (e != hipSuccess) return fail_hip(h, e, "launch_score_few");
   h->bytes_job.n = 0;
@@ -1740,6 +1781,7 @@ int run_few_launch(ndt2d_context * h, const double * arg_beams, size_t n_beams, 
   h->last_variant = h->grid.pow2 ? "poses/block-per-pose/pow2" : "poses/block-per-pose/div";
   h->few_pending = true;
   h->few_seq = out.seq;
+  h->few_pos = flag_pos;
   h->few_n_poses = n_poses;
   h->few_stats = stats;
   return NDT2D_OK;
@@ -1825,14 +1867,14 @@ int ndt2d_convert_scan(ndt2d_handle h, const float * h_ranges, size_t n_ranges,
   if (rc != NDT2D_OK) return rc;
   double info[2] = {0.0, 0.0};
   NDT2D_HIP(h, hipMemcpyAsync(info, h->scan_info.ptr, sizeof(info), hipMemcpyDeviceToHost, h->stream));
-  NDT2D_HIP(h, hipStreamSynchronize(h->stream));
+  NDT2D_SYNC(h);
   const size_t n = static_cast<size_t>(info[0]);
   h->n_scan_points = n;
   if (n > 0)
   {
     NDT2D_HIP(h, hipMemcpyAsync(h_points_xy_out, h->scan_points.ptr, 2 * n * sizeof(double),
                                 hipMemcpyDeviceToHost, h->stream));
-    NDT2D_HIP(h, hipStreamSynchronize(h->stream));
+    NDT2D_SYNC(h);
   }
   *n_points_out = n;
   return NDT2D_OK;
@@ -1858,12 +1900,6 @@ int ndt2d_set_beams_from_ranges(ndt2d_handle h, const float * h_ranges, size_t n
   const size_t cap = std::min(laser_max_beams, n_ranges);
   rc = ensure(h, h->beams, 2 * cap + 2);
   if (rc != NDT2D_OK) return rc;
-  // the beam buffer may still be the target of a pending staged upload
-  if (h->stage_beams.pending)
-  {
-    NDT2D_HIP(h, hipEventSynchronize(h->stage_beams.done));
-    h->stage_beams.pending = false;
-  }
   hipError_t e = ndt2d::launch_subsample(h->scan_points.ptr, h->scan_info.ptr,
                                          static_cast<uint32_t>(laser_max_beams), h->beams.ptr,
                                          h->scan_info.ptr + 2, h->stream);
@@ -1871,7 +1907,7 @@ int ndt2d_set_beams_from_ranges(ndt2d_handle h, const float * h_ranges, size_t n
   double info[3] = {0.0, 0.0, 0.0};
   NDT2D_HIP(h, hipMemcpyAsync(info, h->scan_info.ptr + 2, sizeof(info), hipMemcpyDeviceToHost,
                               h->stream));
-  NDT2D_HIP(h, hipStreamSynchronize(h->stream));
+  NDT2D_SYNC(h);
   h->n_scan_points = static_cast<size_t>(info[0]);
   if (n_points_out != nullptr) *n_points_out = h->n_scan_points;
   const size_t use = static_cast<size_t>(info[1]);
@@ -1914,7 +1950,7 @@ int ndt2d_occupancy_grid(ndt2d_handle h, double resolution, double occ_thresh,
   NDT2D_HIP(h, hipSetDevice(h->device));
 
   // scans and points to the device (the NDT build's buffers and staging are reused)
-  NDT2D_HIP(h, hipStreamSynchronize(h->stream));
+  NDT2D_SYNC(h);
   h->stage_scans.resize(4 * n_scans + 4);
   h->stage_offsets.resize(((n_scans + 1) + 1) & ~size_t(1));
   for (size_t k = 0; k < n_scans; ++k)
@@ -1963,7 +1999,7 @@ int ndt2d_occupancy_grid(ndt2d_handle h, double resolution, double occ_thresh,
                                                     h->ws_poses.ptr, h->stats.ptr, h->stream);
       if (e != hipSuccess) return fail_hip(h, e, "launch_occupancy_bounds");
       NDT2D_HIP(h, hipMemcpyAsync(found, h->stats.ptr, sizeof(found), hipMemcpyDeviceToHost, h->stream));
-      NDT2D_HIP(h, hipStreamSynchronize(h->stream));
+      NDT2D_SYNC(h);
     }
     const double min_x = std::min(found[0], bounds_inout[0]);
     const double max_x = std::max(found[1], bounds_inout[1]);
@@ -1996,7 +2032,7 @@ int ndt2d_occupancy_grid(ndt2d_handle h, double resolution, double occ_thresh,
   info_out->origin_y = args.origin_y;
   if (data_out == nullptr)
   {
-    NDT2D_HIP(h, hipStreamSynchronize(h->stream));  // the staged uploads are done with
+    NDT2D_SYNC(h);  // the staged uploads are done with
     return NDT2D_OK;
   }
   const size_t n_cells = static_cast<size_t>(args.width) * args.height;
@@ -2009,7 +2045,7 @@ int ndt2d_occupancy_grid(ndt2d_handle h, double resolution, double occ_thresh,
   hipError_t e = ndt2d::launch_occupancy_render(args, occ_thresh, counts, d_data, h->stream);
   if (e != hipSuccess) return fail_hip(h, e, "launch_occupancy_render");
   NDT2D_HIP(h, hipMemcpyAsync(data_out, d_data, n_cells, hipMemcpyDeviceToHost, h->stream));
-  NDT2D_HIP(h, hipStreamSynchronize(h->stream));
+  NDT2D_SYNC(h);
   return NDT2D_OK;
 }
 
@@ -2028,7 +2064,7 @@ int ndt2d_device_free(ndt2d_handle h, void * d_ptr)
   if (h == nullptr) return NDT2D_ERR_INVALID;
   if (d_ptr == nullptr) return NDT2D_OK;
   NDT2D_HIP(h, hipSetDevice(h->device));
-  NDT2D_HIP(h, hipStreamSynchronize(h->stream));  // nothing in flight may still use it
+  NDT2D_SYNC(h);  // nothing in flight may still use it
   NDT2D_HIP(h, hipFree(d_ptr));
   return NDT2D_OK;
 }
@@ -2040,7 +2076,7 @@ int ndt2d_copy_to_device(ndt2d_handle h, void * d_dst, const void * h_src, size_
   if (d_dst == nullptr || h_src == nullptr) return fail(h, NDT2D_ERR_INVALID, "ndt2d_copy_to_device: null pointer");
   NDT2D_HIP(h, hipSetDevice(h->device));
   NDT2D_HIP(h, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, h->stream));
-  NDT2D_HIP(h, hipStreamSynchronize(h->stream));
+  NDT2D_SYNC(h);
   return NDT2D_OK;
 }
 
@@ -2051,7 +2087,7 @@ int ndt2d_copy_to_host(ndt2d_handle h, void * h_dst, const void * d_src, size_t 
   if (h_dst == nullptr || d_src == nullptr) return fail(h, NDT2D_ERR_INVALID, "ndt2d_copy_to_host: null pointer");
   NDT2D_HIP(h, hipSetDevice(h->device));
   NDT2D_HIP(h, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, h->stream));
-  NDT2D_HIP(h, hipStreamSynchronize(h->stream));
+  NDT2D_SYNC(h);
   return NDT2D_OK;
 }
 
@@ -2083,7 +2119,7 @@ int ndt2d_host_free(ndt2d_handle h, void * ptr)
     return e == hipSuccess ? NDT2D_OK : NDT2D_ERR_HIP;
   }
   NDT2D_HIP(h, hipSetDevice(h->device));
-  NDT2D_HIP(h, hipStreamSynchronize(h->stream));  // nothing in flight may still use it
+  NDT2D_SYNC(h);  // nothing in flight may still use it
   NDT2D_HIP(h, hipHostFree(ptr));
   return NDT2D_OK;
 }
@@ -2092,7 +2128,7 @@ int ndt2d_synchronize(ndt2d_handle h)
 {
   if (h == nullptr) return NDT2D_ERR_INVALID;
   NDT2D_HIP(h, hipSetDevice(h->device));
-  NDT2D_HIP(h, hipStreamSynchronize(h->stream));
+  NDT2D_SYNC(h);
   return NDT2D_OK;
 }
 
