@@ -1616,3 +1616,47 @@ def test_score_scan_launches_the_search_of_its_scan_ahead():
     gpu.scoreScan(guess, pts)
     assert blob(gpu.matchScan(guess, pts)) == blob(want["a"])
     assert gpu.search_ahead_stats() == (launched + 1, 4)
+
+
+def test_score_launch_and_fetch_in_two_steps(cfg1):
+    """ndt2d_score_poses_beams_launch / ndt2d_score_fetch (the kernel-argument launch of
+    ndt2d_score_poses_beams without the wait): the scores of the one-call form bit for bit;
+    what is not a kernel-argument launch is refused, a fetch without a launch is a state
+    error, results nobody fetched are dropped by the next launch."""
+    gpu, ref, scans, guess, pts = cfg1
+    cells, sx, sy, _, ox, oy = gpu.grid()
+    beams = np.ascontiguousarray(pts[:100])
+    poses = np.stack([guess + np.array([0.01 * k, -0.02 * k, 0.003 * k]) for k in range(8)])
+    L = _capi.lib()
+    h = C.c_void_p()
+    assert L.ndt2d_create(C.byref(h), 0) == 0
+    try:
+        assert L.ndt2d_set_grid(h, _capi.dptr(cells), sx, sy, 0.25, ox, oy) == 0
+        want = np.zeros(8)
+        assert L.ndt2d_score_poses_beams(h, _capi.dptr(beams), 100, _capi.dptr(poses), 8, _capi.dptr(want)) == 0
+        got = np.zeros(8)
+        assert L.ndt2d_score_fetch(h, _capi.dptr(got)) == 5                      # NDT2D_ERR_STATE: nothing launched
+        assert L.ndt2d_score_poses_beams_launch(h, _capi.dptr(beams), 100, _capi.dptr(poses), 8) == 0
+        assert L.ndt2d_score_fetch(h, _capi.dptr(got)) == 0
+        assert np.array_equal(got, want)
+        # the beams the context now holds (NULL), fewer poses; a launch nobody fetches, then another
+        assert L.ndt2d_score_poses_beams_launch(h, None, 0, _capi.dptr(poses), 8) == 0
+        assert L.ndt2d_score_poses_beams_launch(h, None, 0, _capi.dptr(poses[3:]), 2) == 0
+        got2 = np.zeros(2)
+        assert L.ndt2d_score_fetch(h, _capi.dptr(got2)) == 0
+        assert np.array_equal(got2, want[3:5])
+        assert L.ndt2d_score_fetch(h, _capi.dptr(got2)) == 5
+        # not kernel-argument launches: more than 8 poses, more than 208 beams
+        many = np.tile(poses, (2, 1))
+        assert L.ndt2d_score_poses_beams_launch(h, _capi.dptr(beams), 100, _capi.dptr(many), 16) == 5
+        wide = np.ascontiguousarray(pts[:300])
+        assert L.ndt2d_score_poses_beams_launch(h, _capi.dptr(wide), 300, _capi.dptr(poses), 8) == 5
+        # ... and the context still scores with the beams it held
+        again = np.zeros(8)
+        assert L.ndt2d_score_poses(h, _capi.dptr(poses), 8, _capi.dptr(again), None) == 0
+        assert np.array_equal(again, want)
+        # (ref was initialised with laser_max_beams = 720: 100 points are taken whole)
+        for k in range(8):
+            assert abs(want[k] - ref.scorePoints(beams, poses[k])) < TOL_TIGHT
+    finally:
+        L.ndt2d_destroy(h)
