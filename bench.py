@@ -450,7 +450,10 @@ def default_search_bench(matcher_cls, synth, device_index, reps=300, with_cpu=Tr
             raise SystemExit("bench.py: the real-lidar-map search differs from the oracle's")
     if c_host is not None:
         out["c_host"] = dict(c_host, what="ndt_2d_amd/tools/latency_probe.c: the same calls through the C-ABI "
-                                          "from a C program, medians of 2000 (500 for addScans / the cycle)")
+                                          "from a C program, medians of 2000 (500 for addScans / the cycle); "
+                                          "in the cycle scoreScan queues the scan's search behind itself once the "
+                                          "library has seen the mapper's scoreScan / matchScan pair "
+                                          "(mapper_cycle_no_search_ahead_us: with that turned off)")
         out["match_scan_ms"] = c_host["match_scan_us"] * 1e-3
         out["mapper_cycle_ms"] = c_host["mapper_cycle_us"] * 1e-3
         out["match_scan_value"] = units / (c_host["match_scan_us"] * 1e-6)

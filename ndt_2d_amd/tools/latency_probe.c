@@ -13,6 +13,7 @@
  */
 #define _POSIX_C_SOURCE 199309L
 #include <math.h>
+#include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -144,7 +145,7 @@ int main(void)
   ndt2d_set_timing(ndt2d_matcher_device(m), 0);   /* as the shim does */
   op_add();
 
-  double med[7], p99[7];
+  double med[8], p99[8];
   measure(op_match, REPS, &med[0], &p99[0]);
   measure(op_score_scan, REPS, &med[1], &p99[1]);
   measure(op_add, REPS / 4, &med[2], &p99[2]);
@@ -152,6 +153,13 @@ int main(void)
   measure(op_pf_loop, 20, &med[4], &p99[4]);
   measure(op_pf_batch, REPS / 4, &med[5], &p99[5]);
   measure(op_pf_measure, REPS / 4, &med[6], &p99[6]);
+  /* the cycle once more with scoreScan NOT launching the scan's search ahead (the library does that
+   * once it has seen the mapper's scoreScan / matchScan pair; ndt2d_matcher_set_search_ahead) */
+  ndt2d_matcher_set_search_ahead(m, 0);
+  measure(op_cycle, REPS / 4, &med[7], &p99[7]);
+  ndt2d_matcher_set_search_ahead(m, 1);
+  uint64_t ahead_launched = 0, ahead_collected = 0;
+  ndt2d_matcher_search_ahead_stats(m, &ahead_launched, &ahead_collected);
   double pose[3] = {0, 0, 0}, cov[9], score;
   ndt2d_matcher_match_scan(m, guess, scan_pts, N_BEAMS, pose, cov, &score);
   char variant[128];
@@ -190,32 +198,39 @@ int main(void)
   ndt2d_matcher_initialize(m, 0.25, 0.0025, 0.1, 0.005, 0.05, 100, 30.0);
   ndt2d_set_timing(ndt2d_matcher_device(m), 0);
   op_add();
-  double rmed[4], rp99[4];
+  double rmed[5], rp99[5];
   measure(op_match, REPS, &rmed[0], &rp99[0]);
   measure(op_score_scan, REPS, &rmed[1], &rp99[1]);
   measure(op_add, REPS / 4, &rmed[2], &rp99[2]);
   measure(op_cycle, REPS / 4, &rmed[3], &rp99[3]);
+  ndt2d_matcher_set_search_ahead(m, 0);
+  measure(op_cycle, REPS / 4, &rmed[4], &rp99[4]);
+  ndt2d_matcher_set_search_ahead(m, 1);
   uint32_t gsx = 0, gsy = 0;
   ndt2d_matcher_grid_info(m, &gsx, &gsy, NULL, NULL, NULL);
   double rpose[3] = {0, 0, 0}, rscore;
   ndt2d_matcher_match_scan(m, guess, scan_pts, N_BEAMS, rpose, cov, &rscore);
   char rvariant[128];
   snprintf(rvariant, sizeof(rvariant), "%s", ndt2d_last_variant(ndt2d_matcher_device(m)));
-  char real[640];
+  char real[800];
   snprintf(real, sizeof(real),
            "{\"grid\": [%u, %u], \"map_scans\": %zu, \"range_max_m\": 30.0, \"match_scan_us\": %.2f, "
            "\"match_scan_p99_us\": %.2f, \"score_scan_us\": %.2f, \"add_scans_us\": %.2f, "
-           "\"mapper_cycle_us\": %.2f, \"mapper_cycle_p99_us\": %.2f, \"variant\": \"%s\", "
+           "\"mapper_cycle_us\": %.2f, \"mapper_cycle_p99_us\": %.2f, "
+           "\"mapper_cycle_no_search_ahead_us\": %.2f, \"variant\": \"%s\", "
            "\"check_pose\": [%.17g, %.17g, %.17g], \"check_score\": %.17g}",
-           gsx, gsy, n_map_scans, rmed[0], rp99[0], rmed[1], rmed[2], rmed[3], rp99[3], rvariant, rpose[0],
-           rpose[1], rpose[2], rscore);
+           gsx, gsy, n_map_scans, rmed[0], rp99[0], rmed[1], rmed[2], rmed[3], rp99[3], rmed[4], rvariant,
+           rpose[0], rpose[1], rpose[2], rscore);
   printf("{\"match_scan_us\": %.2f, \"match_scan_p99_us\": %.2f, \"score_scan_us\": %.2f, "
          "\"add_scans_us\": %.2f, \"mapper_cycle_us\": %.2f, \"mapper_cycle_p99_us\": %.2f, "
+         "\"mapper_cycle_no_search_ahead_us\": %.2f, \"search_ahead_launched\": %llu, "
+         "\"search_ahead_collected\": %llu, "
          "\"measure_500_particles_unchanged_loop_us\": %.1f, \"score_points_call_us\": %.2f, "
          "\"measure_500_particles_batched_us\": %.2f, \"pf_measure_500_particles_us\": %.2f, "
          "\"variant\": \"%s\", "
          "\"check_pose\": [%.17g, %.17g, %.17g], \"check_score\": %.17g, \"real_lidar_map\": %s}\n",
-         med[0], p99[0], med[1], med[2], med[3], p99[3], med[4], med[4] / 500.0, med[5], med[6],
+         med[0], p99[0], med[1], med[2], med[3], p99[3], med[7], (unsigned long long)ahead_launched,
+         (unsigned long long)ahead_collected, med[4], med[4] / 500.0, med[5], med[6],
          variant, pose[0], pose[1], pose[2], score, real);
   ndt2d_matcher_destroy(m);
   return 0;
