@@ -44,6 +44,7 @@ int main(int argc, char ** argv)
     const double e = now_us();
     if (r >= 0) { t[0] += b - a; t[1] += c - b; t[2] += d - c; t[3] += e - d; }
   }
+  { unsigned long long hsh = 1469598103934665603ull; for (double d : c6) { unsigned long long b; memcpy(&b, &d, 8); hsh = (hsh ^ b) * 1099511628211ull; } printf("cells hash %016llx  ", hsh); }
   printf("toy=%d cells touched %zu of %zu: reset %.2f us, add_scan x%zu %.2f us, compute %.2f us, sparse6 %.2f us\n", toy, idx.size(), ndt->ncell(), t[0]/reps, n, t[1]/reps, t[2]/reps, t[3]/reps);
   return 0;
 }
