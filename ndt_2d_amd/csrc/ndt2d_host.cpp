@@ -929,6 +929,16 @@ int ndt2d_matcher_score_scan(ndt2d_matcher * m, const double * scan_pose_xyt,
     if (use > 0)
     {
       rc = ndt2d_score_poses_beams_launch(m->dev, pending ? m->beams.data() : nullptr, use, scan_pose_xyt, 1);
+      if (rc == NDT2D_ERR_STATE && pending)
+      {
+        // more beams than travel as kernel arguments: one staged upload, then the launch on
+        // the beams the device holds
+        rc = ndt2d_set_beams(m->dev, m->beams.data(), use);
+        if (rc != NDT2D_OK) return dev_fail(m, rc, "ndt2d_set_beams");
+        m->beams_on_device = true;
+        pending = false;
+        rc = ndt2d_score_poses_beams_launch(m->dev, nullptr, use, scan_pose_xyt, 1);
+      }
       if (rc == NDT2D_OK)
       {
         m->beams_on_device = true;
@@ -946,9 +956,10 @@ int ndt2d_matcher_score_scan(ndt2d_matcher * m, const double * scan_pose_xyt,
         rc = ndt2d_score_fetch(m->dev, score_out);
         if (rc != NDT2D_OK)
         {
+          const int frc = dev_fail(m, rc, "ndt2d_score_fetch");   // (the message, before anything else talks to the device)
           discard_ahead(m);
           m->beams_on_device = false;
-          return dev_fail(m, rc, "ndt2d_score_fetch");
+          return frc;
         }
         m->score_scan_last = true;
         std::memcpy(m->score_scan_pose, scan_pose_xyt, sizeof(m->score_scan_pose));

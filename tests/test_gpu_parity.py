@@ -1541,14 +1541,16 @@ def test_list_install_rejects_a_cell_listed_twice():
         L.ndt2d_destroy(h)
 
 
-def test_score_scan_launches_the_search_of_its_scan_ahead():
+@pytest.mark.parametrize("max_beams", [100, 720])
+def test_score_scan_launches_the_search_of_its_scan_ahead(max_beams):
     """The mapper's pair scoreScan(scan), matchScan(scan, ...) (reference src/ndt_mapper.cpp:
     514-515): once a matcher has seen it, scoreScan queues the search behind its own kernel and
     matchScan collects it.  Same bits as a matcher that never launches ahead, and the oracle's;
     calls that break the pattern (another pose, another scan, per-candidate scores wanted, a
     scorePoints or a reset in between) drop the search and still get their own results."""
     over = dict(search_angular_size=0.1, search_angular_resolution=0.0025, search_linear_size=0.05,
-                search_linear_resolution=0.005, laser_max_beams=100)
+                search_linear_resolution=0.005, laser_max_beams=max_beams)
+    # (720 beams do not travel as kernel arguments: one staged upload, then the same two launches)
     scans = synth.map_scans(1)
     params = synth.matcher_params(1, **over)
     ref = O.ScanMatcherNDT()
@@ -1570,7 +1572,7 @@ def test_score_scan_launches_the_search_of_its_scan_ahead():
     plain.addScans(scans)
     want = {k: plain.matchScan(g, p) for k, (g, p) in dict(a=(guess, pts), b=(other, pts), c=(guess, pts2)).items()}
     for k in want:
-        _check_match(want[k], exp[k], 100)
+        _check_match(want[k], exp[k], max_beams)
     assert plain.search_ahead_stats() == (0, 0)
 
     gpu = ScanMatcherNDT(0)
@@ -1593,7 +1595,7 @@ def test_score_scan_launches_the_search_of_its_scan_ahead():
             assert blob(gpu.matchScan(guess, pts2)) == blob(want["c"])
         elif breaker == "scores":
             got = gpu.matchScan(guess, pts, want_scores=True)
-            _check_match(got, exp["a"], 100)
+            _check_match(got, exp["a"], max_beams)
             assert blob(got) == blob(want["a"])
         elif breaker == "scorePoints":
             assert abs(gpu.scorePoints(pts, guess) - exp_score) < TOL_TIGHT
