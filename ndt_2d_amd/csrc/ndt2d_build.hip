@@ -389,21 +389,6 @@ __global__ void __launch_bounds__(256) grid_install_kernel(const GridDesc g, con
   const uint32_t n_bytes = (g.size_x + 2) * (g.size_y + 2);
   uint32_t * b32 = reinterpret_cast<uint32_t *>(bytes);
   for (uint32_t i = blockIdx.x * 256 + tid; i < (n_bytes + 3) / 4; i += stride) b32[i] = 0u;
-
-  if (im.consumed_flag != nullptr)
-  {
-    // everything this block reads of the staged image has arrived (it has been used above)
-    __syncthreads();
-    if (tid == 0)
-    {
-      const uint32_t arrived = __hip_atomic_fetch_add(im.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
-      if (arrived == gridDim.x)
-      {
-        __hip_atomic_store(im.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        raise_host_flag(reinterpret_cast<double *>(im.consumed_flag), im.consumed_seq);
-      }
-    }
-  }
 }
 
 // The map bytes around the listed cells (sparse_byte_rows, ndt2d_lane_fn.h) as a launch of its own.

@@ -37,9 +37,6 @@ struct PinnedStage
   // buffer may be written again once the stream is known to have passed it
   bool pending = false;
   uint64_t needed = 0;
-  // (optional) a host-coherent word the buffer's reader raises to `needed` when it is done
-  // reading: what a host that refills the buffer before any later result is back spins on
-  volatile unsigned long long * consumed = nullptr;
 };
 
 struct ndt2d_context
@@ -198,16 +195,10 @@ int stage_wait(ndt2d_context * h, PinnedStage & st)
 {
   if (st.pending)
   {
-    if (h->reached < st.needed && st.consumed != nullptr)
-    {
-      for (int i = 0; i < (1 << 18) && *st.consumed < st.needed; ++i) __builtin_ia32_pause();
-      if (*st.consumed >= st.needed)
-      {
-        __atomic_thread_fence(__ATOMIC_ACQUIRE);
-        st.pending = false;
-        return NDT2D_OK;
-      }
-    }
+    // (nobody has fetched a result since the mark -- back-to-back addScans, say: the stream is
+    // asked.  A word the reader raises in host memory when it has read the buffer was tried: it
+    // costs the install kernel 1.3 us in every mapper cycle to save 8 us in a sequence no node
+    // produces; hipStreamQuery is slower than the synchronisation.)
     if (h->reached < st.needed) NDT2D_SYNC(h);
     st.pending = false;
   }
@@ -309,7 +300,6 @@ ndt2d::MotionParams motion_params(double dx, double dy, double dth, const double
 }
 
 constexpr int kScoreFlagSlot = 24;
-constexpr int kGridConsumedSlot = 20;   // raised by the install kernel: the grid's staging buffer has been read
 constexpr int kScoreSlot = 32;                                             // scores / weights of a small batch
 constexpr int kPfOutSlot = kScoreSlot + static_cast<int>(ndt2d::kFewPosesMax);   // its statistics
 constexpr int kHostResDoubles = kPfOutSlot + 32;
@@ -653,7 +643,6 @@ int ndt2d_set_grid(ndt2d_handle h, const double * cells6, uint32_t size_x, uint3
                                          reinterpret_cast<uint32_t *>(h->occ_bits.ptr),
                                          reinterpret_cast<uint8_t *>(h->cell_bytes.ptr), h->stream);
   if (e != hipSuccess) return fail_hip(h, e, "launch_pack_grid");
-  h->stage_grid.consumed = nullptr;   // (no kernel of this path says when the buffer has been read)
   if ((rc = stage_mark(h, h->stage_grid)) != NDT2D_OK) return rc;   // (behind the kernel, see stage_copy)
   g.cells_lds_image = h->cells_lds_image.ptr;
   g.cells_global = h->cells_global.ptr;
@@ -914,18 +903,12 @@ int ndt2d_set_grid_sparse(ndt2d_handle h, const uint32_t * cell_index, const dou
   {
     image.src = h->stage_grid.dev;
     image.dst = h->compact.ptr;
-    if ((rc = ensure_host_res(h)) != NDT2D_OK) return rc;
-    image.consumed_flag = reinterpret_cast<unsigned long long *>(h->host_res_dev + kGridConsumedSlot);
-    image.consumed_seq = h->queued + 1;   // = the mark stage_mark hands out below
-    image.ticket = reinterpret_cast<uint32_t *>(h->done_words + ndt2d::kFewPosesMax);
-    h->stage_grid.consumed = reinterpret_cast<volatile unsigned long long *>(h->host_res + kGridConsumedSlot);
   }
   else
   {
     if ((rc = stage_copy(h, h->stage_grid, h->compact.ptr, n_upload)) != NDT2D_OK) return rc;
     image.src = h->compact.ptr;
     image.dst = nullptr;
-    h->stage_grid.consumed = nullptr;
   }
 
   GridDesc g{};

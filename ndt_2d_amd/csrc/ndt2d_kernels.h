@@ -159,12 +159,6 @@ struct SparseImage
   double * dst;
   uint32_t n;            // listed cells
   size_t off_idx, off_rk, off_compact, n_compact, off_occ;
-  // (optional) host-coherent word that receives `consumed_seq` once every block has read what it
-  // reads of src -- a host that wants to refill the staging buffer before any later result is
-  // back spins on it; ticket: a zeroed device word the blocks count themselves in
-  unsigned long long * consumed_flag;
-  unsigned long long consumed_seq;
-  uint32_t * ticket;
 };
 hipError_t launch_grid_install(const GridDesc & geometry, const SparseImage & image, double * cells_lds_image,
                                double * cells_global, uint32_t * occ_bits, uint8_t * cell_bytes,

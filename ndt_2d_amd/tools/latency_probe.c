@@ -86,20 +86,31 @@ static void op_pf_batch(void)
   if (ndt2d_matcher_score_poses(m, scan_pts, N_BEAMS, pf_poses, 500, w) != NDT2D_OK) exit(8);
 }
 
-static void measure(void (*op)(void), int reps, double * median, double * p99)
+/* between (optional): an untimed call after every timed one */
+static void measure_between(void (*op)(void), void (*between)(void), int reps, double * median, double * p99)
 {
   double * t = (double *)malloc(sizeof(double) * (size_t)reps);
-  for (int i = 0; i < reps / 10 + 5; ++i) op();
+  for (int i = 0; i < reps / 10 + 5; ++i)
+  {
+    op();
+    if (between != NULL) between();
+  }
   for (int i = 0; i < reps; ++i)
   {
     const double t0 = now_us();
     op();
     t[i] = now_us() - t0;
+    if (between != NULL) between();
   }
   qsort(t, (size_t)reps, sizeof(double), cmp);
   *median = t[reps / 2];
   *p99 = t[(int)(reps * 0.99)];
   free(t);
+}
+
+static void measure(void (*op)(void), int reps, double * median, double * p99)
+{
+  measure_between(op, NULL, reps, median, p99);
 }
 
 int main(void)
@@ -148,7 +159,12 @@ int main(void)
   double med[8], p99[8];
   measure(op_match, REPS, &med[0], &p99[0]);
   measure(op_score_scan, REPS, &med[1], &p99[1]);
-  measure(op_add, REPS / 4, &med[2], &p99[2]);
+  /* reset + addScans as the node issues it: a call that returns a result (scoreScan) follows
+   * every one (untimed here).  Back to back -- nothing fetched in between -- each install first
+   * has to ask the stream whether the one before has read the staging buffer. */
+  measure_between(op_add, op_score_scan, REPS / 4, &med[2], &p99[2]);
+  double add_b2b, add_b2b_p99;
+  measure(op_add, REPS / 4, &add_b2b, &add_b2b_p99);
   measure(op_cycle, REPS / 4, &med[3], &p99[3]);
   measure(op_pf_loop, 20, &med[4], &p99[4]);
   measure(op_pf_batch, REPS / 4, &med[5], &p99[5]);
@@ -201,7 +217,9 @@ int main(void)
   double rmed[5], rp99[5];
   measure(op_match, REPS, &rmed[0], &rp99[0]);
   measure(op_score_scan, REPS, &rmed[1], &rp99[1]);
-  measure(op_add, REPS / 4, &rmed[2], &rp99[2]);
+  measure_between(op_add, op_score_scan, REPS / 4, &rmed[2], &rp99[2]);
+  double radd_b2b, radd_b2b_p99;
+  measure(op_add, REPS / 4, &radd_b2b, &radd_b2b_p99);
   measure(op_cycle, REPS / 4, &rmed[3], &rp99[3]);
   ndt2d_matcher_set_search_ahead(m, 0);
   measure(op_cycle, REPS / 4, &rmed[4], &rp99[4]);
@@ -212,24 +230,26 @@ int main(void)
   ndt2d_matcher_match_scan(m, guess, scan_pts, N_BEAMS, rpose, cov, &rscore);
   char rvariant[128];
   snprintf(rvariant, sizeof(rvariant), "%s", ndt2d_last_variant(ndt2d_matcher_device(m)));
-  char real[800];
+  char real[900];
   snprintf(real, sizeof(real),
            "{\"grid\": [%u, %u], \"map_scans\": %zu, \"range_max_m\": 30.0, \"match_scan_us\": %.2f, "
            "\"match_scan_p99_us\": %.2f, \"score_scan_us\": %.2f, \"add_scans_us\": %.2f, "
+           "\"add_scans_back_to_back_us\": %.2f, "
            "\"mapper_cycle_us\": %.2f, \"mapper_cycle_p99_us\": %.2f, "
            "\"mapper_cycle_no_search_ahead_us\": %.2f, \"variant\": \"%s\", "
            "\"check_pose\": [%.17g, %.17g, %.17g], \"check_score\": %.17g}",
-           gsx, gsy, n_map_scans, rmed[0], rp99[0], rmed[1], rmed[2], rmed[3], rp99[3], rmed[4], rvariant,
+           gsx, gsy, n_map_scans, rmed[0], rp99[0], rmed[1], rmed[2], radd_b2b, rmed[3], rp99[3], rmed[4], rvariant,
            rpose[0], rpose[1], rpose[2], rscore);
   printf("{\"match_scan_us\": %.2f, \"match_scan_p99_us\": %.2f, \"score_scan_us\": %.2f, "
-         "\"add_scans_us\": %.2f, \"mapper_cycle_us\": %.2f, \"mapper_cycle_p99_us\": %.2f, "
+         "\"add_scans_us\": %.2f, \"add_scans_back_to_back_us\": %.2f, "
+         "\"mapper_cycle_us\": %.2f, \"mapper_cycle_p99_us\": %.2f, "
          "\"mapper_cycle_no_search_ahead_us\": %.2f, \"search_ahead_launched\": %llu, "
          "\"search_ahead_collected\": %llu, "
          "\"measure_500_particles_unchanged_loop_us\": %.1f, \"score_points_call_us\": %.2f, "
          "\"measure_500_particles_batched_us\": %.2f, \"pf_measure_500_particles_us\": %.2f, "
          "\"variant\": \"%s\", "
          "\"check_pose\": [%.17g, %.17g, %.17g], \"check_score\": %.17g, \"real_lidar_map\": %s}\n",
-         med[0], p99[0], med[1], med[2], med[3], p99[3], med[7], (unsigned long long)ahead_launched,
+         med[0], p99[0], med[1], med[2], add_b2b, med[3], p99[3], med[7], (unsigned long long)ahead_launched,
          (unsigned long long)ahead_collected, med[4], med[4] / 500.0, med[5], med[6],
          variant, pose[0], pose[1], pose[2], score, real);
   ndt2d_matcher_destroy(m);
