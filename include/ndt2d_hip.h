@@ -87,6 +87,16 @@ int ndt2d_set_grid(ndt2d_handle h, const double * cells6, uint32_t size_x, uint3
 int ndt2d_set_grid_sparse(ndt2d_handle h, const uint32_t * cell_index, const double * cells6,
                           size_t n_listed, uint32_t size_x, uint32_t size_y, double cell_size,
                           double origin_x, double origin_y);
+
+/* The same in two steps, for a host that can write its list straight into the library's pinned
+ * staging buffer (no intermediate copy): begin hands out room for up to `capacity` listed cells
+ * (cell_index_out[k], cells6_out[6 k .. 6 k + 5]), commit installs the first n_listed of them.
+ * Nothing else may be called on the context in between. */
+int ndt2d_grid_stage_begin(ndt2d_handle h, uint32_t size_x, uint32_t size_y, size_t capacity,
+                           uint32_t ** cell_index_out, double ** cells6_out);
+int ndt2d_grid_stage_commit(ndt2d_handle h, size_t n_listed, double cell_size, double origin_x,
+                            double origin_y);
+
 /* Build the NDT on the device from the scans themselves and install it: the
  * whole of ScanMatcherNDT::addScans (src/scan_matcher_ndt.cpp:49-74) --
  * bounding box of the scan poses +- range_max, NDT::addScan for every scan in

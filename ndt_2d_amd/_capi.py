@@ -90,6 +90,9 @@ SIGNATURES = {
     "ndt2d_score_poses_launch": (C.c_int, [_vp, _vp, _sz, _vp, _vp]),
     "ndt2d_score_poses": (C.c_int, [_vp, _dp, _sz, _dp, _dp]),
     "ndt2d_score_poses_beams": (C.c_int, [_vp, _dp, _sz, _dp, _sz, _dp]),
+    "ndt2d_grid_stage_begin": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _sz, C.POINTER(C.POINTER(C.c_uint32)),
+                                         C.POINTER(C.POINTER(C.c_double))]),
+    "ndt2d_grid_stage_commit": (C.c_int, [_vp, _sz, _d, _d, _d]),
     "ndt2d_score_poses_beams_launch": (C.c_int, [_vp, _dp, _sz, _dp, _sz]),
     "ndt2d_score_fetch": (C.c_int, [_vp, _dp]),
     "ndt2d_pf_finalize_launch": (C.c_int, [_vp, _vp, _sz, _vp, _vp, _vp]),

@@ -56,6 +56,10 @@ struct ndt2d_context
   // Only the small-lattice search reads them: the job rides along in the next few-pose launch
   // (the mapper's scoreScan) or runs ahead of the next search, whichever comes first.
   ndt2d::SparseBytesJob bytes_job{};
+  // ndt2d_grid_stage_begin ... _commit: capacity (0: none open) and grid size of the open list
+  size_t stage_cap = 0;
+  uint32_t stage_sx = 0, stage_sy = 0;
+  bool stage_may_compact = false;
   DeviceBuffer compact;     // [cells6 | compact records | cell ranks]: ndt2d_set_grid's upload
   DeviceBuffer cells6;    // raw {mean, information, n} records of a device-built grid
   const double * cells6_ptr = nullptr;  // ... of the installed grid, wherever they live
@@ -800,57 +804,94 @@ int ndt2d_build_grid(ndt2d_handle h, double ndt_resolution, double range_max,
 // CU's LDS minus its map): beyond it the compacted form is not prepared.
 static constexpr size_t kCompactImageBudget = 80 * 1024;
 
-int ndt2d_set_grid_sparse(ndt2d_handle h, const uint32_t * cell_index, const double * cells6,
-                          size_t n_listed, uint32_t size_x, uint32_t size_y, double cell_size,
-                          double origin_x, double origin_y)
+// Layout of the staged image of a list install for a capacity of `cap` listed cells (doubles):
+// [cells6: 6 cap][cell indices: cap u32][ranks of the listed cells: cap u16][compact records:
+// (cap + 1) x 6][occupancy words of the grid]
+struct StageLayout
+{
+  size_t n6, n_idx, n_rk, n_compact_max, off_occ, n_words, n_upload;
+};
+static StageLayout stage_layout(size_t cap, uint32_t ncell, bool with_compact)
+{
+  StageLayout l{};
+  l.n6 = cap * 6;
+  l.n_idx = (cap + 1) / 2;
+  l.n_rk = (cap + 3) / 4;
+  if ((l.n6 + l.n_idx + l.n_rk) & 1) ++l.n_rk;   // the compact records are read with 16-byte loads
+  l.n_compact_max = with_compact ? (cap + 1) * kCellDoubles : 0;
+  // (occupancy words of the cells that can score: they tell the install kernel which cells
+  // the list will write, ndt2d_build.hip)
+  l.n_words = (static_cast<size_t>(ncell) + 1 + 31) / 32;
+  l.off_occ = l.n6 + l.n_idx + l.n_rk + l.n_compact_max;
+  l.n_upload = l.off_occ + (l.n_words + 1) / 2 + 2;
+  return l;
+}
+
+int ndt2d_grid_stage_begin(ndt2d_handle h, uint32_t size_x, uint32_t size_y, size_t capacity,
+                           uint32_t ** cell_index_out, double ** cells6_out)
 {
   if (h == nullptr) return NDT2D_ERR_INVALID;
-  if ((n_listed > 0 && (cell_index == nullptr || cells6 == nullptr)) || size_x == 0 || size_y == 0 ||
-      !(cell_size > 0.0) || n_listed >= (1ull << 31))
+  h->stage_cap = 0;
+  if (cell_index_out == nullptr || cells6_out == nullptr || size_x == 0 || size_y == 0 || capacity >= (1ull << 31))
   {
-    return fail(h, NDT2D_ERR_INVALID, "ndt2d_set_grid_sparse: bad argument");
+    return fail(h, NDT2D_ERR_INVALID, "ndt2d_grid_stage_begin: bad argument");
   }
   const uint64_t ncell64 = static_cast<uint64_t>(size_x) * size_y;
-  if (ncell64 >= (1ull << 31)) return fail(h, NDT2D_ERR_INVALID, "ndt2d_set_grid_sparse: grid too large");
+  if (ncell64 >= (1ull << 31)) return fail(h, NDT2D_ERR_INVALID, "ndt2d_grid_stage_begin: grid too large");
   const uint32_t ncell = static_cast<uint32_t>(ncell64);
-  const uint32_t n = static_cast<uint32_t>(n_listed);
-  for (uint32_t k = 0; k < n; ++k)
-  {
-    if (cell_index[k] >= ncell) return fail(h, NDT2D_ERR_INVALID, "ndt2d_set_grid_sparse: cell index out of range");
-  }
   NDT2D_HIP(h, hipSetDevice(h->device));
   h->has_grid = false;   // (see ndt2d_set_grid)
   h->bytes_job.n = 0;
-
-  uint32_t n_occ = 0;
-  for (uint32_t k = 0; k < n; ++k) n_occ += !(cells6[6 * static_cast<size_t>(k) + 5] < 5.0) ? 1u : 0u;
+  const size_t cap = capacity > 0 ? capacity : 1;
+  // the compacted records are prepared only when their image could fit a search kernel's LDS
   const size_t rank_table_bytes = (static_cast<size_t>(ncell) + 1 + 7) / 8 * 16;
-  const bool compactable = n_occ > 0 && n_occ < 65535u &&
-                           rank_table_bytes + (static_cast<size_t>(n_occ) + 1) * kCellDoubles * sizeof(double) <=
-                             kCompactImageBudget;
-  // one staged copy: [cells6: 6 n][cell indices: n u32][ranks of the listed cells: n u16][compact records]
-  const size_t n6 = static_cast<size_t>(n) * 6;
-  const size_t n_idx = (static_cast<size_t>(n) + 1) / 2;
-  size_t n_rk = (static_cast<size_t>(n) + 3) / 4;
-  if ((n6 + n_idx + n_rk) & 1) ++n_rk;   // the compact records are read with 16-byte loads
-  const size_t n_compact = compactable ? static_cast<size_t>(n_occ + 1) * kCellDoubles : 0;
-  // (occupancy words of the cells that can score: they tell the install kernel which cells
-  // the list will write, ndt2d_build.hip)
-  const size_t n_words = (static_cast<size_t>(ncell) + 1 + 31) / 32;
-  const size_t off_occ = n6 + n_idx + n_rk + n_compact;
-  const size_t n_upload = off_occ + (n_words + 1) / 2 + 2;
+  const bool may_compact = rank_table_bytes + 2 * kCellDoubles * sizeof(double) <= kCompactImageBudget;
+  const StageLayout l = stage_layout(cap, ncell, may_compact);
   int rc;
-  if ((rc = ensure(h, h->compact, n_upload)) != NDT2D_OK) return rc;
+  if ((rc = ensure(h, h->compact, l.n_upload)) != NDT2D_OK) return rc;
   if ((rc = ensure(h, h->cells_lds_image, static_cast<size_t>(ncell + 1) * kCellDoubles)) != NDT2D_OK) return rc;
   if ((rc = ensure(h, h->cells_global, static_cast<size_t>(ncell + 1) * kCellStrideGlobal)) != NDT2D_OK) return rc;
   if ((rc = ensure(h, h->occ_bits, ((static_cast<size_t>(ncell) + 1 + 31) / 32 + 2) / 2)) != NDT2D_OK) return rc;
   if ((rc = ensure(h, h->cell_bytes, (static_cast<size_t>(size_x) + 2) * (size_y + 2) / 8 + 1)) != NDT2D_OK) return rc;
-  if (compactable && (rc = ensure(h, h->ranks, rank_table_bytes / sizeof(double) + 2)) != NDT2D_OK) return rc;
-  if ((rc = stage_acquire(h, h->stage_grid, n_upload)) != NDT2D_OK) return rc;
+  if (may_compact && (rc = ensure(h, h->ranks, rank_table_bytes / sizeof(double) + 2)) != NDT2D_OK) return rc;
+  if ((rc = stage_acquire(h, h->stage_grid, l.n_upload)) != NDT2D_OK) return rc;
+  h->stage_cap = cap;
+  h->stage_sx = size_x;
+  h->stage_sy = size_y;
+  h->stage_may_compact = may_compact;
+  *cells6_out = h->stage_grid.ptr;
+  *cell_index_out = reinterpret_cast<uint32_t *>(h->stage_grid.ptr + l.n6);
+  return NDT2D_OK;
+}
+
+int ndt2d_grid_stage_commit(ndt2d_handle h, size_t n_listed, double cell_size, double origin_x, double origin_y)
+{
+  if (h == nullptr) return NDT2D_ERR_INVALID;
+  if (h->stage_cap == 0) return fail(h, NDT2D_ERR_STATE, "ndt2d_grid_stage_commit: no ndt2d_grid_stage_begin before it");
+  const size_t cap = h->stage_cap;
+  h->stage_cap = 0;
+  if (n_listed > cap || !(cell_size > 0.0)) return fail(h, NDT2D_ERR_INVALID, "ndt2d_grid_stage_commit: bad argument");
+  const uint32_t size_x = h->stage_sx, size_y = h->stage_sy;
+  const uint32_t ncell = size_x * size_y;
+  const uint32_t n = static_cast<uint32_t>(n_listed);
+  const StageLayout l = stage_layout(cap, ncell, h->stage_may_compact);
+  const size_t n6 = l.n6, n_idx = l.n_idx, n_rk = l.n_rk, off_occ = l.off_occ, n_words = l.n_words, n_upload = l.n_upload;
   double * st = h->stage_grid.ptr;
-  if (n > 0) std::memcpy(st, cells6, n6 * sizeof(double));
+  const double * cells6 = st;
   uint32_t * st_idx = reinterpret_cast<uint32_t *>(st + n6);
-  if (n > 0) std::memcpy(st_idx, cell_index, static_cast<size_t>(n) * sizeof(uint32_t));
+  const uint32_t * cell_index = st_idx;
+  for (uint32_t k = 0; k < n; ++k)
+  {
+    if (cell_index[k] >= ncell) return fail(h, NDT2D_ERR_INVALID, "ndt2d_set_grid_sparse: cell index out of range");
+  }
+  uint32_t n_occ = 0;
+  for (uint32_t k = 0; k < n; ++k) n_occ += !(cells6[6 * static_cast<size_t>(k) + 5] < 5.0) ? 1u : 0u;
+  const size_t rank_table_bytes = (static_cast<size_t>(ncell) + 1 + 7) / 8 * 16;
+  const bool compactable = h->stage_may_compact && n_occ > 0 && n_occ < 65535u &&
+                           rank_table_bytes + (static_cast<size_t>(n_occ) + 1) * kCellDoubles * sizeof(double) <=
+                             kCompactImageBudget;
+  const size_t n_compact = compactable ? static_cast<size_t>(n_occ + 1) * kCellDoubles : 0;
+  int rc;
   uint16_t * st_rk = reinterpret_cast<uint16_t *>(st + n6 + n_idx);
   double * st_rec = st + n6 + n_idx + n_rk;
   uint32_t * st_occ = reinterpret_cast<uint32_t *>(st + off_occ);
@@ -952,6 +993,28 @@ int ndt2d_set_grid_sparse(ndt2d_handle h, const uint32_t * cell_index, const dou
   h->block_bytes_log2 = -1;
   h->has_grid = true;
   return NDT2D_OK;
+}
+
+int ndt2d_set_grid_sparse(ndt2d_handle h, const uint32_t * cell_index, const double * cells6,
+                          size_t n_listed, uint32_t size_x, uint32_t size_y, double cell_size,
+                          double origin_x, double origin_y)
+{
+  if (h == nullptr) return NDT2D_ERR_INVALID;
+  if ((n_listed > 0 && (cell_index == nullptr || cells6 == nullptr)) || size_x == 0 || size_y == 0 ||
+      !(cell_size > 0.0) || n_listed >= (1ull << 31))
+  {
+    return fail(h, NDT2D_ERR_INVALID, "ndt2d_set_grid_sparse: bad argument");
+  }
+  uint32_t * st_idx = nullptr;
+  double * st_cells6 = nullptr;
+  const int rc = ndt2d_grid_stage_begin(h, size_x, size_y, n_listed, &st_idx, &st_cells6);
+  if (rc != NDT2D_OK) return rc;
+  if (n_listed > 0)
+  {
+    std::memcpy(st_cells6, cells6, n_listed * 6 * sizeof(double));
+    std::memcpy(st_idx, cell_index, n_listed * sizeof(uint32_t));
+  }
+  return ndt2d_grid_stage_commit(h, n_listed, cell_size, origin_x, origin_y);
 }
 
 int ndt2d_get_grid(ndt2d_handle h, double * cells6_out, size_t capacity_cells, uint32_t * size_x,

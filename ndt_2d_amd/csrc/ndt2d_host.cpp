@@ -210,14 +210,14 @@ public:
   }
 
   // The cells that hold points, as ndt2d_set_grid_sparse takes them.
-  void sparse6(std::vector<uint32_t> & index, std::vector<double> & cells6) const
+  size_t n_touched() const { return touched_.size(); }
+  void sparse6(uint32_t * index, double * cells6) const
   {
-    index.assign(touched_.begin(), touched_.end());
-    cells6.resize(6 * touched_.size());
     for (size_t k = 0; k < touched_.size(); ++k)
     {
+      index[k] = touched_[k];
       const HostCell & c = cells_[touched_[k]];
-      double * out = cells6.data() + 6 * k;
+      double * out = cells6 + 6 * k;
       out[0] = c.mean_x;
       out[1] = c.mean_y;
       out[2] = c.info_xx;
@@ -345,8 +345,6 @@ struct ndt2d_matcher
   double range_max = 0.0;
   std::unique_ptr<HostNdt> ndt;   // host copy; empty when the NDT was built on the device
   std::unique_ptr<HostNdt> spare; // the storage of the NDT that reset() dropped, for the next build
-  std::vector<uint32_t> sparse_index;   // addScans' list of touched cells (storage reused)
-  std::vector<double> sparse_cells6;
   bool have_ndt = false;          // `ndt_` is set (reference scan_matcher_ndt.hpp:102)
   int build_mode = 0;             // 0 auto, 1 host, 2 device
   // state of the last prepare_search (subsampled beams + visited offsets)
@@ -585,11 +583,18 @@ int ndt2d_matcher_add_scans(ndt2d_matcher * m, const double * poses_xyt,
   // reads the staged list in place, two launches and no copy; 245 x 245 cells: 297 us dense ->
   // 29 us per addScans, and at 41 x 41 the list is ahead as well: 34 -> 32 us plus 7 us less
   // for the stream to be ready for the call that follows, experiments/cycle_breakdown.c).
-  m->ndt->sparse6(m->sparse_index, m->sparse_cells6);
-  const int rc = ndt2d_set_grid_sparse(m->dev, m->sparse_index.data(), m->sparse_cells6.data(),
-                                       m->sparse_index.size(), static_cast<uint32_t>(m->ndt->size_x()),
-                                       static_cast<uint32_t>(m->ndt->size_y()), m->ndt->cell_size(),
-                                       m->ndt->origin_x(), m->ndt->origin_y());
+  // (written straight into the library's pinned staging buffer: ndt2d_grid_stage_begin / _commit)
+  uint32_t * list_index = nullptr;
+  double * list_cells6 = nullptr;
+  int rc = ndt2d_grid_stage_begin(m->dev, static_cast<uint32_t>(m->ndt->size_x()),
+                                  static_cast<uint32_t>(m->ndt->size_y()), m->ndt->n_touched(), &list_index,
+                                  &list_cells6);
+  if (rc == NDT2D_OK)
+  {
+    m->ndt->sparse6(list_index, list_cells6);
+    rc = ndt2d_grid_stage_commit(m->dev, m->ndt->n_touched(), m->ndt->cell_size(), m->ndt->origin_x(),
+                                 m->ndt->origin_y());
+  }
   if (rc != NDT2D_OK)
   {
     m->ndt.reset();
