@@ -175,6 +175,10 @@ int ndt2d_match_launch_strided(ndt2d_handle h, size_t th_first, size_t th_stride
  * writes the record into host-coherent pinned memory and then raises a flag there; the
  * host spins on the flag, which returns ~4 us sooner than a stream synchronisation.) */
 int ndt2d_match_fetch(ndt2d_handle h, ndt2d_match_result * out);
+/* Searches launched and results fetched on this context so far: a layer that leaves a search
+ * pending across calls (ndt2d_matcher_score_scan launches the next matchScan's search) checks
+ * with these that nobody else launched or fetched on the context in between. */
+int ndt2d_match_status(ndt2d_handle h, uint64_t * n_launched, uint64_t * n_fetched);
 /* launch + fetch; h_scores (host pointer, optional) receives the slab scores. */
 int ndt2d_match(ndt2d_handle h, size_t th_begin, size_t th_end, double * h_scores,
                 ndt2d_match_result * out);
@@ -351,6 +355,11 @@ int ndt2d_device_alloc(ndt2d_handle h, size_t bytes, void ** d_out);
 int ndt2d_device_free(ndt2d_handle h, void * d_ptr);
 int ndt2d_copy_to_device(ndt2d_handle h, void * d_dst, const void * h_src, size_t bytes);
 int ndt2d_copy_to_host(ndt2d_handle h, void * h_dst, const void * d_src, size_t bytes);
+/* The same copies queued on the context's stream without the wait: the host buffer must stay
+ * valid (and, for a copy that really is asynchronous, be pinned: ndt2d_host_alloc) until
+ * ndt2d_synchronize.  A multi-device matcher feeds its devices with these. */
+int ndt2d_copy_to_device_async(ndt2d_handle h, void * d_dst, const void * h_src, size_t bytes);
+int ndt2d_copy_to_host_async(ndt2d_handle h, void * h_dst, const void * d_src, size_t bytes);
 
 /* Pinned, GPU-mapped host memory: poses / weights buffers allocated here are read and
  * written by the kernels of the host-pointer entry points directly over PCIe (no staging
@@ -405,9 +414,47 @@ int ndt2d_set_variant(ndt2d_handle h, const char * name);
 typedef struct ndt2d_matcher ndt2d_matcher;
 
 int ndt2d_matcher_create(ndt2d_matcher ** out, int device_id);
+/* One matcher over n_dev GPUs of this process (`ndt2d_create(handle*, const int*
+ * device_ids, int n_dev)`): the plugin object the unchanged node holds, with the 8-GPU split of
+ * the loop-closure search (reference src/ndt_mapper.cpp:634-643 calls a plain matchScan) behind
+ * it.  One device context and stream per entry of device_ids, all driven by the calling thread;
+ * grid, beams and search tables are replicated by host-to-device copies.
+ *
+ *   matchScan   theta steps dealt round-robin (device r takes r, r + n_dev, ...: the cost of a
+ *               step varies across the angular range), one 12-double record per device, the
+ *               records exchanged ONCE and combined with the reference's first-wins rule
+ *               (strict `<` in visiting order, src/scan_matcher_ndt.cpp:128: the lower score,
+ *               between equal scores the lower flat index), accumulators summed in device order;
+ *   scorePoses / pf_measure   contiguous particle ranges, one exchange of the [n_dev, 8] moment
+ *               sums (the "total particle weight" of src/particle_filter.cpp:166-174), and the
+ *               theta variance of the reference's second pass (:213-217) with a second one.
+ *
+ * The exchange (ndt2d_matcher_set_exchange): "rccl" = ONE in-place ncclAllReduce(sum) of the
+ * [n_dev, 12] (or [n_dev, 8]) table per device -- every device fills its own row, x + 0 is
+ * exact -- in one ncclGroupStart / ncclGroupEnd over single-process communicators
+ * (ncclCommInitAll; xGMI between the devices), the table then read back from the first device;
+ * "host" = no collective: every device's final reduction writes its record into its context's
+ * host-coherent result block and the host combines them (a device may then appear more than
+ * once in device_ids: several contexts on one GPU, which RCCL refuses).  "auto" (default):
+ * "rccl" when all devices differ and librccl.so.1 loads, "host" otherwise.  Both give the same
+ * bits.  Work smaller than ndt2d_matcher_set_multi_min_units (candidates x beams, particles x
+ * beams; default 2e8, ~0.1 ms of one GPU) and every single-pose call stay on the first device.
+ * n_dev == 1 behaves exactly as ndt2d_matcher_create. */
+int ndt2d_matcher_create_multi(ndt2d_matcher ** out, const int * device_ids, int n_dev);
 int ndt2d_matcher_destroy(ndt2d_matcher * m);
 const char * ndt2d_matcher_last_error(ndt2d_matcher * m);
-/* The device context the matcher drives (for sharded launches / streams).  The matcher
+int ndt2d_matcher_device_count(ndt2d_matcher * m);
+/* The device context of rank `rank` (0 <= rank < device_count), NULL otherwise. */
+ndt2d_handle ndt2d_matcher_device_at(ndt2d_matcher * m, int rank);
+int ndt2d_matcher_set_exchange(ndt2d_matcher * m, const char * mode);
+int ndt2d_matcher_set_multi_min_units(ndt2d_matcher * m, double units);
+/* What the last matchScan / scorePoses / pf_measure ran as: the kernel variant of the first
+ * device (ndt2d_last_variant), prefixed "multi[n]/rccl/" or "multi[n]/host/" when the call was
+ * dealt to n devices. */
+const char * ndt2d_matcher_last_variant(ndt2d_matcher * m);
+/* ndt2d_set_timing on every device of the matcher. */
+int ndt2d_matcher_set_timing(ndt2d_matcher * m, int enabled);
+/* The (first) device context the matcher drives (for sharded launches / streams).  The matcher
  * remembers which beams it put there (a scan that arrives again is not uploaded again):
  * it must remain the only writer of this context's beams. */
 ndt2d_handle ndt2d_matcher_device(ndt2d_matcher * m);

@@ -116,6 +116,9 @@ SIGNATURES = {
     "ndt2d_device_free": (C.c_int, [_vp, _vp]),
     "ndt2d_copy_to_device": (C.c_int, [_vp, _vp, _vp, _sz]),
     "ndt2d_copy_to_host": (C.c_int, [_vp, _vp, _vp, _sz]),
+    "ndt2d_copy_to_device_async": (C.c_int, [_vp, _vp, _vp, _sz]),
+    "ndt2d_copy_to_host_async": (C.c_int, [_vp, _vp, _vp, _sz]),
+    "ndt2d_match_status": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "ndt2d_launch_history_ms": (C.c_int, [_vp, C.POINTER(C.c_float), _sz, _szp]),
     "ndt2d_host_alloc": (C.c_int, [_vp, _sz, C.POINTER(_vp)]),
     "ndt2d_host_free": (C.c_int, [_vp, _vp]),
@@ -125,6 +128,13 @@ SIGNATURES = {
     "ndt2d_last_variant": (C.c_char_p, [_vp]),
     "ndt2d_set_variant": (C.c_int, [_vp, C.c_char_p]),
     "ndt2d_matcher_create": (C.c_int, [C.POINTER(_vp), C.c_int]),
+    "ndt2d_matcher_create_multi": (C.c_int, [C.POINTER(_vp), C.POINTER(C.c_int), C.c_int]),
+    "ndt2d_matcher_device_count": (C.c_int, [_vp]),
+    "ndt2d_matcher_device_at": (_vp, [_vp, C.c_int]),
+    "ndt2d_matcher_set_exchange": (C.c_int, [_vp, C.c_char_p]),
+    "ndt2d_matcher_set_multi_min_units": (C.c_int, [_vp, _d]),
+    "ndt2d_matcher_last_variant": (C.c_char_p, [_vp]),
+    "ndt2d_matcher_set_timing": (C.c_int, [_vp, C.c_int]),
     "ndt2d_matcher_destroy": (C.c_int, [_vp]),
     "ndt2d_matcher_last_error": (C.c_char_p, [_vp]),
     "ndt2d_matcher_device": (_vp, [_vp]),

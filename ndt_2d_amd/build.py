@@ -15,8 +15,8 @@ _ROOT = os.path.dirname(_PKG)
 _CSRC = os.path.join(_PKG, "csrc")
 LIB_PATH = os.path.join(_PKG, "libndt2d_hip.so")
 
-SOURCES = ["ndt2d_kernels.hip", "ndt2d_match_lane.hip", "ndt2d_match_small.hip", "ndt2d_poses_compact.hip", "ndt2d_build.hip", "ndt2d_motion.hip", "ndt2d_scan.hip", "ndt2d_occupancy.hip", "ndt2d_device.hip", "ndt2d_host.cpp"]
-HEADERS = [os.path.join(_CSRC, "ndt2d_kernels.h"), os.path.join(_CSRC, "ndt2d_device_fn.h"), os.path.join(_CSRC, "ndt2d_lane_fn.h"), os.path.join(_ROOT, "include", "ndt2d_hip.h")]
+SOURCES = ["ndt2d_kernels.hip", "ndt2d_match_lane.hip", "ndt2d_match_small.hip", "ndt2d_poses_compact.hip", "ndt2d_build.hip", "ndt2d_motion.hip", "ndt2d_scan.hip", "ndt2d_occupancy.hip", "ndt2d_device.hip", "ndt2d_exchange.hip", "ndt2d_host.cpp"]
+HEADERS = [os.path.join(_CSRC, "ndt2d_kernels.h"), os.path.join(_CSRC, "ndt2d_device_fn.h"), os.path.join(_CSRC, "ndt2d_lane_fn.h"), os.path.join(_CSRC, "ndt2d_exchange.h"), os.path.join(_ROOT, "include", "ndt2d_hip.h")]
 ARCH = "gfx950"
 # -ffp-contract=off: the reference's x86-64 build has no fused multiply-add; the
 # kernels keep its separate roundings (see DESIGN.md "Numerics").
@@ -78,7 +78,7 @@ def build_all(force=False, verbose=False, jobs=4):
         with ThreadPoolExecutor(max_workers=max(1, min(jobs, len(stale)))) as pool:
             list(pool.map(compile_one, stale))
     cmd = [hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC"] + [_obj(s) for s in SOURCES] + \
-        ["-o", LIB_PATH]
+        ["-ldl", "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -80,6 +80,7 @@ struct ndt2d_context
   DeviceBuffer b_points, b_scans, b_offsets, b_world, b_keys, b_vals, b_temp, b_seg;
   std::vector<double> stage_scans;
   std::vector<uint32_t> stage_offsets;
+  std::vector<uint32_t> stage_seen;   // list install: one bit per cell already listed
 
   DeviceBuffer beams;
   size_t n_beams = 0;
@@ -135,6 +136,7 @@ struct ndt2d_context
   bool batched_only = false;   // "batched": small pose batches stay on the batched kernels
 
   bool match_pending = false;
+  uint64_t match_launches = 0, match_fetches = 0;   // searches launched / fetched so far (ndt2d_match_status)
   // a few-pose launch whose results have not been collected (ndt2d_score_poses_beams_launch)
   bool few_pending = false;
   unsigned long long few_seq = 0;
@@ -457,7 +459,7 @@ bool is_pow2(double v)
 
 extern "C" {
 
-int ndt2d_abi_version(void) { return 2; }
+int ndt2d_abi_version(void) { return 3; }
 
 int ndt2d_create(ndt2d_handle * out, int device_id)
 {
@@ -549,6 +551,7 @@ int ndt2d_set_stream(ndt2d_handle h, void * hip_stream)
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
   h->stream = hip_stream != nullptr ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
+  h->stage_cap = 0;
   return NDT2D_OK;
 }
 
@@ -572,6 +575,7 @@ int ndt2d_set_grid(ndt2d_handle h, const double * cells6, uint32_t size_x, uint3
   // below leaves the context without a grid, never with dangling pointers.
   h->has_grid = false;
   h->bytes_job.n = 0;
+  h->stage_cap = 0;   // an open ndt2d_grid_stage_begin is void: this call takes the staging buffer
 
   // The cells6 records travel once, through pinned staging (the caller's buffer is
   // free on return); the device derives the layouts the scorers read -- packed records
@@ -705,6 +709,7 @@ int ndt2d_build_grid(ndt2d_handle h, double ndt_resolution, double range_max,
   // as in ndt2d_set_grid: no grid until the new one is complete
   h->has_grid = false;
   h->bytes_job.n = 0;
+  h->stage_cap = 0;
 
   // staging that must stay alive until the copies are done: kept in the context
   NDT2D_SYNC(h);
@@ -897,17 +902,23 @@ int ndt2d_grid_stage_commit(ndt2d_handle h, size_t n_listed, double cell_size, d
   uint32_t * st_occ = reinterpret_cast<uint32_t *>(st + off_occ);
   std::memset(st_occ, 0, (n_words + 1) / 2 * sizeof(double));
   uint32_t k_occ = 0;
+  // every cell at most once, whether it can score or not (two records for one cell: whichever
+  // thread stored last would win, in the install kernel or in ndt2d_get_grid's scatter)
+  h->stage_seen.assign(n_words, 0u);
   for (uint32_t k = 0; k < n; ++k)
   {
     const double * c = cells6 + 6 * static_cast<size_t>(k);
+    {
+      const uint32_t bit = 1u << (cell_index[k] & 31u);
+      if (h->stage_seen[cell_index[k] >> 5] & bit)
+      {
+        return fail(h, NDT2D_ERR_INVALID, "ndt2d_set_grid_sparse: a cell is listed twice");
+      }
+      h->stage_seen[cell_index[k] >> 5] |= bit;
+    }
     if (!(c[5] < 5.0))
     {
       const uint32_t bit = 1u << (cell_index[k] & 31u);
-      if (st_occ[cell_index[k] >> 5] & bit)
-      {
-        // two records for one cell: whichever thread stored last would win
-        return fail(h, NDT2D_ERR_INVALID, "ndt2d_set_grid_sparse: a cell is listed twice");
-      }
       st_occ[cell_index[k] >> 5] |= bit;
       if (compactable)
       {
@@ -1054,6 +1065,7 @@ int ndt2d_clear_grid(ndt2d_handle h)
   if (h == nullptr) return NDT2D_ERR_INVALID;
   h->has_grid = false;
   h->bytes_job.n = 0;
+  h->stage_cap = 0;   // (an open list is dropped with the grid it was for)
   return NDT2D_OK;
 }
 
@@ -1294,6 +1306,7 @@ int ndt2d_match_launch_strided(ndt2d_handle h, size_t th_first, size_t th_stride
   h->last_kernels = info.n_kernels;
   h->last_variant = info.variant;
   h->match_pending = true;
+  ++h->match_launches;
   h->last_candidates = static_cast<uint64_t>(th_end - th_begin) * h->n_lin * h->n_lin;
   return NDT2D_OK;
 }
@@ -1312,6 +1325,15 @@ int ndt2d_match_fetch(ndt2d_handle h, ndt2d_match_result * out)
   out->best_index = rec[1] < 0.0 ? NDT2D_NO_INDEX : static_cast<uint64_t>(rec[1]);
   for (int k = 0; k < 10; ++k) out->acc[k] = rec[2 + k];
   out->n_candidates = h->last_candidates;
+  ++h->match_fetches;
+  return NDT2D_OK;
+}
+
+int ndt2d_match_status(ndt2d_handle h, uint64_t * n_launched, uint64_t * n_fetched)
+{
+  if (h == nullptr) return NDT2D_ERR_INVALID;
+  if (n_launched != nullptr) *n_launched = h->match_launches;
+  if (n_fetched != nullptr) *n_fetched = h->match_fetches;
   return NDT2D_OK;
 }
 
@@ -1818,9 +1840,12 @@ int run_few_launch(ndt2d_context * h, const double * arg_beams, size_t n_beams, 
     out.dev_poses = poses_in_place ? h->tmp_poses.ptr : nullptr;
   }
   out.side = h->bytes_job;   // (n == 0: none)
-  const uint64_t flag_pos = h->queued;   // (every mark so far is behind work queued before this kernel)
   hipError_t e = ndt2d::launch_score_few(a, &few, out, arg_beams, h->stream);
   if (e != hipSuccess) return fail_hip(h, e, "launch_score_few");
+  // the kernel reads the staged poses in place: the buffer is its until it has finished
+  if (poses_in_place && (rc = stage_mark(h, h->stage_call)) != NDT2D_OK) return rc;
+  // (every mark so far is behind this kernel or behind work queued before it: its flag proves them all)
+  const uint64_t flag_pos = h->queued;
   h->bytes_job.n = 0;
   h->timed = false;
   h->last_kernels = 1;
@@ -2134,6 +2159,26 @@ int ndt2d_copy_to_host(ndt2d_handle h, void * h_dst, const void * d_src, size_t 
   NDT2D_HIP(h, hipSetDevice(h->device));
   NDT2D_HIP(h, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, h->stream));
   NDT2D_SYNC(h);
+  return NDT2D_OK;
+}
+
+int ndt2d_copy_to_device_async(ndt2d_handle h, void * d_dst, const void * h_src, size_t bytes)
+{
+  if (h == nullptr) return NDT2D_ERR_INVALID;
+  if (bytes == 0) return NDT2D_OK;
+  if (d_dst == nullptr || h_src == nullptr) return fail(h, NDT2D_ERR_INVALID, "ndt2d_copy_to_device_async: null pointer");
+  NDT2D_HIP(h, hipSetDevice(h->device));
+  NDT2D_HIP(h, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, h->stream));
+  return NDT2D_OK;
+}
+
+int ndt2d_copy_to_host_async(ndt2d_handle h, void * h_dst, const void * d_src, size_t bytes)
+{
+  if (h == nullptr) return NDT2D_ERR_INVALID;
+  if (bytes == 0) return NDT2D_OK;
+  if (h_dst == nullptr || d_src == nullptr) return fail(h, NDT2D_ERR_INVALID, "ndt2d_copy_to_host_async: null pointer");
+  NDT2D_HIP(h, hipSetDevice(h->device));
+  NDT2D_HIP(h, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, h->stream));
   return NDT2D_OK;
 }
 

@@ -20,6 +20,7 @@
 #include <unordered_set>
 #include <vector>
 
+#include "ndt2d_exchange.h"
 #include "ndt2d_hip.h"
 
 namespace
@@ -333,9 +334,33 @@ double normalize_angle(double a)
 
 }  // namespace
 
+// What one device of a multi-device matcher keeps for the sharded calls (device memory of
+// ITS GPU, sized on demand).
+struct MatcherShard
+{
+  double * d_table = nullptr;     // [n_dev][12] record / [n_dev][8] moment table of the exchange
+  double * d_sum = nullptr;       // 8 moment sums (all devices) | 8 statistics of this device
+  double * d_scores = nullptr;    // per-candidate scores of this device's theta steps (optional)
+  size_t scores_cap = 0;
+  double * d_poses = nullptr;     // this device's particle range
+  double * d_weights = nullptr;
+  size_t poses_cap = 0;
+};
+
 struct ndt2d_matcher
 {
-  ndt2d_handle dev = nullptr;
+  ndt2d_handle dev = nullptr;            // == devs[0]: every single-pose and small call runs here
+  std::vector<ndt2d_handle> devs;        // one context per entry of device_ids
+  std::vector<int> device_ids;
+  std::vector<MatcherShard> shards;
+  int exchange_mode = 0;                 // 0 auto, 1 host, 2 rccl (ndt2d_matcher_set_exchange)
+  ndt2d::Exchange * exchange = nullptr;  // RCCL communicators, made when first needed
+  bool exchange_tried = false;
+  std::string exchange_note;             // why "auto" did not take RCCL
+  double multi_min_units = 2.0e8;        // work below this stays on the first device
+  double * pinned = nullptr;             // host block of the exchanges (layout: multi_pinned_*)
+  std::string variant;                   // ndt2d_matcher_last_variant
+  bool last_multi = false;
   std::string err;
   // the six declared parameters, reference src/scan_matcher_ndt.cpp:37-44
   double resolution = 0.25;
@@ -370,6 +395,7 @@ struct ndt2d_matcher
   bool ahead = false;             // a search launched by scoreScan has not been collected
   double ahead_pose[3] = {0.0, 0.0, 0.0};
   size_t ahead_n_th = 0;
+  uint64_t ahead_launch_id = 0, ahead_fetch_id = 0;   // ndt2d_match_status right after that launch
   int ahead_enabled = 1;          // ndt2d_matcher_set_search_ahead
   uint64_t ahead_launched = 0, ahead_collected = 0;
 };
@@ -468,42 +494,537 @@ void discard_ahead(ndt2d_matcher * m)
 {
   m->score_scan_last = false;
   if (!m->ahead) return;
-  ndt2d_match_result res;
-  (void)ndt2d_match_fetch(m->dev, &res);
+  uint64_t launched = 0, fetched = 0;
+  if (ndt2d_match_status(m->dev, &launched, &fetched) == NDT2D_OK && launched == m->ahead_launch_id &&
+      fetched == m->ahead_fetch_id)
+  {
+    ndt2d_match_result res;
+    (void)ndt2d_match_fetch(m->dev, &res);
+  }
   m->ahead = false;
   m->pair_seen = false;
+}
+
+// ---------------------------------------------------------------------------
+// Multi-device matcher (ndt2d_matcher_create_multi): the sharded calls
+// ---------------------------------------------------------------------------
+
+constexpr size_t kRec = NDT2D_MATCH_RECORD_DOUBLES;
+constexpr size_t kStats = NDT2D_POSE_STATS_DOUBLES;
+
+// Layout of m->pinned (doubles; n = number of devices):
+//   [r n 12 .. (r + 1) n 12)  initial image of device r's record table: zero, its own row {0, -1, 0 ...}
+//   zeros [n 12]              initial image of a moment table
+//   rows  [n 12]              the table read back from the first device / the rows the host combines
+//   sum   [8]                 the summed moments on their way to the devices (host exchange)
+size_t pinned_init_off(size_t n, size_t r) { return r * n * kRec; }
+size_t pinned_zero_off(size_t n) { return n * n * kRec; }
+size_t pinned_rows_off(size_t n) { return n * n * kRec + n * kRec; }
+size_t pinned_sum_off(size_t n) { return n * n * kRec + 2 * n * kRec; }
+size_t pinned_doubles(size_t n) { return pinned_sum_off(n) + kStats; }
+
+int dev_fail_at(ndt2d_matcher * m, size_t r, int code, const char * what)
+{
+  return mfail(m, code, std::string(what) + " (device " + std::to_string(m->device_ids[r]) + ", rank " +
+                          std::to_string(r) + "): " + ndt2d_last_error(m->devs[r]));
+}
+
+// The exchange buffers every sharded call needs: made on the first one.
+int ensure_multi(ndt2d_matcher * m)
+{
+  const size_t n = m->devs.size();
+  if (m->pinned == nullptr)
+  {
+    void * p = nullptr;
+    const int rc = ndt2d_host_alloc(m->dev, pinned_doubles(n) * sizeof(double), &p);
+    if (rc != NDT2D_OK) return dev_fail_at(m, 0, rc, "ndt2d_host_alloc");
+    m->pinned = static_cast<double *>(p);
+    std::memset(m->pinned, 0, pinned_doubles(n) * sizeof(double));
+    for (size_t r = 0; r < n; ++r) m->pinned[pinned_init_off(n, r) + r * kRec + 1] = -1.0;   // "no candidate"
+  }
+  for (size_t r = 0; r < n; ++r)
+  {
+    MatcherShard & sh = m->shards[r];
+    if (sh.d_table == nullptr)
+    {
+      void * d = nullptr;
+      int rc = ndt2d_device_alloc(m->devs[r], n * kRec * sizeof(double), &d);
+      if (rc != NDT2D_OK) return dev_fail_at(m, r, rc, "ndt2d_device_alloc");
+      sh.d_table = static_cast<double *>(d);
+      rc = ndt2d_device_alloc(m->devs[r], 2 * kStats * sizeof(double), &d);
+      if (rc != NDT2D_OK) return dev_fail_at(m, r, rc, "ndt2d_device_alloc");
+      sh.d_sum = static_cast<double *>(d);
+    }
+  }
+  return NDT2D_OK;
+}
+
+// Which exchange this call takes (ndt2d_matcher_set_exchange).
+int pick_exchange(ndt2d_matcher * m, bool * rccl)
+{
+  *rccl = false;
+  if (m->exchange_mode == 1) return NDT2D_OK;
+  if (!m->exchange_tried)
+  {
+    m->exchange_tried = true;
+    std::string why;
+    const int rc = ndt2d::exchange_create(&m->exchange, m->device_ids.data(), static_cast<int>(m->device_ids.size()), &why);
+    if (rc != NDT2D_OK)
+    {
+      m->exchange = nullptr;
+      m->exchange_note = why;
+    }
+  }
+  if (m->exchange == nullptr)
+  {
+    if (m->exchange_mode == 2) return mfail(m, NDT2D_ERR_HIP, "exchange \"rccl\" is not available: " + m->exchange_note);
+    return NDT2D_OK;   // "auto": the host exchange
+  }
+  *rccl = true;
+  return NDT2D_OK;
+}
+
+bool multi_search_wanted(const ndt2d_matcher * m, size_t n_th, size_t n_lin, size_t use)
+{
+  // (a one-device matcher told to use "rccl" takes the dealt path with one rank: the collective
+  // code can then be exercised on a single-GPU box)
+  return (m->devs.size() > 1 || m->exchange_mode == 2) && n_th >= 2 &&
+         static_cast<double>(n_th) * static_cast<double>(n_lin) * static_cast<double>(n_lin) * static_cast<double>(use) >=
+           m->multi_min_units;
+}
+
+bool multi_poses_wanted(const ndt2d_matcher * m, size_t n_poses, size_t use)
+{
+  return (m->devs.size() > 1 || m->exchange_mode == 2) && n_poses >= m->devs.size() &&
+         static_cast<double>(n_poses) * static_cast<double>(use) >= m->multi_min_units;
+}
+
+void note_variant(ndt2d_matcher * m, bool multi, bool rccl)
+{
+  m->last_multi = multi;
+  m->variant.clear();
+  if (multi)
+  {
+    m->variant = "multi[" + std::to_string(m->devs.size()) + "]/" + (rccl ? "rccl" : "host") + "/";
+  }
+  m->variant += ndt2d_last_variant(m->dev);
+}
+
+// The reference's first-wins rule over the devices' records (src/scan_matcher_ndt.cpp:128, strict
+// `<` in visiting order): the lower score, and between equal scores the lower flat index -- the
+// candidate the reference's loops visit first; accumulators summed in device order.
+// rows[n][12], used[r] = device r searched; out[12].
+void combine_records(const double * rows, const std::vector<size_t> & count, double * out)
+{
+  out[0] = 0.0;
+  out[1] = -1.0;
+  for (size_t k = 2; k < kRec; ++k) out[k] = 0.0;
+  bool first = true;
+  for (size_t r = 0; r < count.size(); ++r)
+  {
+    if (count[r] == 0) continue;
+    const double * rec = rows + r * kRec;
+    if (rec[1] >= 0.0 && rec[0] < 0.0)
+    {
+      if (out[1] < 0.0 || rec[0] < out[0] || (rec[0] == out[0] && rec[1] < out[1]))
+      {
+        out[0] = rec[0];
+        out[1] = rec[1];
+      }
+    }
+    // (the first device's sums are taken as they are: one device gives the single-device bits)
+    for (size_t k = 2; k < kRec; ++k) out[k] = first ? rec[k] : out[k] + rec[k];
+    first = false;
+  }
+}
+
+// matchScan's search dealt to all devices.  The first device has been prepared by the caller
+// (beams + tables); m->beams holds the subsampled beams unless `beams_everywhere` (every device
+// converted the LaserScan itself).  all_scores (host, optional): the whole lattice's scores.
+int multi_match(ndt2d_matcher * m, const double * scan_pose_xyt, size_t n_th, size_t n_lin, size_t use,
+                bool beams_everywhere, double * all_scores, double * record_out)
+{
+  const size_t n = m->devs.size();
+  int rc = ensure_multi(m);
+  if (rc != NDT2D_OK) return rc;
+  bool rccl = false;
+  if ((rc = pick_exchange(m, &rccl)) != NDT2D_OK) return rc;
+  for (size_t r = 1; r < n; ++r)
+  {
+    if (beams_everywhere)
+    {
+      rc = ndt2d_set_search(m->devs[r], scan_pose_xyt[0], scan_pose_xyt[1], m->dth.data(), m->cos_th.data(),
+                            m->sin_th.data(), n_th, m->dlin.data(), n_lin);
+    }
+    else
+    {
+      rc = ndt2d_set_search_beams(m->devs[r], m->beams.data(), use, scan_pose_xyt[0], scan_pose_xyt[1], m->dth.data(),
+                                  m->cos_th.data(), m->sin_th.data(), n_th, m->dlin.data(), n_lin);
+    }
+    if (rc != NDT2D_OK) return dev_fail_at(m, r, rc, "ndt2d_set_search_beams");
+  }
+  const size_t per_th = n_lin * n_lin;
+  std::vector<size_t> count(n, 0);
+  for (size_t r = 0; r < n; ++r) count[r] = r < n_th ? (n_th - r + n - 1) / n : 0;
+  if (all_scores != nullptr)
+  {
+    for (size_t r = 0; r < n; ++r)
+    {
+      MatcherShard & sh = m->shards[r];
+      const size_t want = count[r] * per_th;
+      if (want > sh.scores_cap)
+      {
+        if (sh.d_scores != nullptr) ndt2d_device_free(m->devs[r], sh.d_scores);
+        sh.d_scores = nullptr;
+        sh.scores_cap = 0;
+        void * d = nullptr;
+        rc = ndt2d_device_alloc(m->devs[r], want * sizeof(double), &d);
+        if (rc != NDT2D_OK) return dev_fail_at(m, r, rc, "ndt2d_device_alloc");
+        sh.d_scores = static_cast<double *>(d);
+        sh.scores_cap = want;
+      }
+    }
+  }
+  if (rccl)
+  {
+    for (size_t r = 0; r < n; ++r)
+    {
+      rc = ndt2d_copy_to_device_async(m->devs[r], m->shards[r].d_table, m->pinned + pinned_init_off(n, r),
+                                      n * kRec * sizeof(double));
+      if (rc != NDT2D_OK) return dev_fail_at(m, r, rc, "ndt2d_copy_to_device_async");
+    }
+  }
+  // every device's search goes out before any result is waited for
+  for (size_t r = 0; r < n; ++r)
+  {
+    if (count[r] == 0) continue;
+    MatcherShard & sh = m->shards[r];
+    rc = ndt2d_match_launch_strided(m->devs[r], r, n, count[r], all_scores != nullptr ? sh.d_scores : nullptr,
+                                    rccl ? sh.d_table + r * kRec : nullptr);
+    if (rc != NDT2D_OK) return dev_fail_at(m, r, rc, "ndt2d_match_launch_strided");
+  }
+  double * rows = m->pinned + pinned_rows_off(n);
+  if (rccl)
+  {
+    // the ONE collective of the search: all-reduce(sum) of the [n, 12] table, every device its own row
+    std::vector<double *> tables(n);
+    std::vector<void *> streams(n);
+    for (size_t r = 0; r < n; ++r)
+    {
+      tables[r] = m->shards[r].d_table;
+      streams[r] = ndt2d_get_stream(m->devs[r]);
+    }
+    std::string why;
+    rc = ndt2d::exchange_all_reduce(m->exchange, tables.data(), n * kRec, streams.data(), &why);
+    if (rc != NDT2D_OK) return mfail(m, rc, why);
+    rc = ndt2d_copy_to_host_async(m->dev, rows, m->shards[0].d_table, n * kRec * sizeof(double));
+    if (rc == NDT2D_OK) rc = ndt2d_synchronize(m->dev);
+    if (rc != NDT2D_OK) return dev_fail_at(m, 0, rc, "ndt2d_copy_to_host_async");
+  }
+  for (size_t r = 0; r < n; ++r)
+  {
+    if (count[r] == 0) continue;
+    // host exchange: the record through the context's host-coherent result block.  (After an
+    // all-reduce the flags are up already -- every stream's collective follows its search --
+    // and the fetch only settles the context's state.)
+    ndt2d_match_result res;
+    rc = ndt2d_match_fetch(m->devs[r], &res);
+    if (rc != NDT2D_OK) return dev_fail_at(m, r, rc, "ndt2d_match_fetch");
+    if (!rccl)
+    {
+      double * rec = rows + r * kRec;
+      rec[0] = res.best_score;
+      rec[1] = res.best_index == NDT2D_NO_INDEX ? -1.0 : static_cast<double>(res.best_index);
+      for (int i = 0; i < 10; ++i) rec[2 + i] = res.acc[i];
+    }
+  }
+  if (all_scores != nullptr)
+  {
+    // device r holds the scores of the steps r, r + n, ... in that order
+    std::vector<double> tmp;
+    for (size_t r = 0; r < n; ++r)
+    {
+      if (count[r] == 0) continue;
+      tmp.resize(count[r] * per_th);
+      rc = ndt2d_copy_to_host(m->devs[r], tmp.data(), m->shards[r].d_scores, tmp.size() * sizeof(double));
+      if (rc != NDT2D_OK) return dev_fail_at(m, r, rc, "ndt2d_copy_to_host");
+      for (size_t k = 0; k < count[r]; ++k)
+      {
+        std::memcpy(all_scores + (r + k * n) * per_th, tmp.data() + k * per_th, per_th * sizeof(double));
+      }
+    }
+  }
+  combine_records(rows, count, record_out);
+  note_variant(m, true, rccl);
+  return NDT2D_OK;
+}
+
+// Room for `n_poses` particles and their weights on device r.
+int ensure_shard_poses(ndt2d_matcher * m, size_t r, size_t n_poses)
+{
+  MatcherShard & sh = m->shards[r];
+  if (n_poses <= sh.poses_cap) return NDT2D_OK;
+  if (sh.d_poses != nullptr) ndt2d_device_free(m->devs[r], sh.d_poses);
+  if (sh.d_weights != nullptr) ndt2d_device_free(m->devs[r], sh.d_weights);
+  sh.d_poses = sh.d_weights = nullptr;
+  sh.poses_cap = 0;
+  const size_t cap = n_poses + n_poses / 8;
+  void * d = nullptr;
+  int rc = ndt2d_device_alloc(m->devs[r], 3 * cap * sizeof(double), &d);
+  if (rc != NDT2D_OK) return dev_fail_at(m, r, rc, "ndt2d_device_alloc");
+  sh.d_poses = static_cast<double *>(d);
+  rc = ndt2d_device_alloc(m->devs[r], cap * sizeof(double), &d);
+  if (rc != NDT2D_OK) return dev_fail_at(m, r, rc, "ndt2d_device_alloc");
+  sh.d_weights = static_cast<double *>(d);
+  sh.poses_cap = cap;
+  return NDT2D_OK;
+}
+
+// Contiguous share [begin, end) of n items for rank r of `world` (sizes differ by at most one).
+void shard_range(size_t n, size_t r, size_t world, size_t * begin, size_t * end)
+{
+  const size_t base = n / world, rem = n % world;
+  *begin = r * base + std::min(r, rem);
+  *end = *begin + base + (r < rem ? 1 : 0);
+}
+
+// scorePoses / ParticleFilter::measure over all devices: contiguous particle ranges.  The first
+// device holds the beams (the caller staged them), m->beams is their host copy.  stats_out ==
+// nullptr: scores only.  Otherwise the whole of measure: scores_out receives the normalised
+// weights and stats_out NDT2D_PF_RESULT_DOUBLES values as ndt2d_pf_finalize_launch defines them
+// ([7] summed over the devices in device order).
+int multi_score_poses(ndt2d_matcher * m, const double * poses_xyt, size_t n_poses, size_t use, double * scores_out,
+                      double * stats_out)
+{
+  const size_t n = m->devs.size();
+  int rc = ensure_multi(m);
+  if (rc != NDT2D_OK) return rc;
+  bool rccl = false;
+  if (stats_out != nullptr && (rc = pick_exchange(m, &rccl)) != NDT2D_OK) return rc;
+  std::vector<size_t> begin(n), end(n);
+  for (size_t r = 0; r < n; ++r)
+  {
+    shard_range(n_poses, r, n, &begin[r], &end[r]);
+    if ((rc = ensure_shard_poses(m, r, end[r] - begin[r])) != NDT2D_OK) return rc;
+    if (r > 0)
+    {
+      rc = ndt2d_set_beams(m->devs[r], m->beams.data(), use);
+      if (rc != NDT2D_OK) return dev_fail_at(m, r, rc, "ndt2d_set_beams");
+    }
+  }
+  const double * zeros = m->pinned + pinned_zero_off(n);
+  double * rows = m->pinned + pinned_rows_off(n);
+  for (size_t r = 0; r < n; ++r)
+  {
+    MatcherShard & sh = m->shards[r];
+    const size_t nr = end[r] - begin[r];
+    rc = ndt2d_copy_to_device_async(m->devs[r], sh.d_poses, poses_xyt + 3 * begin[r], 3 * nr * sizeof(double));
+    if (rc == NDT2D_OK && rccl)
+    {
+      rc = ndt2d_copy_to_device_async(m->devs[r], sh.d_table, zeros, n * kStats * sizeof(double));
+    }
+    if (rc != NDT2D_OK) return dev_fail_at(m, r, rc, "ndt2d_copy_to_device_async");
+    double * d_stats = stats_out == nullptr ? nullptr : (rccl ? sh.d_table + r * kStats : sh.d_sum + kStats);
+    rc = ndt2d_score_poses_launch(m->devs[r], sh.d_poses, nr, sh.d_weights, d_stats);
+    if (rc != NDT2D_OK) return dev_fail_at(m, r, rc, "ndt2d_score_poses_launch");
+  }
+  if (stats_out != nullptr)
+  {
+    std::vector<double *> tables(n);
+    std::vector<void *> streams(n);
+    for (size_t r = 0; r < n; ++r)
+    {
+      tables[r] = m->shards[r].d_table;
+      streams[r] = ndt2d_get_stream(m->devs[r]);
+    }
+    std::string why;
+    if (rccl)
+    {
+      // the "total particle weight" all-reduce (src/particle_filter.cpp:166-174) with the other
+      // seven moment sums: [n, 8], every device its own row; then the rows summed in device order
+      rc = ndt2d::exchange_all_reduce(m->exchange, tables.data(), n * kStats, streams.data(), &why);
+      if (rc != NDT2D_OK) return mfail(m, rc, why);
+      for (size_t r = 0; r < n; ++r)
+      {
+        rc = ndt2d::sum_rows_launch(m->device_ids[r], tables[r], static_cast<int>(n), static_cast<int>(kStats),
+                                    m->shards[r].d_sum, streams[r], &why);
+        if (rc != NDT2D_OK) return mfail(m, rc, why);
+        // (the table serves the second exchange: cleared behind the summation)
+        rc = ndt2d_copy_to_device_async(m->devs[r], tables[r], zeros, n * kStats * sizeof(double));
+        if (rc != NDT2D_OK) return dev_fail_at(m, r, rc, "ndt2d_copy_to_device_async");
+      }
+    }
+    else
+    {
+      for (size_t r = 0; r < n; ++r)
+      {
+        rc = ndt2d_copy_to_host_async(m->devs[r], rows + r * kStats, m->shards[r].d_sum + kStats, kStats * sizeof(double));
+        if (rc != NDT2D_OK) return dev_fail_at(m, r, rc, "ndt2d_copy_to_host_async");
+      }
+      for (size_t r = 0; r < n; ++r)
+      {
+        rc = ndt2d_synchronize(m->devs[r]);
+        if (rc != NDT2D_OK) return dev_fail_at(m, r, rc, "ndt2d_synchronize");
+      }
+      double * sum = m->pinned + pinned_sum_off(n);
+      for (size_t k = 0; k < kStats; ++k)
+      {
+        double acc = rows[k];
+        for (size_t r = 1; r < n; ++r) acc += rows[r * kStats + k];
+        sum[k] = acc;
+      }
+      for (size_t r = 0; r < n; ++r)
+      {
+        rc = ndt2d_copy_to_device_async(m->devs[r], m->shards[r].d_sum, sum, kStats * sizeof(double));
+        if (rc != NDT2D_OK) return dev_fail_at(m, r, rc, "ndt2d_copy_to_device_async");
+      }
+    }
+    // updateStatistics on every device with the total sums: normalised weights, the mean and
+    // covariance (the same on all), and the device's part of the theta variance (:213-217)
+    for (size_t r = 0; r < n; ++r)
+    {
+      MatcherShard & sh = m->shards[r];
+      double * d_out = rccl ? sh.d_table + r * kStats : sh.d_sum + kStats;
+      rc = ndt2d_pf_finalize_launch(m->devs[r], sh.d_poses, end[r] - begin[r], sh.d_weights, sh.d_sum, d_out);
+      if (rc != NDT2D_OK) return dev_fail_at(m, r, rc, "ndt2d_pf_finalize_launch");
+    }
+    if (rccl)
+    {
+      rc = ndt2d::exchange_all_reduce(m->exchange, tables.data(), n * kStats, streams.data(), &why);
+      if (rc != NDT2D_OK) return mfail(m, rc, why);
+      rc = ndt2d_copy_to_host_async(m->dev, rows, tables[0], n * kStats * sizeof(double));
+      if (rc != NDT2D_OK) return dev_fail_at(m, 0, rc, "ndt2d_copy_to_host_async");
+    }
+    else
+    {
+      for (size_t r = 0; r < n; ++r)
+      {
+        rc = ndt2d_copy_to_host_async(m->devs[r], rows + r * kStats, m->shards[r].d_sum + kStats, kStats * sizeof(double));
+        if (rc != NDT2D_OK) return dev_fail_at(m, r, rc, "ndt2d_copy_to_host_async");
+      }
+    }
+  }
+  for (size_t r = 0; r < n; ++r)
+  {
+    rc = ndt2d_copy_to_host_async(m->devs[r], scores_out + begin[r], m->shards[r].d_weights,
+                                  (end[r] - begin[r]) * sizeof(double));
+    if (rc != NDT2D_OK) return dev_fail_at(m, r, rc, "ndt2d_copy_to_host_async");
+  }
+  for (size_t r = 0; r < n; ++r)
+  {
+    rc = ndt2d_synchronize(m->devs[r]);
+    if (rc != NDT2D_OK) return dev_fail_at(m, r, rc, "ndt2d_synchronize");
+  }
+  if (stats_out != nullptr)
+  {
+    for (size_t k = 0; k < NDT2D_PF_RESULT_DOUBLES; ++k) stats_out[k] = rows[k];
+    for (size_t r = 1; r < n; ++r) stats_out[7] += rows[r * kStats + 7];
+  }
+  note_variant(m, true, rccl);
+  return NDT2D_OK;
+}
+
+void destroy_matcher(ndt2d_matcher * m)
+{
+  for (size_t r = 0; r < m->devs.size(); ++r)
+  {
+    MatcherShard & sh = m->shards[r];
+    (void)ndt2d_synchronize(m->devs[r]);
+    if (sh.d_table != nullptr) ndt2d_device_free(m->devs[r], sh.d_table);
+    if (sh.d_sum != nullptr) ndt2d_device_free(m->devs[r], sh.d_sum);
+    if (sh.d_scores != nullptr) ndt2d_device_free(m->devs[r], sh.d_scores);
+    if (sh.d_poses != nullptr) ndt2d_device_free(m->devs[r], sh.d_poses);
+    if (sh.d_weights != nullptr) ndt2d_device_free(m->devs[r], sh.d_weights);
+  }
+  if (m->exchange != nullptr) ndt2d::exchange_destroy(m->exchange);
+  if (m->pinned != nullptr && !m->devs.empty()) ndt2d_host_free(m->dev, m->pinned);
+  for (ndt2d_handle h : m->devs) ndt2d_destroy(h);
+  delete m;
 }
 
 }  // namespace
 
 extern "C" {
 
-int ndt2d_matcher_create(ndt2d_matcher ** out, int device_id)
+int ndt2d_matcher_create_multi(ndt2d_matcher ** out, const int * device_ids, int n_dev)
 {
   if (out == nullptr) return NDT2D_ERR_INVALID;
   *out = nullptr;
-  ndt2d_handle dev = nullptr;
-  int rc = ndt2d_create(&dev, device_id);
-  if (rc != NDT2D_OK) return rc;
+  if (device_ids == nullptr || n_dev <= 0 || n_dev > 64) return NDT2D_ERR_INVALID;
   ndt2d_matcher * m = new (std::nothrow) ndt2d_matcher();
-  if (m == nullptr)
+  if (m == nullptr) return NDT2D_ERR_INVALID;
+  for (int r = 0; r < n_dev; ++r)
   {
-    ndt2d_destroy(dev);
-    return NDT2D_ERR_INVALID;
+    ndt2d_handle dev = nullptr;
+    const int rc = ndt2d_create(&dev, device_ids[r]);
+    if (rc != NDT2D_OK)
+    {
+      destroy_matcher(m);
+      return rc;
+    }
+    m->devs.push_back(dev);
+    m->device_ids.push_back(device_ids[r]);
   }
-  m->dev = dev;
+  m->shards.resize(m->devs.size());
+  m->dev = m->devs[0];
   m->dth = search_offsets(m->angular_size, m->angular_res);
   m->dlin = search_offsets(m->linear_size, m->linear_res);
   *out = m;
   return NDT2D_OK;
 }
 
+int ndt2d_matcher_create(ndt2d_matcher ** out, int device_id)
+{
+  return ndt2d_matcher_create_multi(out, &device_id, 1);
+}
+
 int ndt2d_matcher_destroy(ndt2d_matcher * m)
 {
   if (m == nullptr) return NDT2D_ERR_INVALID;
   discard_ahead(m);
-  ndt2d_destroy(m->dev);
-  delete m;
+  destroy_matcher(m);
+  return NDT2D_OK;
+}
+
+int ndt2d_matcher_device_count(ndt2d_matcher * m) { return m != nullptr ? static_cast<int>(m->devs.size()) : 0; }
+
+ndt2d_handle ndt2d_matcher_device_at(ndt2d_matcher * m, int rank)
+{
+  return (m != nullptr && rank >= 0 && static_cast<size_t>(rank) < m->devs.size()) ? m->devs[static_cast<size_t>(rank)] : nullptr;
+}
+
+int ndt2d_matcher_set_exchange(ndt2d_matcher * m, const char * mode)
+{
+  if (m == nullptr || mode == nullptr) return NDT2D_ERR_INVALID;
+  if (std::strcmp(mode, "auto") == 0) m->exchange_mode = 0;
+  else if (std::strcmp(mode, "host") == 0) m->exchange_mode = 1;
+  else if (std::strcmp(mode, "rccl") == 0) m->exchange_mode = 2;
+  else return mfail(m, NDT2D_ERR_INVALID, "set_exchange: unknown mode (auto, host, rccl)");
+  return NDT2D_OK;
+}
+
+int ndt2d_matcher_set_multi_min_units(ndt2d_matcher * m, double units)
+{
+  if (m == nullptr || !(units >= 0.0)) return NDT2D_ERR_INVALID;
+  m->multi_min_units = units;
+  return NDT2D_OK;
+}
+
+const char * ndt2d_matcher_last_variant(ndt2d_matcher * m)
+{
+  if (m == nullptr) return "";
+  if (!m->last_multi) note_variant(m, false, false);   // whatever the first device ran last
+  return m->variant.c_str();
+}
+
+int ndt2d_matcher_set_timing(ndt2d_matcher * m, int enabled)
+{
+  if (m == nullptr) return NDT2D_ERR_INVALID;
+  for (ndt2d_handle h : m->devs)
+  {
+    const int rc = ndt2d_set_timing(h, enabled);
+    if (rc != NDT2D_OK) return rc;
+  }
   return NDT2D_OK;
 }
 
@@ -559,12 +1080,17 @@ int ndt2d_matcher_add_scans(ndt2d_matcher * m, const double * poses_xyt,
   if (on_device)
   {
     m->ndt.reset();
-    int rc = ndt2d_build_grid(m->dev, m->resolution, m->range_max, poses_xyt, points_xy, offsets,
-                              n_scans);
-    if (rc != NDT2D_OK)
+    // (every device of a multi-device matcher builds its own copy: the builds run side by side)
+    for (size_t r = 0; r < m->devs.size(); ++r)
     {
-      ndt2d_clear_grid(m->dev);
-      return dev_fail(m, rc, "ndt2d_build_grid");
+      const int rc = ndt2d_build_grid(m->devs[r], m->resolution, m->range_max, poses_xyt, points_xy, offsets,
+                                      n_scans);
+      if (rc != NDT2D_OK)
+      {
+        const int frc = dev_fail_at(m, r, rc, "ndt2d_build_grid");
+        for (ndt2d_handle h : m->devs) ndt2d_clear_grid(h);
+        return frc;
+      }
     }
     m->have_ndt = true;
     return NDT2D_OK;
@@ -576,7 +1102,7 @@ int ndt2d_matcher_add_scans(ndt2d_matcher * m, const double * poses_xyt,
   if (ncell == 0 || m->ndt->size_x() > 0xffffffffull || m->ndt->size_y() > 0xffffffffull)
   {
     m->ndt.reset();
-    ndt2d_clear_grid(m->dev);
+    for (ndt2d_handle h : m->devs) ndt2d_clear_grid(h);
     return mfail(m, NDT2D_ERR_INVALID, "add_scans: degenerate grid extent");
   }
   // The cells that hold points travel, not the grid (ndt2d_set_grid_sparse: the install kernel
@@ -584,22 +1110,26 @@ int ndt2d_matcher_add_scans(ndt2d_matcher * m, const double * poses_xyt,
   // 29 us per addScans, and at 41 x 41 the list is ahead as well: 34 -> 32 us plus 7 us less
   // for the stream to be ready for the call that follows, experiments/cycle_breakdown.c).
   // (written straight into the library's pinned staging buffer: ndt2d_grid_stage_begin / _commit)
-  uint32_t * list_index = nullptr;
-  double * list_cells6 = nullptr;
-  int rc = ndt2d_grid_stage_begin(m->dev, static_cast<uint32_t>(m->ndt->size_x()),
-                                  static_cast<uint32_t>(m->ndt->size_y()), m->ndt->n_touched(), &list_index,
-                                  &list_cells6);
-  if (rc == NDT2D_OK)
+  for (size_t r = 0; r < m->devs.size(); ++r)
   {
-    m->ndt->sparse6(list_index, list_cells6);
-    rc = ndt2d_grid_stage_commit(m->dev, m->ndt->n_touched(), m->ndt->cell_size(), m->ndt->origin_x(),
-                                 m->ndt->origin_y());
-  }
-  if (rc != NDT2D_OK)
-  {
-    m->ndt.reset();
-    ndt2d_clear_grid(m->dev);
-    return dev_fail(m, rc, "ndt2d_set_grid");
+    uint32_t * list_index = nullptr;
+    double * list_cells6 = nullptr;
+    int rc = ndt2d_grid_stage_begin(m->devs[r], static_cast<uint32_t>(m->ndt->size_x()),
+                                    static_cast<uint32_t>(m->ndt->size_y()), m->ndt->n_touched(), &list_index,
+                                    &list_cells6);
+    if (rc == NDT2D_OK)
+    {
+      m->ndt->sparse6(list_index, list_cells6);
+      rc = ndt2d_grid_stage_commit(m->devs[r], m->ndt->n_touched(), m->ndt->cell_size(), m->ndt->origin_x(),
+                                   m->ndt->origin_y());
+    }
+    if (rc != NDT2D_OK)
+    {
+      const int frc = dev_fail_at(m, r, rc, "ndt2d_set_grid");
+      m->ndt.reset();
+      for (ndt2d_handle h : m->devs) ndt2d_clear_grid(h);
+      return frc;
+    }
   }
   m->have_ndt = true;
   return NDT2D_OK;
@@ -621,7 +1151,13 @@ int ndt2d_matcher_reset(ndt2d_matcher * m)
   discard_ahead(m);
   if (m->ndt) m->spare = std::move(m->ndt);   // `ndt_.reset()`; the storage serves the next addScans
   m->have_ndt = false;
-  return ndt2d_clear_grid(m->dev);
+  int rc = NDT2D_OK;
+  for (ndt2d_handle h : m->devs)
+  {
+    const int crc = ndt2d_clear_grid(h);
+    if (rc == NDT2D_OK) rc = crc;
+  }
+  return rc;
 }
 
 int ndt2d_matcher_has_ndt(ndt2d_matcher * m) { return (m != nullptr && m->have_ndt) ? 1 : 0; }
@@ -725,6 +1261,7 @@ int ndt2d_matcher_match_scan_ex(ndt2d_matcher * m, const double * scan_pose_xyt,
     *score_out = 0.0;
     return NDT2D_OK;
   }
+  m->last_multi = false;
   if (m->ahead)
   {
     // scoreScan launched a search ahead: is this the matchScan it was launched for -- the same
@@ -736,6 +1273,14 @@ int ndt2d_matcher_match_scan_ex(ndt2d_matcher * m, const double * scan_pose_xyt,
       subsample_into(m->scratch_beams, points_xy, n_points, m->laser_max_beams);
       hit = m->scratch_beams.size() == m->beams.size() && !m->beams.empty() &&
             std::memcmp(m->beams.data(), m->scratch_beams.data(), m->beams.size() * sizeof(double)) == 0;
+    }
+    if (hit)
+    {
+      // ... and still the search that is pending on the context?  (A caller may have launched or
+      // fetched on ndt2d_matcher_device(m) itself in between: then the record is not ours.)
+      uint64_t launched = 0, fetched = 0;
+      hit = ndt2d_match_status(m->dev, &launched, &fetched) == NDT2D_OK && launched == m->ahead_launch_id &&
+            fetched == m->ahead_fetch_id;
     }
     if (hit)
     {
@@ -795,14 +1340,23 @@ int ndt2d_matcher_match_scan_ex(ndt2d_matcher * m, const double * scan_pose_xyt,
         scores_ptr = tmp.data();
       }
     }
-    ndt2d_match_result res;
-    rc = ndt2d_match(m->dev, 0, n_th, scores_ptr, &res);
-    if (rc != NDT2D_OK) return dev_fail(m, rc, "ndt2d_match");
+    if (multi_search_wanted(m, n_th, n_lin, use))
+    {
+      // the lattice dealt to all devices of the matcher (ndt2d_matcher_create_multi)
+      rc = multi_match(m, scan_pose_xyt, n_th, n_lin, use, false, scores_ptr, record);
+      if (rc != NDT2D_OK) return rc;
+    }
+    else
+    {
+      ndt2d_match_result res;
+      rc = ndt2d_match(m->dev, 0, n_th, scores_ptr, &res);
+      if (rc != NDT2D_OK) return dev_fail(m, rc, "ndt2d_match");
+      record[0] = res.best_score;
+      record[1] = res.best_index == NDT2D_NO_INDEX ? -1.0 : static_cast<double>(res.best_index);
+      for (int i = 0; i < 10; ++i) record[2 + i] = res.acc[i];
+    }
     if (!tmp.empty()) std::memcpy(all_scores, tmp.data(), all_scores_cap * sizeof(double));
-    record[0] = res.best_score;
-    record[1] = res.best_index == NDT2D_NO_INDEX ? -1.0 : static_cast<double>(res.best_index);
-    for (int i = 0; i < 10; ++i) record[2 + i] = res.acc[i];
-    if (best_index_out != nullptr) *best_index_out = res.best_index;
+    if (best_index_out != nullptr) *best_index_out = record[1] < 0.0 ? NDT2D_NO_INDEX : static_cast<uint64_t>(record[1]);
   }
   return ndt2d_matcher_finish_match(m, record, pose_inout, covariance_out, score_out);
 }
@@ -846,7 +1400,21 @@ int ndt2d_matcher_match_laser_scan(ndt2d_matcher * m, const double * scan_pose_x
   rc = prepare_tables(m, scan_pose_xyt, use, nullptr, false, &n_th, &n_lin);
   if (rc != NDT2D_OK) return rc;
   double record[NDT2D_MATCH_RECORD_DOUBLES] = {0, -1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  if (m->search_ready)
+  m->last_multi = false;
+  if (m->search_ready && multi_search_wanted(m, n_th, n_lin, use))
+  {
+    // every device converts the ranges itself (4 B/beam to each), then takes its theta steps
+    for (size_t r = 1; r < m->devs.size(); ++r)
+    {
+      size_t np = 0, nu = 0;
+      rc = ndt2d_set_beams_from_ranges(m->devs[r], ranges, n_ranges, scan, m->laser_max_beams, &np, &nu);
+      if (rc != NDT2D_OK) return dev_fail_at(m, r, rc, "ndt2d_set_beams_from_ranges");
+      if (np != n_points || nu != use) return mfail(m, NDT2D_ERR_HIP, "match_laser_scan: the devices disagree on the conversion");
+    }
+    rc = multi_match(m, scan_pose_xyt, n_th, n_lin, use, true, nullptr, record);
+    if (rc != NDT2D_OK) return rc;
+  }
+  else if (m->search_ready)
   {
     ndt2d_match_result res;
     rc = ndt2d_match(m->dev, 0, n_th, nullptr, &res);
@@ -883,6 +1451,18 @@ int ndt2d_matcher_score_poses(ndt2d_matcher * m, const double * points_xy, size_
     // score = 0.0 / 0 (:177)
     for (size_t i = 0; i < n_poses; ++i) scores_out[i] = std::numeric_limits<double>::quiet_NaN();
     return NDT2D_OK;
+  }
+  m->last_multi = false;
+  if (multi_poses_wanted(m, n_poses, use))
+  {
+    // contiguous ranges of the batch on all devices of the matcher
+    if (pending)
+    {
+      rc = ndt2d_set_beams(m->dev, m->beams.data(), use);
+      if (rc != NDT2D_OK) return dev_fail(m, rc, "ndt2d_set_beams");
+      m->beams_on_device = true;
+    }
+    return multi_score_poses(m, poses_xyt, n_poses, use, scores_out, nullptr);
   }
   if (pending)
   {
@@ -922,8 +1502,10 @@ int ndt2d_matcher_score_scan(ndt2d_matcher * m, const double * scan_pose_xyt,
   // scoreScan(scan) = scorePoints(scan->getPoints(), scan->getPose()) (:151-154)
   if (m == nullptr || scan_pose_xyt == nullptr || score_out == nullptr) return NDT2D_ERR_INVALID;
   discard_ahead(m);
+  m->last_multi = false;
   if (m->ahead_enabled && m->pair_seen && m->have_ndt && (n_points == 0 || points_xy != nullptr) &&
-      !m->dth.empty() && !m->dlin.empty())
+      !m->dth.empty() && !m->dlin.empty() &&
+      !multi_search_wanted(m, m->dth.size(), m->dlin.size(), std::min(m->laser_max_beams, n_points)))
   {
     // The matchScan of this scan is coming (see `ahead`): its search goes onto the stream
     // behind the scoring kernel, then the score is waited for.
@@ -953,6 +1535,7 @@ int ndt2d_matcher_score_scan(ndt2d_matcher * m, const double * scan_pose_xyt,
             ndt2d_match_launch(m->dev, 0, n_th, nullptr, nullptr) == NDT2D_OK)
         {
           m->ahead = true;
+          (void)ndt2d_match_status(m->dev, &m->ahead_launch_id, &m->ahead_fetch_id);
           ++m->ahead_launched;
           std::memcpy(m->ahead_pose, scan_pose_xyt, sizeof(m->ahead_pose));
           m->ahead_n_th = n_th;
@@ -1019,8 +1602,17 @@ int ndt2d_matcher_pf_measure(ndt2d_matcher * m, const double * particles_xyt,
     int rc = stage_beams(m, points_xy, n_points, &use);
     if (rc != NDT2D_OK) return rc;
     double out[NDT2D_PF_RESULT_DOUBLES];
-    rc = ndt2d_pf_measure(m->dev, particles_xyt, n_particles, weights_out, out);
-    if (rc != NDT2D_OK) return dev_fail(m, rc, "ndt2d_pf_measure");
+    m->last_multi = false;
+    if (multi_poses_wanted(m, n_particles, use))
+    {
+      rc = multi_score_poses(m, particles_xyt, n_particles, use, weights_out, out);
+      if (rc != NDT2D_OK) return rc;
+    }
+    else
+    {
+      rc = ndt2d_pf_measure(m->dev, particles_xyt, n_particles, weights_out, out);
+      if (rc != NDT2D_OK) return dev_fail(m, rc, "ndt2d_pf_measure");
+    }
     mean_out[0] = out[1];
     mean_out[1] = out[2];
     mean_out[2] = out[3];

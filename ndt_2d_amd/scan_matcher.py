@@ -74,15 +74,42 @@ def _free_pinned(lib, state, address):
 class ScanMatcherNDT:
     """ndt_2d::ScanMatcherNDT over the MI355X kernels."""
 
-    def __init__(self, device_id=0):
+    def __init__(self, device_id=0, device_ids=None):
+        """device_ids (a list): one matcher over several GPUs of this process
+        (ndt2d_matcher_create_multi) -- matchScan's theta steps and particle batches are
+        dealt to them; a device may be named twice (several contexts on one GPU, host
+        exchange)."""
         self._L = _capi.lib()
         self._m = C.c_void_p()
-        rc = self._L.ndt2d_matcher_create(C.byref(self._m), int(device_id))
+        if device_ids is None:
+            rc = self._L.ndt2d_matcher_create(C.byref(self._m), int(device_id))
+        else:
+            ids = (C.c_int * len(device_ids))(*[int(d) for d in device_ids])
+            rc = self._L.ndt2d_matcher_create_multi(C.byref(self._m), ids, len(device_ids))
         if rc != _capi.OK:
             self._m = None
             raise Ndt2dError(rc, "ndt2d_matcher_create",
                              "no usable GPU; this library has no CPU fallback")
         self.params = dict(DEFAULT_PARAMS, range_max=0.0)
+
+    def device_count(self):
+        return self._L.ndt2d_matcher_device_count(self._m)
+
+    def set_exchange(self, mode):
+        """How a multi-device matcher exchanges its per-device records: "auto", "host"
+        (host-coherent result blocks, no collective) or "rccl" (one all-reduce)."""
+        self._check(self._L.ndt2d_matcher_set_exchange(self._m, mode.encode()), "set_exchange")
+
+    def set_multi_min_units(self, units):
+        """Work (candidates x beams, particles x beams) below which a multi-device matcher
+        stays on its first device."""
+        self._check(self._L.ndt2d_matcher_set_multi_min_units(self._m, float(units)),
+                    "set_multi_min_units")
+
+    def matcher_variant(self):
+        """ndt2d_matcher_last_variant: "multi[n]/rccl/..." when the last call was dealt out."""
+        v = self._L.ndt2d_matcher_last_variant(self._m)
+        return v.decode() if v else ""
 
     def close(self):
         if getattr(self, "_m", None):
