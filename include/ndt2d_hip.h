@@ -520,6 +520,17 @@ int ndt2d_matcher_prepare_beams(ndt2d_matcher * m, const double * points_xy, siz
 int ndt2d_matcher_score_scan(ndt2d_matcher * m, const double * scan_pose_xyt,
                              const double * points_xy, size_t n_points, double * score_out);
 int ndt2d_matcher_set_search_ahead(ndt2d_matcher * m, int enabled);
+/* Where ONE pose is scored (scorePoints, scoreScan).  "host" (default): a scan of at most
+ * max_beams subsampled beams (default 256; 0 keeps the current value) is scored by the calling
+ * thread from the host copy of the NDT, in the reference's order with libm's exp
+ * (src/scan_matcher_ndt.cpp:156-178, src/ndt_model.cpp:105-116,162-170,203-218) -- the unchanged
+ * ParticleFilter::measure calls scorePoints once per particle (src/particle_filter.cpp:81-87),
+ * and a kernel launch plus a PCIe round trip per call costs several times the ~100 cell
+ * evaluations it is for (SURVEY.md 8b foresees exactly this path for the per-pose virtual
+ * call).  It needs a live matcher -- a GPU -- all the same: searches, batches
+ * (ndt2d_matcher_score_poses / _pf_measure) and longer scans always run on the device, and
+ * "device" sends the single poses there as well (the parity tests run both and compare). */
+int ndt2d_matcher_set_single_pose_path(ndt2d_matcher * m, const char * where, size_t max_beams);
 /* Searches launched ahead by scoreScan, and how many of them a matchScan collected. */
 int ndt2d_matcher_search_ahead_stats(ndt2d_matcher * m, uint64_t * launched, uint64_t * collected);
 int ndt2d_matcher_score_points(ndt2d_matcher * m, const double * points_xy, size_t n_points,

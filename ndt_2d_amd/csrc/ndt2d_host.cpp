@@ -141,8 +141,13 @@ public:
   // and of its cells only the few hundred that received points need clearing.
   void reset(double cell_size, double size_x, double size_y, double origin_x, double origin_y)
   {
-    const size_t sx = static_cast<size_t>((size_x / cell_size) + 1);
-    const size_t sy = static_cast<size_t>((size_y / cell_size) + 1);
+    reset_cells(cell_size, static_cast<size_t>((size_x / cell_size) + 1), static_cast<size_t>((size_y / cell_size) + 1),
+                origin_x, origin_y);
+  }
+
+  // ... given its size in cells
+  void reset_cells(double cell_size, size_t sx, size_t sy, double origin_x, double origin_y)
+  {
     // The storage is a pool of cells of which only the touched ones are not in their initial
     // state: clearing those makes it an empty grid of ANY geometry that fits (the extent
     // follows the scan poses, so its size changes by a cell now and then; a real lidar's
@@ -200,6 +205,41 @@ public:
         if (c.n == 0.0) touched_.push_back(static_cast<uint32_t>(i));
         c.add(wx, wy);
       }
+    }
+  }
+
+  // NDT::likelihood(Vector2d) (reference src/ndt_model.cpp:162-170) with Cell::score (:105-116)
+  // inlined: exp(((-0.5 * q^T) * information) * q) in that order, libm's exp.  Used by the
+  // single-pose calls (scorePoints once per particle, src/particle_filter.cpp:81-87) and by the
+  // adjudication of near-ties -- never by a search or a batch.
+  __attribute__((always_inline)) double likelihood(double x, double y) const
+  {
+    const long i = index(x, y);
+    if (i < 0) return 0.0;
+    const HostCell & c = cells_[static_cast<size_t>(i)];
+    if (c.n < 5) return 0.0;
+    const double q0 = x - c.mean_x, q1 = y - c.mean_y;
+    const double a0 = -0.5 * q0, a1 = -0.5 * q1;
+    const double r0 = a0 * c.info_xx + a1 * c.info_xy;
+    const double r1 = a0 * c.info_xy + a1 * c.info_yy;
+    return std::exp(r0 * q0 + r1 * q1);
+  }
+
+  // A grid from its packed records (a grid that was built on the device, fetched back once).
+  void load6(const double * cells6)
+  {
+    for (size_t i = 0; i < n_cells_; ++i)
+    {
+      const double * r = cells6 + 6 * i;
+      HostCell & c = cells_[i];
+      if (r[5] == 0.0) continue;
+      c.mean_x = r[0];
+      c.mean_y = r[1];
+      c.info_xx = r[2];
+      c.info_xy = r[3];
+      c.info_yy = r[4];
+      c.n = r[5];
+      touched_.push_back(static_cast<uint32_t>(i));
     }
   }
 
@@ -396,6 +436,13 @@ struct ndt2d_matcher
   double ahead_pose[3] = {0.0, 0.0, 0.0};
   size_t ahead_n_th = 0;
   uint64_t ahead_launch_id = 0, ahead_fetch_id = 0;   // ndt2d_match_status right after that launch
+  // One pose at a time (scorePoints, scoreScan): scored on the host from the host NDT when the
+  // scan is short (ndt2d_matcher_set_single_pose_path).  `scored` = the subsampled beams of the
+  // last scoreScan (the pair detection above compares the next matchScan's scan with it).
+  bool single_pose_host = true;
+  size_t single_pose_max_beams = 256;
+  std::unique_ptr<HostNdt> fetched;  // host copy of a grid that was built on the device
+  std::vector<double> scored;
   int ahead_enabled = 1;          // ndt2d_matcher_set_search_ahead
   uint64_t ahead_launched = 0, ahead_collected = 0;
 };
@@ -503,6 +550,67 @@ void discard_ahead(ndt2d_matcher * m)
   }
   m->ahead = false;
   m->pair_seen = false;
+}
+
+// The host NDT the single-pose path scores against: the one addScans built on the host, or --
+// for a grid built on the device -- its records fetched back once per addScans.
+const HostNdt * host_ndt(ndt2d_matcher * m)
+{
+  if (m->ndt) return m->ndt.get();
+  if (m->fetched) return m->fetched.get();
+  uint32_t sx = 0, sy = 0;
+  double cs = 0.0, ox = 0.0, oy = 0.0;
+  if (ndt2d_get_grid(m->dev, nullptr, 0, &sx, &sy, &cs, &ox, &oy) != NDT2D_OK) return nullptr;
+  std::vector<double> cells(static_cast<size_t>(sx) * sy * 6);
+  if (ndt2d_get_grid(m->dev, cells.data(), static_cast<size_t>(sx) * sy, nullptr, nullptr, nullptr, nullptr, nullptr) !=
+      NDT2D_OK)
+  {
+    return nullptr;
+  }
+  std::unique_ptr<HostNdt> g(new HostNdt(cs, 0.0, 0.0, ox, oy));
+  g->reset_cells(cs, sx, sy, ox, oy);
+  g->load6(cells.data());
+  m->fetched = std::move(g);
+  return m->fetched.get();
+}
+
+// ScanMatcherNDT::scorePoints on the host (reference src/scan_matcher_ndt.cpp:156-178): the
+// pose as toEigen makes it (conversions.hpp:64-68: [[c, -s], [s, c]] and the translation),
+// the subsampling of :165-171, `score += -likelihood(p)` in beam order, score / N.
+double host_score_points(const HostNdt & ndt, const double * points_xy, size_t n_points, size_t laser_max_beams,
+                         const double * pose_xyt)
+{
+  double c, s;
+  ndt2d_cos_sin(pose_xyt[2], &c, &s);
+  const size_t use = std::min(laser_max_beams, n_points);
+  const double scan_step = static_cast<double>(n_points) / use;
+  double score = 0.0;
+  for (size_t i = 0; i < use; ++i)
+  {
+    const size_t idx = static_cast<size_t>(i * scan_step);
+    const double x = points_xy[2 * idx], y = points_xy[2 * idx + 1];
+    const double px = pose_xyt[0] + (c * x + (-s) * y);
+    const double py = pose_xyt[1] + (s * x + c * y);
+    score += -ndt.likelihood(px, py);
+  }
+  return score / use;
+}
+
+// One candidate of matchScan's lattice as the reference scores it (src/scan_matcher_ndt.cpp:
+// 106-127): points_outer from the subsampled beams `beams` (m->beams) and cos/sin of
+// scan_pose.theta + dth, points_inner = outer + (dx, dy), score = -(likelihoods summed in order).
+double host_score_candidate(const HostNdt & ndt, const double * beams_xy, size_t use, const double * scan_pose_xyt,
+                            double costh, double sinth, double dx, double dy)
+{
+  double sum = 0.0;
+  for (size_t i = 0; i < use; ++i)
+  {
+    const double bx = beams_xy[2 * i], by = beams_xy[2 * i + 1];
+    const double ox = bx * costh - by * sinth + scan_pose_xyt[0];
+    const double oy = bx * sinth + by * costh + scan_pose_xyt[1];
+    sum += ndt.likelihood(ox + dx, oy + dy);
+  }
+  return -sum;
 }
 
 // ---------------------------------------------------------------------------
@@ -1066,6 +1174,7 @@ int ndt2d_matcher_add_scans(ndt2d_matcher * m, const double * poses_xyt,
     return mfail(m, NDT2D_ERR_INVALID, "add_scans: null input");
   }
   discard_ahead(m);
+  m->fetched.reset();
   static const double no_points[2] = {0.0, 0.0};
   if (points_xy == nullptr) points_xy = no_points;
   static const size_t no_offsets[1] = {0};
@@ -1150,6 +1259,7 @@ int ndt2d_matcher_reset(ndt2d_matcher * m)
   if (m == nullptr) return NDT2D_ERR_INVALID;
   discard_ahead(m);
   if (m->ndt) m->spare = std::move(m->ndt);   // `ndt_.reset()`; the storage serves the next addScans
+  m->fetched.reset();
   m->have_ndt = false;
   int rc = NDT2D_OK;
   for (ndt2d_handle h : m->devs)
@@ -1309,7 +1419,13 @@ int ndt2d_matcher_match_scan_ex(ndt2d_matcher * m, const double * scan_pose_xyt,
   bool same_scan = false;
   int rc = prepare_search_impl(m, scan_pose_xyt, points_xy, n_points, &n_th, &n_lin, &use, &same_scan);
   if (rc != NDT2D_OK) return rc;
-  if (after_score_scan && same_scan) m->pair_seen = true;
+  // (m->beams now holds this scan's subsampled beams, whether they were uploaded or found in place)
+  (void)same_scan;
+  if (after_score_scan && !m->beams.empty() && m->beams.size() == m->scored.size() &&
+      std::memcmp(m->beams.data(), m->scored.data(), m->beams.size() * sizeof(double)) == 0)
+  {
+    m->pair_seen = true;
+  }
   const size_t n_cand = n_th * n_lin * n_lin;
   if (n_candidates_out != nullptr) *n_candidates_out = n_cand;
 
@@ -1493,6 +1609,21 @@ int ndt2d_matcher_score_points(ndt2d_matcher * m, const double * points_xy, size
                                const double * pose_xyt, double * score_out)
 {
   if (pose_xyt == nullptr || score_out == nullptr) return NDT2D_ERR_INVALID;
+  if (m != nullptr && m->single_pose_host && m->have_ndt && n_points > 0 && points_xy != nullptr &&
+      m->laser_max_beams > 0 && std::min(m->laser_max_beams, n_points) <= m->single_pose_max_beams)
+  {
+    // One pose of a short scan -- the unchanged ParticleFilter::measure calls this once per
+    // particle (reference src/particle_filter.cpp:81-87): a kernel launch and a round trip over
+    // PCIe per call would cost several times the arithmetic, so the host scores it, from the host
+    // NDT, in the reference's order ("the unchanged node + unchanged ParticleFilter
+    // keep working via per-pose scorePoints").  Nothing on the device is touched: a search
+    // launched ahead by scoreScan stays pending.
+    if (const HostNdt * ndt = host_ndt(m))
+    {
+      *score_out = host_score_points(*ndt, points_xy, n_points, m->laser_max_beams, pose_xyt);
+      return NDT2D_OK;
+    }
+  }
   return ndt2d_matcher_score_poses(m, points_xy, n_points, pose_xyt, 1, score_out);
 }
 
@@ -1503,9 +1634,37 @@ int ndt2d_matcher_score_scan(ndt2d_matcher * m, const double * scan_pose_xyt,
   if (m == nullptr || scan_pose_xyt == nullptr || score_out == nullptr) return NDT2D_ERR_INVALID;
   discard_ahead(m);
   m->last_multi = false;
-  if (m->ahead_enabled && m->pair_seen && m->have_ndt && (n_points == 0 || points_xy != nullptr) &&
-      !m->dth.empty() && !m->dlin.empty() &&
-      !multi_search_wanted(m, m->dth.size(), m->dlin.size(), std::min(m->laser_max_beams, n_points)))
+  const bool ahead_wanted =
+    m->ahead_enabled && m->pair_seen && m->have_ndt && (n_points == 0 || points_xy != nullptr) && !m->dth.empty() &&
+    !m->dlin.empty() && !multi_search_wanted(m, m->dth.size(), m->dlin.size(), std::min(m->laser_max_beams, n_points));
+  if (m->single_pose_host && m->have_ndt && n_points > 0 && points_xy != nullptr && m->laser_max_beams > 0 &&
+      std::min(m->laser_max_beams, n_points) <= m->single_pose_max_beams)
+  {
+    if (const HostNdt * ndt = host_ndt(m))
+    {
+      // The host scores the pose (see ndt2d_matcher_score_points) -- and when the matchScan of
+      // this scan is coming (`ahead`), its search is launched first and runs meanwhile.
+      subsample_into(m->scored, points_xy, n_points, m->laser_max_beams);
+      if (ahead_wanted)
+      {
+        size_t n_th = 0, n_lin = 0, use = 0;
+        if (prepare_search_impl(m, scan_pose_xyt, points_xy, n_points, &n_th, &n_lin, &use, nullptr) == NDT2D_OK &&
+            m->search_ready && ndt2d_match_launch(m->dev, 0, n_th, nullptr, nullptr) == NDT2D_OK)
+        {
+          m->ahead = true;
+          (void)ndt2d_match_status(m->dev, &m->ahead_launch_id, &m->ahead_fetch_id);
+          ++m->ahead_launched;
+          std::memcpy(m->ahead_pose, scan_pose_xyt, sizeof(m->ahead_pose));
+          m->ahead_n_th = n_th;
+        }
+      }
+      *score_out = host_score_points(*ndt, points_xy, n_points, m->laser_max_beams, scan_pose_xyt);
+      m->score_scan_last = true;
+      std::memcpy(m->score_scan_pose, scan_pose_xyt, sizeof(m->score_scan_pose));
+      return NDT2D_OK;
+    }
+  }
+  if (ahead_wanted)
   {
     // The matchScan of this scan is coming (see `ahead`): its search goes onto the stream
     // behind the scoring kernel, then the score is waited for.
@@ -1550,6 +1709,7 @@ int ndt2d_matcher_score_scan(ndt2d_matcher * m, const double * scan_pose_xyt,
           return frc;
         }
         m->score_scan_last = true;
+        m->scored = m->beams;
         std::memcpy(m->score_scan_pose, scan_pose_xyt, sizeof(m->score_scan_pose));
         return NDT2D_OK;
       }
@@ -1561,9 +1721,20 @@ int ndt2d_matcher_score_scan(ndt2d_matcher * m, const double * scan_pose_xyt,
   if (rc == NDT2D_OK && m->have_ndt)
   {
     m->score_scan_last = true;
+    m->scored = m->beams;
     std::memcpy(m->score_scan_pose, scan_pose_xyt, sizeof(m->score_scan_pose));
   }
   return rc;
+}
+
+int ndt2d_matcher_set_single_pose_path(ndt2d_matcher * m, const char * where, size_t max_beams)
+{
+  if (m == nullptr || where == nullptr) return NDT2D_ERR_INVALID;
+  if (std::strcmp(where, "host") == 0) m->single_pose_host = true;
+  else if (std::strcmp(where, "device") == 0) m->single_pose_host = false;
+  else return mfail(m, NDT2D_ERR_INVALID, "set_single_pose_path: unknown path (host, device)");
+  if (max_beams > 0) m->single_pose_max_beams = max_beams;
+  return NDT2D_OK;
 }
 
 int ndt2d_matcher_search_ahead_stats(ndt2d_matcher * m, uint64_t * launched, uint64_t * collected)

@@ -8,6 +8,9 @@
 #include "scan_matcher_ndt_hip.hpp"
 
 #include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
 
 namespace ndt_2d_hip
 {
@@ -44,16 +47,29 @@ void ScanMatcherNDTHip::initialize(const std::string & name, rclcpp::Node * node
     node->declare_parameter<double>(name + ".search_linear_resolution", 0.005);
   const double linear_size = node->declare_parameter<double>(name + ".search_linear_size", 0.05);
   const int laser_max_beams = node->declare_parameter<int>(name + ".laser_max_beams", 100);
-  // new, additive: which GPU this instance runs on
+  // new, additive: which GPU this instance runs on ...
   const int device_id = node->declare_parameter<int>(name + ".device_id", 0);
+  // ... or which GPUs: the instance then deals its searches (matchScan's theta steps) and pose
+  // batches to all of them and exchanges the per-device records once per call
+  // (ndt2d_matcher_create_multi).  The loop-closure matcher of an 8-GPU node:
+  //   global_scan_matcher.device_ids: [0, 1, 2, 3, 4, 5, 6, 7]
+  // -- reached by the unchanged `global_scan_matcher_->matchScan(...)` of src/ndt_mapper.cpp:643.
+  const std::vector<int64_t> device_ids =
+    node->declare_parameter<std::vector<int64_t>>(name + ".device_ids", std::vector<int64_t>());
+  // "auto" | "rccl" (one all-reduce of the record table) | "host" (no collective)
+  const std::string exchange = node->declare_parameter<std::string>(name + ".exchange", "auto");
 
-  if (!ok(ndt2d_matcher_create(&matcher_, device_id), "ndt2d_matcher_create"))
+  std::vector<int> ids(device_ids.begin(), device_ids.end());
+  if (ids.empty()) ids.push_back(device_id);
+  if (!ok(ndt2d_matcher_create_multi(&matcher_, ids.data(), static_cast<int>(ids.size())),
+          "ndt2d_matcher_create_multi"))
   {
     matcher_ = nullptr;
     return;
   }
+  ok(ndt2d_matcher_set_exchange(matcher_, exchange.c_str()), "ndt2d_matcher_set_exchange");
   // no per-launch timing events in production: they cost ~4.5 us of every call
-  ndt2d_set_timing(ndt2d_matcher_device(matcher_), 0);
+  ndt2d_matcher_set_timing(matcher_, 0);
   ok(ndt2d_matcher_initialize(matcher_, resolution, angular_res, angular_size, linear_res,
                               linear_size, static_cast<std::size_t>(laser_max_beams), range_max),
      "ndt2d_matcher_initialize");

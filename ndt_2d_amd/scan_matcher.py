@@ -281,6 +281,12 @@ class ScanMatcherNDT:
         self._check(self._L.ndt2d_matcher_search_ahead_stats(self._m, C.byref(a), C.byref(b)), "search_ahead_stats")
         return a.value, b.value
 
+    def set_single_pose_path(self, where, max_beams=0):
+        """Where scorePoints / scoreScan score their one pose: "host" (default; scans of up to
+        max_beams subsampled beams, from the host NDT in the reference's order) or "device"."""
+        self._check(self._L.ndt2d_matcher_set_single_pose_path(self._m, where.encode(), int(max_beams)),
+                    "set_single_pose_path")
+
     def set_build_mode(self, mode):
         """Where addScans builds the NDT: "host", "device" or "auto" (bit-identical grids)."""
         self._check(self._L.ndt2d_matcher_set_build_mode(self._m, mode.encode()), "set_build_mode")

@@ -113,8 +113,95 @@ static void measure(void (*op)(void), int reps, double * median, double * p99)
   measure_between(op, NULL, reps, median, p99);
 }
 
-int main(void)
+/* --devices 0,1,..: the loop-closure search of cfg-4 (+-5 m / 0.02 m x +-pi /
+ * 0.005 rad = 315,508,257 candidates x 720 beams) and cfg-2's (2,000,000 candidates) through ONE
+ * multi-device matcher (ndt2d_matcher_create_multi) -- what the unchanged node's
+ * global_scan_matcher_->matchScan() (reference src/ndt_mapper.cpp:634-643) costs with the
+ * plugin's device_ids parameter set.  [--exchange auto|host|rccl].  One JSON object. */
+static int multi_mode(const char * id_list, const char * exchange)
 {
+  int ids[64], n_dev = 0;
+  char buf[256];
+  snprintf(buf, sizeof(buf), "%s", id_list);
+  for (char * tok = strtok(buf, ","); tok != NULL && n_dev < 64; tok = strtok(NULL, ",")) ids[n_dev++] = atoi(tok);
+  if (n_dev == 0) return 64;
+  const ndt2d_world world = {4.0, 4.0, 0.25};
+  int k = 0;
+  for (int j = -1; j <= 1; ++j)
+  {
+    for (int i = -1; i <= 1; ++i, ++k)
+    {
+      map_poses[3 * k] = 0.25 * i;
+      map_poses[3 * k + 1] = 0.25 * j;
+      map_poses[3 * k + 2] = 0.0;
+      if (ndt2d_synth_scan(&world, map_poses + 3 * k, N_BEAMS, 0.01, 1000003u + (unsigned)k, map_pts + 2 * N_BEAMS * k) !=
+          NDT2D_OK)
+        return 1;
+      map_off[k] = (size_t)N_BEAMS * (size_t)k;
+    }
+  }
+  map_off[N_SCANS] = (size_t)N_BEAMS * N_SCANS;
+  const double truth[3] = {0.13, -0.07, 0.031};
+  if (ndt2d_synth_scan(&world, truth, N_BEAMS, 0.01, 101u, scan_pts) != NDT2D_OK) return 1;
+  int rc = ndt2d_matcher_create_multi(&m, ids, n_dev);
+  if (rc != NDT2D_OK)
+  {
+    fprintf(stderr, "ndt2d_matcher_create_multi -> %d (no GPU: there is no CPU fallback)\n", rc);
+    return 2;
+  }
+  if (ndt2d_matcher_set_exchange(m, exchange) != NDT2D_OK) return 3;
+  ndt2d_matcher_set_timing(m, 0);
+  const double zero[3] = {0.0, 0.0, 0.0};
+  const double cfgs[2][4] = {{1.0, 0.02, 0.5, 0.005}, {5.0, 0.02, 3.14159265358979323846, 0.005}};
+  const char * names[2] = {"cfg2", "cfg4"};
+  /* (one line at the end: RCCL prints its version banner to stdout when it is first used) */
+  char out[2048];
+  size_t len = (size_t)snprintf(out, sizeof(out), "{\"devices\": %d, \"exchange_requested\": \"%s\"", n_dev, exchange);
+  for (int c = 0; c < 2; ++c)
+  {
+    if (ndt2d_matcher_initialize(m, 0.25, cfgs[c][3], cfgs[c][2], cfgs[c][1], cfgs[c][0], N_BEAMS, 4.75) != NDT2D_OK) return 4;
+    if (ndt2d_matcher_reset(m) != NDT2D_OK || ndt2d_matcher_add_scans(m, map_poses, map_pts, map_off, N_SCANS) != NDT2D_OK) return 5;
+    const int reps = c == 0 ? 40 : 7;
+    double t[40], pose[3], cov[9], score = 0.0;
+    size_t n_cand = 0;
+    uint64_t best = 0;
+    for (int r = -2; r < reps; ++r)
+    {
+      pose[0] = pose[1] = pose[2] = 0.0;
+      const double t0 = now_us();
+      if (ndt2d_matcher_match_scan_ex(m, zero, scan_pts, N_BEAMS, pose, cov, &score, NULL, 0, &n_cand, &best) != NDT2D_OK)
+      {
+        fprintf(stderr, "match_scan: %s\n", ndt2d_matcher_last_error(m));
+        return 6;
+      }
+      if (r >= 0) t[r] = now_us() - t0;
+    }
+    qsort(t, (size_t)reps, sizeof(double), cmp);
+    const double ms = t[reps / 2] * 1e-3;
+    len += (size_t)snprintf(out + len, sizeof(out) - len,
+                            ", \"%s\": {\"n_candidates\": %zu, \"best_index\": %llu, \"score\": %.17g, \"step_ms\": %.4f, "
+                            "\"units_per_s\": %.4e, \"variant\": \"%s\"}",
+                            names[c], n_cand, (unsigned long long)best, score, ms,
+                            (double)n_cand * N_BEAMS / (ms * 1e-3), ndt2d_matcher_last_variant(m));
+    if (len >= sizeof(out)) return 7;
+  }
+  printf("\n%s}\n", out);
+  ndt2d_matcher_destroy(m);
+  return 0;
+}
+
+int main(int argc, char ** argv)
+{
+  {
+    const char * devices = NULL;
+    const char * exchange = "auto";
+    for (int i = 1; i + 1 < argc; ++i)
+    {
+      if (strcmp(argv[i], "--devices") == 0) devices = argv[i + 1];
+      if (strcmp(argv[i], "--exchange") == 0) exchange = argv[i + 1];
+    }
+    if (devices != NULL) return multi_mode(devices, exchange);
+  }
   /* cfg-1's world and map (ndt_2d_amd/synth.py): room 8 x 8 m, pillars at (+-2, +-2),
    * 9 map scans on a 3 x 3 lattice of pitch 0.25 m, seeds 1000003 + k; query scan from
    * (0.13, -0.07, 0.031), seed 101 */

@@ -29,4 +29,6 @@ def test_c_probe_matches_the_python_path():
     assert np.array_equal(out["check_pose"], want["pose"])
     assert out["check_score"] == want["score"]
     for key in ("match_scan_us", "score_scan_us", "add_scans_us", "mapper_cycle_us"):
-        assert 1.0 < out[key] < 5000.0
+        assert 0.05 < out[key] < 5000.0    # (scoreScan of 100 beams is scored on the host: ~1 us)
+    # the unchanged ParticleFilter::measure loop (500 scorePoints calls) through the host path
+    assert out["measure_500_particles_unchanged_loop_us"] < 2000.0
