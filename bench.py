@@ -42,7 +42,7 @@ HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MAX_CLOCK_HZ = 2.4e9         # MI355X_MICROARCH.md chip table
 VALU_CYCLES_PER_INST = 4.0   # FP64 and VOP3 wave64 instructions issue in 4 cycles (experiments/ubench_f64.hip)
 FP64_PEAK_TFLOPS = 78.6      # vector FP64
-PMC_CANDIDATES = ("r03_pmc.json", "r02_pmc.json")   # the newest committed counter passes win
+PMC_CANDIDATES = ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json")   # the newest committed counter passes win
 PMC_NAME = next((n for n in PMC_CANDIDATES if os.path.exists(os.path.join(_ROOT, "profiles", n))),
                 PMC_CANDIDATES[0])
 PMC_FILE = os.path.join(_ROOT, "profiles", PMC_NAME)
@@ -148,7 +148,50 @@ def load_pmc():
         return None
 
 
-def roofline(kernel, kernel_ms, units, n_cu, pmc, expected_dispatch_note):
+def source_hash():
+    """sha256 over the kernel sources (ndt_2d_amd/csrc/*.hip, *.h, sorted by name): the profile
+    script stores it in pmc.json, so that counters committed for other kernels than the ones
+    being timed are noticed (`pmc_matches_source`)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(_ROOT, "ndt_2d_amd", "csrc")
+    for path in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h"))):
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def pmc_matches_source(pmc):
+    return bool(pmc) and pmc.get("source_sha256") == source_hash()
+
+
+SHARE_COUNTERS = ("SQ_INSTS_VALU", "SQ_BUSY_CU_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU",
+                  "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64",
+                  "SQ_INSTS_VALU_TRANS_F64", "SQ_INSTS_VALU_FMA_F32", "FETCH_SIZE", "WRITE_SIZE")
+
+
+def share_counters(pmc, workload, rank, world):
+    """Counters of ONE rank's share of an 8-GPU workload, from the committed per-share passes
+    (pmc["shares"][workload] = 8 dicts, share r of 8 = theta steps r, r + 8, ... of cfg-4 /
+    particle range r of cfg-5, each measured as one launch on one GPU by
+    experiments/profile_r04.sh).  A rank of a world that divides 8 holds the shares rank,
+    rank + world, ...: instruction counts add (the per-launch set-up, repeated in each of the
+    summed launches, is < 0.1 % of them)."""
+    shares = (pmc or {}).get("shares", {}).get(workload)
+    if not shares or len(shares) != 8 or 8 % world != 0:
+        return None
+    mine = [shares[r] for r in range(rank, 8, world)]
+    out = {}
+    for c in SHARE_COUNTERS:
+        if all(c in sh for sh in mine):
+            out[c] = sum(sh[c] for sh in mine)
+    out["shares_summed"] = list(range(rank, 8, world))
+    return out
+
+
+def roofline(kernel, kernel_ms, units, n_cu, pmc, expected_dispatch_note, counters=None):
     """(roofline, roofline_hbm) for `kernel`.
 
     VALU issue: achieved = VALU wave-instructions per launch (SQ_INSTS_VALU, committed PMC
@@ -172,7 +215,8 @@ def roofline(kernel, kernel_ms, units, n_cu, pmc, expected_dispatch_note):
                    "and grid are SGPR / LDS resident and empty cells are skipped -- not a roofline"}
     roof = {"bound": "valu_issue", "achieved": None, "peak": None, "unit": "G wave-instr/s",
             "frac": None, "traffic": None, "kernel": kernel, "kernel_ms_avg": kernel_ms}
-    k = (pmc or {}).get("kernels", {}).get(kernel)
+    k = counters if counters is not None else (pmc or {}).get("kernels", {}).get(kernel)
+    roof["pmc_matches_source"] = hbm["pmc_matches_source"] = pmc_matches_source(pmc)
     if not k or "SQ_INSTS_VALU" not in k:
         roof["note"] = "profiles/%s has no counters for this kernel" % PMC_NAME
         return roof, hbm
@@ -184,17 +228,23 @@ def roofline(kernel, kernel_ms, units, n_cu, pmc, expected_dispatch_note):
     clock = busy_cycles / t
     dur_pmc = k.get("avg_duration_ns", {}).get("sq1")
     achieved = k["SQ_INSTS_VALU"] / t / 1e9
-    peak = n_simd * MAX_CLOCK_HZ / VALU_CYCLES_PER_INST / 1e9
+    # FP32 arithmetic issues in 2 cycles per wave-instruction (MI355X_MICROARCH.md, "Per-instruction
+    # cycle constants": v_fma_f32 wave64 2 cyc), FP64 / VOP3 / integer in 4 (experiments/ubench_f64.hip):
+    # the peak is that of this kernel's instruction mix
+    n_f32 = sum(k.get(c, 0.0) for c in ("SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32"))
+    n_f32 = min(n_f32, k["SQ_INSTS_VALU"])
+    cycles_per_inst = (VALU_CYCLES_PER_INST * (k["SQ_INSTS_VALU"] - n_f32) + 2.0 * n_f32) / k["SQ_INSTS_VALU"]
+    peak = n_simd * MAX_CLOCK_HZ / cycles_per_inst / 1e9
     roof.update(
         achieved=achieved, peak=peak, frac=achieved / peak,
-        peak_note="%d SIMDs x %.1f GHz / %.0f cycles per wave-instruction" % (n_simd, MAX_CLOCK_HZ / 1e9,
-                                                                             VALU_CYCLES_PER_INST),
-        issue_slot_occupancy_pmc=k["SQ_INSTS_VALU"] * VALU_CYCLES_PER_INST / (4.0 * k["SQ_BUSY_CU_CYCLES"]),
+        peak_note="%d SIMDs x %.1f GHz / %.3f cycles per wave-instruction (FP32 share %.3f at 2 cycles, the rest at %.0f)"
+                  % (n_simd, MAX_CLOCK_HZ / 1e9, cycles_per_inst, n_f32 / k["SQ_INSTS_VALU"], VALU_CYCLES_PER_INST),
+        issue_slot_occupancy_pmc=k["SQ_INSTS_VALU"] * cycles_per_inst / (4.0 * k["SQ_BUSY_CU_CYCLES"]),
         sustained_clock_GHz_est=clock / 1e9,
         clock_in_pmc_pass_GHz=(busy_cycles / (dur_pmc * 1e-9) / 1e9) if dur_pmc else None,
         valu_insts_per_launch=k["SQ_INSTS_VALU"],
         valu_insts_per_unit=k["SQ_INSTS_VALU"] * 64.0 / units,
-        source="profiles/%s (experiments/profile_r03.sh) + live HIP-event kernel time; " % PMC_NAME
+        source="profiles/%s (experiments/profile_r0N.sh) + live HIP-event kernel time; " % PMC_NAME
                + expected_dispatch_note)
     if "SQ_ACTIVE_INST_VALU" in k and "SQ_BUSY_CYCLES" in k:
         # SQ_ACTIVE_INST_VALU counts quad-cycles a SIMD spends issuing VALU work
@@ -582,10 +632,24 @@ def main():
     ap.add_argument("--no-default-search", action="store_true")
     ap.add_argument("--no-anchors", action="store_true",
                     help="N = 1: skip the cfg-4 / cfg-5 single-GPU anchors of the 8-GPU workloads")
+    ap.add_argument("--host", choices=["python", "c"], default="python",
+                    help="c: the headline step is ndt2d_matcher_match_scan on ONE multi-device matcher "
+                         "(ndt2d_matcher_create_multi over the N GPUs) driven by rank 0 through the plain-C "
+                         "probe; python (default): one rank per GPU, torch.distributed")
+    ap.add_argument("--no-c-host", action="store_true", help="skip the C-ABI multi-device leg")
+    ap.add_argument("--profile-shares", action="store_true",
+                    help="(profiling aid, N = 1) one launch per 1-of-8 share of cfg-4 and cfg-5 on this GPU, "
+                         "in rank order; prints the dispatch plan (experiments/profile_r04.sh)")
+    ap.add_argument("--print-source-hash", action="store_true")
     ap.add_argument("--prewarm", type=float, default=PREWARM_SECONDS,
                     help="seconds of untimed launches before --warmup (profiler passes use 0)")
     args = ap.parse_args()
 
+    if args.print_source_hash:
+        print(source_hash())
+        return
+    if args.profile_shares:
+        return profile_shares()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # run directly (`python bench.py --gpus N`): start the N ranks as a CHILD job before
         # anything here has touched the GPU (never exec: see gpurun's rules), relay its line
@@ -633,6 +697,8 @@ def main():
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+
+    store = dist.distributed_c10d._get_default_store() if collective else None
 
     def all_reduce(tensor, op, async_op=False):
         if backend == "gloo":
@@ -796,8 +862,18 @@ def main():
         pmc = load_pmc()
         kname = ("match_lane_compact_kernel" if "compact-records" in variant else
                  "match_lane_kernel" if "lane" in variant else "match_kernel")
-        roof, hbm = roofline(kname, avg_kernel_ms, my_units, n_cu, pmc if cfg == 2 and world == 1 else None,
-                             "counters of the cfg-2 launch of the same bench command")
+        if cfg == 2 and world == 1:
+            roof, hbm = roofline(kname, avg_kernel_ms, my_units, n_cu, pmc,
+                                 "counters of the cfg-2 launch of the same bench command")
+        else:
+            # cfg-4: the counters of this rank's share of the lattice (rank 0: theta steps 0, N, 2N, ...),
+            # from the committed per-share passes; the kernel time is this rank's, live
+            sc = share_counters(pmc, "cfg4", rank, world) if cfg == 4 else None
+            roof, hbm = roofline(kname, avg_kernel_ms, my_units, n_cu, pmc,
+                                 "counters of rank 0's share of the cfg-4 lattice (sum of the 1-of-8 shares %s, "
+                                 "each one launch on one GPU under rocprofv3)" % (sc or {}).get("shares_summed"),
+                                 counters=sc if sc is not None else {})
+            roof["kernel_launches_per_step"] = "one per step on this rank (larger shares are cut into theta slabs)"
         grid = m.grid()
         line = {
             "metric": "pose-candidates x beams scored per second",
@@ -850,9 +926,13 @@ def main():
                 e2e.append(time.perf_counter() - t0)
             line["host_call"] = {"ms": min(e2e) * 1e3, "value": total_units / min(e2e),
                                  "what": "ndt2d_matcher_match_scan, host buffers in/out"}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and cfg == 2 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(synth.matcher_params(2), synth.map_scans(2),
                                                 *synth.query_scan(2)[:2])
+        elif cfg == 4:
+            line["cpu_baseline"] = committed_cpu_baseline("cfg4_match")
+            if pf5 is not None:
+                pf5["cpu_baseline"] = committed_cpu_baseline("cfg5_particles")
         if world == 1 and not args.no_particles:
             m.set_stream(None)
             line["particle_filter"] = particle_bench_1gpu(ScanMatcherNDT, synth, torch, dev_index, pmc, n_cu)
@@ -861,17 +941,47 @@ def main():
         if world == 1 and cfg == 2 and not args.no_anchors:
             # the single-GPU points of the two 8-GPU workloads (BASELINE.json configs[3], [4])
             m.set_stream(None)
-            line["cfg4_single_gpu"] = cfg4_single_gpu_bench(ScanMatcherNDT, synth, shard, np, torch, dev_index)
+            a4 = cfg4_single_gpu_bench(ScanMatcherNDT, synth, shard, np, torch, dev_index)
+            sc4 = share_counters(pmc, "cfg4", 0, 1)
+            a4["roofline"], a4["roofline_hbm"] = roofline(
+                "match_lane_compact_kernel", a4["kernel_ms"], a4["units_per_step"], n_cu, pmc,
+                "counters of the whole cfg-4 lattice = the sum of its eight 1-of-8 shares (one launch each on one GPU "
+                "under rocprofv3); kernel_ms = the step's search launches (theta slabs) together",
+                counters=sc4 if sc4 is not None else {})
+            a4["cpu_baseline"] = committed_cpu_baseline("cfg4_match")
+            line["cfg4_single_gpu"] = a4
             if pf5 is None and not args.no_particles:
-                line["cfg5_single_gpu"] = particle_bench_sharded(
+                a5 = particle_bench_sharded(
                     ScanMatcherNDT, synth, shard, torch, dist, dev, dev_index, 0, 1, backend, None,
                     torch.cuda.synchronize)
+                a5["cpu_baseline"] = committed_cpu_baseline("cfg5_particles")
+                line["cfg5_single_gpu"] = a5
         if world == 1 and not args.no_default_search:
             line["default_search"] = default_search_bench(ScanMatcherNDT, synth, dev_index,
                                                           with_cpu=not args.no_cpu_baseline)
             line["cfg1_search"] = cfg1_search_bench(ScanMatcherNDT, synth, dev_index,
                                                     not args.no_cpu_baseline)
+        if not args.no_c_host:
+            # ONE matcher over all N GPUs through the plain-C host (the unchanged node's
+            # global_scan_matcher_->matchScan with the plugin's device_ids parameter); the other
+            # ranks idle at the barrier below meanwhile
+            ids = [dev_index] * world if backend == "gloo" else list(range(world))
+            line["c_host_multi_device"] = c_host_multi_device(ids)
+            if args.host == "c" and line["c_host_multi_device"].get("cfg4"):
+                c4 = line["c_host_multi_device"]["cfg4"]
+                line.update(value=c4["units_per_s"], ms_per_step=c4["step_ms"], steps=c4.get("steps", 7),
+                            scaling="strong")
+                line["config"]["workload"] = ("cfg-4 (BASELINE.json configs[3]) through ndt2d_matcher_match_scan on one "
+                                              "multi-device matcher over %d GPU(s), C host" % world)
+                line["config"]["kernel_variant"] = c4["variant"]
         os.write(json_fd, (json.dumps(line) + "\n").encode())
+        if collective:
+            store.set("ndt2d_bench_rank0_done", "1")
+    elif collective:
+        # rank 0 is still measuring (the C-host leg drives every GPU from its own process): wait on
+        # the host, not in a collective -- a pending RCCL kernel would spin on this rank's GPU
+        from datetime import timedelta
+        store.wait(["ndt2d_bench_rank0_done"], timedelta(seconds=3600))
 
     m.set_stream(None)
     m.close()
@@ -947,9 +1057,120 @@ def particle_bench_sharded(matcher_cls, synth, shard, torch, dist, dev, dev_inde
            "result": {"sum_w": float(out_h[0]), "mean": [float(v) for v in out_h[1:4]],
                       "cov_xx_xy_yy": [float(v) for v in out_h[4:7]],
                       "theta_variance": float(d_var.cpu()[0])}}
+    # roofline of this rank's scoring kernel: live HIP-event time of its launches, counters of its
+    # share of the particle set from the committed per-share passes
+    try:
+        hist = m.launch_history_ms(steps)      # (the scoring launches: the statistics kernel records no events)
+        score_ms = statistics.median(hist) if hist else None
+    except Exception:   # noqa: BLE001 -- a missing figure, not a failed bench
+        score_ms = None
+    if score_ms:
+        pmc = load_pmc()
+        n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+        sc = share_counters(pmc, "cfg5", rank, world)
+        res["kernel_ms"] = score_ms
+        res["roofline"], res["roofline_hbm"] = roofline(
+            "score_poses_compact_kernel", score_ms, n_local * n_beams, n_cu, pmc,
+            "counters of rank %d's particle range (sum of the 1-of-8 shares, one launch each on one GPU under "
+            "rocprofv3)" % rank, counters=sc if sc is not None else {})
     m.set_stream(None)
     m.close()
     return res
+
+
+def committed_cpu_baseline(key):
+    """The CPU oracle on an 8-GPU workload: the medians committed in profiles/r02_cpu_baselines.json
+    (measured on the GPU box's host by experiments/cpu_baselines.py on a bounded sample -- the
+    full lattice would take 16 minutes single-threaded), not re-timed while N ranks wait."""
+    try:
+        with open(CPU_BASELINE_FILE) as f:
+            doc = json.load(f)
+        c = doc[key]
+        return {"value": c["all_cores"]["units_per_s"], "unit": "candidate-beams/s",
+                "cores": c["all_cores"]["threads"], "kind": "port",
+                "sample": "COMMITTED figure (profiles/r02_cpu_baselines.json, %s on %s): oracle, %s subset = %.3g units, "
+                          "%d OpenMP threads, %.3f s; not re-timed in this run"
+                          % (key, doc["host"]["cpu_model"],
+                             c["all_cores"].get("theta_subset", c["all_cores"].get("particle_subset")),
+                             c["all_cores"]["sample_units"], c["all_cores"]["threads"], c["all_cores"]["seconds"]),
+                "single_thread_value": c["single"]["units_per_s"],
+                "single_thread_sample": "%s subset, 1 thread (the reference's execution model), %.3f s"
+                                        % (c["single"].get("theta_subset", c["single"].get("particle_subset")),
+                                           c["single"]["seconds"])}
+    except (OSError, KeyError, ValueError) as exc:
+        return {"value": None, "unit": "candidate-beams/s", "cores": None, "kind": "port",
+                "sample": "profiles/r02_cpu_baselines.json unreadable: %s" % exc}
+
+
+def c_host_multi_device(ids, exchange="auto"):
+    """ndt_2d_amd/tools/latency_probe.c --devices ids: cfg-2 and cfg-4 through
+    ndt2d_matcher_match_scan of ONE multi-device matcher (whole call: host buffers in,
+    result out), run as a child process."""
+    import subprocess
+    probe = os.path.join(_ROOT, "ndt_2d_amd", "ndt2d_latency_probe")
+    if not os.path.exists(probe):
+        return {"error": "ndt2d_latency_probe not built"}
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    r = subprocess.run([probe, "--devices", ",".join(str(i) for i in ids), "--exchange", exchange],
+                       capture_output=True, text=True, timeout=900, env=env)
+    if r.returncode != 0:
+        return {"error": "probe exit %d: %s" % (r.returncode, r.stderr[-500:])}
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    for key in ("cfg2", "cfg4"):
+        if key in out:
+            out[key]["steps"] = 40 if key == "cfg2" else 7
+    if out.get("cfg4", {}).get("best_index") != 80443810:
+        return {"error": "cfg-4 winner differs from the oracle's", "got": out}
+    out["what"] = ("one ndt2d_matcher over devices %s (ndt2d_matcher_create_multi), plain-C host: median "
+                   "wall time of the whole ndt2d_matcher_match_scan call" % ids)
+    return out
+
+
+def profile_shares():
+    """One launch per 1-of-8 share of the two 8-GPU workloads on this GPU, preceded by one
+    warm-up launch of share 0 each: under `rocprofv3 --pmc` the LAST eight dispatches of
+    match_lane_compact_kernel are cfg-4's shares 0..7 and the last eight of
+    score_poses_compact_kernel cfg-5's."""
+    import torch
+    from ndt_2d_amd import ScanMatcherNDT, synth
+    from ndt_2d_amd import dist as shard
+    dev = torch.device("cuda", 0)
+    plan = {}
+    m = ScanMatcherNDT(0)
+    m.initialize("global_scan_matcher", **synth.matcher_params(4))
+    m.addScans(synth.map_scans(4))
+    guess, pts, _ = synth.query_scan(4)
+    n_th, n_lin, n_beams = m.prepare_search(guess, pts)
+    units = []
+    for r in [0] + list(range(8)):
+        first, stride, count = shard.shard_strided(n_th, r, 8)
+        m.match_launch_strided(first, stride, count)
+        rec = m.match_fetch()
+        units.append(count * n_lin * n_lin * n_beams)
+    plan["cfg4"] = {"kernel": m.last_variant(), "units_per_share": units[1:], "last_record_index": int(rec[1])}
+    m.close()
+    m = ScanMatcherNDT(0)
+    m.initialize("global_scan_matcher", **synth.matcher_params(5))
+    m.addScans(synth.map_scans(5))
+    _, pts, _ = synth.query_scan(5)
+    parts = synth.particles(5)
+    nb = m.prepare_beams(pts)
+    d_parts = torch.from_numpy(parts).to(dev)
+    d_w = torch.zeros(len(parts), dtype=torch.float64, device=dev)
+    d_st = torch.zeros(8, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    units = []
+    for r in [0] + list(range(8)):
+        b, e = shard.shard_range(len(parts), r, 8)
+        m.score_poses_launch(d_parts[b:e].data_ptr(), e - b, d_w[b:e].data_ptr(), d_st.data_ptr())
+        m.synchronize()
+        units.append((e - b) * nb)
+    plan["cfg5"] = {"kernel": m.last_variant(), "units_per_share": units[1:]}
+    m.close()
+    print(json.dumps(plan))
 
 
 if __name__ == "__main__":

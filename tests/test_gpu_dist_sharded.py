@@ -163,7 +163,16 @@ def test_bench_with_eight_ranks_on_one_gpu_finds_the_cfg4_winner():
     assert [float(v).hex() for v in line["match_result"]["pose"]] == want["pose_hex"]
     assert abs(line["match_result"]["score"] - want["score"]) < 1e-9
     assert line["single_gpu_same_workload"]["ms_per_step"] > 0
+    # the N > 1 line counts as measured: a roofline for rank 0's share, the CPU baseline beside it
+    assert line["roofline"]["frac"] is not None and 0.0 < line["roofline"]["frac"] <= 1.0
+    assert line["roofline"]["valu_insts_per_launch"] > 0
+    assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["cores"] >= 1
+    # ... and the multi-device handle behind the C-ABI found the same winner (8 contexts on this GPU)
+    ch = line["c_host_multi_device"]
+    assert ch["devices"] == 8 and ch["cfg4"]["best_index"] == want["best_index"]
+    assert ch["cfg4"]["variant"].startswith("multi[8]/host/")
     pf = line["particle_filter"]
+    assert pf["roofline"]["frac"] is not None and pf["cpu_baseline"]["value"] > 0
     assert "configs[4]" in pf["workload"] and pf["n_gpus"] == 8
     # the same statistics from one process
     env1 = dict(env, NDT2D_BENCH_FORCE_COLLECTIVE="1")
