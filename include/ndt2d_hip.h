@@ -149,10 +149,17 @@ typedef struct ndt2d_match_result
   uint64_t best_index;    /* flat index of the winner, NDT2D_NO_INDEX if none (:128) */
   double acc[10];         /* k00,k01,k02,k11,k12,k22, u0,u1,u2, s  (:137-140) */
   uint64_t n_candidates;  /* candidates evaluated by this call */
+  /* 1: another candidate scored within NDT2D_NEAR_TIE of the winner (the kernels' scores
+   * differ from the CPU reference's in the last bits -- device exp vs libm -- so the two could
+   * come out in the other order there); ndt2d_match_near_best lists such candidates and
+   * ndt2d_matcher_match_scan settles them with the reference's own arithmetic.  0 proves
+   * that no other candidate lies that close. */
+  uint64_t near_tie;
 } ndt2d_match_result;
+#define NDT2D_NEAR_TIE 1.0e-9
 
 /* Number of doubles of the device-resident result record
- * {best_score, best_index (exact double, -1 if none), acc[10]}. */
+ * {best_score, best_index (exact double, -1 if none; + 0.5 = near_tie, truncate), acc[10]}. */
 #define NDT2D_MATCH_RECORD_DOUBLES 12
 
 /* Evaluate the theta slab [th_begin, th_end) of the lattice (all n_lin x n_lin
@@ -175,6 +182,13 @@ int ndt2d_match_launch_strided(ndt2d_handle h, size_t th_first, size_t th_stride
  * writes the record into host-coherent pinned memory and then raises a flag there; the
  * host spins on the flag, which returns ~4 us sooner than a stream synchronisation.) */
 int ndt2d_match_fetch(ndt2d_handle h, ndt2d_match_result * out);
+/* Search the slab [th_begin, th_end) keeping every candidate's score on the device, and list the
+ * candidates that scored below 0 and within eps of the slab's best (flat indices in the whole
+ * lattice, ascending; *n_out = how many there are, of which the first `capacity` are written).
+ * result_out (optional) = the slab's result.  Synchronous.  This is the slow path behind a
+ * near_tie result: one more search plus one pass over its scores. */
+int ndt2d_match_near_best(ndt2d_handle h, size_t th_begin, size_t th_end, double eps, uint64_t * index_out,
+                          size_t capacity, size_t * n_out, ndt2d_match_result * result_out);
 /* Searches launched and results fetched on this context so far: a layer that leaves a search
  * pending across calls (ndt2d_matcher_score_scan launches the next matchScan's search) checks
  * with these that nobody else launched or fetched on the context in between. */
@@ -520,6 +534,17 @@ int ndt2d_matcher_prepare_beams(ndt2d_matcher * m, const double * points_xy, siz
 int ndt2d_matcher_score_scan(ndt2d_matcher * m, const double * scan_pose_xyt,
                              const double * points_xy, size_t n_points, double * score_out);
 int ndt2d_matcher_set_search_ahead(ndt2d_matcher * m, int enabled);
+/* Near-tie adjudication (default: on).  When a search's winner comes back with near_tie set,
+ * matchScan lists the candidates within NDT2D_NEAR_TIE of the best (ndt2d_match_near_best, up to
+ * 256), rescores each on the host exactly as the reference does (points_outer / points_inner,
+ * NDT::likelihood in beam order, libm's exp; src/scan_matcher_ndt.cpp:106-127) and applies the
+ * reference's rule -- strict `<` in visiting order (:128-134): the lowest host score, between equal
+ * ones the lowest flat index.  The returned pose / score are then that candidate's (the score
+ * the reference's own bits); the covariance sums are unaffected.  Needs the host copy of the
+ * NDT and of the beams (not available to ndt2d_matcher_match_laser_scan, which skips it).
+ * stats: searches that came back marked, and how many of those changed the winner. */
+int ndt2d_matcher_set_adjudication(ndt2d_matcher * m, int enabled);
+int ndt2d_matcher_adjudication_stats(ndt2d_matcher * m, uint64_t * marked, uint64_t * changed, uint64_t * truncated);
 /* Where ONE pose is scored (scorePoints, scoreScan).  "host" (default): a scan of at most
  * max_beams subsampled beams (default 256; 0 keeps the current value) is scored by the calling
  * thread from the host copy of the NDT, in the reference's order with libm's exp

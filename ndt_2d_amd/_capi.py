@@ -35,7 +35,7 @@ class Ndt2dError(RuntimeError):
 
 class MatchResult(C.Structure):
     _fields_ = [("best_score", C.c_double), ("best_index", C.c_uint64),
-                ("acc", C.c_double * 10), ("n_candidates", C.c_uint64)]
+                ("acc", C.c_double * 10), ("n_candidates", C.c_uint64), ("near_tie", C.c_uint64)]
 
 
 class LaserScan(C.Structure):
@@ -118,6 +118,8 @@ SIGNATURES = {
     "ndt2d_copy_to_host": (C.c_int, [_vp, _vp, _vp, _sz]),
     "ndt2d_copy_to_device_async": (C.c_int, [_vp, _vp, _vp, _sz]),
     "ndt2d_copy_to_host_async": (C.c_int, [_vp, _vp, _vp, _sz]),
+    "ndt2d_match_near_best": (C.c_int, [_vp, _sz, _sz, _d, C.POINTER(C.c_uint64), _sz, _szp,
+                                        C.POINTER(MatchResult)]),
     "ndt2d_match_status": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "ndt2d_launch_history_ms": (C.c_int, [_vp, C.POINTER(C.c_float), _sz, _szp]),
     "ndt2d_host_alloc": (C.c_int, [_vp, _sz, C.POINTER(_vp)]),
@@ -151,6 +153,9 @@ SIGNATURES = {
     "ndt2d_matcher_prepare_beams": (C.c_int, [_vp, _dp, _sz, _szp]),
     "ndt2d_matcher_score_scan": (C.c_int, [_vp, _dp, _dp, _sz, _dp]),
     "ndt2d_matcher_set_search_ahead": (C.c_int, [_vp, C.c_int]),
+    "ndt2d_matcher_set_adjudication": (C.c_int, [_vp, C.c_int]),
+    "ndt2d_matcher_adjudication_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                                   C.POINTER(C.c_uint64)]),
     "ndt2d_matcher_set_single_pose_path": (C.c_int, [_vp, C.c_char_p, _sz]),
     "ndt2d_matcher_search_ahead_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "ndt2d_matcher_score_points": (C.c_int, [_vp, _dp, _sz, _dp, _dp]),

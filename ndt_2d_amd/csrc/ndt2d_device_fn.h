@@ -274,18 +274,40 @@ __device__ __forceinline__ bool better(double s_a, double i_a, double s_b, doubl
   return (s_a < s_b) | ((s_a == s_b) & (i_a < i_b));
 }
 
-// (score, index) minimum of the wave in lane 63, same network.  A lane outside a
-// step's row mask meets its own pair, which changes nothing.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ void best_step(double & s, double & i)
+// Near-ties.  The kernels' scores differ from the reference's in the last bits (summation
+// order within a candidate is the reference's, but exp() is the device's), so two candidates
+// whose scores lie within kNearTie of each other may come out in the other order than on the
+// CPU.  Every merge of two (score, index) pairs therefore MARKS its winner when the loser was a
+// real candidate within kNearTie of it: the mark is index + 0.5 (indices are exact integers in
+// doubles; every consumer truncates, and the tie-break between different candidates is
+// unaffected).  A marked winner makes the host collect the candidates near the best and rescore
+// them with the reference's arithmetic (ndt2d_match_near_best, ndt2d_matcher_match_scan); an
+// unmarked one proves that no other candidate lies within kNearTie: whatever loses to the final
+// winner within kNearTie does so in a merge against it or against a candidate that itself
+// later loses within kNearTie, and the mark travels with the winner.
+constexpr double kNearTie = 1.0e-9;
+
+__device__ __forceinline__ void merge_best(double os, double oi, double & s, double & i)
 {
-  const double os = dpp_f64<CTRL, ROW_MASK>(s, s);
-  const double oi = dpp_f64<CTRL, ROW_MASK>(i, i);
+  const bool near = (fabs(os - s) <= kNearTie) & (oi < kNoIndex) & (i < kNoIndex);
   if (better(os, oi, s, i))
   {
     s = os;
     i = oi;
   }
+  if (near) i = floor(i) + 0.5;
+}
+
+// (score, index) minimum of the wave in lane 63, same network.  A lane outside a
+// step's row mask meets its own pair, which changes nothing.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void best_step(double & s, double & i)
+{
+  // (a lane outside the row mask meets its own pair: |s - s| = 0 would mark it -- the fallback
+  // index is "no candidate" instead, which never marks and never wins)
+  const double os = dpp_f64<CTRL, ROW_MASK>(s, s);
+  const double oi = dpp_f64<CTRL, ROW_MASK>(i, kNoIndex);
+  merge_best(os, oi, s, i);
 }
 
 __device__ __forceinline__ void wave_best_to_last_lane(double & s, double & i)

@@ -439,6 +439,9 @@ struct ndt2d_matcher
   // One pose at a time (scorePoints, scoreScan): scored on the host from the host NDT when the
   // scan is short (ndt2d_matcher_set_single_pose_path).  `scored` = the subsampled beams of the
   // last scoreScan (the pair detection above compares the next matchScan's scan with it).
+  // near-tie adjudication (ndt2d_matcher_set_adjudication)
+  bool adjudicate = true;
+  uint64_t adj_marked = 0, adj_changed = 0, adj_truncated = 0;
   bool single_pose_host = true;
   size_t single_pose_max_beams = 256;
   std::unique_ptr<HostNdt> fetched;  // host copy of a grid that was built on the device
@@ -613,6 +616,49 @@ double host_score_candidate(const HostNdt & ndt, const double * beams_xy, size_t
   return -sum;
 }
 
+// A search's record came back with its winner marked (index + 0.5: another candidate within
+// NDT2D_NEAR_TIE, ndt2d_device_fn.h merge_best): list the candidates that close to the best,
+// rescore them as the reference would and apply its rule -- strict `<` in visiting order
+// (src/scan_matcher_ndt.cpp:128-134).  The first device holds the prepared search.  record[1]
+// leaves here as a plain index.
+int settle_near_tie(ndt2d_matcher * m, const double * scan_pose_xyt, size_t n_th, size_t n_lin, size_t use, double * record)
+{
+  if (!(record[1] >= 0.0) || record[1] == std::floor(record[1])) return NDT2D_OK;   // not marked
+  record[1] = std::floor(record[1]);
+  ++m->adj_marked;
+  if (!m->adjudicate || m->beams.size() != 2 * use || m->cos_th.size() != n_th) return NDT2D_OK;
+  const HostNdt * ndt = host_ndt(m);
+  if (ndt == nullptr) return NDT2D_OK;
+  constexpr size_t kCap = 256;
+  uint64_t idx[kCap];
+  size_t n = 0;
+  const int rc = ndt2d_match_near_best(m->dev, 0, n_th, NDT2D_NEAR_TIE, idx, kCap, &n, nullptr);
+  if (rc != NDT2D_OK) return dev_fail(m, rc, "ndt2d_match_near_best");
+  if (n > kCap) ++m->adj_truncated;
+  const uint64_t per_th = static_cast<uint64_t>(n_lin) * n_lin;
+  double best_s = 0.0;   // `double best_score = 0;` (:83)
+  uint64_t best_i = NDT2D_NO_INDEX;
+  for (size_t k = 0; k < std::min(n, kCap); ++k)   // ascending flat index = the reference's visiting order
+  {
+    const uint64_t ith = idx[k] / per_th, rem = idx[k] % per_th;
+    if (ith >= n_th) continue;
+    const double score = host_score_candidate(*ndt, m->beams.data(), use, scan_pose_xyt, m->cos_th[ith], m->sin_th[ith],
+                                              m->dlin[rem / n_lin], m->dlin[rem % n_lin]);
+    if (score < best_s)
+    {
+      best_s = score;
+      best_i = idx[k];
+    }
+  }
+  if (best_i != NDT2D_NO_INDEX)
+  {
+    if (static_cast<double>(best_i) != record[1]) ++m->adj_changed;
+    record[0] = best_s;
+    record[1] = static_cast<double>(best_i);
+  }
+  return NDT2D_OK;
+}
+
 // ---------------------------------------------------------------------------
 // Multi-device matcher (ndt2d_matcher_create_multi): the sharded calls
 // ---------------------------------------------------------------------------
@@ -734,11 +780,15 @@ void combine_records(const double * rows, const std::vector<size_t> & count, dou
     const double * rec = rows + r * kRec;
     if (rec[1] >= 0.0 && rec[0] < 0.0)
     {
-      if (out[1] < 0.0 || rec[0] < out[0] || (rec[0] == out[0] && rec[1] < out[1]))
+      // (an index ending in .5 is a winner marked "another candidate within NDT2D_NEAR_TIE": the
+      // mark stays with the winner, and two devices' winners that close mark it as well)
+      const bool near = out[1] >= 0.0 && std::fabs(rec[0] - out[0]) <= NDT2D_NEAR_TIE;
+      if (out[1] < 0.0 || rec[0] < out[0] || (rec[0] == out[0] && std::floor(rec[1]) < std::floor(out[1])))
       {
         out[0] = rec[0];
         out[1] = rec[1];
       }
+      if (near) out[1] = std::floor(out[1]) + 0.5;
     }
     // (the first device's sums are taken as they are: one device gives the single-device bits)
     for (size_t k = 2; k < kRec; ++k) out[k] = first ? rec[k] : out[k] + rec[k];
@@ -842,7 +892,7 @@ int multi_match(ndt2d_matcher * m, const double * scan_pose_xyt, size_t n_th, si
     {
       double * rec = rows + r * kRec;
       rec[0] = res.best_score;
-      rec[1] = res.best_index == NDT2D_NO_INDEX ? -1.0 : static_cast<double>(res.best_index);
+      rec[1] = res.best_index == NDT2D_NO_INDEX ? -1.0 : static_cast<double>(res.best_index) + (res.near_tie ? 0.5 : 0.0);
       for (int i = 0; i < 10; ++i) rec[2 + i] = res.acc[i];
     }
   }
@@ -1321,7 +1371,7 @@ int ndt2d_matcher_finish_match(ndt2d_matcher * m, const double * record, double 
   {
     // reference src/scan_matcher_ndt.cpp:128-134: pose = the accumulated
     // offsets of the winning candidate
-    const uint64_t best_index = static_cast<uint64_t>(record[1]);
+    const uint64_t best_index = static_cast<uint64_t>(record[1]);   // (truncates a near-tie mark, index + 0.5)
     const uint64_t per_th = static_cast<uint64_t>(n_lin) * n_lin;
     const uint64_t ith = best_index / per_th;
     const uint64_t rem = best_index % per_th;
@@ -1404,9 +1454,11 @@ int ndt2d_matcher_match_scan_ex(ndt2d_matcher * m, const double * scan_pose_xyt,
       if (frc != NDT2D_OK) return dev_fail(m, frc, "ndt2d_match_fetch");
       double rec[NDT2D_MATCH_RECORD_DOUBLES];
       rec[0] = res.best_score;
-      rec[1] = res.best_index == NDT2D_NO_INDEX ? -1.0 : static_cast<double>(res.best_index);
+      rec[1] = res.best_index == NDT2D_NO_INDEX ? -1.0 : static_cast<double>(res.best_index) + (res.near_tie ? 0.5 : 0.0);
       for (int i = 0; i < 10; ++i) rec[2 + i] = res.acc[i];
-      if (best_index_out != nullptr) *best_index_out = res.best_index;
+      const int src = settle_near_tie(m, scan_pose_xyt, m->ahead_n_th, n_lin_a, m->n_use, rec);
+      if (src != NDT2D_OK) return src;
+      if (best_index_out != nullptr) *best_index_out = rec[1] < 0.0 ? NDT2D_NO_INDEX : static_cast<uint64_t>(rec[1]);
       return ndt2d_matcher_finish_match(m, rec, pose_inout, covariance_out, score_out);
     }
     discard_ahead(m);
@@ -1468,9 +1520,10 @@ int ndt2d_matcher_match_scan_ex(ndt2d_matcher * m, const double * scan_pose_xyt,
       rc = ndt2d_match(m->dev, 0, n_th, scores_ptr, &res);
       if (rc != NDT2D_OK) return dev_fail(m, rc, "ndt2d_match");
       record[0] = res.best_score;
-      record[1] = res.best_index == NDT2D_NO_INDEX ? -1.0 : static_cast<double>(res.best_index);
+      record[1] = res.best_index == NDT2D_NO_INDEX ? -1.0 : static_cast<double>(res.best_index) + (res.near_tie ? 0.5 : 0.0);
       for (int i = 0; i < 10; ++i) record[2 + i] = res.acc[i];
     }
+    if ((rc = settle_near_tie(m, scan_pose_xyt, n_th, n_lin, use, record)) != NDT2D_OK) return rc;
     if (!tmp.empty()) std::memcpy(all_scores, tmp.data(), all_scores_cap * sizeof(double));
     if (best_index_out != nullptr) *best_index_out = record[1] < 0.0 ? NDT2D_NO_INDEX : static_cast<uint64_t>(record[1]);
   }
@@ -1529,6 +1582,9 @@ int ndt2d_matcher_match_laser_scan(ndt2d_matcher * m, const double * scan_pose_x
     }
     rc = multi_match(m, scan_pose_xyt, n_th, n_lin, use, true, nullptr, record);
     if (rc != NDT2D_OK) return rc;
+    // (no host copy of the converted beams: a near-tie mark is counted, not settled)
+    if (record[1] >= 0.0 && record[1] != std::floor(record[1])) ++m->adj_marked;
+    if (record[1] >= 0.0) record[1] = std::floor(record[1]);
   }
   else if (m->search_ready)
   {
@@ -1538,6 +1594,7 @@ int ndt2d_matcher_match_laser_scan(ndt2d_matcher * m, const double * scan_pose_x
     record[0] = res.best_score;
     record[1] = res.best_index == NDT2D_NO_INDEX ? -1.0 : static_cast<double>(res.best_index);
     for (int i = 0; i < 10; ++i) record[2 + i] = res.acc[i];
+    if (res.near_tie) ++m->adj_marked;
   }
   return ndt2d_matcher_finish_match(m, record, pose_inout, covariance_out, score_out);
 }
@@ -1725,6 +1782,22 @@ int ndt2d_matcher_score_scan(ndt2d_matcher * m, const double * scan_pose_xyt,
     std::memcpy(m->score_scan_pose, scan_pose_xyt, sizeof(m->score_scan_pose));
   }
   return rc;
+}
+
+int ndt2d_matcher_set_adjudication(ndt2d_matcher * m, int enabled)
+{
+  if (m == nullptr) return NDT2D_ERR_INVALID;
+  m->adjudicate = enabled != 0;
+  return NDT2D_OK;
+}
+
+int ndt2d_matcher_adjudication_stats(ndt2d_matcher * m, uint64_t * marked, uint64_t * changed, uint64_t * truncated)
+{
+  if (m == nullptr) return NDT2D_ERR_INVALID;
+  if (marked != nullptr) *marked = m->adj_marked;
+  if (changed != nullptr) *changed = m->adj_changed;
+  if (truncated != nullptr) *truncated = m->adj_truncated;
+  return NDT2D_OK;
 }
 
 int ndt2d_matcher_set_single_pose_path(ndt2d_matcher * m, const char * where, size_t max_beams)

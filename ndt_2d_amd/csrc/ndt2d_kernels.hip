@@ -146,11 +146,7 @@ __global__ void __launch_bounds__(kMatchThreads) match_kernel(const MatchArgs a)
       const double score = -sum;
 
       const double flat = static_cast<double>(static_cast<uint64_t>(ith) * m + f);
-      if (score < best_s)
-      {
-        best_s = score;
-        best_i = flat;
-      }
+      if (score < 0.0) merge_best(score, flat, best_s, best_i);   // (:128; marks near-ties, see merge_best)
 
       const double xa = sel_a == 0 ? dx : (sel_a == 1 ? dy : (sel_a == 2 ? dt : (sel_a == 3 ? 1.0 : 0.0)));
       const double xb = sel_b == 0 ? dx : (sel_b == 1 ? dy : (sel_b == 2 ? dt : (sel_b == 3 ? 1.0 : 0.0)));
@@ -203,11 +199,7 @@ __global__ void __launch_bounds__(256) match_reduce_kernel(const double * partia
   for (uint32_t w = begin + t; w < end; w += 256)
   {
     const double * p = partials + static_cast<size_t>(w) * kRecord;
-    if (better(p[0], p[1], v[0], v[1]))
-    {
-      v[0] = p[0];
-      v[1] = p[1];
-    }
+    merge_best(p[0], p[1], v[0], v[1]);
 #pragma unroll
     for (int k = 2; k < kRecord; ++k) v[k] += p[k];
   }
@@ -220,11 +212,7 @@ __global__ void __launch_bounds__(256) match_reduce_kernel(const double * partia
     {
       double * mine = sh + t * kRecord;
       const double * other = sh + (t + s) * kRecord;
-      if (better(other[0], other[1], mine[0], mine[1]))
-      {
-        mine[0] = other[0];
-        mine[1] = other[1];
-      }
+      merge_best(other[0], other[1], mine[0], mine[1]);
 #pragma unroll
       for (int k = 2; k < kRecord; ++k) mine[k] += other[k];
     }
@@ -266,11 +254,7 @@ __global__ void __launch_bounds__(kFinalThreads) match_reduce_final_kernel(
     for (uint32_t r = lane; r < n; r += kWave)
     {
       const double2 p = *reinterpret_cast<const double2 *>(partials + static_cast<size_t>(r) * kRecord);
-      if (better(p.x, p.y, bs, bi))
-      {
-        bs = p.x;
-        bi = p.y;
-      }
+      merge_best(p.x, p.y, bs, bi);
     }
     wave_best_to_last_lane(bs, bi);
     if (lane == kWave - 1)
@@ -309,6 +293,24 @@ __global__ void __launch_bounds__(kFinalThreads) match_reduce_final_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) raise_host_flag(host_out + kHostFlagSlot, seq);
+  }
+}
+
+// Near-tie adjudication, device side (see merge_best in ndt2d_device_fn.h): every candidate
+// that scored below 0 and within eps of the best.  Runs only behind a search whose winner
+// came back marked.
+__global__ void __launch_bounds__(256) collect_near_kernel(const double * scores, uint64_t n, const double * record,
+                                                           double eps, unsigned long long * out, uint32_t cap)
+{
+  const double limit = record[0] + eps;
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += static_cast<uint64_t>(gridDim.x) * 256ull)
+  {
+    const double s = scores[i];
+    if (s < 0.0 && s <= limit)
+    {
+      const unsigned long long k = atomicAdd(out, 1ull);
+      if (k < cap) out[1 + k] = i;
+    }
   }
 }
 
@@ -847,6 +849,17 @@ __global__ void __launch_bounds__(256) pf_finalize_reduce_kernel(const double * 
 }
 
 }  // namespace
+
+hipError_t launch_collect_near(const double * scores, uint64_t n, const double * record, double eps,
+                               unsigned long long * out, uint32_t cap, hipStream_t stream)
+{
+  hipError_t e = hipMemsetAsync(out, 0, sizeof(unsigned long long), stream);
+  if (e != hipSuccess) return e;
+  const uint64_t blocks = (n + 255) / 256;
+  collect_near_kernel<<<dim3(static_cast<uint32_t>(blocks < 4096 ? (blocks > 0 ? blocks : 1) : 4096)), dim3(256), 0, stream>>>(
+    scores, n, record, eps, out, cap);
+  return hipGetLastError();
+}
 
 hipError_t launch_pf_finalize(const double * poses_xyt, uint64_t n_poses, double * weights,
                               const double * stats, double * workspace, double * out,

@@ -49,6 +49,8 @@ struct LaneGeom
   // block, and a lane in a block that can score takes the reference's own index arithmetic.
   int32_t block_log2;
   double unit_scale;  // fixed-point units per cell = 2^16 << sub_log2 (>> block_log2)
+  double inv_scaled;  // grid.inv_cell_size * unit_scale: fixed-point units per metre (a kernel argument,
+                      // so that the lane kernels find it in SGPRs instead of holding the product in VGPRs)
   int32_t map_h;   // map rows of kMapStride bytes: (win_h + 2 * pad) << sub_log2 (>> block_log2)
   // Window of grid cells the map covers: every point this search can produce
   // (scan pose +- (longest beam + largest offset)) lies inside it or outside the
@@ -617,6 +619,7 @@ inline bool lane_geometry(const MatchArgs & args, size_t lds_per_block, LaneGeom
   }
   geo->sub_log2 = sub_log2;
   geo->unit_scale = kFracScale * static_cast<double>(1 << sub_log2) / static_cast<double>(1 << block_log2);
+  geo->inv_scaled = args.grid.inv_cell_size * geo->unit_scale;
   geo->map_h = static_cast<int32_t>((need_h << sub_log2) >> block_log2);
   // lanes add |d| <= lin_cells * unit_scale (+0.5 rounding); one cell of margin each side
   const double reach_units = (lin_cells + 1.0) * geo->unit_scale;

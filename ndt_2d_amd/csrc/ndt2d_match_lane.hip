@@ -152,6 +152,16 @@ __device__ __forceinline__ double packed_offset(double dx, double dy, double inv
 // compacted records of the cells that can score and the cell -> record table
 // (GridDesc::compact_records / cell_rank): at cfg-2 15 KB instead of 81 KB, so that two
 // blocks share a CU (match_lane_compact_kernel below).
+// kNoIndex made where it is needed: held in a register pair across the beam loop it was the
+// one value the 80-VGPR kernels still spilled (the compiler would not rematerialise it).
+__device__ __forceinline__ double no_index_here()
+{
+  static_assert(kNoIndex == 1.0e308, "the literal below is 1.0e308");
+  uint32_t lo, hi;
+  asm volatile("v_mov_b32 %0, 0x85ebc8a0\n\tv_mov_b32 %1, 0x7fe1ccf3" : "=v"(lo), "=v"(hi));
+  return __hiloint2double(static_cast<int>(hi), static_cast<int>(lo));
+}
+
 template <int THREADS, bool POW2, bool LDS_RECORDS, bool DYNAMIC_ITEMS, bool COMPACT, bool PARTS = false>
 __device__ __forceinline__ void match_lane_body(
   const MatchArgs & a, const double4 * __restrict__ outer, const uint8_t * __restrict__ map_image,
@@ -211,7 +221,6 @@ __device__ __forceinline__ void match_lane_body(
 
   const uint32_t lane = threadIdx.x & (kWave - 1);
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const uint32_t lx = lane >> 3, ly = lane & 7;
   const uint32_t n_lin = a.n_lin;
   const uint32_t patches_1d = (n_lin + kPatch - 1) / kPatch;
   const uint32_t patches = patches_1d * patches_1d;
@@ -224,7 +233,7 @@ __device__ __forceinline__ void match_lane_body(
   const uint64_t per_theta = static_cast<uint64_t>(n_lin) * n_lin;
   const uint32_t th_mid = (a.th_end - a.th_begin - 1u) / 2u;
   const uint32_t home_shard = blockIdx.x % kItemShards;
-  const double inv_scaled = g.inv_cell_size * geo.unit_scale;
+  const double inv_scaled = geo.inv_scaled;
 
   // One record per ITEM (not per wave): a wave takes its first item by its index and
   // every further one from an atomic counter, so which wave ran an item leaves no
@@ -240,9 +249,11 @@ __device__ __forceinline__ void match_lane_body(
     const uint32_t whole_item = PARTS ? item / a.beam_parts : item;
     const uint32_t part = PARTS ? item - whole_item * a.beam_parts : 0u;
     item_place(whole_item, patches, patches_1d, th_mid, t, pxi, pyi);
-    const uint32_t ix = pxi * kPatch + lx;
-    const uint32_t iy = pyi * kPatch + ly;
-    const bool valid = (ix < n_lin) & (iy < n_lin);
+    // (lane -> patch position per item, two instructions, rather than two registers held for good)
+    uint32_t lane_here = lane;
+    asm volatile("" : "+v"(lane_here));
+    const uint32_t ix = pxi * kPatch + (lane_here >> 3);
+    const uint32_t iy = pyi * kPatch + (lane_here & 7);
     // lanes beyond the lattice edge shadow the edge candidate and are dropped below
     const double dx = a.dlin[min(ix, n_lin - 1)];
     const double dy = a.dlin[min(iy, n_lin - 1)];
@@ -312,16 +323,31 @@ __device__ __forceinline__ void match_lane_body(
       item = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(next), kWave - 1));
       continue;
     }
-    if (valid)
+    // (the candidate's lattice indices are made again here, from the lane number, rather than
+    // held in registers across the beam loop: the kernel runs at 80 VGPRs and used to spill them)
+    uint32_t lane_again = lane;
+    asm volatile("" : "+v"(lane_again));
+    const uint32_t ix_e = pxi * kPatch + (lane_again >> 3);
+    const uint32_t iy_e = pyi * kPatch + (lane_again & 7);
+    if ((ix_e < n_lin) & (iy_e < n_lin))
     {
+      const uint32_t ix = ix_e, iy = iy_e;
       const double score = -sum;  // (:127)
       const uint64_t local = static_cast<uint64_t>(t) * per_theta + static_cast<uint64_t>(ix) * n_lin + iy;
       const double flat = static_cast<double>(
         static_cast<uint64_t>(a.th_begin + t * a.th_stride) * per_theta + static_cast<uint64_t>(ix) * n_lin + iy);
-      if (score < best_s)
+      if (DYNAMIC_ITEMS)
       {
-        best_s = score;
-        best_i = flat;
+        // (the lane's one candidate of this item: best_s is still 0)
+        if (score < best_s)
+        {
+          best_s = score;
+          best_i = flat;
+        }
+      }
+      else if (score < 0.0)
+      {
+        merge_best(score, flat, best_s, best_i);   // the lane's running best over its items; marks near-ties
       }
       // k += x x^T score, u += x score, s += score (:137-140)
       const double dt = a.dth[a.th_begin + t * a.th_stride];
@@ -378,7 +404,7 @@ __device__ __forceinline__ void match_lane_body(
     }
     item = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(next), kWave - 1));
     best_s = 0.0;
-    best_i = kNoIndex;
+    best_i = no_index_here();
 #pragma unroll
     for (int k = 0; k < 10; ++k) acc[k] = 0.0;
   }

@@ -123,19 +123,24 @@ __device__ __forceinline__ void small_final_reduction(const MatchArgs & a, const
   for (int k = 0; k < 10; ++k) acc[k] = 0.0;
   for (uint32_t r = threadIdx.x; r < n_records; r += n_threads)
   {
+    // Forward progress: this block is the launch's LAST (index search_blocks), and workgroups are
+    // dispatched in index order on this hardware, so every producer is resident or done before
+    // the first poll -- an assumption of the design (HIP does not promise it; kSmallMaxItems keeps
+    // the launch far below the chip's resident-block capacity).  Should it ever fail, the poll
+    // gives up after ~1 s and traps: the host's wait then returns NDT2D_ERR_HIP instead of hanging.
+    uint32_t polls = 0;
     while (__hip_atomic_load(fin.done + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != fin.seq)
     {
       __builtin_amdgcn_s_sleep(2);
+      if (++polls > (1u << 24)) __builtin_trap();
     }
+    // the record's words are read only after its `done` word has been seen (acquire)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     const double * p = a.partials + static_cast<size_t>(r) * kRecord;
     double v[kRecord];
 #pragma unroll
     for (int k = 0; k < kRecord; ++k) v[k] = load_agent(p + k);
-    if (better(v[0], v[1], bs, bi))
-    {
-      bs = v[0];
-      bi = v[1];
-    }
+    merge_best(v[0], v[1], bs, bi);
 #pragma unroll
     for (int k = 0; k < 10; ++k) acc[k] += v[2 + k];
   }
@@ -160,11 +165,7 @@ __device__ __forceinline__ void small_final_reduction(const MatchArgs & a, const
       for (uint32_t w = 1; w < n_waves; ++w)
       {
         const double sw = scratch[w * kRecord], iw = scratch[w * kRecord + 1];
-        if (better(sw, iw, s0, i0))
-        {
-          s0 = sw;
-          i0 = iw;
-        }
+        merge_best(sw, iw, s0, i0);
       }
       val = k == 0 ? s0 : (s0 < 0.0 ? i0 : -1.0);   // no candidate scored below 0: no index
     }

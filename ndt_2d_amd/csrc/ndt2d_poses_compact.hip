@@ -529,11 +529,18 @@ __global__ void __launch_bounds__(kFewThreads) score_few_kernel(const PosesArgs 
   {
     for (uint32_t k = threadIdx.x; k < n; k += kFewThreads)
     {
+      // (the last block of the launch, dispatched after all the others -- the assumption and the
+      // bounded poll of ndt2d_match_small.hip's reducing block: kFewPosesMax keeps the launch far
+      // below the chip's resident-block capacity)
+      uint32_t polls = 0;
       while (__hip_atomic_load(f.done + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != f.seq)
       {
         __builtin_amdgcn_s_sleep(2);
+        if (++polls > (1u << 24)) __builtin_trap();
       }
     }
+    // what the other blocks wrote before their `done` words is read after this point only
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     __syncthreads();
     if (!f.stats)
     {

@@ -49,16 +49,32 @@ def combine_match_records(records):
     visiting order): the lower score wins, and between equal scores the lower flat
     index -- for contiguous slabs that is the lower rank, for interleaved shares it
     is whoever holds the earlier candidate.  The accumulators are summed in rank order."""
+    best_score, best_index, acc, _ = combine_match_records_ex(records)
+    return best_score, best_index, acc
+
+
+NEAR_TIE = 1.0e-9
+
+
+def combine_match_records_ex(records):
+    """combine_match_records plus the near-tie mark: a record's index ending in .5 says another
+    candidate of that rank's share scored within NEAR_TIE of its winner (include/ndt2d_hip.h,
+    ndt2d_match_result.near_tie); two ranks' winners that close mark the result as well.  Returns
+    (best_score, best_index, acc, near_tie): with near_tie the caller should settle the winner as
+    ndt2d_matcher_match_scan does (ndt2d_match_near_best + the reference's arithmetic)."""
     records = np.asarray(records, dtype=np.float64).reshape(-1, MATCH_RECORD)
-    best_score, best_index = 0.0, None
+    best_score, best_index, marked = 0.0, None, False
     acc = np.zeros(10, dtype=np.float64)
     for rec in records:
         if rec[1] >= 0.0 and rec[0] < 0.0:
+            near = best_index is not None and abs(rec[0] - best_score) <= NEAR_TIE
             if best_index is None or rec[0] < best_score or \
                     (rec[0] == best_score and int(rec[1]) < best_index):
                 best_score, best_index = float(rec[0]), int(rec[1])
+                marked = rec[1] != math.floor(rec[1])
+            marked = marked or near
         acc += rec[2:]
-    return best_score, best_index, acc
+    return best_score, best_index, acc, marked
 
 
 def match_scan_sharded(matcher, scan_pose, points, rank, world, dist, pose=None):

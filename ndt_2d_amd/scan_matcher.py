@@ -281,6 +281,27 @@ class ScanMatcherNDT:
         self._check(self._L.ndt2d_matcher_search_ahead_stats(self._m, C.byref(a), C.byref(b)), "search_ahead_stats")
         return a.value, b.value
 
+    def set_adjudication(self, enabled):
+        """Near-tie adjudication of matchScan (on by default): candidates within 1e-9 of the best
+        are rescored on the host with the reference's arithmetic and its first-wins rule."""
+        self._check(self._L.ndt2d_matcher_set_adjudication(self._m, 1 if enabled else 0), "set_adjudication")
+
+    def adjudication_stats(self):
+        """(searches whose winner came back marked near-tie, of those: winner changed, list truncated)."""
+        a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        self._check(self._L.ndt2d_matcher_adjudication_stats(self._m, C.byref(a), C.byref(b), C.byref(c)),
+                    "adjudication_stats")
+        return a.value, b.value, c.value
+
+    def match_near_best(self, th_begin, th_end, eps=1e-9, capacity=256):
+        """ndt2d_match_near_best on the prepared search: flat indices (ascending) of the candidates
+        within eps of the slab's best, and how many there are."""
+        idx = (C.c_uint64 * capacity)()
+        n = C.c_size_t(0)
+        self._dev_check(self._L.ndt2d_match_near_best(self.device_handle, th_begin, th_end, eps, idx, capacity,
+                                                      C.byref(n), None), "ndt2d_match_near_best")
+        return [idx[k] for k in range(min(n.value, capacity))], n.value
+
     def set_single_pose_path(self, where, max_beams=0):
         """Where scorePoints / scoreScan score their one pose: "host" (default; scans of up to
         max_beams subsampled beams, from the host NDT in the reference's order) or "device"."""
@@ -348,7 +369,7 @@ class ScanMatcherNDT:
                         "ndt2d_match_fetch")
         rec = np.zeros(_capi.MATCH_RECORD_DOUBLES)
         rec[0] = res.best_score
-        rec[1] = -1.0 if res.best_index == _capi.NO_INDEX else float(res.best_index)
+        rec[1] = -1.0 if res.best_index == _capi.NO_INDEX else float(res.best_index) + (0.5 if res.near_tie else 0.0)
         rec[2:] = res.acc[:]
         return rec
 
