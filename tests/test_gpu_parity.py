@@ -331,6 +331,9 @@ def test_score_scan_then_match_scan_share_the_beams(max_beams):
                                     search_angular_size=0.05)
     fresh, _, _, _, _ = _pair(1, laser_max_beams=max_beams, search_linear_size=0.1,
                               search_angular_size=0.05)
+    # (this test is about the DEVICE's single-pose path; scans of up to 256 beams would
+    # otherwise be scored on the host, tests/test_gpu_single_pose_host.py)
+    gpu.set_single_pose_path("device")
     other = pts[::-1].copy() * 0.9
     s_other = gpu.scoreScan(guess, other)
     assert abs(s_other - ref.scoreScan(guess, other)) < TOL_TIGHT
@@ -350,6 +353,7 @@ def test_few_poses_take_the_block_per_pose_kernel_bit_identically():
     """scorePoints / scoreScan (ONE pose) and up to 8 poses run a block-per-pose kernel
     whose sums are built in the batched kernel's order: bit-identical scores."""
     gpu, ref, _, guess, pts = _pair(3)
+    gpu.set_single_pose_path("device")     # (the device's single-pose kernel is what is compared here)
     parts = synth.particles(3, 4096)
     parts[:128, :2] = guess[:2] + parts[:128, :2] / 23.0 * 0.4
     parts[:128, 2] = guess[2] + parts[:128, 2] / np.pi * 0.1
@@ -1577,6 +1581,10 @@ def test_score_scan_launches_the_search_of_its_scan_ahead(max_beams):
 
     gpu = ScanMatcherNDT(0)
     gpu.initialize("ahead", **params)
+    # the single poses on the device, so that scoreScan's kernel carries the search behind it and a
+    # scorePoints in between breaks the pattern (scored on the host it would leave the pending
+    # search alone: tests/test_gpu_single_pose_host.py covers that form of the cycle)
+    gpu.set_single_pose_path("device")
     for cycle in range(4):
         gpu.reset()
         gpu.addScans(scans)
