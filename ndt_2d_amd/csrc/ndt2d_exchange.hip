@@ -111,6 +111,9 @@ int exchange_create(Exchange ** out, const int * device_ids, int n, std::string 
   if (ex == nullptr) return fail(err, NDT2D_ERR_INVALID, "exchange_create: out of memory");
   ex->devices.assign(device_ids, device_ids + n);
   ex->comms.assign(static_cast<size_t>(n), nullptr);
+  // (the node's two matcher instances live on two threads: one communicator set is made at a time)
+  static std::mutex init_mutex;
+  std::lock_guard<std::mutex> lock(init_mutex);
   const ncclResult_t r = api->comm_init_all(ex->comms.data(), n, ex->devices.data());
   if (r != ncclSuccess)
   {
