@@ -1124,15 +1124,16 @@ def c_host_multi_device(ids):
     def run(exchange):
         try:
             r = subprocess.run([probe, "--devices", ",".join(str(i) for i in ids), "--exchange", exchange],
-                               capture_output=True, text=True, timeout=240, env=env)
-        except subprocess.TimeoutExpired:
-            return {"error": "probe timed out (240 s)", "exchange_requested": exchange}
+                               capture_output=True, text=True, timeout=150, env=env)
+        except subprocess.TimeoutExpired as exc:
+            tail = exc.stdout.decode(errors="replace") if isinstance(exc.stdout, bytes) else (exc.stdout or "")
+            return {"error": "probe timed out (150 s)", "exchange_requested": exchange, "stdout_tail": tail[-1500:]}
         if r.returncode != 0:
             return {"error": "probe exit %d: %s" % (r.returncode, r.stderr[-500:]), "exchange_requested": exchange}
-        try:
-            out = json.loads(r.stdout.strip().splitlines()[-1])
+        try:   # (RCCL writes its own lines to stdout: the probe's is the one that opens the object)
+            out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{"devices"')][-1])
         except (ValueError, IndexError):
-            return {"error": "no JSON from the probe", "exchange_requested": exchange}
+            return {"error": "no JSON from the probe", "exchange_requested": exchange, "stdout_tail": r.stdout[-500:]}
         for key in ("cfg2", "cfg4"):
             if key in out:
                 out[key]["steps"] = 40 if key == "cfg2" else 7

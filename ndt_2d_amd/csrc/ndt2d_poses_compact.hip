@@ -34,6 +34,7 @@
 // contribute is queued, in the same order, and a queued pair that turns out to be
 // empty adds exactly +0.0, so the scores are those of the unscreened kernel bit for
 // bit (variant "compact-exact" is that kernel; the tests compare the two).
+#include <cstdlib>
 #include <cstring>
 
 #include "ndt2d_device_fn.h"
@@ -948,7 +949,12 @@ hipError_t launch_poses_compact(const PosesArgs & args_in, int cus, bool screen,
   const uint64_t groups = (args.n_poses + kWave - 1) / kWave;
   const uint64_t groups_per_block = waves_per_block / split;
   const uint64_t need = (groups + groups_per_block - 1) / groups_per_block;
-  const uint64_t cap = use_small ? 4096 : static_cast<uint64_t>(cus);
+  uint64_t cap = use_small ? 4096 : static_cast<uint64_t>(cus);
+  if (const char * env = std::getenv("NDT2D_POSES_BLOCK_CAP"))   // A/B knob (experiments/particles_rounds.py)
+  {
+    const long v = std::atol(env);
+    if (v > 0 && use_small) cap = static_cast<uint64_t>(v);
+  }
   const uint32_t blocks = static_cast<uint32_t>(need < cap ? need : cap);
   if (blocks_out != nullptr) *blocks_out = blocks;
   return use_small ? launch_compact<256>(args, blocks, split, lds_bytes, screen, stream)

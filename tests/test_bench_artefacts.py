@@ -1,4 +1,4 @@
-"""The committed bench line (profiles/r03_bench.json, written by `python bench.py` on an
+"""The committed bench line (profiles/r04_bench.json, written by `python bench.py` on an
 MI355X) keeps the driver's contract and agrees with the committed counters and golden
 results.  No GPU needed."""
 import json
@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.fixture(scope="module")
 def line():
-    with open(os.path.join(ROOT, "profiles", "r03_bench.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r04_bench.json")) as f:
         return json.load(f)
 
 
@@ -38,7 +38,7 @@ def test_roofline_is_a_fraction_of_something_that_binds(line):
     # the peak is the chip's fixed issue peak (1,024 SIMDs x 2.4 GHz / 4 cycles), the time is
     # the run's own: achieved = committed SQ_INSTS_VALU / live kernel time
     assert r["peak"] == pytest.approx(1024 * 2.4e9 / 4.0 / 1e9, rel=1e-9)
-    with open(os.path.join(ROOT, "profiles", "r03_pmc.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r04_pmc.json")) as f:
         pmc = json.load(f)
     k = pmc["kernels"][r["kernel"]]
     assert r["achieved"] == pytest.approx(k["SQ_INSTS_VALU"] / (r["kernel_ms_avg"] * 1e-3) / 1e9, rel=1e-9)
@@ -48,7 +48,7 @@ def test_roofline_is_a_fraction_of_something_that_binds(line):
         k["SQ_INSTS_VALU"] * 4.0 / (4.0 * k["SQ_BUSY_CU_CYCLES"]), rel=1e-6)
     assert r["frac"] < r["issue_slot_occupancy_pmc"]          # the chip sustains less than 2.4 GHz
     # ... and it does move with the run: the same command with the driver's flags
-    with open(os.path.join(ROOT, "profiles", "r03_bench_driver_flags.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r04_bench_driver_flags.json")) as f:
         other = json.load(f)
     assert other["steps"] == 20 and other["warmup"] == 5
     assert other["roofline"]["frac"] != r["frac"]
@@ -56,7 +56,7 @@ def test_roofline_is_a_fraction_of_something_that_binds(line):
         r["frac"] * r["kernel_ms_avg"], rel=1e-9)
     assert other["value"] == pytest.approx(line["value"], rel=0.03)   # the pre-warm: within 3 %
     # the kernel's average duration under rocprofv3 (--kernel-trace --stats) agrees with the HIP events
-    with open(os.path.join(ROOT, "profiles", "r03_kernel_stats.csv")) as f:
+    with open(os.path.join(ROOT, "profiles", "r04_kernel_stats.csv")) as f:
         row = next(ln for ln in f if "match_lane_compact_kernel" in ln)
     avg_ns = float(row.rsplit('"', 1)[1].split(",")[3])
     assert avg_ns * 1e-6 == pytest.approx(r["kernel_ms_avg"], rel=0.03)
@@ -75,9 +75,48 @@ def test_single_gpu_anchors_of_the_eight_gpu_workloads(line):
     assert c5["units_per_step"] == 1000000 * 720 and c5["n_gpus"] == 1
     d = line["default_search"]["cpu_single_thread"]
     assert d["match_scan_ms"] > line["default_search"]["match_scan_ms"] > 0
-    # the honest comparison: through the unchanged per-particle loop the plugin is slower than the CPU
-    assert d["measure_500_particles_ms"] * 1e3 < line["default_search"]["c_host"]["measure_500_particles_unchanged_loop_us"]
-    assert d["measure_500_particles_ms"] * 1e3 > line["default_search"]["c_host"]["pf_measure_500_particles_us"]
+    # round 4: through the UNCHANGED per-particle loop (scorePoints per particle, scored on the host
+    # from the host NDT) the plugin now beats the CPU reference path; the one-launch measure beats both
+    ch = line["default_search"]["c_host"]
+    assert ch["measure_500_particles_unchanged_loop_us"] < d["measure_500_particles_ms"] * 1e3
+    assert ch["pf_measure_500_particles_us"] < ch["measure_500_particles_unchanged_loop_us"] <= 600.0
+    # the anchors carry their own roofline (counters of the whole workload = the sum of its eight shares)
+    assert 0.0 < c4["roofline"]["frac"] <= 1.0 and c4["cpu_baseline"]["value"] > 0
+    assert 0.0 < c5["roofline"]["frac"] <= 1.0 and c5["cpu_baseline"]["value"] > 0
+    # ... and one multi-device matcher through the plain-C host found the cfg-4 winner
+    assert line["c_host_multi_device"]["cfg4"]["best_index"] == 80443810
+
+
+def test_counters_belong_to_the_kernels_being_shipped(line):
+    """profiles/r04_pmc.json carries the sha256 of csrc/*.hip, *.h it was taken with: a kernel
+    edit without a re-profile makes the committed roofline stale, and this test fail."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    with open(os.path.join(ROOT, "profiles", "r04_pmc.json")) as f:
+        pmc = json.load(f)
+    assert pmc["source_sha256"] == bench.source_hash()
+    assert line["roofline"]["pmc_matches_source"] is True
+    assert len(pmc["shares"]["cfg4"]) == 8 and len(pmc["shares"]["cfg5"]) == 8
+    for sh in pmc["shares"]["cfg4"] + pmc["shares"]["cfg5"]:
+        assert sh["SQ_INSTS_VALU"] > 0 and sh["SQ_BUSY_CU_CYCLES"] > 0 and "WRITE_SIZE" in sh
+    # the headline kernel no longer spills (round 3: 32 bytes of scratch per lane)
+    assert all(sh["scratch_size"] == 0 for sh in pmc["shares"]["cfg4"])
+
+
+def test_eight_rank_line_counts_as_measured():
+    """`bench.py --gpus 8` (8 ranks on the box's one GPU, gloo): roofline of rank 0's share,
+    CPU baseline, and the C-ABI multi-device leg -- none of them null."""
+    with open(os.path.join(ROOT, "profiles", "r04_bench_8ranks_one_gpu_gloo.json")) as f:
+        ln = json.load(f)
+    assert ln["n_gpus"] == 8 and ln["scaling"] == "strong" and "configs[3]" in ln["config"]["workload"]
+    assert 0.0 < ln["roofline"]["frac"] <= 1.0
+    assert ln["cpu_baseline"]["value"] > 0 and ln["cpu_baseline"]["kind"] == "port"
+    assert ln["match_result"]["best_index"] == 80443810
+    assert ln["c_host_multi_device"]["devices"] == 8 and ln["c_host_multi_device"]["cfg4"]["best_index"] == 80443810
+    pf = ln["particle_filter"]
+    assert 0.0 < pf["roofline"]["frac"] <= 1.0 and pf["cpu_baseline"]["value"] > 0
 
 
 def test_cpu_baseline_and_results(line):
