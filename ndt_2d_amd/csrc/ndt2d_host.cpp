@@ -1084,7 +1084,8 @@ int multi_score_poses(ndt2d_matcher * m, const double * poses_xyt, size_t n_pose
 
 void destroy_matcher(ndt2d_matcher * m)
 {
-  for (size_t r = 0; r < m->devs.size(); ++r)
+  // (a matcher whose creation failed half-way has contexts but no shard records yet)
+  for (size_t r = 0; r < m->devs.size() && r < m->shards.size(); ++r)
   {
     MatcherShard & sh = m->shards[r];
     (void)ndt2d_synchronize(m->devs[r]);

@@ -143,3 +143,19 @@ def test_multi_device_particle_measure_against_the_oracle():
         # scorePoses dealt out: the un-normalised scores
         s = m.scorePoses(pts, parts)
         assert float(np.max(np.abs(s - w_ref))) < 1e-9
+
+
+def test_bad_device_lists_are_refused_cleanly():
+    import ctypes as C
+    from ndt_2d_amd import _capi
+    L = _capi.lib()
+    m = C.c_void_p()
+    ids = (C.c_int * 2)(0, 99)                 # the second device does not exist: the first context is released
+    assert L.ndt2d_matcher_create_multi(C.byref(m), ids, 2) == _capi.ERR_INVALID and not m.value
+    assert L.ndt2d_matcher_create_multi(C.byref(m), ids, 0) == _capi.ERR_INVALID
+    assert L.ndt2d_matcher_create_multi(C.byref(m), None, 2) == _capi.ERR_INVALID
+    one = (C.c_int * 1)(0)
+    assert L.ndt2d_matcher_create_multi(C.byref(m), one, 1) == _capi.OK
+    assert L.ndt2d_matcher_device_count(m) == 1 and L.ndt2d_matcher_device_at(m, 1) is None
+    assert L.ndt2d_matcher_set_exchange(m, b"bogus") == _capi.ERR_INVALID
+    assert L.ndt2d_matcher_destroy(m) == _capi.OK
