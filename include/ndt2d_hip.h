@@ -544,6 +544,12 @@ int ndt2d_matcher_set_search_ahead(ndt2d_matcher * m, int enabled);
  * NDT and of the beams (not available to ndt2d_matcher_match_laser_scan, which skips it).
  * stats: searches that came back marked, and how many of those changed the winner. */
 int ndt2d_matcher_set_adjudication(ndt2d_matcher * m, int enabled);
+/* The same for a search that was sharded from outside (one process per GPU, ndt_2d_amd/dist.py):
+ * record_inout[NDT2D_MATCH_RECORD_DOUBLES] is the COMBINED record of all shards; if its winner
+ * is marked (index + 0.5) it is settled as above -- on this matcher's own device, over the whole
+ * lattice of the last ndt2d_matcher_prepare_search, which every rank holds: all ranks reach the
+ * same verdict without talking to each other -- and leaves with a plain index either way. */
+int ndt2d_matcher_settle_near_tie(ndt2d_matcher * m, const double * scan_pose_xyt, double * record_inout);
 int ndt2d_matcher_adjudication_stats(ndt2d_matcher * m, uint64_t * marked, uint64_t * changed, uint64_t * truncated);
 /* Where ONE pose is scored (scorePoints, scoreScan).  "host" (default): a scan of at most
  * max_beams subsampled beams (default 256; 0 keeps the current value) is scored by the calling

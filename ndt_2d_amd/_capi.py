@@ -154,6 +154,7 @@ SIGNATURES = {
     "ndt2d_matcher_score_scan": (C.c_int, [_vp, _dp, _dp, _sz, _dp]),
     "ndt2d_matcher_set_search_ahead": (C.c_int, [_vp, C.c_int]),
     "ndt2d_matcher_set_adjudication": (C.c_int, [_vp, C.c_int]),
+    "ndt2d_matcher_settle_near_tie": (C.c_int, [_vp, _dp, _dp]),
     "ndt2d_matcher_adjudication_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                                    C.POINTER(C.c_uint64)]),
     "ndt2d_matcher_set_single_pose_path": (C.c_int, [_vp, C.c_char_p, _sz]),

@@ -1785,6 +1785,14 @@ int ndt2d_matcher_score_scan(ndt2d_matcher * m, const double * scan_pose_xyt,
   return rc;
 }
 
+int ndt2d_matcher_settle_near_tie(ndt2d_matcher * m, const double * scan_pose_xyt, double * record_inout)
+{
+  if (m == nullptr || scan_pose_xyt == nullptr || record_inout == nullptr) return NDT2D_ERR_INVALID;
+  if (!m->search_ready) return mfail(m, NDT2D_ERR_STATE, "settle_near_tie: ndt2d_matcher_prepare_search first");
+  discard_ahead(m);
+  return settle_near_tie(m, scan_pose_xyt, m->dth.size(), m->dlin.size(), m->n_use, record_inout);
+}
+
 int ndt2d_matcher_set_adjudication(ndt2d_matcher * m, int enabled)
 {
   if (m == nullptr) return NDT2D_ERR_INVALID;

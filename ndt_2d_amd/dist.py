@@ -113,10 +113,17 @@ def match_scan_sharded(matcher, scan_pose, points, rank, world, dist, pose=None)
         stream.synchronize()
     finally:
         matcher.set_stream(previous)
-    best_score, best_index, acc = combine_match_records(records)
-    rec = np.concatenate([[best_score, -1.0 if best_index is None else float(best_index)], acc])
+    best_score, best_index, acc, marked = combine_match_records_ex(records)
+    rec = np.concatenate([[best_score, -1.0 if best_index is None else float(best_index) + (0.5 if marked else 0.0)],
+                          acc])
+    if marked:
+        # a rival within 1e-9 of the winner: every rank settles it for itself on the whole lattice
+        # (same data, same arithmetic, same verdict -- no further exchange)
+        rec = matcher.settle_near_tie(scan_pose, rec)
+        best_index = int(rec[1]) if rec[1] >= 0.0 else None
     out = matcher.finish_match(rec, pose=pose)
     out["best_index"] = best_index
+    out["near_tie"] = bool(marked)
     out["n_candidates"] = n_th * n_lin * n_lin
     return out
 

@@ -286,6 +286,14 @@ class ScanMatcherNDT:
         are rescored on the host with the reference's arithmetic and its first-wins rule."""
         self._check(self._L.ndt2d_matcher_set_adjudication(self._m, 1 if enabled else 0), "set_adjudication")
 
+    def settle_near_tie(self, scan_pose, record):
+        """A combined record of a search sharded from outside: a marked winner (index + 0.5) is
+        settled with the reference's arithmetic; returns the record with a plain index."""
+        sp = _f64(scan_pose, (3,))
+        rec = _f64(record, (_capi.MATCH_RECORD_DOUBLES,)).copy()
+        self._check(self._L.ndt2d_matcher_settle_near_tie(self._m, dptr(sp), dptr(rec)), "settle_near_tie")
+        return rec
+
     def adjudication_stats(self):
         """(searches whose winner came back marked near-tie, of those: winner changed, list truncated)."""
         a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)

@@ -158,3 +158,22 @@ def test_mirrored_beam_sets_tie_up_to_summation_order():
     assert marked == cases and changed == differ_raw
     print("mirrored-beam cases: %d, device order differs from the CPU's in %d (all settled)" % (cases, differ_raw))
     assert differ_raw > 0     # the cases exist: without the adjudication the winner would differ
+
+
+def test_sharded_search_driven_from_outside_settles_its_near_ties_too():
+    """ndt_2d_amd/dist.py::match_scan_sharded (one process per GPU): the combined record carries
+    the mark, and every rank settles it on its own (ndt2d_matcher_settle_near_tie)."""
+    from ndt_2d_amd import dist as shard
+    gpu, ref = _matchers()
+    rng = np.random.default_rng(77)
+    settled = 0
+    for _ in range(12):
+        d = np.round(rng.uniform(-0.4, 0.4, size=(12, 2)) * 4096.0) / 4096.0
+        beams = np.concatenate([2.0 + d, 2.0 - d])
+        exp = ref.matchScan(SCAN_POSE, beams)
+        got = shard.match_scan_sharded(gpu, SCAN_POSE, beams, 0, 1, None)
+        assert got["near_tie"] is True
+        assert got["best_index"] == exp["best_index"] and np.array_equal(got["pose"], exp["pose"])
+        assert got["score"] == exp["score"]
+        settled += 1
+    assert gpu.adjudication_stats()[0] == settled
