@@ -149,14 +149,16 @@ typedef struct ndt2d_match_result
   uint64_t best_index;    /* flat index of the winner, NDT2D_NO_INDEX if none (:128) */
   double acc[10];         /* k00,k01,k02,k11,k12,k22, u0,u1,u2, s  (:137-140) */
   uint64_t n_candidates;  /* candidates evaluated by this call */
-  /* 1: another candidate scored within NDT2D_NEAR_TIE of the winner (the kernels' scores
-   * differ from the CPU reference's in the last bits -- device exp vs libm -- so the two could
-   * come out in the other order there); ndt2d_match_near_best lists such candidates and
-   * ndt2d_matcher_match_scan settles them with the reference's own arithmetic.  0 proves
-   * that no other candidate lies that close. */
+  /* 1: another candidate scored within the near-tie tolerance of the winner --
+   * |difference| <= NDT2D_NEAR_TIE_REL * (the larger magnitude) + NDT2D_NEAR_TIE_ABS; the
+   * kernels' scores differ from the CPU reference's in the last bits (device exp vs libm: a
+   * relative error below 1e-13), so the two could come out in the other order there;
+   * ndt2d_match_near_best lists such candidates and ndt2d_matcher_match_scan settles them with
+   * the reference's own arithmetic.  0 proves that no other candidate lies that close. */
   uint64_t near_tie;
 } ndt2d_match_result;
-#define NDT2D_NEAR_TIE 1.0e-9
+#define NDT2D_NEAR_TIE_REL 1.0e-11
+#define NDT2D_NEAR_TIE_ABS 1.0e-300
 
 /* Number of doubles of the device-resident result record
  * {best_score, best_index (exact double, -1 if none; + 0.5 = near_tie, truncate), acc[10]}. */
@@ -183,11 +185,12 @@ int ndt2d_match_launch_strided(ndt2d_handle h, size_t th_first, size_t th_stride
  * host spins on the flag, which returns ~4 us sooner than a stream synchronisation.) */
 int ndt2d_match_fetch(ndt2d_handle h, ndt2d_match_result * out);
 /* Search the slab [th_begin, th_end) keeping every candidate's score on the device, and list the
- * candidates that scored below 0 and within eps of the slab's best (flat indices in the whole
- * lattice, ascending; *n_out = how many there are, of which the first `capacity` are written).
- * result_out (optional) = the slab's result.  Synchronous.  This is the slow path behind a
- * near_tie result: one more search plus one pass over its scores. */
-int ndt2d_match_near_best(ndt2d_handle h, size_t th_begin, size_t th_end, double eps, uint64_t * index_out,
+ * candidates that scored below 0 and within rel * |best| + NDT2D_NEAR_TIE_ABS of the slab's best
+ * (flat indices in the whole lattice, ascending).  *n_out = how many there are; when that exceeds
+ * `capacity` the list holds the first `capacity`-or-fewer of them in visiting order (further passes
+ * over the scores).  result_out (optional) = the slab's result.  Synchronous.  This is the slow path
+ * behind a near_tie result: one more search plus one pass over its scores. */
+int ndt2d_match_near_best(ndt2d_handle h, size_t th_begin, size_t th_end, double rel, uint64_t * index_out,
                           size_t capacity, size_t * n_out, ndt2d_match_result * result_out);
 /* Searches launched and results fetched on this context so far: a layer that leaves a search
  * pending across calls (ndt2d_matcher_score_scan launches the next matchScan's search) checks
@@ -535,8 +538,8 @@ int ndt2d_matcher_score_scan(ndt2d_matcher * m, const double * scan_pose_xyt,
                              const double * points_xy, size_t n_points, double * score_out);
 int ndt2d_matcher_set_search_ahead(ndt2d_matcher * m, int enabled);
 /* Near-tie adjudication (default: on).  When a search's winner comes back with near_tie set,
- * matchScan lists the candidates within NDT2D_NEAR_TIE of the best (ndt2d_match_near_best, up to
- * 256), rescores each on the host exactly as the reference does (points_outer / points_inner,
+ * matchScan lists the candidates within the tolerance of the best (ndt2d_match_near_best with
+ * NDT2D_NEAR_TIE_REL, the first 256 in visiting order), rescores each on the host exactly as the reference does (points_outer / points_inner,
  * NDT::likelihood in beam order, libm's exp; src/scan_matcher_ndt.cpp:106-127) and applies the
  * reference's rule -- strict `<` in visiting order (:128-134): the lowest host score, between equal
  * ones the lowest flat index.  The returned pose / score are then that candidate's (the score

@@ -1325,7 +1325,7 @@ int ndt2d_match_fetch(ndt2d_handle h, ndt2d_match_result * out)
   for (int k = 0; k < NDT2D_MATCH_RECORD_DOUBLES; ++k) rec[k] = h->host_res[k];
   out->best_score = rec[0];
   out->best_index = rec[1] < 0.0 ? NDT2D_NO_INDEX : static_cast<uint64_t>(rec[1]);
-  // (index + 0.5: another candidate lies within NDT2D_NEAR_TIE of the winner, ndt2d_device_fn.h merge_best)
+  // (index + 0.5: another candidate lies within the near-tie tolerance of the winner, ndt2d_device_fn.h merge_best)
   out->near_tie = (rec[1] >= 0.0 && rec[1] != std::floor(rec[1])) ? 1u : 0u;
   for (int k = 0; k < 10; ++k) out->acc[k] = rec[2 + k];
   out->n_candidates = h->last_candidates;
@@ -1333,12 +1333,12 @@ int ndt2d_match_fetch(ndt2d_handle h, ndt2d_match_result * out)
   return NDT2D_OK;
 }
 
-int ndt2d_match_near_best(ndt2d_handle h, size_t th_begin, size_t th_end, double eps, uint64_t * index_out,
+int ndt2d_match_near_best(ndt2d_handle h, size_t th_begin, size_t th_end, double rel, uint64_t * index_out,
                           size_t capacity, size_t * n_out, ndt2d_match_result * result_out)
 {
   if (h == nullptr || n_out == nullptr || (capacity > 0 && index_out == nullptr)) return NDT2D_ERR_INVALID;
   *n_out = 0;
-  if (!(eps >= 0.0) || th_begin >= th_end || th_end > h->n_th || capacity > 65536)
+  if (!(rel >= 0.0) || th_begin >= th_end || th_end > h->n_th || capacity > 65536)
   {
     return fail(h, NDT2D_ERR_INVALID, "ndt2d_match_near_best: bad argument");
   }
@@ -1351,19 +1351,38 @@ int ndt2d_match_near_best(ndt2d_handle h, size_t th_begin, size_t th_end, double
   rc = ndt2d_match_launch(h, th_begin, th_end, h->tmp_scores.ptr, nullptr);
   if (rc != NDT2D_OK) return rc;
   unsigned long long * list = reinterpret_cast<unsigned long long *>(h->near_list.ptr);
-  hipError_t e = ndt2d::launch_collect_near(h->tmp_scores.ptr, n_scores, h->record.ptr, eps, list,
-                                            static_cast<uint32_t>(capacity), h->stream);
-  if (e != hipSuccess) return fail_hip(h, e, "launch_collect_near");
   std::vector<unsigned long long> host(capacity + 1);
-  NDT2D_HIP(h, hipMemcpyAsync(host.data(), list, (capacity + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost,
-                              h->stream));
-  NDT2D_SYNC(h);
+  // one pass over all scores; should more candidates qualify than the list holds, further passes
+  // over a shrinking index range until the list holds exactly the FIRST ones in visiting order
+  // (bisection on the upper index; a plateau of equal scores is the only realistic way there)
+  auto collect = [&](uint64_t hi) -> int {
+    hipError_t e = ndt2d::launch_collect_near(h->tmp_scores.ptr, n_scores, hi, h->record.ptr, rel, NDT2D_NEAR_TIE_ABS, list,
+                                              static_cast<uint32_t>(capacity), h->stream);
+    if (e != hipSuccess) return fail_hip(h, e, "launch_collect_near");
+    NDT2D_HIP(h, hipMemcpyAsync(host.data(), list, (capacity + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                                h->stream));
+    NDT2D_SYNC(h);
+    return NDT2D_OK;
+  };
+  if ((rc = collect(n_scores)) != NDT2D_OK) return rc;
+  const size_t total = static_cast<size_t>(host[0]);
+  if (total > capacity && capacity > 0)
+  {
+    uint64_t lo = 0, hi = n_scores;   // count(lo) <= capacity < count(hi)
+    while (hi - lo > 1)
+    {
+      const uint64_t mid = lo + (hi - lo) / 2;
+      if ((rc = collect(mid)) != NDT2D_OK) return rc;
+      if (host[0] <= capacity) lo = mid; else hi = mid;
+    }
+    if ((rc = collect(lo)) != NDT2D_OK) return rc;
+  }
   ndt2d_match_result res;
   rc = ndt2d_match_fetch(h, &res);
   if (rc != NDT2D_OK) return rc;
   if (result_out != nullptr) *result_out = res;
-  *n_out = static_cast<size_t>(host[0]);
-  const size_t kept = std::min<size_t>(*n_out, capacity);
+  *n_out = total;
+  const size_t kept = std::min<size_t>(static_cast<size_t>(host[0]), capacity);
   const uint64_t base = static_cast<uint64_t>(th_begin) * h->n_lin * h->n_lin;
   for (size_t k = 0; k < kept; ++k) index_out[k] = base + host[1 + k];
   std::sort(index_out, index_out + kept);

@@ -276,20 +276,25 @@ __device__ __forceinline__ bool better(double s_a, double i_a, double s_b, doubl
 
 // Near-ties.  The kernels' scores differ from the reference's in the last bits (summation
 // order within a candidate is the reference's, but exp() is the device's), so two candidates
-// whose scores lie within kNearTie of each other may come out in the other order than on the
-// CPU.  Every merge of two (score, index) pairs therefore MARKS its winner when the loser was a
-// real candidate within kNearTie of it: the mark is index + 0.5 (indices are exact integers in
-// doubles; every consumer truncates, and the tie-break between different candidates is
-// unaffected).  A marked winner makes the host collect the candidates near the best and rescore
-// them with the reference's arithmetic (ndt2d_match_near_best, ndt2d_matcher_match_scan); an
-// unmarked one proves that no other candidate lies within kNearTie: whatever loses to the final
-// winner within kNearTie does so in a merge against it or against a candidate that itself
-// later loses within kNearTie, and the mark travels with the winner.
-constexpr double kNearTie = 1.0e-9;
+// whose scores agree to within that rounding may come out in the other order than on the CPU.
+// A score is a sum of at most a few thousand non-negative terms, each within ~2 ulp of the
+// reference's: its RELATIVE error is below 1e-13, whatever its magnitude (scores of 1e-150 are
+// as common as scores of -300 in degenerate maps -- an absolute tolerance would call all of the
+// former ties).  Every merge of two (score, index) pairs therefore MARKS its winner when the loser
+// was a real candidate within kNearTieRel (relative; + kNearTieAbs for the denormal range) of it:
+// the mark is index + 0.5 (indices are exact integers in doubles; every consumer truncates, and the
+// tie-break between different candidates is unaffected).  A marked winner makes the host collect
+// the candidates that close to the best and rescore them with the reference's arithmetic
+// (ndt2d_match_near_best, ndt2d_matcher_match_scan); an unmarked one proves that no other candidate
+// lies that close: whatever loses to the final winner W within the tolerance (which is taken from
+// the larger magnitude, W's) does so in a merge against W or against a candidate between the two,
+// which then meets W within the tolerance itself -- and the mark travels with the winner.
+constexpr double kNearTieRel = 1.0e-11;   // NDT2D_NEAR_TIE_REL
+constexpr double kNearTieAbs = 1.0e-300;  // NDT2D_NEAR_TIE_ABS
 
 __device__ __forceinline__ void merge_best(double os, double oi, double & s, double & i)
 {
-  const bool near = (fabs(os - s) <= kNearTie) & (oi < kNoIndex) & (i < kNoIndex);
+  const bool near = (fabs(os - s) <= fmax(fabs(os), fabs(s)) * kNearTieRel + kNearTieAbs) & (oi < kNoIndex) & (i < kNoIndex);
   if (better(os, oi, s, i))
   {
     s = os;

@@ -617,7 +617,7 @@ double host_score_candidate(const HostNdt & ndt, const double * beams_xy, size_t
 }
 
 // A search's record came back with its winner marked (index + 0.5: another candidate within
-// NDT2D_NEAR_TIE, ndt2d_device_fn.h merge_best): list the candidates that close to the best,
+// the near-tie tolerance, ndt2d_device_fn.h merge_best): list the candidates that close to the best,
 // rescore them as the reference would and apply its rule -- strict `<` in visiting order
 // (src/scan_matcher_ndt.cpp:128-134).  The first device holds the prepared search.  record[1]
 // leaves here as a plain index.
@@ -632,7 +632,7 @@ int settle_near_tie(ndt2d_matcher * m, const double * scan_pose_xyt, size_t n_th
   constexpr size_t kCap = 256;
   uint64_t idx[kCap];
   size_t n = 0;
-  const int rc = ndt2d_match_near_best(m->dev, 0, n_th, NDT2D_NEAR_TIE, idx, kCap, &n, nullptr);
+  const int rc = ndt2d_match_near_best(m->dev, 0, n_th, NDT2D_NEAR_TIE_REL, idx, kCap, &n, nullptr);
   if (rc != NDT2D_OK) return dev_fail(m, rc, "ndt2d_match_near_best");
   if (n > kCap) ++m->adj_truncated;
   const uint64_t per_th = static_cast<uint64_t>(n_lin) * n_lin;
@@ -780,9 +780,10 @@ void combine_records(const double * rows, const std::vector<size_t> & count, dou
     const double * rec = rows + r * kRec;
     if (rec[1] >= 0.0 && rec[0] < 0.0)
     {
-      // (an index ending in .5 is a winner marked "another candidate within NDT2D_NEAR_TIE": the
+      // (an index ending in .5 is a winner marked "another candidate within the near-tie tolerance": the
       // mark stays with the winner, and two devices' winners that close mark it as well)
-      const bool near = out[1] >= 0.0 && std::fabs(rec[0] - out[0]) <= NDT2D_NEAR_TIE;
+      const bool near = out[1] >= 0.0 && std::fabs(rec[0] - out[0]) <=
+                                           std::max(std::fabs(rec[0]), std::fabs(out[0])) * NDT2D_NEAR_TIE_REL + NDT2D_NEAR_TIE_ABS;
       if (out[1] < 0.0 || rec[0] < out[0] || (rec[0] == out[0] && std::floor(rec[1]) < std::floor(out[1])))
       {
         out[0] = rec[0];

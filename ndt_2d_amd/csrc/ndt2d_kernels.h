@@ -216,11 +216,12 @@ hipError_t launch_match(const MatchArgs & args, double * workspace, double * out
                         hipEvent_t ev_main_start, hipEvent_t ev_main_done, LaunchInfo * info);
 
 size_t poses_workspace_doubles(uint64_t n_poses);
-// The candidates whose score lies within `eps` of the search's best: scores[n] (slab-local order),
-// record = the search's result record (record[0] = best score).  out[0] = how many there are,
-// out[1 .. cap] = their slab-local indices (in no particular order; only the first cap are kept).
-hipError_t launch_collect_near(const double * scores, uint64_t n, const double * record, double eps,
-                               unsigned long long * out, uint32_t cap, hipStream_t stream);
+// The candidates (slab-local index < hi) that scored below 0 and within rel * |best| + abs_tol of
+// the search's best: scores[n] (slab-local order), record = the search's result record (record[0] =
+// best score).  out[0] = how many there are, out[1 .. cap] = their slab-local indices (in no
+// particular order; only the first cap to arrive are kept).
+hipError_t launch_collect_near(const double * scores, uint64_t n, uint64_t hi, const double * record, double rel,
+                               double abs_tol, unsigned long long * out, uint32_t cap, hipStream_t stream);
 hipError_t launch_score_poses(const PosesArgs & args, double * workspace, double * stats_out,
                               int force_variant, hipStream_t stream, hipEvent_t ev_main_done,
                               LaunchInfo * info);

@@ -296,14 +296,17 @@ __global__ void __launch_bounds__(kFinalThreads) match_reduce_final_kernel(
   }
 }
 
-// Near-tie adjudication, device side (see merge_best in ndt2d_device_fn.h): every candidate
-// that scored below 0 and within eps of the best.  Runs only behind a search whose winner
-// came back marked.
-__global__ void __launch_bounds__(256) collect_near_kernel(const double * scores, uint64_t n, const double * record,
-                                                           double eps, unsigned long long * out, uint32_t cap)
+// Near-tie adjudication, device side (see merge_best in ndt2d_device_fn.h): every candidate with
+// an index below `hi` that scored below 0 and within the tolerance of the best.  Runs only behind a
+// search whose winner came back marked.
+__global__ void __launch_bounds__(256) collect_near_kernel(const double * scores, uint64_t n, uint64_t hi,
+                                                           const double * record, double rel, double abs_tol,
+                                                           unsigned long long * out, uint32_t cap)
 {
-  const double limit = record[0] + eps;
-  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += static_cast<uint64_t>(gridDim.x) * 256ull)
+  const double best = record[0];
+  const double limit = best + (fabs(best) * rel + abs_tol);
+  const uint64_t end = hi < n ? hi : n;
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < end; i += static_cast<uint64_t>(gridDim.x) * 256ull)
   {
     const double s = scores[i];
     if (s < 0.0 && s <= limit)
@@ -850,14 +853,14 @@ __global__ void __launch_bounds__(256) pf_finalize_reduce_kernel(const double * 
 
 }  // namespace
 
-hipError_t launch_collect_near(const double * scores, uint64_t n, const double * record, double eps,
-                               unsigned long long * out, uint32_t cap, hipStream_t stream)
+hipError_t launch_collect_near(const double * scores, uint64_t n, uint64_t hi, const double * record, double rel,
+                               double abs_tol, unsigned long long * out, uint32_t cap, hipStream_t stream)
 {
   hipError_t e = hipMemsetAsync(out, 0, sizeof(unsigned long long), stream);
   if (e != hipSuccess) return e;
   const uint64_t blocks = (n + 255) / 256;
   collect_near_kernel<<<dim3(static_cast<uint32_t>(blocks < 4096 ? (blocks > 0 ? blocks : 1) : 4096)), dim3(256), 0, stream>>>(
-    scores, n, record, eps, out, cap);
+    scores, n, hi, record, rel, abs_tol, out, cap);
   return hipGetLastError();
 }
 

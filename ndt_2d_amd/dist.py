@@ -53,12 +53,12 @@ def combine_match_records(records):
     return best_score, best_index, acc
 
 
-NEAR_TIE = 1.0e-9
+NEAR_TIE_REL, NEAR_TIE_ABS = 1.0e-11, 1.0e-300      # NDT2D_NEAR_TIE_REL / _ABS of include/ndt2d_hip.h
 
 
 def combine_match_records_ex(records):
     """combine_match_records plus the near-tie mark: a record's index ending in .5 says another
-    candidate of that rank's share scored within NEAR_TIE of its winner (include/ndt2d_hip.h,
+    candidate of that rank's share scored within the near-tie tolerance of its winner (include/ndt2d_hip.h,
     ndt2d_match_result.near_tie); two ranks' winners that close mark the result as well.  Returns
     (best_score, best_index, acc, near_tie): with near_tie the caller should settle the winner as
     ndt2d_matcher_match_scan does (ndt2d_match_near_best + the reference's arithmetic)."""
@@ -67,7 +67,8 @@ def combine_match_records_ex(records):
     acc = np.zeros(10, dtype=np.float64)
     for rec in records:
         if rec[1] >= 0.0 and rec[0] < 0.0:
-            near = best_index is not None and abs(rec[0] - best_score) <= NEAR_TIE
+            near = best_index is not None and \
+                abs(rec[0] - best_score) <= max(abs(rec[0]), abs(best_score)) * NEAR_TIE_REL + NEAR_TIE_ABS
             if best_index is None or rec[0] < best_score or \
                     (rec[0] == best_score and int(rec[1]) < best_index):
                 best_score, best_index = float(rec[0]), int(rec[1])

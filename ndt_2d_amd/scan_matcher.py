@@ -282,8 +282,8 @@ class ScanMatcherNDT:
         return a.value, b.value
 
     def set_adjudication(self, enabled):
-        """Near-tie adjudication of matchScan (on by default): candidates within 1e-9 of the best
-        are rescored on the host with the reference's arithmetic and its first-wins rule."""
+        """Near-tie adjudication of matchScan (on by default): candidates within 1e-11 (relative) of the
+        best are rescored on the host with the reference's arithmetic and its first-wins rule."""
         self._check(self._L.ndt2d_matcher_set_adjudication(self._m, 1 if enabled else 0), "set_adjudication")
 
     def settle_near_tie(self, scan_pose, record):
@@ -301,12 +301,13 @@ class ScanMatcherNDT:
                     "adjudication_stats")
         return a.value, b.value, c.value
 
-    def match_near_best(self, th_begin, th_end, eps=1e-9, capacity=256):
+    def match_near_best(self, th_begin, th_end, rel=1e-11, capacity=256):
         """ndt2d_match_near_best on the prepared search: flat indices (ascending) of the candidates
-        within eps of the slab's best, and how many there are."""
+        within rel * |best| of the slab's best (the first `capacity` in visiting order), and how many
+        there are."""
         idx = (C.c_uint64 * capacity)()
         n = C.c_size_t(0)
-        self._dev_check(self._L.ndt2d_match_near_best(self.device_handle, th_begin, th_end, eps, idx, capacity,
+        self._dev_check(self._L.ndt2d_match_near_best(self.device_handle, th_begin, th_end, rel, idx, capacity,
                                                       C.byref(n), None), "ndt2d_match_near_best")
         return [idx[k] for k in range(min(n.value, capacity))], n.value
 

@@ -229,7 +229,7 @@ def test_random_case_multi_device_and_host_paths(seed):
     interleaved, host exchange) and -- every fourth seed -- over one device with the RCCL
     exchange must reproduce the single-device matcher bit for bit on every candidate score
     and on the winner; scorePoints of short scans, scored on the host, must give the oracle's
-    bits; ndt2d_match_near_best must list exactly the candidates within 1e-9 of the best."""
+    bits; ndt2d_match_near_best must list exactly the candidates within 1e-9 (relative) of the best."""
     rng = np.random.default_rng(9000 + seed)
     params, scans, scan_pose, query, poses = _random_case(rng)
     ref = O.ScanMatcherNDT()
@@ -267,9 +267,13 @@ def test_random_case_multi_device_and_host_paths(seed):
     finite = exp["scores"][~np.isnan(exp["scores"])]
     if finite.size and finite.min() < 0.0 and not np.isnan(exp["scores"]).any():
         n_th, _, _ = one.prepare_search(scan_pose, query)
-        near, n = one.match_near_best(0, n_th, eps=1e-9, capacity=256)
+        near, n = one.match_near_best(0, n_th, rel=1e-9, capacity=256)
+        # (tolerance = rel * |best| + NDT2D_NEAR_TIE_ABS: in the denormal range everything is a tie)
         d = exp["scores"] - exp["scores"].min()
-        sure = set(int(i) for i in np.flatnonzero((d <= 0.9e-9) & (exp["scores"] < 0.0)))
-        maybe = set(int(i) for i in np.flatnonzero((d <= 1.1e-9) & (exp["scores"] < 0.0)))
+        b = abs(exp["scores"].min())
+        sure = set(int(i) for i in np.flatnonzero((d <= 0.9e-9 * b + 0.9e-300) & (exp["scores"] < 0.0)))
+        maybe = set(int(i) for i in np.flatnonzero((d <= 1.1e-9 * b + 1.1e-300) & (exp["scores"] < 0.0)))
         if n <= 256:
             assert sure <= set(near) <= maybe, (seed, n)
+        else:
+            assert len(near) <= 256 and set(near) <= maybe and near == sorted(near)
