@@ -150,15 +150,14 @@ typedef struct ndt2d_match_result
   double acc[10];         /* k00,k01,k02,k11,k12,k22, u0,u1,u2, s  (:137-140) */
   uint64_t n_candidates;  /* candidates evaluated by this call */
   /* 1: another candidate scored within the near-tie tolerance of the winner --
-   * |difference| <= NDT2D_NEAR_TIE_REL * (the larger magnitude) + NDT2D_NEAR_TIE_ABS; the
+   * |difference| <= NDT2D_NEAR_TIE_REL * (the larger magnitude); the
    * kernels' scores differ from the CPU reference's in the last bits (device exp vs libm: a
    * relative error below 1e-13), so the two could come out in the other order there;
    * ndt2d_match_near_best lists such candidates and ndt2d_matcher_match_scan settles them with
    * the reference's own arithmetic.  0 proves that no other candidate lies that close. */
   uint64_t near_tie;
 } ndt2d_match_result;
-#define NDT2D_NEAR_TIE_REL 1.0e-11
-#define NDT2D_NEAR_TIE_ABS 1.0e-300
+#define NDT2D_NEAR_TIE_REL 1.4551915228366852e-11   /* 2^-36 */
 
 /* Number of doubles of the device-resident result record
  * {best_score, best_index (exact double, -1 if none; + 0.5 = near_tie, truncate), acc[10]}. */
@@ -185,7 +184,7 @@ int ndt2d_match_launch_strided(ndt2d_handle h, size_t th_first, size_t th_stride
  * host spins on the flag, which returns ~4 us sooner than a stream synchronisation.) */
 int ndt2d_match_fetch(ndt2d_handle h, ndt2d_match_result * out);
 /* Search the slab [th_begin, th_end) keeping every candidate's score on the device, and list the
- * candidates that scored below 0 and within rel * |best| + NDT2D_NEAR_TIE_ABS of the slab's best
+ * candidates that scored below 0 and within rel * |best| of the slab's best
  * (flat indices in the whole lattice, ascending).  *n_out = how many there are; when that exceeds
  * `capacity` the list holds the first `capacity`-or-fewer of them in visiting order (further passes
  * over the scores).  result_out (optional) = the slab's result.  Synchronous.  This is the slow path

@@ -1356,7 +1356,7 @@ int ndt2d_match_near_best(ndt2d_handle h, size_t th_begin, size_t th_end, double
   // over a shrinking index range until the list holds exactly the FIRST ones in visiting order
   // (bisection on the upper index; a plateau of equal scores is the only realistic way there)
   auto collect = [&](uint64_t hi) -> int {
-    hipError_t e = ndt2d::launch_collect_near(h->tmp_scores.ptr, n_scores, hi, h->record.ptr, rel, NDT2D_NEAR_TIE_ABS, list,
+    hipError_t e = ndt2d::launch_collect_near(h->tmp_scores.ptr, n_scores, hi, h->record.ptr, rel, 0.0, list,
                                               static_cast<uint32_t>(capacity), h->stream);
     if (e != hipSuccess) return fail_hip(h, e, "launch_collect_near");
     NDT2D_HIP(h, hipMemcpyAsync(host.data(), list, (capacity + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost,

@@ -281,7 +281,7 @@ __device__ __forceinline__ bool better(double s_a, double i_a, double s_b, doubl
 // reference's: its RELATIVE error is below 1e-13, whatever its magnitude (scores of 1e-150 are
 // as common as scores of -300 in degenerate maps -- an absolute tolerance would call all of the
 // former ties).  Every merge of two (score, index) pairs therefore MARKS its winner when the loser
-// was a real candidate within kNearTieRel (relative; + kNearTieAbs for the denormal range) of it:
+// was a real candidate within 2^-kNearTieLog2 (relative) of it:
 // the mark is index + 0.5 (indices are exact integers in doubles; every consumer truncates, and the
 // tie-break between different candidates is unaffected).  A marked winner makes the host collect
 // the candidates that close to the best and rescore them with the reference's arithmetic
@@ -289,12 +289,15 @@ __device__ __forceinline__ bool better(double s_a, double i_a, double s_b, doubl
 // lies that close: whatever loses to the final winner W within the tolerance (which is taken from
 // the larger magnitude, W's) does so in a merge against W or against a candidate between the two,
 // which then meets W within the tolerance itself -- and the mark travels with the winner.
-constexpr double kNearTieRel = 1.0e-11;   // NDT2D_NEAR_TIE_REL
-constexpr double kNearTieAbs = 1.0e-300;  // NDT2D_NEAR_TIE_ABS
+// The tolerance is 2^-36 (1.46e-11) so that the test needs no constant in a register:
+// |os - s| * 2^36 <= max(|os|, |s|), four instructions (add, max with |.| modifiers, ldexp, compare).
+constexpr int kNearTieLog2 = 36;   // NDT2D_NEAR_TIE_REL = 2^-36
 
 __device__ __forceinline__ void merge_best(double os, double oi, double & s, double & i)
 {
-  const bool near = (fabs(os - s) <= fmax(fabs(os), fabs(s)) * kNearTieRel + kNearTieAbs) & (oi < kNoIndex) & (i < kNoIndex);
+  double larger;
+  asm("v_max_f64 %0, |%1|, |%2|" : "=v"(larger) : "v"(os), "v"(s));
+  const bool near = (ldexp(fabs(os - s), kNearTieLog2) <= larger) & (oi < kNoIndex) & (i < kNoIndex);
   if (better(os, oi, s, i))
   {
     s = os;

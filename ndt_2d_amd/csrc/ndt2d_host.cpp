@@ -783,7 +783,7 @@ void combine_records(const double * rows, const std::vector<size_t> & count, dou
       // (an index ending in .5 is a winner marked "another candidate within the near-tie tolerance": the
       // mark stays with the winner, and two devices' winners that close mark it as well)
       const bool near = out[1] >= 0.0 && std::fabs(rec[0] - out[0]) <=
-                                           std::max(std::fabs(rec[0]), std::fabs(out[0])) * NDT2D_NEAR_TIE_REL + NDT2D_NEAR_TIE_ABS;
+                                           std::max(std::fabs(rec[0]), std::fabs(out[0])) * NDT2D_NEAR_TIE_REL;
       if (out[1] < 0.0 || rec[0] < out[0] || (rec[0] == out[0] && std::floor(rec[1]) < std::floor(out[1])))
       {
         out[0] = rec[0];

@@ -53,7 +53,7 @@ def combine_match_records(records):
     return best_score, best_index, acc
 
 
-NEAR_TIE_REL, NEAR_TIE_ABS = 1.0e-11, 1.0e-300      # NDT2D_NEAR_TIE_REL / _ABS of include/ndt2d_hip.h
+NEAR_TIE_REL = 2.0 ** -36      # NDT2D_NEAR_TIE_REL of include/ndt2d_hip.h
 
 
 def combine_match_records_ex(records):
@@ -68,7 +68,7 @@ def combine_match_records_ex(records):
     for rec in records:
         if rec[1] >= 0.0 and rec[0] < 0.0:
             near = best_index is not None and \
-                abs(rec[0] - best_score) <= max(abs(rec[0]), abs(best_score)) * NEAR_TIE_REL + NEAR_TIE_ABS
+                abs(rec[0] - best_score) <= max(abs(rec[0]), abs(best_score)) * NEAR_TIE_REL
             if best_index is None or rec[0] < best_score or \
                     (rec[0] == best_score and int(rec[1]) < best_index):
                 best_score, best_index = float(rec[0]), int(rec[1])

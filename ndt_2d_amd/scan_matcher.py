@@ -301,7 +301,7 @@ class ScanMatcherNDT:
                     "adjudication_stats")
         return a.value, b.value, c.value
 
-    def match_near_best(self, th_begin, th_end, rel=1e-11, capacity=256):
+    def match_near_best(self, th_begin, th_end, rel=2.0 ** -36, capacity=256):
         """ndt2d_match_near_best on the prepared search: flat indices (ascending) of the candidates
         within rel * |best| of the slab's best (the first `capacity` in visiting order), and how many
         there are."""

@@ -268,11 +268,10 @@ def test_random_case_multi_device_and_host_paths(seed):
     if finite.size and finite.min() < 0.0 and not np.isnan(exp["scores"]).any():
         n_th, _, _ = one.prepare_search(scan_pose, query)
         near, n = one.match_near_best(0, n_th, rel=1e-9, capacity=256)
-        # (tolerance = rel * |best| + NDT2D_NEAR_TIE_ABS: in the denormal range everything is a tie)
         d = exp["scores"] - exp["scores"].min()
         b = abs(exp["scores"].min())
-        sure = set(int(i) for i in np.flatnonzero((d <= 0.9e-9 * b + 0.9e-300) & (exp["scores"] < 0.0)))
-        maybe = set(int(i) for i in np.flatnonzero((d <= 1.1e-9 * b + 1.1e-300) & (exp["scores"] < 0.0)))
+        sure = set(int(i) for i in np.flatnonzero((d <= 0.9e-9 * b) & (exp["scores"] < 0.0)))
+        maybe = set(int(i) for i in np.flatnonzero((d <= 1.1e-9 * b + 5e-324) & (exp["scores"] < 0.0)))
         if n <= 256:
             assert sure <= set(near) <= maybe, (seed, n)
         else:

@@ -54,7 +54,7 @@ def test_exact_tie_goes_to_the_first_candidate_visited(variant):
     # the candidates within 1e-9 of the best, as the device lists them
     gpu.prepare_search(SCAN_POSE, beam)
     near, n = gpu.match_near_best(0, 1)
-    want = [int(i) for i in np.flatnonzero(exp["scores"] <= exp["scores"].min() * (1.0 - 1e-11))]
+    want = [int(i) for i in np.flatnonzero(exp["scores"] <= exp["scores"].min() * (1.0 - 2.0 ** -36))]
     assert n == len(near) == len(want) and near == want
 
 
