@@ -217,3 +217,20 @@ def test_tiny_scores_are_not_ties_and_plateaus_keep_the_first_candidate():
     got2 = gpu2.matchScan(SCAN_POSE, beam)
     assert got2["best_index"] == exp2["best_index"] == int(np.argmin(exp2["scores"]))
     assert gpu2.adjudication_stats()[2] == 1                 # the list was truncated -- to its head
+
+
+def test_near_best_over_the_whole_cfg4_lattice():
+    """The slow path at the size of the 8-GPU workload: 315.5 M candidates searched in theta slabs
+    with every score kept (2.5 GB), one pass over them -- the winner is alone within the tolerance."""
+    from ndt_2d_amd import ScanMatcherNDT, synth
+    gpu = ScanMatcherNDT(0)
+    gpu.initialize("global_scan_matcher", **synth.matcher_params(4))
+    gpu.addScans(synth.map_scans(4))
+    guess, pts, _ = synth.query_scan(4)
+    n_th, n_lin, _ = gpu.prepare_search(guess, pts)
+    assert n_th * n_lin * n_lin == 315508257
+    near, n = gpu.match_near_best(0, n_th)
+    assert n == 1 and near == [80443810]
+    # a tolerance wide enough to catch the runners-up of the same basin: ascending, the winner among them
+    near, n = gpu.match_near_best(0, n_th, rel=0.05, capacity=64)
+    assert n >= 2 and near == sorted(near) and 80443810 in near and len(near) == min(n, 64)
