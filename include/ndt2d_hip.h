@@ -454,7 +454,8 @@ int ndt2d_matcher_create(ndt2d_matcher ** out, int device_id);
  * once in device_ids: several contexts on one GPU, which RCCL refuses).  "auto" (default):
  * "rccl" when all devices differ and librccl.so.1 loads, "host" otherwise.  Both give the same
  * bits.  Work smaller than ndt2d_matcher_set_multi_min_units (candidates x beams, particles x
- * beams; default 2e8, ~0.1 ms of one GPU) and every single-pose call stay on the first device.
+ * beams; default 1e9, ~0.3 ms of one GPU: dealing a call out costs ~20 us of
+ * host time per device before the last one starts) and every single-pose call stay on the first device.
  * n_dev == 1 behaves exactly as ndt2d_matcher_create. */
 int ndt2d_matcher_create_multi(ndt2d_matcher ** out, const int * device_ids, int n_dev);
 int ndt2d_matcher_destroy(ndt2d_matcher * m);

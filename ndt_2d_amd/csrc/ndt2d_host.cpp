@@ -397,7 +397,7 @@ struct ndt2d_matcher
   ndt2d::Exchange * exchange = nullptr;  // RCCL communicators, made when first needed
   bool exchange_tried = false;
   std::string exchange_note;             // why "auto" did not take RCCL
-  double multi_min_units = 2.0e8;        // work below this stays on the first device
+  double multi_min_units = 1.0e9;        // work below this stays on the first device (~0.3 ms of one GPU)
   double * pinned = nullptr;             // host block of the exchanges (layout: multi_pinned_*)
   std::string variant;                   // ndt2d_matcher_last_variant
   bool last_multi = false;
