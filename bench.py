@@ -603,6 +603,23 @@ def cfg4_single_gpu_bench(matcher_cls, synth, shard, np, torch, dev_index, steps
     res = m.finish_match(rec)
     variant = m.last_variant()
     best_index = int(rec[1])
+    # The eight 1-of-8 shares an 8-GPU run deals out (theta steps r, r + 8, ...), each run ALONE on this
+    # GPU: what every rank of `--gpus 8` would spend in its search -- the step of such a run is the
+    # slowest share plus the exchange of the records (<= 768 bytes).  No 8-GPU node has been available:
+    # this is the measured part of the scaling claim.
+    share_ms, share_kernel_ms = [], []
+    for r in range(8):
+        first, stride, count = shard.shard_strided(n_th, r, 8)
+        best = None
+        for _ in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            m.match_launch_strided(first, stride, count)
+            m.match_fetch()
+            dt = (time.perf_counter() - t0) * 1e3
+            best = dt if best is None else min(best, dt)
+        share_ms.append(best)
+        share_kernel_ms.append(m.last_launch_ms()[0])
     expect = 80443810   # tests/golden/big_winners.json cfg4: the oracle over all 315,508,257 candidates
     if best_index != expect:
         raise SystemExit("bench.py: cfg-4 winner %d differs from the oracle's %d" % (best_index, expect))
@@ -616,6 +633,12 @@ def cfg4_single_gpu_bench(matcher_cls, synth, shard, np, torch, dev_index, steps
             "in_grid_share_of_units": share, "value_in_grid_units": units * share / (t * 1e-3),
             "best_index": best_index, "score": res["score"], "pose": [float(v) for v in res["pose"]],
             "kernel_variant": variant,
+            "eight_shares_alone_on_this_gpu": {
+                "ms": share_ms, "kernel_ms": share_kernel_ms, "max_ms": max(share_ms),
+                "max_over_mean": max(share_ms) / (sum(share_ms) / 8.0),
+                "whole_over_slowest_share": t / max(share_ms),
+                "what": "each 1-of-8 share (theta steps r, r + 8, ...) searched alone on this GPU, launch to result, "
+                        "best of 2: an 8-GPU step is the slowest share plus the record exchange"},
             "what": "the N = 1 point of the strong-scaling curve `bench.py --gpus N` (N > 1) reports"}
 
 
@@ -1076,6 +1099,20 @@ def particle_bench_sharded(matcher_cls, synth, shard, torch, dist, dev, dev_inde
             "score_poses_compact_kernel", score_ms, n_local * n_beams, n_cu, pmc,
             "counters of rank %d's particle range (sum of the 1-of-8 shares, one launch each on one GPU under "
             "rocprofv3)" % rank, counters=sc if sc is not None else {})
+    if world == 1 and all_reduce is None:
+        # the eight particle ranges an 8-GPU run deals out, each scored alone on this GPU (kernel time)
+        sh = []
+        for r in range(8):
+            b, e = shard.shard_range(n_total, r, 8)
+            ks = []
+            for _ in range(3):
+                m.score_poses_launch(d_parts[b:e].data_ptr(), e - b, d_w[b:e].data_ptr(), table[0].data_ptr())
+                ks.append(m.last_launch_ms()[0])
+            sh.append(min(ks))
+        res["eight_shares_alone_on_this_gpu"] = {
+            "scoring_kernel_ms": sh, "max_ms": max(sh),
+            "what": "each 1-of-8 particle range scored alone on this GPU (scoring kernel, best of 3): an 8-GPU "
+                    "step is the slowest range plus the statistics kernels and the two small all-reduces"}
     m.set_stream(None)
     m.close()
     return res

@@ -84,6 +84,10 @@ def test_single_gpu_anchors_of_the_eight_gpu_workloads(line):
     # the anchors carry their own roofline (counters of the whole workload = the sum of its eight shares)
     assert 0.0 < c4["roofline"]["frac"] <= 1.0 and c4["cpu_baseline"]["value"] > 0
     assert 0.0 < c5["roofline"]["frac"] <= 1.0 and c5["cpu_baseline"]["value"] > 0
+    # the measurable part of the 8-GPU claim: each 1-of-8 share alone on this GPU
+    sh = c4["eight_shares_alone_on_this_gpu"]
+    assert len(sh["ms"]) == 8 and sh["max_over_mean"] < 1.05 and sh["whole_over_slowest_share"] > 6.0
+    assert len(c5["eight_shares_alone_on_this_gpu"]["scoring_kernel_ms"]) == 8
     # ... and one multi-device matcher through the plain-C host found the cfg-4 winner
     assert line["c_host_multi_device"]["cfg4"]["best_index"] == 80443810
 
