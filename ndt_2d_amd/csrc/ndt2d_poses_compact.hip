@@ -731,8 +731,10 @@ size_t compact_lds_bytes(const PosesArgs & args, int threads, uint32_t split, bo
 {
   const size_t fixed = threads == 1024 ? (screen ? CompactLayout<1024, true>::kFixedDoubles
                                                  : CompactLayout<1024, false>::kFixedDoubles)
-                                       : (screen ? CompactLayout<256, true>::kFixedDoubles
-                                                 : CompactLayout<256, false>::kFixedDoubles);
+                       : threads == 512 ? (screen ? CompactLayout<512, true>::kFixedDoubles
+                                                  : CompactLayout<512, false>::kFixedDoubles)
+                                        : (screen ? CompactLayout<256, true>::kFixedDoubles
+                                                  : CompactLayout<256, false>::kFixedDoubles);
   // f64 beams + (screening) their f32 copy, 1.5 doubles per coordinate
   const size_t beams = static_cast<size_t>(3) * ((args.n_beams + 1) & ~1u) + kScreenPadFloats / 2;
   const size_t words = args.coarse_log2 > 0 ? poses_coarse_words(args.grid, args.coarse_log2)
@@ -755,6 +757,17 @@ uint32_t choose_split(const PosesArgs & args, int cus, uint32_t waves_per_block)
     split *= 2;
   }
   return split;
+}
+
+// (A/B knob NDT2D_POSES_EIGHT_WAVES: 1 forces the eight-wave groups wherever they fit, 0 turns them off.)
+// Measured (experiments/particles_rounds.py, cfg-3 map, kernel ms, four- vs eight-wave groups): 16,384
+// particles 0.0377 / 0.0262, 32,768 0.0425 / 0.0351, 81,920 0.0758 / 0.0694, 98,304 0.0832 / 0.0813,
+// 100,000 0.0848 / 0.0865: worth it while the eight-wave launch stays within three rounds of the chip's
+// wave slots.  The scores do not depend on it (chunk sums are added in a fixed order whatever the split).
+bool poses_eight_wave_groups(uint64_t groups, int cus)
+{
+  if (const char * env = std::getenv("NDT2D_POSES_EIGHT_WAVES")) return env[0] == '1';
+  return groups * 8 <= static_cast<uint64_t>(cus) * 16 * 3;
 }
 
 template <int THREADS>
@@ -957,6 +970,20 @@ hipError_t launch_poses_compact(const PosesArgs & args_in, int cus, bool screen,
   }
   const uint32_t blocks = static_cast<uint32_t>(need < cap ? need : cap);
   if (blocks_out != nullptr) *blocks_out = blocks;
+  // Eight waves per group of 64 poses (512-thread blocks, one group each) when the particle set is
+  // too small to fill the chip otherwise: a wave then walks one chunk of the beams instead of two.
+  if (use_small && poses_eight_wave_groups(groups, cus))
+  {
+    const uint32_t split8 = choose_split(args, cus, 8);
+    const size_t lds8 = compact_lds_bytes(args, 512, split8, screen);
+    if (split8 == 8 && lds8 <= 48 * 1024)
+    {
+      const uint64_t need8 = groups;   // one group per block
+      const uint32_t blocks8 = static_cast<uint32_t>(need8 < cap ? need8 : cap);
+      if (blocks_out != nullptr) *blocks_out = blocks8;
+      return launch_compact<512>(args, blocks8, split8, lds8, screen, stream);
+    }
+  }
   return use_small ? launch_compact<256>(args, blocks, split, lds_bytes, screen, stream)
                    : launch_compact<1024>(args, blocks, split, lds_bytes, screen, stream);
 }

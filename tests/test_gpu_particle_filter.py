@@ -333,3 +333,29 @@ def test_particle_filter_cycle_matches_oracle(torch):
     check(p2, w_norm)
     msg = pf.getMsg()
     assert msg.shape == (m, 4) and np.allclose(msg[:, 2] ** 2 + msg[:, 3] ** 2, 1.0)
+
+
+def test_eight_wave_groups_give_the_four_wave_bits():
+    """Particle sets too small to fill the chip put EIGHT waves on each group of 64 particles
+    (512-thread blocks, one chunk of the beams per wave) instead of four: the weights and the
+    statistics must not depend on it (ndt2d_poses_compact.hip, poses_eight_wave_groups)."""
+    import os
+    from ndt_2d_amd import ScanMatcherNDT, pf_measure, synth
+    m = ScanMatcherNDT(0)
+    m.initialize("pf", **synth.matcher_params(3))
+    m.addScans(synth.map_scans(3))
+    _, pts, _ = synth.query_scan(3)
+    parts = synth.particles(3, 20000)
+    out = {}
+    for knob in ("0", "1"):
+        os.environ["NDT2D_POSES_EIGHT_WAVES"] = knob
+        try:
+            out[knob] = (m.scorePoses(pts, parts), pf_measure(m, parts, pts))
+        finally:
+            del os.environ["NDT2D_POSES_EIGHT_WAVES"]
+    assert np.array_equal(out["0"][0], out["1"][0])
+    assert np.count_nonzero(out["0"][0]) > 1000
+    for a, b in zip(out["0"][1], out["1"][1]):
+        assert np.allclose(a, b, rtol=1e-12, atol=1e-15)       # (the moment sums meet in another order)
+    auto = m.scorePoses(pts, parts)                              # the policy's own choice: the same bits
+    assert np.array_equal(auto, out["0"][0])
