@@ -772,7 +772,9 @@ def main():
     # every 8th (a recorded event holds the stream up for ~5 us; the pluginlib shim runs
     # with none at all) -- the kernel's average duration is taken over the timed launches
     # of the timed region
-    time_every = 1 if args.steps < 32 else 8
+    # (the driver's --steps 20: every 4th step, five samples -- a pair on every step made the 20-step
+    # line read 1.7 % below the 200-step one)
+    time_every = 1 if args.steps < 8 else (4 if args.steps < 64 else 8)
     n_timed = [0]
 
     def step():
