@@ -90,6 +90,29 @@ __device__ __forceinline__ double fma3(double a, double b, double c)
   asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
   return d;
 }
+// The polynomial constant as a template argument.  NDT2D_EXP_SCALAR_CONSTANTS=1 makes it in a
+// scalar register pair right where it is used (two s_mov_b32, `volatile` so that they stay there)
+// instead of the 18 VECTOR registers the compiler otherwise keeps the nine constants in for the
+// whole kernel: the large search then needs 61 instead of 80 registers -- and is 2.5 % SLOWER
+// (0.4720 against 0.4599 ms at cfg-2; eight waves per SIMD instead of six buy nothing either,
+// 0.478 ms: the kernel is issue bound).  Measured, off.
+#ifndef NDT2D_EXP_SCALAR_CONSTANTS
+#define NDT2D_EXP_SCALAR_CONSTANTS 0
+#endif
+template <uint32_t HI, uint32_t LO>
+__device__ __forceinline__ double fma3k(double a, double b)
+{
+  double d;
+#if NDT2D_EXP_SCALAR_CONSTANTS
+  uint32_t lo, hi;
+  asm volatile("s_mov_b32 %0, %2\n\ts_mov_b32 %1, %3" : "=s"(lo), "=s"(hi) : "n"(LO), "n"(HI));
+  const double c = __hiloint2double(static_cast<int>(hi), static_cast<int>(lo));
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
+#else
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(__hiloint2double(static_cast<int>(HI), static_cast<int>(LO))));
+#endif
+  return d;
+}
 
 __device__ __forceinline__ double exp_of_exponent(double x)
 {
@@ -98,15 +121,16 @@ __device__ __forceinline__ double exp_of_exponent(double x)
   const double n = rint(x * 1.4426950408889634);             // 0x3ff71547652b82fe
   double r = fma(n, -0.6931471805599453, x);                  // 0xbfe62e42fefa39ef
   r = fma(n, -2.3190468138462996e-17, r);                     // 0xbc7abc9e3b39803f
-  double p = fma3(r, 0x1.ade156a5dcb37p-26, 0x1.28af3fca7ab0cp-22);
-  p = fma3(r, p, 0x1.71dee623fde64p-19);
-  p = fma3(r, p, 0x1.a01997c89e6b0p-16);
-  p = fma3(r, p, 0x1.a01a014761f6ep-13);
-  p = fma3(r, p, 0x1.6c16c1852b7b0p-10);
-  p = fma3(r, p, 0x1.1111111122322p-7);
-  p = fma3(r, p, 0x1.55555555502a1p-5);
-  p = fma3(r, p, 0x1.5555555555511p-3);
-  p = fma3(r, p, 0x1.000000000000bp-1);
+  // p = c0; p = fma(r, p, c_k) ...: the first step's multiplier is the constant 0x1.ade156a5dcb37p-26
+  double p = fma3k<0x3e928af3u, 0xfca7ab0cu>(r, 0x1.ade156a5dcb37p-26);   // + 0x1.28af3fca7ab0cp-22
+  p = fma3k<0x3ec71deeu, 0x623fde64u>(r, p);   // + 0x1.71dee623fde64p-19
+  p = fma3k<0x3efa0199u, 0x7c89e6b0u>(r, p);   // + 0x1.a01997c89e6b0p-16
+  p = fma3k<0x3f2a01a0u, 0x14761f6eu>(r, p);   // + 0x1.a01a014761f6ep-13
+  p = fma3k<0x3f56c16cu, 0x1852b7b0u>(r, p);   // + 0x1.6c16c1852b7b0p-10
+  p = fma3k<0x3f811111u, 0x11122322u>(r, p);   // + 0x1.1111111122322p-7
+  p = fma3k<0x3fa55555u, 0x555502a1u>(r, p);   // + 0x1.55555555502a1p-5
+  p = fma3k<0x3fc55555u, 0x55555511u>(r, p);   // + 0x1.5555555555511p-3
+  p = fma3k<0x3fe00000u, 0x0000000bu>(r, p);   // + 0x1.000000000000bp-1
   // (the last two constants are the inline operand 1.0: no register holds them)
   asm("v_fma_f64 %0, %1, %2, 1.0" : "=v"(p) : "v"(r), "v"(p));
   asm("v_fma_f64 %0, %1, %2, 1.0" : "=v"(p) : "v"(r), "v"(p));
@@ -123,15 +147,17 @@ __device__ __forceinline__ bool wave_any(bool p)
 
 // exp() of a Cell::score exponent for the register-tight kernels (lane mapping,
 // compacted particle scoring; the wave mapping keeps the library exp, whose
-// constants live in SGPRs there): the lean evaluation above, except that a wave
-// holding a NaN exponent (degenerate cell) takes the library path so that the NaN
-// propagates as in the reference.
+// constants live in SGPRs there): the lean evaluation above, except that a NaN
+// exponent (degenerate cell) propagates as in the reference.
 __device__ __forceinline__ double exp_score(double e)
 {
-  // (unlikely: otherwise the NaN path is laid out in line and the common one is reached
-  // and left through a far trampoline, two taken branches per exp())
-  if (__builtin_expect(wave_any(e != e), 0)) return exp(e);
-  return exp_of_exponent(e);
+  // A NaN goes through as the reference's exp(NaN) has it (quiet NaN); the wave-level test keeps
+  // the select off the common path.  (Round 4: this used to call the library's exp for such a
+  // wave -- whose polynomial constants the compiler then kept in 20 vector registers for the
+  // whole kernel, on behalf of a path no healthy map ever takes.)
+  double r = exp_of_exponent(e);
+  if (__builtin_expect(wave_any(e != e), 0)) r = (e != e) ? e + e : r;
+  return r;
 }
 
 // A non-negative term t = exp(e) leaves a running sum s > 0 unchanged,

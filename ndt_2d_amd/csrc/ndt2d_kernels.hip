@@ -242,8 +242,9 @@ __global__ void __launch_bounds__(256) match_reduce_kernel(const double * partia
 // (device, optional) and host_out (host-coherent memory, optional) followed there by
 // `seq` at host_out[kHostFlagSlot], which the host spins on.
 constexpr int kFinalThreads = 11 * kWave;
+constexpr uint32_t kFinalBatch = 8;
 __global__ void __launch_bounds__(kFinalThreads) match_reduce_final_kernel(
-  const double * partials, uint32_t n, double * out, double * out2, double * host_out,
+  const double * __restrict__ partials, uint32_t n, double * out, double * out2, double * host_out,
   unsigned long long seq)
 {
   const uint32_t lane = threadIdx.x & (kWave - 1);
@@ -251,7 +252,21 @@ __global__ void __launch_bounds__(kFinalThreads) match_reduce_final_kernel(
   if (wave == 0)
   {
     double bs = 0.0, bi = kNoIndex;
-    for (uint32_t r = lane; r < n; r += kWave)
+    // (eight loads in flight, merged in the same order as one at a time: a lane's chain of
+    // dependent loads was 33 us at 6,760 records)
+    uint32_t r = lane;
+    for (; r + (kFinalBatch - 1) * kWave < n; r += kFinalBatch * kWave)
+    {
+      double2 p[kFinalBatch];
+#pragma unroll
+      for (uint32_t u = 0; u < kFinalBatch; ++u)
+      {
+        p[u] = *reinterpret_cast<const double2 *>(partials + static_cast<size_t>(r + u * kWave) * kRecord);
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < kFinalBatch; ++u) merge_best(p[u].x, p[u].y, bs, bi);
+    }
+    for (; r < n; r += kWave)
     {
       const double2 p = *reinterpret_cast<const double2 *>(partials + static_cast<size_t>(r) * kRecord);
       merge_best(p.x, p.y, bs, bi);
@@ -278,7 +293,16 @@ __global__ void __launch_bounds__(kFinalThreads) match_reduce_final_kernel(
   {
     const uint32_t k = 1 + wave;   // columns 2 .. 11
     double v = 0.0;
-    for (uint32_t r = lane; r < n; r += kWave) v += partials[static_cast<size_t>(r) * kRecord + k];
+    uint32_t r = lane;
+    for (; r + (kFinalBatch - 1) * kWave < n; r += kFinalBatch * kWave)
+    {
+      double x[kFinalBatch];
+#pragma unroll
+      for (uint32_t u = 0; u < kFinalBatch; ++u) x[u] = partials[static_cast<size_t>(r + u * kWave) * kRecord + k];
+#pragma unroll
+      for (uint32_t u = 0; u < kFinalBatch; ++u) v += x[u];
+    }
+    for (; r < n; r += kWave) v += partials[static_cast<size_t>(r) * kRecord + k];
     v = wave_sum_to_last_lane(v);
     if (lane == kWave - 1)
     {

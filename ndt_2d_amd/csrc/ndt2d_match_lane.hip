@@ -48,6 +48,7 @@
 // evaluation; the tests compare the two bitwise).
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 
 #include <type_traits>
 
@@ -62,7 +63,11 @@ namespace
 constexpr uint32_t kDynamicItemsFromBeams = 256;
 constexpr int kLaneThreads = 1024;       // large searches: one block per CU
 constexpr int kLaneThreadsSmall = 256;   // small searches: spread the few work items over more CUs
-constexpr int kLaneThreadsCompact = 768; // compacted records: two blocks per CU, six waves per SIMD
+#ifndef NDT2D_LANE_THREADS_COMPACT
+#define NDT2D_LANE_THREADS_COMPACT 768
+#endif
+constexpr int kLaneThreadsCompact = NDT2D_LANE_THREADS_COMPACT; // compacted records: two blocks per CU
+#define NDT2D_LANE_COMPACT_WAVES_PER_EU (NDT2D_LANE_THREADS_COMPACT / 128)   // 768 threads: six waves per SIMD
 
 // points_outer for the slab (reference :106-115) plus the packed fixed-point
 // map coordinate of each rotated beam:
@@ -210,6 +215,12 @@ __device__ __forceinline__ void match_lane_body(
   }
   __syncthreads();
 
+#ifdef NDT2D_LANE_TRACE
+  // experiments/lane_wave_trace.py: when a wave starts / ends its items and how many it ran
+  const unsigned long long trace_t0 = wall_clock64();
+  unsigned long long trace_last = trace_t0, trace_max = 0, trace_last_start = trace_t0;
+  uint32_t trace_items = 0, trace_prev_item = 0, trace_flagged = 0;
+#endif
   LaneCtx c;
   c.rank_address = map_bytes + (COMPACT ? kRankLead : 0u);
   c.lds_cells_address = map_bytes + rank_bytes;
@@ -246,6 +257,26 @@ __device__ __forceinline__ void match_lane_body(
   for (uint32_t item = worker; item < n_items;)
   {
     uint32_t t, pxi, pyi;
+#ifdef NDT2D_LANE_TRACE
+    {
+      const unsigned long long now = wall_clock64();
+      if (trace_items > 0 && now - trace_last > trace_max) trace_max = now - trace_last;
+      if (trace_items > 0 && a.scores != nullptr && lane == 0)
+      {
+        a.scores[5 * 8192 + 150000 + trace_prev_item] = static_cast<double>(now - trace_last);   // item duration
+      }
+      if (trace_items > 0 && a.scores != nullptr && lane == 0)
+      {
+        a.scores[5 * 8192 + 300000 + trace_prev_item] = static_cast<double>(trace_flagged);
+      }
+      trace_flagged = 0;
+      trace_prev_item = item;
+      trace_last = now;
+      trace_last_start = now;
+      ++trace_items;
+      if (a.scores != nullptr && lane == 0) a.scores[5 * 8192 + item] = static_cast<double>(now);   // item start
+    }
+#endif
     const uint32_t whole_item = PARTS ? item / a.beam_parts : item;
     const uint32_t part = PARTS ? item - whole_item * a.beam_parts : 0u;
     item_place(whole_item, patches, patches_1d, th_mid, t, pxi, pyi);
@@ -280,6 +311,9 @@ __device__ __forceinline__ void match_lane_body(
         const double k = row[min(b0 + lane, a.n_beams - 1u)].z;
         can_score = __builtin_amdgcn_ballot_w64(patch_can_score(k + dxy_corner, geo.box_span));
       }
+#ifdef NDT2D_LANE_TRACE
+      trace_flagged += static_cast<uint32_t>(__popcll(can_score));
+#endif
       const uint32_t chunk_end = min(b0 + static_cast<uint32_t>(kWave), beams_end);
       uint32_t b = b0;
       for (; b + kUnroll <= chunk_end; b += kUnroll, can_score >>= kUnroll)
@@ -361,7 +395,7 @@ __device__ __forceinline__ void match_lane_body(
       acc[7] += dy * score;
       acc[8] += dt * score;
       acc[9] += score;
-#ifndef NDT2D_LANE_HIST
+#if !defined(NDT2D_LANE_HIST) && !defined(NDT2D_LANE_TRACE)
       if (a.scores != nullptr) a.scores[local] = score;
 #endif
     }
@@ -408,6 +442,20 @@ __device__ __forceinline__ void match_lane_body(
 #pragma unroll
     for (int k = 0; k < 10; ++k) acc[k] = 0.0;
   }
+#ifdef NDT2D_LANE_TRACE
+  if (a.scores != nullptr && lane == 0)
+  {
+    const unsigned long long now = wall_clock64();
+    if (trace_items > 0 && now - trace_last > trace_max) trace_max = now - trace_last;
+    if (trace_items > 0) a.scores[5 * 8192 + 150000 + trace_prev_item] = static_cast<double>(now - trace_last);
+    if (trace_items > 0) a.scores[5 * 8192 + 300000 + trace_prev_item] = static_cast<double>(trace_flagged);
+    a.scores[5 * worker] = static_cast<double>(trace_t0);
+    a.scores[5 * worker + 1] = static_cast<double>(now);
+    a.scores[5 * worker + 2] = static_cast<double>(trace_items);
+    a.scores[5 * worker + 3] = static_cast<double>(trace_max);
+    a.scores[5 * worker + 4] = static_cast<double>(trace_last_start);
+  }
+#endif
   if (!DYNAMIC_ITEMS)
   {
     wave_best_to_last_lane(best_s, best_i);
@@ -435,7 +483,7 @@ __global__ void __launch_bounds__(THREADS) match_lane_kernel(
 // The compacted-records form: 768-thread blocks held to 80 VGPRs, two per CU = six waves
 // per SIMD (a block's waves must spread evenly over the four SIMDs: 640-thread blocks
 // would put six waves of two blocks on one SIMD, which its register file cannot hold).
-__global__ void __launch_bounds__(kLaneThreadsCompact) __attribute__((amdgpu_waves_per_eu(6)))
+__global__ void __launch_bounds__(kLaneThreadsCompact) __attribute__((amdgpu_waves_per_eu(NDT2D_LANE_COMPACT_WAVES_PER_EU)))
 match_lane_compact_kernel(const MatchArgs a, const double4 * __restrict__ outer,
                           const uint8_t * __restrict__ map_image, const LaneGeom geo)
 {
@@ -446,7 +494,7 @@ match_lane_compact_kernel(const MatchArgs a, const double4 * __restrict__ outer,
 // the LDS image is the occupancy map alone, so two 768-thread blocks fit a CU as well --
 // six waves per SIMD to cover the gathers' latency instead of four.
 template <bool POW2>
-__global__ void __launch_bounds__(kLaneThreadsCompact) __attribute__((amdgpu_waves_per_eu(6)))
+__global__ void __launch_bounds__(kLaneThreadsCompact) __attribute__((amdgpu_waves_per_eu(NDT2D_LANE_COMPACT_WAVES_PER_EU)))
 match_lane_gather6_kernel(const MatchArgs a, const double4 * __restrict__ outer,
                           const uint8_t * __restrict__ map_image, const LaneGeom geo)
 {
@@ -454,7 +502,7 @@ match_lane_gather6_kernel(const MatchArgs a, const double4 * __restrict__ outer,
 }
 
 // The beam-part forms of the two six-wave kernels (mid-size lattices, MatchArgs::beam_parts).
-__global__ void __launch_bounds__(kLaneThreadsCompact) __attribute__((amdgpu_waves_per_eu(6)))
+__global__ void __launch_bounds__(kLaneThreadsCompact) __attribute__((amdgpu_waves_per_eu(NDT2D_LANE_COMPACT_WAVES_PER_EU)))
 match_lane_compact_parts_kernel(const MatchArgs a, const double4 * __restrict__ outer,
                                 const uint8_t * __restrict__ map_image, const LaneGeom geo)
 {
@@ -462,7 +510,7 @@ match_lane_compact_parts_kernel(const MatchArgs a, const double4 * __restrict__ 
 }
 
 template <bool POW2>
-__global__ void __launch_bounds__(kLaneThreadsCompact) __attribute__((amdgpu_waves_per_eu(6)))
+__global__ void __launch_bounds__(kLaneThreadsCompact) __attribute__((amdgpu_waves_per_eu(NDT2D_LANE_COMPACT_WAVES_PER_EU)))
 match_lane_gather6_parts_kernel(const MatchArgs a, const double4 * __restrict__ outer,
                                 const uint8_t * __restrict__ map_image, const LaneGeom geo)
 {
@@ -521,7 +569,9 @@ __global__ void __launch_bounds__(256) match_lane_combine_kernel(const MatchArgs
     acc[7] = dy * score;
     acc[8] = dt * score;
     acc[9] = score;
+#ifndef NDT2D_LANE_TRACE
     if (a.scores != nullptr) a.scores[static_cast<uint64_t>(t) * per_theta + in_theta] = score;
+#endif
   }
   wave_best_to_last_lane(best_s, best_i);
 #pragma unroll
@@ -647,15 +697,6 @@ hipError_t launch_match_lane(const MatchArgs & args_in, double * outer, double *
   uint32_t part_beams = 0;
   uint32_t beam_parts = dynamic_items ? lane_beam_parts(args, &part_beams) : 1u;
   args.part_sums = outer + n_outer * 4 + static_cast<size_t>(kMapStride) * kMaxMapCells / sizeof(double);
-  hipLaunchKernelGGL(outer_table_kernel, dim3(oblocks), dim3(256), 0, stream, args,
-                     reinterpret_cast<double4 *>(outer), map_image, geo);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  if (ev_after_pre_kernel != nullptr)
-  {
-    e = hipEventRecord(ev_after_pre_kernel, stream);
-    if (e != hipSuccess) return e;
-  }
 
   // (NDT2D_LANE_RECORDS=global: gather the records from HBM although they would fit LDS --
   // what a map too large for LDS costs, measured on a workload that has both forms)
@@ -718,6 +759,16 @@ hipError_t launch_match_lane(const MatchArgs & args_in, double * outer, double *
     if (cap * wpb > max_workers) cap = max_workers / wpb;
     if (blocks > cap) blocks = cap;
     if (blocks == 0) blocks = 1;
+  }
+  // the table pre-kernel (it also clears the item counters of the search that follows)
+  hipLaunchKernelGGL(outer_table_kernel, dim3(oblocks), dim3(256), 0, stream, args,
+                     reinterpret_cast<double4 *>(outer), map_image, geo);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  if (ev_after_pre_kernel != nullptr)
+  {
+    e = hipEventRecord(ev_after_pre_kernel, stream);
+    if (e != hipSuccess) return e;
   }
   auto launch = [&](auto kernel, int threads) -> hipError_t {
     if (lds_bytes > 48 * 1024)
