@@ -242,9 +242,9 @@ __global__ void __launch_bounds__(256) match_reduce_kernel(const double * partia
 // (device, optional) and host_out (host-coherent memory, optional) followed there by
 // `seq` at host_out[kHostFlagSlot], which the host spins on.
 constexpr int kFinalThreads = 11 * kWave;
-constexpr uint32_t kFinalBatch = 8;
+constexpr uint32_t kFinalAloneMax = 1024;   // records the last stage takes on its own (launch_match)
 __global__ void __launch_bounds__(kFinalThreads) match_reduce_final_kernel(
-  const double * __restrict__ partials, uint32_t n, double * out, double * out2, double * host_out,
+  const double * partials, uint32_t n, double * out, double * out2, double * host_out,
   unsigned long long seq)
 {
   const uint32_t lane = threadIdx.x & (kWave - 1);
@@ -252,21 +252,7 @@ __global__ void __launch_bounds__(kFinalThreads) match_reduce_final_kernel(
   if (wave == 0)
   {
     double bs = 0.0, bi = kNoIndex;
-    // (eight loads in flight, merged in the same order as one at a time: a lane's chain of
-    // dependent loads was 33 us at 6,760 records)
-    uint32_t r = lane;
-    for (; r + (kFinalBatch - 1) * kWave < n; r += kFinalBatch * kWave)
-    {
-      double2 p[kFinalBatch];
-#pragma unroll
-      for (uint32_t u = 0; u < kFinalBatch; ++u)
-      {
-        p[u] = *reinterpret_cast<const double2 *>(partials + static_cast<size_t>(r + u * kWave) * kRecord);
-      }
-#pragma unroll
-      for (uint32_t u = 0; u < kFinalBatch; ++u) merge_best(p[u].x, p[u].y, bs, bi);
-    }
-    for (; r < n; r += kWave)
+    for (uint32_t r = lane; r < n; r += kWave)
     {
       const double2 p = *reinterpret_cast<const double2 *>(partials + static_cast<size_t>(r) * kRecord);
       merge_best(p.x, p.y, bs, bi);
@@ -293,16 +279,7 @@ __global__ void __launch_bounds__(kFinalThreads) match_reduce_final_kernel(
   {
     const uint32_t k = 1 + wave;   // columns 2 .. 11
     double v = 0.0;
-    uint32_t r = lane;
-    for (; r + (kFinalBatch - 1) * kWave < n; r += kFinalBatch * kWave)
-    {
-      double x[kFinalBatch];
-#pragma unroll
-      for (uint32_t u = 0; u < kFinalBatch; ++u) x[u] = partials[static_cast<size_t>(r + u * kWave) * kRecord + k];
-#pragma unroll
-      for (uint32_t u = 0; u < kFinalBatch; ++u) v += x[u];
-    }
-    for (; r < n; r += kWave) v += partials[static_cast<size_t>(r) * kRecord + k];
+    for (uint32_t r = lane; r < n; r += kWave) v += partials[static_cast<size_t>(r) * kRecord + k];
     v = wave_sum_to_last_lane(v);
     if (lane == kWave - 1)
     {
@@ -772,15 +749,18 @@ hipError_t launch_match(const MatchArgs & args_in, double * workspace, double * 
     if (e != hipSuccess) return e;
   }
 
-  // Up to 8,192 records: one block.  More (the lane mapping leaves one per work item):
-  // 256 blocks first, each over a contiguous share.
+  // Up to kFinalAloneMax records: one block.  More (the lane mapping leaves one per work item):
+  // 256 blocks first, each over a contiguous share.  (The one block reads a record's words from
+  // 64 different cache lines per load instruction, one line per cycle on its CU: 31 us for the
+  // 6,760 records of a mid-size lattice, experiments/pmc_midsize.sh -- against 5 + 4 us in two stages.)
   const double * records = workspace;
+  bool staged_here = false;
   if (n_staged > 0)
   {
     records = staged;
     n_workers = n_staged;
   }
-  else if (n_workers > kMaxMatchBlocks * kMatchWaves)
+  else if (n_workers > kFinalAloneMax)
   {
     const uint32_t per_block = (n_workers + 255) / 256;
     const uint32_t stage_blocks = (n_workers + per_block - 1) / per_block;
@@ -790,6 +770,7 @@ hipError_t launch_match(const MatchArgs & args_in, double * workspace, double * 
     if (e != hipSuccess) return e;
     records = staged;
     n_workers = stage_blocks;
+    staged_here = true;
   }
   hipLaunchKernelGGL(match_reduce_final_kernel, dim3(1), dim3(kFinalThreads), 0, stream, records,
                      n_workers, record_out, record_out2, host_record, seq);
@@ -801,7 +782,7 @@ hipError_t launch_match(const MatchArgs & args_in, double * workspace, double * 
       info->variant = lane_variant_name(lane_records_mode & 3, (lane_records_mode & 4) != 0, pow2, lane_parts > 1);
       // per slab: table pre-kernel, search, (combine,) first reduction stage; then the final stage
       info->n_kernels = n_staged > 0 ? static_cast<int>((lane_parts > 1 ? 4 : 3) * slabs_run + 1)
-                                     : (lane_parts > 1 ? 4 : 3);
+                                     : (lane_parts > 1 ? 4 : 3) + (staged_here ? 1 : 0);
     }
     else
     {

@@ -612,7 +612,7 @@ def test_lattice_beyond_two_to_the_24_work_items_keeps_the_lane_mapping():
     for a, b in zip(bounds[:-1], bounds[1:]):
         gpu.match_launch(int(a), int(b))
         recs.append(gpu.match_fetch())
-        assert gpu.last_launch_ms()[1] == 3          # each a single slab
+        assert gpu.last_launch_ms()[1] == 4          # each a single slab: table, search, two reduction stages
     s, i, acc = shard.combine_match_records(recs)
     assert (s, i) == (full[0], int(full[1]))
     assert np.allclose(acc, full[2:], rtol=1e-10, atol=0)
@@ -655,7 +655,7 @@ def test_mid_size_lattices_cut_a_candidates_beams_into_parts(monkeypatch):
     exp = ref.matchScan(guess, pts, want_scores=True)
     got = gpu.matchScan(guess, pts, want_scores=True)           # 40 x 169 = 6,760 items
     assert "compact-records/beam-parts" in gpu.last_variant(), gpu.last_variant()
-    assert gpu.last_launch_ms()[1] == 4
+    assert gpu.last_launch_ms()[1] == 5   # table, search, combine, two reduction stages
     _check_match(got, exp, 720)
     gpu.set_variant("lane-noskip")
     full = gpu.matchScan(guess, pts, want_scores=True)
