@@ -48,7 +48,6 @@
 // evaluation; the tests compare the two bitwise).
 #include <cmath>
 #include <cstdlib>
-#include <cstring>
 
 #include <type_traits>
 
@@ -264,10 +263,7 @@ __device__ __forceinline__ void match_lane_body(
       if (trace_items > 0 && a.scores != nullptr && lane == 0)
       {
         a.scores[5 * 8192 + 150000 + trace_prev_item] = static_cast<double>(now - trace_last);   // item duration
-      }
-      if (trace_items > 0 && a.scores != nullptr && lane == 0)
-      {
-        a.scores[5 * 8192 + 300000 + trace_prev_item] = static_cast<double>(trace_flagged);
+        a.scores[5 * 8192 + 300000 + trace_prev_item] = static_cast<double>(trace_flagged);      // beams the pre-test flagged
       }
       trace_flagged = 0;
       trace_prev_item = item;
