@@ -50,6 +50,11 @@ typedef struct ndt2d_context * ndt2d_handle;
 
 /* ABI version of this header (bumped on any signature change). */
 int ndt2d_abi_version(void);
+/* Which sources this library was compiled from: "NDT2D_SOURCE_SHA256=<64 hex digits> arch=...
+ * compiler=...".  The hash is ndt_2d_amd/build.py's source_sha256() (csrc/ *.hip, *.cpp, *.h,
+ * this header, the compiler flags) at build time: the tests, bench.py and tests/conftest.py
+ * compare it with the tree they run from, so a stale binary cannot stand in for the sources. */
+const char * ndt2d_build_info(void);
 
 /* One context per (plugin instance, GPU).  The reference keeps all state per
  * ScanMatcherNDT instance (std::unique_ptr<NDT> ndt_,

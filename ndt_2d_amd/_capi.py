@@ -68,6 +68,7 @@ _szp = C.POINTER(C.c_size_t)
 # name -> (restype, argtypes); one entry per function declared in ndt2d_hip.h
 SIGNATURES = {
     "ndt2d_abi_version": (C.c_int, []),
+    "ndt2d_build_info": (C.c_char_p, []),
     "ndt2d_create": (C.c_int, [C.POINTER(_vp), C.c_int]),
     "ndt2d_destroy": (C.c_int, [_vp]),
     "ndt2d_last_error": (C.c_char_p, [_vp]),
@@ -203,6 +204,19 @@ def lib():
         f.argtypes = args
     _lib = L
     return L
+
+
+def build_info():
+    """ndt2d_build_info() of the loaded library."""
+    return lib().ndt2d_build_info().decode()
+
+
+def lib_source_sha256():
+    """The source hash the loaded library carries (build.source_sha256() at its build time)."""
+    info = build_info()
+    key = "NDT2D_SOURCE_SHA256="
+    at = info.find(key)
+    return info[at + len(key):at + len(key) + 64] if at >= 0 else None
 
 
 def dptr(a):

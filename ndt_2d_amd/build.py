@@ -15,6 +15,8 @@ _ROOT = os.path.dirname(_PKG)
 _CSRC = os.path.join(_PKG, "csrc")
 LIB_PATH = os.path.join(_PKG, "libndt2d_hip.so")
 
+# ndt2d_build_info.cpp is compiled apart (it receives the hash of all the others as a macro)
+BUILD_INFO_SOURCE = "ndt2d_build_info.cpp"
 SOURCES = ["ndt2d_kernels.hip", "ndt2d_match_lane.hip", "ndt2d_match_small.hip", "ndt2d_poses_compact.hip", "ndt2d_build.hip", "ndt2d_motion.hip", "ndt2d_scan.hip", "ndt2d_occupancy.hip", "ndt2d_device.hip", "ndt2d_exchange.hip", "ndt2d_host.cpp"]
 HEADERS = [os.path.join(_CSRC, "ndt2d_kernels.h"), os.path.join(_CSRC, "ndt2d_device_fn.h"), os.path.join(_CSRC, "ndt2d_lane_fn.h"), os.path.join(_CSRC, "ndt2d_exchange.h"), os.path.join(_ROOT, "include", "ndt2d_hip.h")]
 ARCH = "gfx950"
@@ -22,6 +24,49 @@ ARCH = "gfx950"
 # kernels keep its separate roundings (see DESIGN.md "Numerics").
 FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wextra",
          "-Wno-unused-parameter"]
+
+
+SHA_MARKER = b"NDT2D_SOURCE_SHA256="
+
+
+def source_sha256():
+    """sha256 over everything libndt2d_hip.so is compiled from -- csrc/*.hip, *.cpp, the headers,
+    include/ndt2d_hip.h -- and the compiler flags.  build_all() bakes it into the library
+    (ndt2d_build_info()); tests/conftest.py rebuilds a library whose baked hash differs, so a
+    stale .so (it is git-ignored but travels to the GPU box) cannot pass for the sources."""
+    import hashlib
+    h = hashlib.sha256()
+    paths = [os.path.join(_CSRC, s) for s in SOURCES + [BUILD_INFO_SOURCE]] + HEADERS
+    for path in sorted(paths, key=os.path.basename):
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+    h.update((" ".join(FLAGS) + " " + ARCH).encode())
+    return h.hexdigest()
+
+
+def embedded_sha256(lib_path=None):
+    """The hash baked into a built library (read from the file, nothing is loaded); None if the
+    file is missing or carries none."""
+    lib_path = lib_path or LIB_PATH
+    try:
+        with open(lib_path, "rb") as f:
+            blob = f.read()
+    except OSError:
+        return None
+    at = blob.find(SHA_MARKER)
+    if at < 0:
+        return None
+    hexd = blob[at + len(SHA_MARKER):at + len(SHA_MARKER) + 64]
+    try:
+        text = hexd.decode("ascii")
+    except UnicodeDecodeError:
+        return None
+    return text if len(text) == 64 and all(ch in "0123456789abcdef" for ch in text) else None
+
+
+def lib_matches_source(lib_path=None):
+    return embedded_sha256(lib_path) == source_sha256()
 
 
 def hipcc():
@@ -35,28 +80,45 @@ def _obj(src):
     return os.path.join(_CSRC, os.path.splitext(src)[0] + ".o")
 
 
+def _input_sha256(src):
+    """What one object file is compiled from: its source, every header, the flags."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in [os.path.join(_CSRC, src)] + sorted(HEADERS, key=os.path.basename):
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+    h.update((" ".join(FLAGS) + " " + ARCH).encode())
+    return h.hexdigest()
+
+
 def _stale_sources(force):
-    """Sources whose object is missing or older than the source, a header or this file."""
-    common = HEADERS + [os.path.abspath(__file__)]
-    t_common = max(os.path.getmtime(d) for d in common)
+    """Sources whose object is missing or was compiled from other contents (the hash of its
+    inputs is kept beside it in <object>.sha; time stamps are not consulted -- a tree copied to
+    another machine keeps its contents, not its times)."""
     out = []
     for src in SOURCES:
         obj = _obj(src)
-        if force or not os.path.exists(obj) or \
-                os.path.getmtime(obj) < max(t_common, os.path.getmtime(os.path.join(_CSRC, src))):
+        try:
+            with open(obj + ".sha") as f:
+                have = f.read().strip()
+        except OSError:
+            have = None
+        if force or not os.path.exists(obj) or have != _input_sha256(src):
             out.append(src)
     return out
 
 
 def build_all(force=False, verbose=False, jobs=4):
-    stale = _stale_sources(force)
-    if not stale and os.path.exists(LIB_PATH) and \
-            os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(_obj(s)) for s in SOURCES):
+    sha = source_sha256()
+    if not force and os.path.exists(LIB_PATH) and embedded_sha256() == sha:
+        # the library carries the hash of the sources as they are now
         probe_src = os.path.join(_PKG, "tools", "latency_probe.c")
         if not os.path.exists(PROBE_PATH) or os.path.getmtime(PROBE_PATH) < max(
                 os.path.getmtime(probe_src), os.path.getmtime(LIB_PATH)):
             build_tools(verbose)
         return LIB_PATH
+    stale = _stale_sources(force)
 
     def compile_one(src):
         if src.endswith(".cpp"):
@@ -70,15 +132,26 @@ def build_all(force=False, verbose=False, jobs=4):
                 os.path.join(_CSRC, src), "-o", _obj(src)]
         if verbose:
             print(" ".join(cmd))
+        if os.path.exists(_obj(src) + ".sha"):
+            os.remove(_obj(src) + ".sha")
         subprocess.check_call(cmd)
+        with open(_obj(src) + ".sha", "w") as f:
+            f.write(_input_sha256(src) + "\n")
 
     if stale:
         # a few translation units at a time (each hipcc is itself two compiler passes)
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=max(1, min(jobs, len(stale)))) as pool:
             list(pool.map(compile_one, stale))
-    cmd = [hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC"] + [_obj(s) for s in SOURCES] + \
-        ["-ldl", "-o", LIB_PATH]
+    # the hash of the sources, baked in (ndt2d_build_info)
+    cmd = ["g++"] + FLAGS + ["-DNDT2D_SOURCE_SHA=\"" + sha + "\"", "-DNDT2D_BUILD_ARCH=\"" + ARCH + "\"",
+                             "-I", os.path.join(_ROOT, "include"), "-c",
+                             os.path.join(_CSRC, BUILD_INFO_SOURCE), "-o", _obj(BUILD_INFO_SOURCE)]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    cmd = [hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC"] + \
+        [_obj(s) for s in SOURCES + [BUILD_INFO_SOURCE]] + ["-ldl", "-lpthread", "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -12,11 +12,14 @@ for p in (_HERE, _ROOT):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu)")
-    # A fresh checkout has no built library (it is git-ignored): build it once, as
-    # __graft_entry__.build() does.  hipcc cross-compiles for gfx950 without a GPU.
+    # A fresh checkout has no built library (it is git-ignored), and a library that is there
+    # may have been built from other sources than the tree's (it travels to the GPU box with the
+    # snapshot): build_all() compares the hash baked into the .so with the sources' and compiles
+    # what differs.  hipcc cross-compiles for gfx950 without a GPU.  (NDT2D_HIP_LIB: an A/B
+    # library given from outside is taken as it is.)
     from ndt_2d_amd import _capi
-    if not os.path.exists(_capi.LIB_PATH):
-        from ndt_2d_amd import build as _build
+    from ndt_2d_amd import build as _build
+    if not os.environ.get("NDT2D_HIP_LIB") and not _build.lib_matches_source():
         _build.build_all()
 
 

@@ -38,6 +38,19 @@ def test_python_binding_covers_every_declared_symbol():
     assert _capi.lib().ndt2d_abi_version() == 3
 
 
+def test_library_is_built_from_these_sources():
+    """The hash baked into the loaded library is the hash of the sources in this tree: what
+    the tests and the bench exercise is what the repository holds, not a stale binary."""
+    from ndt_2d_amd import _capi
+    from ndt_2d_amd import build as _build
+    if os.environ.get("NDT2D_HIP_LIB"):
+        pytest.skip("an A/B library given through NDT2D_HIP_LIB")
+    want = _build.source_sha256()
+    assert _capi.lib_source_sha256() == want, _capi.build_info()
+    assert _build.embedded_sha256() == want
+    assert "arch=gfx950" in _capi.build_info()
+
+
 def test_no_cpu_fallback_without_gpu():
     """Without a GPU the compute entry points fail loudly instead of falling back."""
     import torch
