@@ -40,9 +40,11 @@ sys.path.insert(0, _ROOT)
 BYTES_PER_UNIT = 64.0        # 16 B beam endpoint + 48 B cell record
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MAX_CLOCK_HZ = 2.4e9         # MI355X_MICROARCH.md chip table
-VALU_CYCLES_PER_INST = 4.0   # FP64 and VOP3 wave64 instructions issue in 4 cycles (experiments/ubench_f64.hip)
+VALU_CYCLES_PER_INST = 4.0   # FP64 / CVT / compare / select / VOP3 wave64 instructions: 4 cycles measured (profiles/r05_ubench_issue.json)
+ISSUE_FILE = os.path.join(_ROOT, "profiles", "r05_ubench_issue.json")   # experiments/ubench_issue.hip
+MIX_FILE = os.path.join(_ROOT, "profiles", "r05_valu_mix.json")         # experiments/asm_loop_mix.py
 FP64_PEAK_TFLOPS = 78.6      # vector FP64
-PMC_CANDIDATES = ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json")   # the newest committed counter passes win
+PMC_CANDIDATES = ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json")   # the newest committed counter passes win
 PMC_NAME = next((n for n in PMC_CANDIDATES if os.path.exists(os.path.join(_ROOT, "profiles", n))),
                 PMC_CANDIDATES[0])
 PMC_FILE = os.path.join(_ROOT, "profiles", PMC_NAME)
@@ -191,6 +193,65 @@ def share_counters(pmc, workload, rank, world):
     return out
 
 
+_ISSUE_CACHE = {}
+
+
+def _load_json(path):
+    if path not in _ISSUE_CACHE:
+        try:
+            with open(path) as f:
+                _ISSUE_CACHE[path] = json.load(f)
+        except (OSError, ValueError):
+            _ISSUE_CACHE[path] = None
+    return _ISSUE_CACHE[path]
+
+
+# counter -> (class of profiles/r05_valu_mix.json, the ubench instruction whose cycles price it
+# when the kernel's own mix is unknown)
+_CLASS_COUNTERS = (("SQ_INSTS_VALU_ADD_F64", "ADD_F64", "v_add_f64"), ("SQ_INSTS_VALU_MUL_F64", "MUL_F64", "v_mul_f64"),
+                   ("SQ_INSTS_VALU_FMA_F64", "FMA_F64", "v_fma_f64"), ("SQ_INSTS_VALU_TRANS_F64", "TRANS_F64", "v_rcp_f64"),
+                   ("SQ_INSTS_VALU_CVT", "CVT", "v_cvt_i32_f64"), ("SQ_INSTS_VALU_INT64", "INT64", "v_mad_u64_u32"),
+                   ("SQ_INSTS_VALU_INT32", "INT32", None), ("SQ_INSTS_VALU_ADD_F32", "ADD_F32", "v_add_f32"),
+                   ("SQ_INSTS_VALU_MUL_F32", "MUL_F32", "v_mul_f32"), ("SQ_INSTS_VALU_FMA_F32", "FMA_F32", "v_pk_fma_f32"),
+                   ("SQ_INSTS_VALU_TRANS_F32", "TRANS_F32", "v_rcp_f32"))
+
+
+def class_pricing(kernel, k):
+    """Issue cycles of one launch from its per-class instruction counts: {"cycles", "cycles_low",
+    "cycles_high", "table"}.  A class's cycles per instruction: the kernel's own static mean
+    (profiles/r05_valu_mix.json) when it lists the class, else the measured cycles of the
+    class's instruction (profiles/r05_ubench_issue.json), else 4.  The two classes that mix 2-
+    and 4-cycle instructions (INT32, and "other" = SQ_INSTS_VALU minus all classes) span 2 .. 4
+    in the bracket."""
+    issue = (_load_json(ISSUE_FILE) or {}).get("cycles", {})
+    mix = ((_load_json(MIX_FILE) or {}).get("kernels", {}).get(kernel, {}) or {}).get("classes", {})
+    total = k["SQ_INSTS_VALU"]
+    table, cycles, low, high, classified = [], 0.0, 0.0, 0.0, 0.0
+    for counter, cls, rep in _CLASS_COUNTERS:
+        n = k.get(counter)
+        if not n:
+            continue
+        n = min(n, total - classified)
+        classified += n
+        c = mix.get(cls, {}).get("mean_cycles") or issue.get(rep or "", VALU_CYCLES_PER_INST)
+        mixed = cls == "INT32"
+        cycles += n * c
+        low += n * (2.0 if mixed else c)
+        high += n * (4.0 if mixed else c)
+        table.append({"class": cls, "instructions": n, "share": n / total, "cycles_per_instruction": c,
+                      "source": "kernel's static mix" if cls in mix else "ubench"})
+    rest = max(total - classified, 0.0)
+    if rest > 0:
+        c = mix.get("other", {}).get("mean_cycles") or VALU_CYCLES_PER_INST
+        cycles += rest * c
+        low += rest * 2.0
+        high += rest * 4.0
+        table.append({"class": "other (no class counter: moves, selects, compares, permutes, v_ldexp_f64 ...)",
+                      "instructions": rest, "share": rest / total, "cycles_per_instruction": c,
+                      "source": "kernel's static mix" if "other" in mix else "assumed"})
+    return {"cycles": cycles, "cycles_low": low, "cycles_high": high, "table": table}
+
+
 def roofline(kernel, kernel_ms, units, n_cu, pmc, expected_dispatch_note, counters=None):
     """(roofline, roofline_hbm) for `kernel`.
 
@@ -228,17 +289,27 @@ def roofline(kernel, kernel_ms, units, n_cu, pmc, expected_dispatch_note, counte
     clock = busy_cycles / t
     dur_pmc = k.get("avg_duration_ns", {}).get("sq1")
     achieved = k["SQ_INSTS_VALU"] / t / 1e9
-    # FP32 arithmetic issues in 2 cycles per wave-instruction (MI355X_MICROARCH.md, "Per-instruction
-    # cycle constants": v_fma_f32 wave64 2 cyc), FP64 / VOP3 / integer in 4 (experiments/ubench_f64.hip):
-    # the peak is that of this kernel's instruction mix
-    n_f32 = sum(k.get(c, 0.0) for c in ("SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32"))
-    n_f32 = min(n_f32, k["SQ_INSTS_VALU"])
-    cycles_per_inst = (VALU_CYCLES_PER_INST * (k["SQ_INSTS_VALU"] - n_f32) + 2.0 * n_f32) / k["SQ_INSTS_VALU"]
+    # The peak is that of THIS kernel's instruction mix: every class the counters tell apart is
+    # priced with the issue cycles measured for it on this chip (experiments/ubench_issue.hip ->
+    # profiles/r05_ubench_issue.json: FP64 add / mul / fma, conversions, 64-bit integer, compares,
+    # selects, v_perm_b32, DPP moves ... 4 cycles per wave64 instruction; v_mov_b32 / v_add_u32 /
+    # v_sub_u32 / v_and|or|xor_b32 / v_lshrrev_b32 and FP32 add / mul / fmac 2; FP32 and FP64
+    # transcendentals 8 / 16).  Two classes MIX 2- and 4-cycle instructions and no counter splits
+    # them -- INT32 and the unclassified rest: priced with the mean over the kernel's own
+    # instructions of that class inside loops (profiles/r05_valu_mix.json, static), and bracketed
+    # by "all of them at 2 cycles" .. "all at 4" (frac_bracket).
+    pricing = class_pricing(kernel, k)
+    cycles_per_inst = pricing["cycles"] / k["SQ_INSTS_VALU"]
     peak = n_simd * MAX_CLOCK_HZ / cycles_per_inst / 1e9
     roof.update(
         achieved=achieved, peak=peak, frac=achieved / peak,
-        peak_note="%d SIMDs x %.1f GHz / %.3f cycles per wave-instruction (FP32 share %.3f at 2 cycles, the rest at %.0f)"
-                  % (n_simd, MAX_CLOCK_HZ / 1e9, cycles_per_inst, n_f32 / k["SQ_INSTS_VALU"], VALU_CYCLES_PER_INST),
+        frac_bracket=[k["SQ_INSTS_VALU"] * (pricing["cycles_low"] / k["SQ_INSTS_VALU"]) / t / (n_simd * MAX_CLOCK_HZ),
+                      k["SQ_INSTS_VALU"] * (pricing["cycles_high"] / k["SQ_INSTS_VALU"]) / t / (n_simd * MAX_CLOCK_HZ)],
+        peak_note="%d SIMDs x %.1f GHz / %.3f cycles per wave-instruction, priced per counter class with the issue cycles "
+                  "measured in profiles/r05_ubench_issue.json (mixed classes: profiles/r05_valu_mix.json); "
+                  "frac_bracket = the two mixed classes all at 2 cycles .. all at 4"
+                  % (n_simd, MAX_CLOCK_HZ / 1e9, cycles_per_inst),
+        issue_pricing=pricing["table"],
         issue_slot_occupancy_pmc=k["SQ_INSTS_VALU"] * cycles_per_inst / (4.0 * k["SQ_BUSY_CU_CYCLES"]),
         sustained_clock_GHz_est=clock / 1e9,
         clock_in_pmc_pass_GHz=(busy_cycles / (dur_pmc * 1e-9) / 1e9) if dur_pmc else None,

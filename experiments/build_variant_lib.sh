@@ -13,4 +13,4 @@ for f in ndt2d_kernels ndt2d_match_lane ndt2d_match_small ndt2d_poses_compact nd
     OBJS="$OBJS $R/ndt_2d_amd/csrc/$f.o"
   fi
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS $R/ndt_2d_amd/csrc/ndt2d_host.o -ldl -o $R/experiments/bin/$NAME.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS $R/ndt_2d_amd/csrc/ndt2d_host.o $R/ndt_2d_amd/csrc/ndt2d_build_info.o -ldl -lpthread -o $R/experiments/bin/$NAME.so

@@ -239,6 +239,37 @@ __global__ void __launch_bounds__(256) k(double * out, Stamp * stamps, int iters
     if constexpr (OP == 67) { I2("v_fmac_f32") }
     if constexpr (OP == 68) { I1("v_mov_b32_dpp", " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf") }
     if constexpr (OP == 69) { I2S("v_add_u32_dpp", " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf") }
+    // one select among seven FP64 instructions: is the e32 (implicit vcc) form's 22 cycles a cost of the
+    // instruction wherever it stands, or of a run of them?
+    if constexpr (OP == 70)
+    {
+      REP16(asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(a0) : "v"(c)); asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(a1) : "v"(c));
+            asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(a2) : "v"(c)); asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(i3) : "v"(j));
+            asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(a4) : "v"(c)); asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(a5) : "v"(c));
+            asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(a6) : "v"(c)); asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(a7) : "v"(c));)
+    }
+    if constexpr (OP == 71)
+    {
+      REP16(asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(a0) : "v"(c)); asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(a1) : "v"(c));
+            asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(a2) : "v"(c)); asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(i3) : "v"(j), "s"(m0));
+            asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(a4) : "v"(c)); asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(a5) : "v"(c));
+            asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(a6) : "v"(c)); asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(a7) : "v"(c));)
+    }
+    // ... and with vcc freshly written by a compare right before it (the usual pair)
+    if constexpr (OP == 72)
+    {
+      REP16(asm volatile("v_cmp_lt_f64 vcc, %1, %2\n\tv_cndmask_b32 %0, %0, %3, vcc" : "+v"(i0) : "v"(a0), "v"(c), "v"(j) : "vcc");
+            asm volatile("v_cmp_lt_f64 vcc, %1, %2\n\tv_cndmask_b32 %0, %0, %3, vcc" : "+v"(i1) : "v"(a1), "v"(c), "v"(j) : "vcc");
+            asm volatile("v_cmp_lt_f64 vcc, %1, %2\n\tv_cndmask_b32 %0, %0, %3, vcc" : "+v"(i2) : "v"(a2), "v"(c), "v"(j) : "vcc");
+            asm volatile("v_cmp_lt_f64 vcc, %1, %2\n\tv_cndmask_b32 %0, %0, %3, vcc" : "+v"(i3) : "v"(a3), "v"(c), "v"(j) : "vcc");)
+    }
+    if constexpr (OP == 73)
+    {
+      REP16(asm volatile("v_cmp_lt_f64 %1, %2, %3\n\tv_cndmask_b32 %0, %0, %4, %1" : "+v"(i0), "=&s"(m0) : "v"(a0), "v"(c), "v"(j));
+            asm volatile("v_cmp_lt_f64 %1, %2, %3\n\tv_cndmask_b32 %0, %0, %4, %1" : "+v"(i1), "=&s"(m1) : "v"(a1), "v"(c), "v"(j));
+            asm volatile("v_cmp_lt_f64 %1, %2, %3\n\tv_cndmask_b32 %0, %0, %4, %1" : "+v"(i2), "=&s"(m0) : "v"(a2), "v"(c), "v"(j));
+            asm volatile("v_cmp_lt_f64 %1, %2, %3\n\tv_cndmask_b32 %0, %0, %4, %1" : "+v"(i3), "=&s"(m1) : "v"(a3), "v"(c), "v"(j));)
+    }
     // two classes interleaved: does an FP64 instruction dual-issue with / hide a 32-bit one?
     if constexpr (OP == 50)
     {
@@ -313,9 +344,9 @@ void run(const char * name, const char * pmc_class)
     const double inst_simd = inst_wave * w;
     // s_memrealtime ticks at 100 MHz: `real` ticks = real * 10 ns
     const double mhz = real > 0 ? cyc / (real * 10.0e-9) / 1.0e6 : 0.0;
-    printf("{\"instruction\": \"%s\", \"pmc_class\": \"%s\", \"waves_per_simd\": %d, \"cyc_wave\": %.3f, "
+    printf("{\"op\": %d, \"instruction\": \"%s\", \"pmc_class\": \"%s\", \"waves_per_simd\": %d, \"cyc_wave\": %.3f, "
            "\"ns_launch\": %.4f, \"ns_span\": %.4f, \"memtime_mhz\": %.1f}\n",
-           name, pmc_class, w, cyc / inst_simd, ms * 1.0e6 / inst_simd,
+           OP, name, pmc_class, w, cyc / inst_simd, ms * 1.0e6 / inst_simd,
            static_cast<double>(last - first) * 10.0 / inst_simd, mhz);
     fflush(stdout);
   }
@@ -402,6 +433,10 @@ int main(int argc, char ** argv)
   run<67>("v_fmac_f32", "FP32");
   run<68>("v_mov_b32_dpp quad_perm", "other");
   run<69>("v_add_u32_dpp quad_perm", "INT32");
+  run<70>("7 x v_fma_f64 + 1 x v_cndmask_b32 vcc", "mix");
+  run<71>("7 x v_fma_f64 + 1 x v_cndmask_b32 sgpr", "mix");
+  run<72>("v_cmp_lt_f64 vcc + v_cndmask_b32 vcc pairs", "mix");
+  run<73>("v_cmp_lt_f64 sgpr + v_cndmask_b32 sgpr pairs", "mix");
   run<50>("v_add_f64 + v_add_u32 alternating", "mix");
   run<51>("v_fma_f64 + v_mov_b32 alternating", "mix");
   return 0;

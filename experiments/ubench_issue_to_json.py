@@ -22,8 +22,25 @@ for name, e in table.items():
     e["cycles_measured"] = round(min(vals), 3)
     nominal = min((2.0, 4.0, 8.0, 16.0), key=lambda c: abs(c - e["cycles_measured"]) / c)
     e["cycles_nominal"] = nominal if abs(nominal - e["cycles_measured"]) / nominal < 0.2 else round(e["cycles_measured"], 1)
-    if " " not in name:
+    if e["pmc_class"] != "mix" and "(dst" not in name:
         cycles[name] = e["cycles_nominal"]
+# which SQ_INSTS_VALU_* counter counts the instruction (second argument: pmc_classes.json of the same run)
+if len(sys.argv) > 2:
+    counted = json.load(open(sys.argv[2]))
+    for name, e in table.items():
+        c = counted.get(name, {})
+        e["counted_by"] = sorted(k for k in c if k not in ("SQ_INSTS_VALU", "busy_cu_cycles_per_inst_x1024")) or ["(no class counter)"]
+        if "busy_cu_cycles_per_inst_x1024" in c:
+            e["busy_cu_cycles_per_instruction"] = c["busy_cu_cycles_per_inst_x1024"]
+# a select on the implicit vcc (VOP2) is slow only in a RUN of them: one among seven v_fma_f64 costs what they cost
+mixed = table.get("7 x v_fma_f64 + 1 x v_cndmask_b32 vcc")
+if mixed is not None:
+    cycles["v_cndmask_b32 vcc"] = 4.0
+    table["v_cndmask_b32 vcc"]["cycles_nominal_isolated"] = 4.0
+    table["v_cndmask_b32 vcc"]["note"] = ("22.7 cycles each in a run of 128; one among seven v_fma_f64 leaves the loop at %.2f "
+                                          "cycles per instruction, a compare + select pair at %.2f: priced at 4"
+                                          % (mixed["cycles_measured"],
+                                             table.get("v_cmp_lt_f64 vcc + v_cndmask_b32 vcc pairs", {}).get("cycles_measured", float("nan"))))
 out = {
     "what": "VALU issue cost per wave64 instruction per SIMD on gfx950 (MI355X), experiments/ubench_issue.hip: "
             "128 copies of one instruction over 8 independent register chains x 1000 iterations, 1-8 waves per SIMD "

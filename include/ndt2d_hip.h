@@ -113,6 +113,14 @@ int ndt2d_grid_stage_commit(ndt2d_handle h, size_t n_listed, double cell_size, d
 int ndt2d_build_grid(ndt2d_handle h, double ndt_resolution, double range_max,
                      const double * poses_xyt, const double * points_xy, const size_t * offsets,
                      size_t n_scans);
+/* How ndt2d_build_grid forms the eigenvalues of Cell::compute (src/ndt_model.cpp:84-85,
+ * Eigen::EigenSolver<Eigen::Matrix2d>): "eigen" (default) = Eigen 3.4.0's RealSchur /
+ * EigenSolver transcribed operation by operation for a 2 x 2 input (csrc/ndt2d_eigen2.h: the
+ * input scaled by its largest entry, the Givens rotation of the 2 x 2 block, the diagonal read
+ * back); "closed" = the closed form (a + d) / 2 +- sqrt(((a - d) / 2)^2 + b^2) of rounds 1-4.
+ * The two differ in the last ulps; the difference reaches a cell's information matrix only
+ * through the clamp branch (:88-96). */
+int ndt2d_set_eigenvalue_form(ndt2d_handle h, const char * form);
 /* Geometry and (optionally) the cells6 records of the installed grid, copied
  * back from the device.  Any output may be NULL. */
 int ndt2d_get_grid(ndt2d_handle h, double * cells6_out, size_t capacity_cells, uint32_t * size_x,
@@ -253,6 +261,23 @@ int ndt2d_score_fetch(ndt2d_handle h, double * h_scores);
 #define NDT2D_PF_RESULT_DOUBLES 8
 int ndt2d_pf_finalize_launch(ndt2d_handle h, const double * d_poses_xyt, size_t n_poses,
                              double * d_weights, const double * d_stats, double * d_out);
+/* The same in the form one device of a SHARDED particle set takes (ndt2d_matcher_create_multi,
+ * host exchange): no copy and no stream synchronisation between the two halves of
+ * ParticleFilter::measure.
+ *   ndt2d_pose_sums_launch   = ndt2d_score_poses_launch whose eight moment sums
+ *       (NDT2D_POSE_STATS_DOUBLES) also go to the context's host-coherent result block, behind
+ *       a flag;  ndt2d_pose_sums_fetch spins on that flag and returns them (this device's row
+ *       of the [n_dev, 8] table: the "total particle weight" exchange, src/particle_filter.cpp:166-174);
+ *   ndt2d_pf_finalize_totals_launch = ndt2d_pf_finalize_launch with the TOTAL sums given as
+ *       eight host values that travel as kernel arguments; its result lands in the host-coherent
+ *       block as well: ndt2d_pf_result_read returns it once the caller has synchronised the
+ *       stream (it does, behind its copy of the weights).
+ * One such pair may be in flight per context. */
+int ndt2d_pose_sums_launch(ndt2d_handle h, const double * d_poses_xyt, size_t n_poses, double * d_scores);
+int ndt2d_pose_sums_fetch(ndt2d_handle h, double * sums_out);
+int ndt2d_pf_finalize_totals_launch(ndt2d_handle h, const double * d_poses_xyt, size_t n_poses,
+                                    double * d_weights, const double * totals);
+int ndt2d_pf_result_read(ndt2d_handle h, double * out);
 /* Host-pointer convenience = ParticleFilter::measure for the beams of
  * ndt2d_set_beams: H2D particles, score, statistics, D2H normalised weights and
  * the NDT2D_PF_RESULT_DOUBLES result. */
@@ -458,9 +483,20 @@ int ndt2d_matcher_create(ndt2d_matcher ** out, int device_id);
  * host-coherent result block and the host combines them (a device may then appear more than
  * once in device_ids: several contexts on one GPU, which RCCL refuses).  "auto" (default):
  * "rccl" when all devices differ and librccl.so.1 loads, "host" otherwise.  Both give the same
- * bits.  Work smaller than ndt2d_matcher_set_multi_min_units (candidates x beams, particles x
- * beams; default 1e9, ~0.3 ms of one GPU: dealing a call out costs ~20 us of
- * host time per device before the last one starts) and every single-pose call stay on the first device.
+ * bits.
+ *
+ * Dealing: one persistent worker thread per device beyond the first (made here, parked on a
+ * condition variable after ~200 us without work), the calling thread drives the first device:
+ * all devices' uploads and launches go out side by side (ndt2d_matcher_last_fanout_us: when
+ * each device's launch had been queued, from the call's start).  Sharded particle sets run
+ * their whole share on the device's thread -- upload, scoring, the sums' meeting on the host
+ * (a barrier between the threads, no stream synchronisation), updateStatistics with the totals
+ * as kernel arguments, the weights' way back.
+ *
+ * Work smaller than the thresholds of ndt2d_matcher_set_multi_thresholds (candidates x beams
+ * of a search, default 1e9 -- ~0.3 ms of one GPU; particles x beams of a batch, default 2e8
+ * -- ~0.2 ms: BASELINE configs[4], 7.2e8, is sharded) and every single-pose call stay on the
+ * first device.  ndt2d_matcher_set_multi_min_units sets both to one value.
  * n_dev == 1 behaves exactly as ndt2d_matcher_create. */
 int ndt2d_matcher_create_multi(ndt2d_matcher ** out, const int * device_ids, int n_dev);
 int ndt2d_matcher_destroy(ndt2d_matcher * m);
@@ -470,6 +506,12 @@ int ndt2d_matcher_device_count(ndt2d_matcher * m);
 ndt2d_handle ndt2d_matcher_device_at(ndt2d_matcher * m, int rank);
 int ndt2d_matcher_set_exchange(ndt2d_matcher * m, const char * mode);
 int ndt2d_matcher_set_multi_min_units(ndt2d_matcher * m, double units);
+int ndt2d_matcher_set_multi_thresholds(ndt2d_matcher * m, double min_search_units, double min_pose_units);
+int ndt2d_matcher_get_multi_thresholds(ndt2d_matcher * m, double * min_search_units, double * min_pose_units);
+/* Of the last call that was dealt to the devices: for device r, microseconds from the call's
+ * start until its (first) launch had been queued -- out_us[r], r < min(capacity, n_dev);
+ * *n_out = n_dev (0 if no call was dealt yet). */
+int ndt2d_matcher_last_fanout_us(ndt2d_matcher * m, double * out_us, size_t capacity, size_t * n_out);
 /* What the last matchScan / scorePoses / pf_measure ran as: the kernel variant of the first
  * device (ndt2d_last_variant), prefixed "multi[n]/rccl/" or "multi[n]/host/" when the call was
  * dealt to n devices. */
@@ -499,6 +541,8 @@ int ndt2d_matcher_add_scans(ndt2d_matcher * m, const double * poses_xyt,
  * (ndt2d_build_grid) or "auto" (device from 32768 map points up).  Both give
  * bit-identical grids. */
 int ndt2d_matcher_set_build_mode(ndt2d_matcher * m, const char * mode);
+/* ndt2d_set_eigenvalue_form for the host build and every device of the matcher. */
+int ndt2d_matcher_set_eigenvalue_form(ndt2d_matcher * m, const char * form);
 /* ScanMatcherNDT::matchScan (src/scan_matcher_ndt.cpp:76-149).  *score_out =
  * the function's return value (best_score / scan_points_to_use; 0.0 and
  * outputs untouched when no NDT, :80).  pose_inout[3] is written only when a

@@ -78,6 +78,7 @@ SIGNATURES = {
     "ndt2d_set_grid": (C.c_int, [_vp, _dp, _u32, _u32, _d, _d, _d]),
     "ndt2d_set_grid_sparse": (C.c_int, [_vp, C.POINTER(C.c_uint32), _dp, _sz, _u32, _u32, _d, _d, _d]),
     "ndt2d_build_grid": (C.c_int, [_vp, _d, _d, _dp, _dp, _szp, _sz]),
+    "ndt2d_set_eigenvalue_form": (C.c_int, [_vp, C.c_char_p]),
     "ndt2d_get_grid": (C.c_int, [_vp, _dp, _sz, C.POINTER(_u32), C.POINTER(_u32), _dp, _dp, _dp]),
     "ndt2d_clear_grid": (C.c_int, [_vp]),
     "ndt2d_has_grid": (C.c_int, [_vp]),
@@ -97,6 +98,10 @@ SIGNATURES = {
     "ndt2d_score_poses_beams_launch": (C.c_int, [_vp, _dp, _sz, _dp, _sz]),
     "ndt2d_score_fetch": (C.c_int, [_vp, _dp]),
     "ndt2d_pf_finalize_launch": (C.c_int, [_vp, _vp, _sz, _vp, _vp, _vp]),
+    "ndt2d_pose_sums_launch": (C.c_int, [_vp, _vp, _sz, _vp]),
+    "ndt2d_pose_sums_fetch": (C.c_int, [_vp, _dp]),
+    "ndt2d_pf_finalize_totals_launch": (C.c_int, [_vp, _vp, _sz, _vp, _dp]),
+    "ndt2d_pf_result_read": (C.c_int, [_vp, _dp]),
     "ndt2d_pf_measure": (C.c_int, [_vp, _dp, _sz, _dp, _dp]),
     "ndt2d_pf_noise_launch": (C.c_int, [_vp, _u64, _u64, _u64, _sz, _vp]),
     "ndt2d_pf_motion_launch": (C.c_int, [_vp, _vp, _sz, _d, _d, _d, _dp, _vp, _u64, _u64, _u64]),
@@ -136,6 +141,9 @@ SIGNATURES = {
     "ndt2d_matcher_device_at": (_vp, [_vp, C.c_int]),
     "ndt2d_matcher_set_exchange": (C.c_int, [_vp, C.c_char_p]),
     "ndt2d_matcher_set_multi_min_units": (C.c_int, [_vp, _d]),
+    "ndt2d_matcher_set_multi_thresholds": (C.c_int, [_vp, _d, _d]),
+    "ndt2d_matcher_get_multi_thresholds": (C.c_int, [_vp, _dp, _dp]),
+    "ndt2d_matcher_last_fanout_us": (C.c_int, [_vp, _dp, _sz, _szp]),
     "ndt2d_matcher_last_variant": (C.c_char_p, [_vp]),
     "ndt2d_matcher_set_timing": (C.c_int, [_vp, C.c_int]),
     "ndt2d_matcher_destroy": (C.c_int, [_vp]),
@@ -143,6 +151,7 @@ SIGNATURES = {
     "ndt2d_matcher_device": (_vp, [_vp]),
     "ndt2d_matcher_initialize": (C.c_int, [_vp, _d, _d, _d, _d, _d, _sz, _d]),
     "ndt2d_matcher_add_scans": (C.c_int, [_vp, _dp, _dp, _szp, _sz]),
+    "ndt2d_matcher_set_eigenvalue_form": (C.c_int, [_vp, C.c_char_p]),
     "ndt2d_matcher_set_build_mode": (C.c_int, [_vp, C.c_char_p]),
     "ndt2d_matcher_match_scan": (C.c_int, [_vp, _dp, _dp, _sz, _dp, _dp, _dp]),
     "ndt2d_matcher_match_scan_ex": (C.c_int, [_vp, _dp, _dp, _sz, _dp, _dp, _dp, _dp, _sz,

@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_PKG, "libndt2d_hip.so")
 # ndt2d_build_info.cpp is compiled apart (it receives the hash of all the others as a macro)
 BUILD_INFO_SOURCE = "ndt2d_build_info.cpp"
 SOURCES = ["ndt2d_kernels.hip", "ndt2d_match_lane.hip", "ndt2d_match_small.hip", "ndt2d_poses_compact.hip", "ndt2d_build.hip", "ndt2d_motion.hip", "ndt2d_scan.hip", "ndt2d_occupancy.hip", "ndt2d_device.hip", "ndt2d_exchange.hip", "ndt2d_host.cpp"]
-HEADERS = [os.path.join(_CSRC, "ndt2d_kernels.h"), os.path.join(_CSRC, "ndt2d_device_fn.h"), os.path.join(_CSRC, "ndt2d_lane_fn.h"), os.path.join(_CSRC, "ndt2d_exchange.h"), os.path.join(_ROOT, "include", "ndt2d_hip.h")]
+HEADERS = [os.path.join(_CSRC, "ndt2d_kernels.h"), os.path.join(_CSRC, "ndt2d_device_fn.h"), os.path.join(_CSRC, "ndt2d_lane_fn.h"), os.path.join(_CSRC, "ndt2d_exchange.h"), os.path.join(_CSRC, "ndt2d_eigen2.h"), os.path.join(_CSRC, "ndt2d_workers.h"), os.path.join(_ROOT, "include", "ndt2d_hip.h")]
 ARCH = "gfx950"
 # -ffp-contract=off: the reference's x86-64 build has no fused multiply-add; the
 # kernels keep its separate roundings (see DESIGN.md "Numerics").
@@ -159,6 +159,47 @@ def build_all(force=False, verbose=False, jobs=4):
     return LIB_PATH
 
 
+HOOKS_LIB_PATH = os.path.join(_PKG, "libndt2d_hip_hooks.so")
+HOOKED_SOURCES = ["ndt2d_match_small.hip", "ndt2d_poses_compact.hip"]
+
+
+def build_test_hooks(verbose=False):
+    """libndt2d_hip_hooks.so: the library with -DNDT2D_TEST_HOOKS in the two translation units
+    whose kernels wait for their own blocks (bounded polls) -- their producers can then be told
+    to withhold a `done` word (ndt2d_test_drop_done_small / _few), which is how
+    tests/test_gpu_bounded_poll.py makes the polls trip.  Test infrastructure: never loaded by
+    the package itself (NDT2D_HIP_LIB selects it in the test's subprocess)."""
+    lib = build_all(verbose=verbose)
+    sha = source_sha256()
+    stamp = HOOKS_LIB_PATH + ".sha"
+    try:
+        with open(stamp) as f:
+            if f.read().strip() == sha and os.path.exists(HOOKS_LIB_PATH):
+                return HOOKS_LIB_PATH
+    except OSError:
+        pass
+    objs = []
+    for src in SOURCES + [BUILD_INFO_SOURCE]:
+        if src in HOOKED_SOURCES:
+            obj = os.path.join(_CSRC, os.path.splitext(src)[0] + ".hooks.o")
+            cmd = [hipcc(), "--offload-arch=" + ARCH] + FLAGS + ["-DNDT2D_TEST_HOOKS", "-I", os.path.join(_ROOT, "include"),
+                                                                 "-I", _CSRC, "-c", os.path.join(_CSRC, src), "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+            objs.append(obj)
+        else:
+            objs.append(_obj(src))
+    cmd = [hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC"] + objs + ["-ldl", "-lpthread", "-o", HOOKS_LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    with open(stamp, "w") as f:
+        f.write(sha + "\n")
+    assert os.path.exists(lib)
+    return HOOKS_LIB_PATH
+
+
 PROBE_PATH = os.path.join(_PKG, "ndt2d_latency_probe")
 
 
@@ -181,3 +222,5 @@ def build_tools(verbose=False):
 
 if __name__ == "__main__":
     print(build_all(force="--force" in sys.argv, verbose=True))
+    if "--test-hooks" in sys.argv:
+        print(build_test_hooks(verbose=True))

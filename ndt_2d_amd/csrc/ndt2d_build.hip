@@ -23,6 +23,7 @@
 // with -ffp-contract=off; '/' and sqrt are correctly rounded).
 #include <hipcub/hipcub.hpp>
 
+#include "ndt2d_eigen2.h"
 #include "ndt2d_lane_fn.h"
 
 namespace ndt2d
@@ -66,32 +67,6 @@ __global__ void __launch_bounds__(256) segments_kernel(const uint32_t * keys, ui
   const uint32_t k = keys[j];
   if (j == 0 || keys[j - 1] != k) seg_begin[k] = j;
   if (j == n - 1 || keys[j + 1] != k) seg_end[k] = j + 1;
-}
-
-// Eigenvalues of the symmetric 2x2 [[a, b], [b, d]] the way
-// Eigen::EigenSolver's real Schur form arrives at them (src/ndt_model.cpp:84-85);
-// same restatement as the host builder (csrc/ndt2d_host.cpp).
-__device__ __forceinline__ void symmetric_eigenvalues(double a, double b, double d, double * e0,
-                                                      double * e1)
-{
-  const double eps = 2.220446049250313e-16;
-  const double tiny_min = 2.2250738585072014e-308;
-  const double norm = fabs(a) + 2.0 * fabs(b) + fabs(d);
-  double tiny = norm * (eps * eps);
-  if (tiny < tiny_min) tiny = tiny_min;
-  double thresh = (fabs(a) + fabs(d)) * eps;
-  if (thresh < tiny) thresh = tiny;
-  if (norm == 0.0 || fabs(b) <= thresh)
-  {
-    *e0 = a;
-    *e1 = d;
-    return;
-  }
-  const double p = 0.5 * (a - d);
-  const double q = p * p + b * b;
-  const double z = sqrt(fabs(q));
-  *e0 = (d + p) + z;
-  *e1 = (d + p) - z;
 }
 
 // One packed record in both strides, and -- from the wave's ballot -- the two words of
@@ -156,7 +131,7 @@ __global__ void __launch_bounds__(256) cells_kernel(const BuildArgs a, const uin
       const double vxy = (cxy - (mean_x * mean_y)) * scale;
       const double vyy = (cyy - (mean_y * mean_y)) * scale;
       double small, large;
-      symmetric_eigenvalues(vxx, vxy, vyy, &small, &large);
+      covariance_eigenvalues(a.eigen_form, vxx, vxy, vyy, &small, &large);   // (:84-85, ndt2d_eigen2.h)
       if (small > large)
       {
         const double t = small;

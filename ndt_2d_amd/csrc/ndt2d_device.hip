@@ -135,6 +135,7 @@ struct ndt2d_context
   const char * last_variant = "";
   int force_variant = ndt2d::kVariantAuto;
   bool batched_only = false;   // "batched": small pose batches stay on the batched kernels
+  int eigen_form = 0;          // ndt2d_set_eigenvalue_form (ndt2d_eigen2.h): 0 Eigen's EigenSolver, 1 closed form
 
   bool match_pending = false;
   uint64_t match_launches = 0, match_fetches = 0;   // searches launched / fetched so far (ndt2d_match_status)
@@ -143,6 +144,10 @@ struct ndt2d_context
   unsigned long long few_seq = 0;
   size_t few_n_poses = 0;
   bool few_stats = false;
+  // the moment sums of a sharded particle launch on their way to the host (ndt2d_pose_sums_launch)
+  bool sums_pending = false;
+  unsigned long long sums_seq = 0;
+  uint64_t sums_pos = 0;
   uint64_t last_candidates = 0;
 };
 
@@ -357,11 +362,19 @@ int wait_host_flag(ndt2d_context * h, int slot, unsigned long long seq, uint64_t
   {
     for (int i = 0; i < 2048; ++i)
     {
-      if (*flag == seq)
+      const unsigned long long seen = *flag;
+      if (seen == seq)
       {
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
         if (h->reached < position) h->reached = position;   // the stream is in order
         return NDT2D_OK;
+      }
+      if (seen == (seq | ndt2d::kHostFlagGaveUp))
+      {
+        // the launch's last block waited in vain for another block's result (its bounded poll):
+        // this call has no result; the kernel ended normally and the context stays usable
+        if (h->reached < position) h->reached = position;
+        return fail(h, NDT2D_ERR_HIP, "the kernel gave up waiting for one of its blocks' results (bounded poll)");
       }
       __builtin_ia32_pause();
     }
@@ -370,6 +383,10 @@ int wait_host_flag(ndt2d_context * h, int slot, unsigned long long seq, uint64_t
     if (q != hipErrorNotReady && q != hipSuccess) return fail_hip(h, q, "hipStreamQuery");
   }
   NDT2D_SYNC(h);
+  if (*flag == (seq | ndt2d::kHostFlagGaveUp))
+  {
+    return fail(h, NDT2D_ERR_HIP, "the kernel gave up waiting for one of its blocks' results (bounded poll)");
+  }
   if (*flag != seq) return fail(h, NDT2D_ERR_HIP, "result flag was not raised");
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
   if (h->reached < position) h->reached = position;
@@ -763,6 +780,7 @@ int ndt2d_build_grid(ndt2d_handle h, double ndt_resolution, double range_max,
   g.origin_y = min_y;
 
   ndt2d::BuildArgs a{};
+  a.eigen_form = h->eigen_form;
   a.grid = g;
   a.points_xy = h->b_points.ptr;
   a.n_points = static_cast<uint32_t>(n_points);
@@ -1028,6 +1046,15 @@ int ndt2d_set_grid_sparse(ndt2d_handle h, const uint32_t * cell_index, const dou
     std::memcpy(st_idx, cell_index, n_listed * sizeof(uint32_t));
   }
   return ndt2d_grid_stage_commit(h, n_listed, cell_size, origin_x, origin_y);
+}
+
+int ndt2d_set_eigenvalue_form(ndt2d_handle h, const char * form)
+{
+  if (h == nullptr || form == nullptr) return NDT2D_ERR_INVALID;
+  if (std::strcmp(form, "eigen") == 0) h->eigen_form = 0;
+  else if (std::strcmp(form, "closed") == 0) h->eigen_form = 1;
+  else return fail(h, NDT2D_ERR_INVALID, "ndt2d_set_eigenvalue_form: unknown form (eigen, closed)");
+  return NDT2D_OK;
 }
 
 int ndt2d_get_grid(ndt2d_handle h, double * cells6_out, size_t capacity_cells, uint32_t * size_x,
@@ -1319,6 +1346,10 @@ int ndt2d_match_fetch(ndt2d_handle h, ndt2d_match_result * out)
   if (!h->match_pending) return fail(h, NDT2D_ERR_STATE, "ndt2d_match_fetch: nothing launched");
   NDT2D_HIP(h, hipSetDevice(h->device));
   // the final reduction wrote the record into host-coherent memory, then its flag
+  // (whatever the wait says, the search is no longer pending: a call that failed leaves the
+  // context ready for the next one)
+  h->match_pending = false;
+  ++h->match_fetches;
   int rc = wait_host_flag(h, ndt2d::kHostFlagSlot, h->match_seq, h->match_pos);
   if (rc != NDT2D_OK) return rc;
   double rec[NDT2D_MATCH_RECORD_DOUBLES];
@@ -1329,7 +1360,6 @@ int ndt2d_match_fetch(ndt2d_handle h, ndt2d_match_result * out)
   out->near_tie = (rec[1] >= 0.0 && rec[1] != std::floor(rec[1])) ? 1u : 0u;
   for (int k = 0; k < 10; ++k) out->acc[k] = rec[2 + k];
   out->n_candidates = h->last_candidates;
-  ++h->match_fetches;
   return NDT2D_OK;
 }
 
@@ -1426,8 +1456,75 @@ int ndt2d_match(ndt2d_handle h, size_t th_begin, size_t th_end, double * h_score
   return ndt2d_match_fetch(h, out);
 }
 
+// slots of the host-coherent block the sharded particle path uses (behind the few-pose path's
+// statistics): a device's eight moment sums, their flag, and its updateStatistics result
+constexpr int kPoseSumsSlot = kPfOutSlot + 8;
+constexpr int kPoseSumsFlagSlot = kPoseSumsSlot + ndt2d::kPoseSumsFlagOffset;
+constexpr int kPfShardOutSlot = kPfOutSlot + 24;
+static_assert(kPfShardOutSlot + 8 <= kHostResDoubles, "host block too small");
+
+static int score_poses_launch_impl(ndt2d_handle h, const double * d_poses_xyt, size_t n_poses,
+                                   double * d_scores, double * d_stats, bool publish_sums);
+
 int ndt2d_score_poses_launch(ndt2d_handle h, const double * d_poses_xyt, size_t n_poses,
                              double * d_scores, double * d_stats)
+{
+  return score_poses_launch_impl(h, d_poses_xyt, n_poses, d_scores, d_stats, false);
+}
+
+int ndt2d_pose_sums_launch(ndt2d_handle h, const double * d_poses_xyt, size_t n_poses, double * d_scores)
+{
+  if (h == nullptr) return NDT2D_ERR_INVALID;
+  NDT2D_HIP(h, hipSetDevice(h->device));
+  int rc = ensure(h, h->stats, NDT2D_POSE_STATS_DOUBLES + NDT2D_PF_RESULT_DOUBLES);
+  if (rc != NDT2D_OK) return rc;
+  if ((rc = ensure_host_res(h)) != NDT2D_OK) return rc;
+  return score_poses_launch_impl(h, d_poses_xyt, n_poses, d_scores, h->stats.ptr, true);
+}
+
+int ndt2d_pose_sums_fetch(ndt2d_handle h, double * sums_out)
+{
+  if (h == nullptr || sums_out == nullptr) return NDT2D_ERR_INVALID;
+  if (!h->sums_pending) return fail(h, NDT2D_ERR_STATE, "ndt2d_pose_sums_fetch: nothing launched");
+  NDT2D_HIP(h, hipSetDevice(h->device));
+  h->sums_pending = false;
+  const int rc = wait_host_flag(h, kPoseSumsFlagSlot, h->sums_seq, h->sums_pos);
+  if (rc != NDT2D_OK) return rc;
+  for (int k = 0; k < NDT2D_POSE_STATS_DOUBLES; ++k) sums_out[k] = h->host_res[kPoseSumsSlot + k];
+  return NDT2D_OK;
+}
+
+int ndt2d_pf_finalize_totals_launch(ndt2d_handle h, const double * d_poses_xyt, size_t n_poses,
+                                    double * d_weights, const double * totals)
+{
+  if (h == nullptr) return NDT2D_ERR_INVALID;
+  if (d_poses_xyt == nullptr || d_weights == nullptr || totals == nullptr || n_poses == 0)
+  {
+    return fail(h, NDT2D_ERR_INVALID, "ndt2d_pf_finalize_totals_launch: bad argument");
+  }
+  NDT2D_HIP(h, hipSetDevice(h->device));
+  int rc = ensure(h, h->ws_poses, ndt2d::poses_workspace_doubles(n_poses));
+  if (rc != NDT2D_OK) return rc;
+  if ((rc = ensure(h, h->stats, NDT2D_POSE_STATS_DOUBLES + NDT2D_PF_RESULT_DOUBLES)) != NDT2D_OK) return rc;
+  if ((rc = ensure_host_res(h)) != NDT2D_OK) return rc;
+  hipError_t e = ndt2d::launch_pf_finalize(d_poses_xyt, n_poses, d_weights, nullptr, totals, h->ws_poses.ptr,
+                                           h->stats.ptr + NDT2D_POSE_STATS_DOUBLES,
+                                           h->host_res_dev + kPfShardOutSlot, h->stream);
+  if (e != hipSuccess) return fail_hip(h, e, "launch_pf_finalize");
+  return NDT2D_OK;
+}
+
+int ndt2d_pf_result_read(ndt2d_handle h, double * out)
+{
+  if (h == nullptr || out == nullptr) return NDT2D_ERR_INVALID;
+  if (h->host_res == nullptr) return fail(h, NDT2D_ERR_STATE, "ndt2d_pf_result_read: nothing launched");
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  for (int k = 0; k < NDT2D_PF_RESULT_DOUBLES; ++k) out[k] = h->host_res[kPfShardOutSlot + k];
+  return NDT2D_OK;
+}
+
+static int score_poses_launch_impl(ndt2d_handle h, const double * d_poses_xyt, size_t n_poses,
+                                   double * d_scores, double * d_stats, bool publish_sums)
 {
   if (h == nullptr) return NDT2D_ERR_INVALID;
   if (!h->has_grid) return fail(h, NDT2D_ERR_NO_GRID, "ndt2d_score_poses_launch: no grid");
@@ -1473,9 +1570,21 @@ int ndt2d_score_poses_launch(ndt2d_handle h, const double * d_poses_xyt, size_t 
     if (int trc = next_timing_slot(h); trc != NDT2D_OK) return trc;
     NDT2D_HIP(h, hipEventRecord(h->ev0, h->stream));
   }
+  unsigned long long sums_seq = 0;
+  if (publish_sums)
+  {
+    sums_seq = ++h->seq;
+    h->sums_pos = h->queued;
+  }
   hipError_t e = ndt2d::launch_score_poses(a, h->ws_poses.ptr, d_stats, h->force_variant,
-                                           h->stream, h->timing ? h->ev1 : nullptr, &info);
+                                           h->stream, h->timing ? h->ev1 : nullptr, &info,
+                                           publish_sums ? h->host_res_dev + kPoseSumsSlot : nullptr, sums_seq);
   if (e != hipSuccess) return fail_hip(h, e, "launch_score_poses");
+  if (publish_sums)
+  {
+    h->sums_seq = sums_seq;
+    h->sums_pending = true;
+  }
   h->timed = h->timing;
   h->last_kernels = info.n_kernels;
   h->last_variant = info.variant;
@@ -1653,8 +1762,8 @@ int ndt2d_pf_finalize_launch(ndt2d_handle h, const double * d_poses_xyt, size_t 
   NDT2D_HIP(h, hipSetDevice(h->device));
   int rc = ensure(h, h->ws_poses, ndt2d::poses_workspace_doubles(n_poses));
   if (rc != NDT2D_OK) return rc;
-  hipError_t e = ndt2d::launch_pf_finalize(d_poses_xyt, n_poses, d_weights, d_stats,
-                                           h->ws_poses.ptr, d_out, h->stream);
+  hipError_t e = ndt2d::launch_pf_finalize(d_poses_xyt, n_poses, d_weights, d_stats, nullptr,
+                                           h->ws_poses.ptr, d_out, nullptr, h->stream);
   if (e != hipSuccess) return fail_hip(h, e, "launch_pf_finalize");
   return NDT2D_OK;
 }

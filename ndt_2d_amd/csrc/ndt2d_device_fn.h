@@ -72,8 +72,9 @@ __device__ __forceinline__ double record_likelihood(double mx, double my, double
   return exp(record_exponent(mx, my, h00, h01, h11, px, py));
 }
 
-// exp(x) for the exponents of Cell::score: x is finite or -inf and far below the
-// overflow range (x <= 0 for any positive semi-definite information matrix).
+// exp(x) for the exponents of Cell::score, x below the overflow threshold (x <= 0 for any
+// positive semi-definite information matrix; exp_score() below handles the rest: NaN, and the
+// positive exponents of an information matrix that rounding made negative definite).
 // Same algorithm and polynomial as the device library's exp (n = rint(x log2 e),
 // r = x - n ln2 in two pieces, degree-11 minimax polynomial, ldexp), minus its
 // range fix-ups: the clamp maps -inf to an exponent whose ldexp underflows to
@@ -149,14 +150,28 @@ __device__ __forceinline__ bool wave_any(bool p)
 // compacted particle scoring; the wave mapping keeps the library exp, whose
 // constants live in SGPRs there): the lean evaluation above, except that a NaN
 // exponent (degenerate cell) propagates as in the reference.
+//
+// ... and an exponent above ln(DBL_MAX) gives +inf, as std::exp does (src/ndt_model.cpp:115).
+// That happens: a cell whose >= 5 points are (nearly) identical -- a robot standing still in
+// front of a distant wall -- has a covariance of rounding noise, which comes out NEGATIVE on
+// both axes for one such cell in eight; Cell::compute's clamp branch (:88-96) then divides by
+// det = 0.001 * large^2 > 0 and the information matrix is negative definite with entries of
+// 1e19: exponents of +1e17, likelihood +inf, score -inf.  exp_of_exponent() is right up to the
+// threshold itself (n = 1024, v_ldexp_f64 rounds p * 2^1024 < DBL_MAX correctly) and garbage
+// above it (the reduced argument cancels away).  ONE compare serves both special cases.
+constexpr double kExpOverflowAbove = 0x1.62e42fefa39efp+9;   // 709.782712893384: exp(x) = +inf for x > this (glibc, IEEE)
+
 __device__ __forceinline__ double exp_score(double e)
 {
   // A NaN goes through as the reference's exp(NaN) has it (quiet NaN); the wave-level test keeps
-  // the select off the common path.  (Round 4: this used to call the library's exp for such a
+  // the selects off the common path.  (Round 4: this used to call the library's exp for such a
   // wave -- whose polynomial constants the compiler then kept in 20 vector registers for the
   // whole kernel, on behalf of a path no healthy map ever takes.)
   double r = exp_of_exponent(e);
-  if (__builtin_expect(wave_any(e != e), 0)) r = (e != e) ? e + e : r;
+  if (__builtin_expect(wave_any(!(e <= kExpOverflowAbove)), 0))
+  {
+    r = (e != e) ? e + e : (e > kExpOverflowAbove ? HUGE_VAL : r);
+  }
   return r;
 }
 
@@ -291,6 +306,24 @@ __device__ __forceinline__ void raise_host_flag(double * flag_slot, unsigned lon
   __hip_atomic_store(reinterpret_cast<unsigned long long *>(flag_slot), seq, __ATOMIC_RELAXED,
                      __HIP_MEMORY_SCOPE_SYSTEM);
 }
+
+// A kernel whose bounded wait for its own blocks' results gave up (the last block of a launch
+// polling the others' `done` words: ndt2d_match_small.hip, score_few_kernel) says so to the host
+// instead of trapping -- a trap faults the whole HIP context and with it every matcher of the
+// process: the flag leaves as seq | kHostFlagGaveUp, which the host's wait turns into
+// NDT2D_ERR_HIP for THIS call only (ndt2d_device.hip wait_host_flag).
+// (kHostFlagGaveUp itself: ndt2d_kernels.h, the host reads it too)
+constexpr uint32_t kDonePollLimit = 1u << 21;   // x (one L2 load + s_sleep(2), ~1 us): a second or two
+
+#ifdef NDT2D_TEST_HOOKS
+// Test builds only (python -m ndt_2d_amd.build --test-hooks -> libndt2d_hip_hooks.so): the
+// producer of record / pose `which - 1` withholds its `done` word (0: nobody does), so that the
+// bounded polls can be made to trip (tests/test_gpu_bounded_poll.py).  One copy per translation unit.
+static __device__ int g_test_drop_done = 0;
+#define NDT2D_TEST_DROPS_DONE(index) (g_test_drop_done != 0 && static_cast<uint32_t>(g_test_drop_done - 1) == static_cast<uint32_t>(index))
+#else
+#define NDT2D_TEST_DROPS_DONE(index) false
+#endif
 
 // (score, index) ordering of the reference's `if (score < best_score)` scan in
 // loop order (src/scan_matcher_ndt.cpp:128): lower score wins, ties go to the

@@ -148,6 +148,12 @@ int exchange_all_reduce(Exchange * ex, double * const * d_buf, size_t count, voi
     return fail(err, NDT2D_ERR_INVALID, "exchange_all_reduce: bad argument");
   }
   RcclApi * api = rccl_api();
+  // One communicator set is enqueued on all its devices before the next one starts: the node
+  // runs its local and its global matcher on two threads (src/ndt_mapper.cpp:141-142), and
+  // two sets over the same GPUs whose collectives reach the devices in different orders can
+  // deadlock (NCCL's rule for concurrent communicators).  Process-wide, held for the group only.
+  static std::mutex group_mutex;
+  std::lock_guard<std::mutex> group_lock(group_mutex);
   ncclResult_t r = api->group_start();
   if (r != ncclSuccess) return fail(err, NDT2D_ERR_HIP, std::string("ncclGroupStart: ") + api->error_string(r));
   ncclResult_t first_bad = ncclSuccess;

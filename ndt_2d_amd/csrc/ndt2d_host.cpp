@@ -6,7 +6,14 @@
 //     device layer -- subsampling, search tables, final covariance formula,
 //   * the batched particle path (ParticleFilter::measure),
 //   * the synthetic workload generator.
-// No scoring arithmetic happens here: every likelihood is evaluated on the GPU.
+// Scoring arithmetic on the HOST exists in exactly two places, both by design
+// and neither a fallback -- a matcher cannot be created without a GPU: (1) one pose of a scan
+// of at most 256 subsampled beams (scorePoints / scoreScan as the unchanged
+// ParticleFilter::measure calls them, once per particle: a launch + PCIe round trip per call
+// costs 25x the arithmetic) is scored by the calling thread from the host copy of the NDT,
+// host_score_points(); (2) the few candidates of a marked near-tie are rescored in the
+// reference's own arithmetic, settle_near_tie().  Every search, every batch of poses and every
+// longer scan is evaluated on the GPU.
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
@@ -20,8 +27,13 @@
 #include <unordered_set>
 #include <vector>
 
+#include <atomic>
+#include <chrono>
+
+#include "ndt2d_eigen2.h"
 #include "ndt2d_exchange.h"
 #include "ndt2d_hip.h"
+#include "ndt2d_workers.h"
 
 namespace
 {
@@ -69,8 +81,9 @@ struct HostCell
     valid = false;
   }
 
-  // Cell::compute, reference src/ndt_model.cpp:65-103
-  void compute()
+  // Cell::compute, reference src/ndt_model.cpp:65-103.  eigen_form: how the eigenvalues of
+  // :84-85 are formed (ndt2d_eigen2.h: Eigen 3.4.0's EigenSolver transcribed, or the closed form).
+  void compute(int eigen_form)
   {
     if (valid || n < 3) return;
     const double scale = n / (n - 1);
@@ -79,7 +92,7 @@ struct HostCell
     cov_yy = (corr_yy - (mean_y * mean_y)) * scale;
 
     double small, large;
-    symmetric_eigenvalues(cov_xx, cov_xy, cov_yy, &small, &large);
+    ndt2d::covariance_eigenvalues(eigen_form, cov_xx, cov_xy, cov_yy, &small, &large);
     if (small > large) std::swap(small, large);
     if (small < 0.001 * large)
     {
@@ -99,30 +112,6 @@ struct HostCell
       info_yy = cov_xx * invdet;
     }
     valid = true;
-  }
-
-  // Eigenvalues of [[a, b], [b, d]] the way Eigen::EigenSolver's real Schur
-  // form arrives at them for a 2x2 (reference src/ndt_model.cpp:84-85):
-  // negligible off-diagonal -> the diagonal itself, else the 2x2 block split
-  // with p = (a - d) / 2, z = sqrt(p*p + b*b).
-  static void symmetric_eigenvalues(double a, double b, double d, double * e0, double * e1)
-  {
-    const double norm = std::fabs(a) + 2.0 * std::fabs(b) + std::fabs(d);
-    double tiny = norm * (DBL_EPSILON * DBL_EPSILON);
-    if (tiny < DBL_MIN) tiny = DBL_MIN;
-    double thresh = (std::fabs(a) + std::fabs(d)) * DBL_EPSILON;
-    if (thresh < tiny) thresh = tiny;
-    if (norm == 0.0 || std::fabs(b) <= thresh)
-    {
-      *e0 = a;
-      *e1 = d;
-      return;
-    }
-    const double p = 0.5 * (a - d);
-    const double q = p * p + b * b;
-    const double z = std::sqrt(std::fabs(q));
-    *e0 = (d + p) + z;
-    *e1 = (d + p) - z;
   }
 };
 
@@ -245,9 +234,9 @@ public:
 
   // NDT::compute, reference src/ndt_model.cpp:154-160 (a cell without points returns
   // at once there: only the cells that received points are visited here)
-  void compute()
+  void compute(int eigen_form)
   {
-    for (const uint32_t i : touched_) cells_[i].compute();
+    for (const uint32_t i : touched_) cells_[i].compute(eigen_form);
   }
 
   // The cells that hold points, as ndt2d_set_grid_sparse takes them.
@@ -303,7 +292,7 @@ private:
 // max_x_/max_y_ start at numeric_limits<double>::min(), as the reference has it.
 std::unique_ptr<HostNdt> build_ndt(double resolution, double range_max, const double * poses,
                                    const double * pts, const size_t * offsets, size_t n_scans,
-                                   std::unique_ptr<HostNdt> reuse = nullptr)
+                                   std::unique_ptr<HostNdt> reuse = nullptr, int eigen_form = ndt2d::kEigenFormSchur)
 {
   double min_x = std::numeric_limits<double>::max();
   double max_x = std::numeric_limits<double>::min();
@@ -330,7 +319,7 @@ std::unique_ptr<HostNdt> build_ndt(double resolution, double range_max, const do
     ndt->add_scan(poses[3 * k], poses[3 * k + 1], poses[3 * k + 2], pts + 2 * offsets[k],
                   offsets[k + 1] - offsets[k]);
   }
-  ndt->compute();
+  ndt->compute(eigen_form);
   return ndt;
 }
 
@@ -385,6 +374,7 @@ struct MatcherShard
   double * d_poses = nullptr;     // this device's particle range
   double * d_weights = nullptr;
   size_t poses_cap = 0;
+  uint64_t beams_epoch = ~0ull;   // ndt2d_matcher::beams_epoch of the beams ndt2d_set_beams put there
 };
 
 struct ndt2d_matcher
@@ -397,7 +387,14 @@ struct ndt2d_matcher
   ndt2d::Exchange * exchange = nullptr;  // RCCL communicators, made when first needed
   bool exchange_tried = false;
   std::string exchange_note;             // why "auto" did not take RCCL
-  double multi_min_units = 1.0e9;        // work below this stays on the first device (~0.3 ms of one GPU)
+  // Work below these stays on the first device: candidates x beams of a search (~0.3 ms of one
+  // GPU) and particles x beams of a batch (~0.2 ms; BASELINE configs[4], 7.2e8, is above it).
+  // Dealing costs the call ~25 us over its slowest share (profiles/r05_multi_device_summary.json).
+  double multi_min_units = 1.0e9;
+  double multi_min_pose_units = 2.0e8;
+  std::unique_ptr<ndt2d::DeviceWorkers> workers;   // one thread per device beyond the first
+  std::vector<double> fanout_us;         // last dealt call: when each device's launch was queued
+  uint64_t beams_epoch = 0;              // counts the changes of `beams` (what the other devices hold: MatcherShard)
   double * pinned = nullptr;             // host block of the exchanges (layout: multi_pinned_*)
   std::string variant;                   // ndt2d_matcher_last_variant
   bool last_multi = false;
@@ -412,6 +409,7 @@ struct ndt2d_matcher
   std::unique_ptr<HostNdt> spare; // the storage of the NDT that reset() dropped, for the next build
   bool have_ndt = false;          // `ndt_` is set (reference scan_matcher_ndt.hpp:102)
   int build_mode = 0;             // 0 auto, 1 host, 2 device
+  int eigen_form = ndt2d::kEigenFormSchur;   // ndt2d_matcher_set_eigenvalue_form
   // state of the last prepare_search (subsampled beams + visited offsets)
   std::vector<double> beams, dth, dlin;
   size_t n_use = 0;               // beams in use (the N of `best / N`, :148)
@@ -528,12 +526,14 @@ int stage_beams(ndt2d_matcher * m, const double * points_xy, size_t n_points, si
   if (pending_out != nullptr)
   {
     m->beams.swap(m->scratch_beams);
+    ++m->beams_epoch;
     *pending_out = true;
     return NDT2D_OK;
   }
   int rc = ndt2d_set_beams(m->dev, m->scratch_beams.data(), use);
   if (rc != NDT2D_OK) return dev_fail(m, rc, "ndt2d_set_beams");
   m->beams.swap(m->scratch_beams);
+  ++m->beams_epoch;
   m->beams_on_device = true;
   return NDT2D_OK;
 }
@@ -555,25 +555,43 @@ void discard_ahead(ndt2d_matcher * m)
   m->pair_seen = false;
 }
 
-// The host NDT the single-pose path scores against: the one addScans built on the host, or --
-// for a grid built on the device -- its records fetched back once per addScans.
-const HostNdt * host_ndt(ndt2d_matcher * m)
+// The host NDT the single-pose path and the near-tie adjudication score against: the one
+// addScans built on the host, or -- for a grid built on the DEVICE (maps of 32768 points and
+// more) -- its records fetched back once per addScans.  That fetch is the whole dense grid
+// (48 bytes per cell, synchronous) plus a host pool of the same size: worth it for the grids
+// the single-pose path exists for, not for a loop-closure map of a million cells, where it
+// would cost tens of megabytes over PCIe to save a 30 us launch.  for_single_pose: the caller
+// can take the device path instead, so a grid above kHostFetchMaxCells is left on the device;
+// the adjudication of a marked near-tie (rare, and it has no device path) fetches any size.
+// nullptr also when memory runs out -- nothing may throw through the C-ABI.
+constexpr size_t kHostFetchMaxCells = 65536;   // 3 MB of records
+
+const HostNdt * host_ndt(ndt2d_matcher * m, bool for_single_pose)
 {
   if (m->ndt) return m->ndt.get();
   if (m->fetched) return m->fetched.get();
   uint32_t sx = 0, sy = 0;
   double cs = 0.0, ox = 0.0, oy = 0.0;
   if (ndt2d_get_grid(m->dev, nullptr, 0, &sx, &sy, &cs, &ox, &oy) != NDT2D_OK) return nullptr;
-  std::vector<double> cells(static_cast<size_t>(sx) * sy * 6);
-  if (ndt2d_get_grid(m->dev, cells.data(), static_cast<size_t>(sx) * sy, nullptr, nullptr, nullptr, nullptr, nullptr) !=
-      NDT2D_OK)
+  const size_t ncell = static_cast<size_t>(sx) * sy;
+  if (for_single_pose && ncell > kHostFetchMaxCells) return nullptr;
+  try
   {
+    std::vector<double> cells(ncell * 6);
+    if (ndt2d_get_grid(m->dev, cells.data(), ncell, nullptr, nullptr, nullptr, nullptr, nullptr) != NDT2D_OK)
+    {
+      return nullptr;
+    }
+    std::unique_ptr<HostNdt> g(new HostNdt(cs, 0.0, 0.0, ox, oy));
+    g->reset_cells(cs, sx, sy, ox, oy);
+    g->load6(cells.data());
+    m->fetched = std::move(g);
+  }
+  catch (const std::bad_alloc &)
+  {
+    m->fetched.reset();
     return nullptr;
   }
-  std::unique_ptr<HostNdt> g(new HostNdt(cs, 0.0, 0.0, ox, oy));
-  g->reset_cells(cs, sx, sy, ox, oy);
-  g->load6(cells.data());
-  m->fetched = std::move(g);
   return m->fetched.get();
 }
 
@@ -627,18 +645,35 @@ int settle_near_tie(ndt2d_matcher * m, const double * scan_pose_xyt, size_t n_th
   record[1] = std::floor(record[1]);
   ++m->adj_marked;
   if (!m->adjudicate || m->beams.size() != 2 * use || m->cos_th.size() != n_th) return NDT2D_OK;
-  const HostNdt * ndt = host_ndt(m);
+  const HostNdt * ndt = host_ndt(m, false);
   if (ndt == nullptr) return NDT2D_OK;
   constexpr size_t kCap = 256;
-  uint64_t idx[kCap];
+  uint64_t idx[kCap + 1];
   size_t n = 0;
   const int rc = ndt2d_match_near_best(m->dev, 0, n_th, NDT2D_NEAR_TIE_REL, idx, kCap, &n, nullptr);
   if (rc != NDT2D_OK) return dev_fail(m, rc, "ndt2d_match_near_best");
   if (n > kCap) ++m->adj_truncated;
+  size_t listed = std::min(n, kCap);
+  // The device's own winner is always among the rescored: a plateau of more than kCap
+  // candidates is cut to the first kCap in visiting order, and the winner may lie beyond the
+  // cut -- it must then not be replaced by a candidate that neither the device nor the
+  // reference would pick (only by one whose reference-order score is strictly lower).
+  {
+    const uint64_t winner = static_cast<uint64_t>(record[1]);
+    uint64_t * const end = idx + listed;
+    uint64_t * const at = std::lower_bound(idx, end, winner);
+    if (at == end || *at != winner)
+    {
+      const size_t pos = static_cast<size_t>(at - idx);
+      for (size_t k = listed; k > pos; --k) idx[k] = idx[k - 1];
+      idx[pos] = winner;
+      ++listed;
+    }
+  }
   const uint64_t per_th = static_cast<uint64_t>(n_lin) * n_lin;
   double best_s = 0.0;   // `double best_score = 0;` (:83)
   uint64_t best_i = NDT2D_NO_INDEX;
-  for (size_t k = 0; k < std::min(n, kCap); ++k)   // ascending flat index = the reference's visiting order
+  for (size_t k = 0; k < listed; ++k)   // ascending flat index = the reference's visiting order
   {
     const uint64_t ith = idx[k] / per_th, rem = idx[k] % per_th;
     if (ith >= n_th) continue;
@@ -750,7 +785,7 @@ bool multi_search_wanted(const ndt2d_matcher * m, size_t n_th, size_t n_lin, siz
 bool multi_poses_wanted(const ndt2d_matcher * m, size_t n_poses, size_t use)
 {
   return (m->devs.size() > 1 || m->exchange_mode == 2) && n_poses >= m->devs.size() &&
-         static_cast<double>(n_poses) * static_cast<double>(use) >= m->multi_min_units;
+         static_cast<double>(n_poses) * static_cast<double>(use) >= m->multi_min_pose_units;
 }
 
 void note_variant(ndt2d_matcher * m, bool multi, bool rccl)
@@ -797,31 +832,62 @@ void combine_records(const double * rows, const std::vector<size_t> & count, dou
   }
 }
 
+// What one device's thread reports of its part of a dealt call (the message is made by the
+// calling thread afterwards: ndt2d_matcher::err is not the threads' to write).
+struct RankStatus
+{
+  int rc = NDT2D_OK;
+  const char * what = "";
+};
+
+double elapsed_us(std::chrono::steady_clock::time_point t0)
+{
+  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// A dealt call is given up: nothing of it may stay in flight once the caller has the error -- copies
+// out of / into the caller's buffers, searches launched but not fetched.  Every device is waited out.
+void drain_devices(ndt2d_matcher * m)
+{
+  for (ndt2d_handle h : m->devs)
+  {
+    uint64_t launched = 0, fetched = 0;
+    if (ndt2d_match_status(h, &launched, &fetched) == NDT2D_OK && launched > fetched)
+    {
+      ndt2d_match_result res;
+      (void)ndt2d_match_fetch(h, &res);
+    }
+    (void)ndt2d_synchronize(h);
+  }
+}
+
+int first_failure(ndt2d_matcher * m, const std::vector<RankStatus> & st)
+{
+  for (size_t r = 0; r < st.size(); ++r)
+  {
+    if (st[r].rc != NDT2D_OK)
+    {
+      const int rc = dev_fail_at(m, r, st[r].rc, st[r].what);   // (the message, before the devices are touched again)
+      drain_devices(m);
+      return rc;
+    }
+  }
+  return NDT2D_OK;
+}
+
 // matchScan's search dealt to all devices.  The first device has been prepared by the caller
 // (beams + tables); m->beams holds the subsampled beams unless `beams_everywhere` (every device
 // converted the LaserScan itself).  all_scores (host, optional): the whole lattice's scores.
+// Every device's tables, beams and launch go out on its own thread (ndt2d_workers.h).
 int multi_match(ndt2d_matcher * m, const double * scan_pose_xyt, size_t n_th, size_t n_lin, size_t use,
                 bool beams_everywhere, double * all_scores, double * record_out)
 {
   const size_t n = m->devs.size();
+  const auto t_start = std::chrono::steady_clock::now();
   int rc = ensure_multi(m);
   if (rc != NDT2D_OK) return rc;
   bool rccl = false;
   if ((rc = pick_exchange(m, &rccl)) != NDT2D_OK) return rc;
-  for (size_t r = 1; r < n; ++r)
-  {
-    if (beams_everywhere)
-    {
-      rc = ndt2d_set_search(m->devs[r], scan_pose_xyt[0], scan_pose_xyt[1], m->dth.data(), m->cos_th.data(),
-                            m->sin_th.data(), n_th, m->dlin.data(), n_lin);
-    }
-    else
-    {
-      rc = ndt2d_set_search_beams(m->devs[r], m->beams.data(), use, scan_pose_xyt[0], scan_pose_xyt[1], m->dth.data(),
-                                  m->cos_th.data(), m->sin_th.data(), n_th, m->dlin.data(), n_lin);
-    }
-    if (rc != NDT2D_OK) return dev_fail_at(m, r, rc, "ndt2d_set_search_beams");
-  }
   const size_t per_th = n_lin * n_lin;
   std::vector<size_t> count(n, 0);
   for (size_t r = 0; r < n; ++r) count[r] = r < n_th ? (n_th - r + n - 1) / n : 0;
@@ -844,24 +910,44 @@ int multi_match(ndt2d_matcher * m, const double * scan_pose_xyt, size_t n_th, si
       }
     }
   }
-  if (rccl)
-  {
-    for (size_t r = 0; r < n; ++r)
-    {
-      rc = ndt2d_copy_to_device_async(m->devs[r], m->shards[r].d_table, m->pinned + pinned_init_off(n, r),
-                                      n * kRec * sizeof(double));
-      if (rc != NDT2D_OK) return dev_fail_at(m, r, rc, "ndt2d_copy_to_device_async");
-    }
-  }
-  // every device's search goes out before any result is waited for
-  for (size_t r = 0; r < n; ++r)
-  {
-    if (count[r] == 0) continue;
+  // every device's search goes out before any result is waited for, all of them side by side
+  std::vector<RankStatus> st(n);
+  m->fanout_us.assign(n, 0.0);
+  auto deal = [&](size_t r) {
+    RankStatus & s = st[r];
     MatcherShard & sh = m->shards[r];
-    rc = ndt2d_match_launch_strided(m->devs[r], r, n, count[r], all_scores != nullptr ? sh.d_scores : nullptr,
-                                    rccl ? sh.d_table + r * kRec : nullptr);
-    if (rc != NDT2D_OK) return dev_fail_at(m, r, rc, "ndt2d_match_launch_strided");
-  }
+    if (r > 0)
+    {
+      s.what = "ndt2d_set_search_beams";
+      if (beams_everywhere)
+      {
+        s.rc = ndt2d_set_search(m->devs[r], scan_pose_xyt[0], scan_pose_xyt[1], m->dth.data(), m->cos_th.data(),
+                                m->sin_th.data(), n_th, m->dlin.data(), n_lin);
+      }
+      else
+      {
+        s.rc = ndt2d_set_search_beams(m->devs[r], m->beams.data(), use, scan_pose_xyt[0], scan_pose_xyt[1], m->dth.data(),
+                                      m->cos_th.data(), m->sin_th.data(), n_th, m->dlin.data(), n_lin);
+      }
+      sh.beams_epoch = ~0ull;   // (the device's beams now live in the search's upload)
+      if (s.rc != NDT2D_OK) return;
+    }
+    if (rccl)
+    {
+      s.what = "ndt2d_copy_to_device_async";
+      s.rc = ndt2d_copy_to_device_async(m->devs[r], sh.d_table, m->pinned + pinned_init_off(n, r), n * kRec * sizeof(double));
+      if (s.rc != NDT2D_OK) return;
+    }
+    if (count[r] > 0)
+    {
+      s.what = "ndt2d_match_launch_strided";
+      s.rc = ndt2d_match_launch_strided(m->devs[r], r, n, count[r], all_scores != nullptr ? sh.d_scores : nullptr,
+                                        rccl ? sh.d_table + r * kRec : nullptr);
+    }
+    m->fanout_us[r] = elapsed_us(t_start);
+  };
+  m->workers->run(deal);
+  if ((rc = first_failure(m, st)) != NDT2D_OK) return rc;
   double * rows = m->pinned + pinned_rows_off(n);
   if (rccl)
   {
@@ -875,10 +961,19 @@ int multi_match(ndt2d_matcher * m, const double * scan_pose_xyt, size_t n_th, si
     }
     std::string why;
     rc = ndt2d::exchange_all_reduce(m->exchange, tables.data(), n * kRec, streams.data(), &why);
-    if (rc != NDT2D_OK) return mfail(m, rc, why);
+    if (rc != NDT2D_OK)
+    {
+      drain_devices(m);
+      return mfail(m, rc, why);
+    }
     rc = ndt2d_copy_to_host_async(m->dev, rows, m->shards[0].d_table, n * kRec * sizeof(double));
     if (rc == NDT2D_OK) rc = ndt2d_synchronize(m->dev);
-    if (rc != NDT2D_OK) return dev_fail_at(m, 0, rc, "ndt2d_copy_to_host_async");
+    if (rc != NDT2D_OK)
+    {
+      const int frc = dev_fail_at(m, 0, rc, "ndt2d_copy_to_host_async");
+      drain_devices(m);
+      return frc;
+    }
   }
   for (size_t r = 0; r < n; ++r)
   {
@@ -888,7 +983,12 @@ int multi_match(ndt2d_matcher * m, const double * scan_pose_xyt, size_t n_th, si
     // and the fetch only settles the context's state.)
     ndt2d_match_result res;
     rc = ndt2d_match_fetch(m->devs[r], &res);
-    if (rc != NDT2D_OK) return dev_fail_at(m, r, rc, "ndt2d_match_fetch");
+    if (rc != NDT2D_OK)
+    {
+      const int frc = dev_fail_at(m, r, rc, "ndt2d_match_fetch");
+      drain_devices(m);
+      return frc;
+    }
     if (!rccl)
     {
       double * rec = rows + r * kRec;
@@ -906,7 +1006,12 @@ int multi_match(ndt2d_matcher * m, const double * scan_pose_xyt, size_t n_th, si
       if (count[r] == 0) continue;
       tmp.resize(count[r] * per_th);
       rc = ndt2d_copy_to_host(m->devs[r], tmp.data(), m->shards[r].d_scores, tmp.size() * sizeof(double));
-      if (rc != NDT2D_OK) return dev_fail_at(m, r, rc, "ndt2d_copy_to_host");
+      if (rc != NDT2D_OK)
+      {
+        const int frc = dev_fail_at(m, r, rc, "ndt2d_copy_to_host");
+        drain_devices(m);
+        return frc;
+      }
       for (size_t k = 0; k < count[r]; ++k)
       {
         std::memcpy(all_scores + (r + k * n) * per_th, tmp.data() + k * per_th, per_th * sizeof(double));
@@ -952,10 +1057,19 @@ void shard_range(size_t n, size_t r, size_t world, size_t * begin, size_t * end)
 // nullptr: scores only.  Otherwise the whole of measure: scores_out receives the normalised
 // weights and stats_out NDT2D_PF_RESULT_DOUBLES values as ndt2d_pf_finalize_launch defines them
 // ([7] summed over the devices in device order).
+//
+// Every device's share runs on its own thread from the upload to the weights' way back.  Host
+// exchange: the device's eight moment sums arrive in its host-coherent block behind a flag
+// (ndt2d_pose_sums_fetch), the threads meet (DeviceWorkers::barrier), each adds the rows in device
+// order -- the "total particle weight" of src/particle_filter.cpp:166-174 -- and launches
+// updateStatistics with the totals as kernel arguments: no copy and no stream synchronisation
+// between the two halves.  RCCL exchange: the shares are dealt the same way, the two
+// all-reduces are issued by the calling thread.
 int multi_score_poses(ndt2d_matcher * m, const double * poses_xyt, size_t n_poses, size_t use, double * scores_out,
                       double * stats_out)
 {
   const size_t n = m->devs.size();
+  const auto t_start = std::chrono::steady_clock::now();
   int rc = ensure_multi(m);
   if (rc != NDT2D_OK) return rc;
   bool rccl = false;
@@ -965,126 +1079,152 @@ int multi_score_poses(ndt2d_matcher * m, const double * poses_xyt, size_t n_pose
   {
     shard_range(n_poses, r, n, &begin[r], &end[r]);
     if ((rc = ensure_shard_poses(m, r, end[r] - begin[r])) != NDT2D_OK) return rc;
-    if (r > 0)
-    {
-      rc = ndt2d_set_beams(m->devs[r], m->beams.data(), use);
-      if (rc != NDT2D_OK) return dev_fail_at(m, r, rc, "ndt2d_set_beams");
-    }
   }
   const double * zeros = m->pinned + pinned_zero_off(n);
   double * rows = m->pinned + pinned_rows_off(n);
+  std::vector<RankStatus> st(n);
+  m->fanout_us.assign(n, 0.0);
+  std::atomic<bool> give_up{false};
+  // (host exchange: the devices' rows of sums and of results, written by their threads)
+  std::vector<double> sums(n * kStats, 0.0), results(n * kStats, 0.0);
+  const bool host_measure = stats_out != nullptr && !rccl;
+
+  auto share = [&](size_t r) {
+    RankStatus & s = st[r];
+    MatcherShard & sh = m->shards[r];
+    const size_t nr = end[r] - begin[r];
+    auto fail = [&](const char * what, bool sync) {
+      s.what = what;
+      give_up.store(true, std::memory_order_release);
+      if (sync) (void)ndt2d_synchronize(m->devs[r]);   // nothing of this share stays in flight
+    };
+    if (r > 0 && sh.beams_epoch != m->beams_epoch)
+    {
+      if ((s.rc = ndt2d_set_beams(m->devs[r], m->beams.data(), use)) != NDT2D_OK) return fail("ndt2d_set_beams", true);
+      sh.beams_epoch = m->beams_epoch;
+    }
+    s.rc = ndt2d_copy_to_device_async(m->devs[r], sh.d_poses, poses_xyt + 3 * begin[r], 3 * nr * sizeof(double));
+    if (s.rc == NDT2D_OK && rccl)
+    {
+      s.rc = ndt2d_copy_to_device_async(m->devs[r], sh.d_table, zeros, n * kStats * sizeof(double));
+    }
+    if (s.rc != NDT2D_OK) return fail("ndt2d_copy_to_device_async", true);
+    if (!host_measure)
+    {
+      // scores only, or the first half of the RCCL form (the moment sums into the device's row)
+      double * d_stats = stats_out == nullptr ? nullptr : sh.d_table + r * kStats;
+      s.rc = ndt2d_score_poses_launch(m->devs[r], sh.d_poses, nr, sh.d_weights, d_stats);
+      m->fanout_us[r] = elapsed_us(t_start);
+      if (s.rc != NDT2D_OK) return fail("ndt2d_score_poses_launch", true);
+      if (stats_out == nullptr)
+      {
+        s.rc = ndt2d_copy_to_host_async(m->devs[r], scores_out + begin[r], sh.d_weights, nr * sizeof(double));
+        if (s.rc == NDT2D_OK) s.rc = ndt2d_synchronize(m->devs[r]);
+        if (s.rc != NDT2D_OK) return fail("ndt2d_copy_to_host_async", true);
+      }
+      return;
+    }
+    s.rc = ndt2d_pose_sums_launch(m->devs[r], sh.d_poses, nr, sh.d_weights);
+    m->fanout_us[r] = elapsed_us(t_start);
+    if (s.rc != NDT2D_OK) return fail("ndt2d_pose_sums_launch", true);
+    if ((s.rc = ndt2d_pose_sums_fetch(m->devs[r], sums.data() + r * kStats)) != NDT2D_OK) return fail("ndt2d_pose_sums_fetch", true);
+    if (!m->workers->barrier(give_up))
+    {
+      // another device's share failed (its status says how) or never came: this one is abandoned
+      if (!give_up.load()) { s.rc = NDT2D_ERR_HIP; fail("the devices' moment sums did not meet", false); }
+      (void)ndt2d_synchronize(m->devs[r]);
+      return;
+    }
+    // the rows summed in device order: the same bits on every thread
+    double totals[kStats];
+    for (size_t k = 0; k < kStats; ++k)
+    {
+      double acc = sums[k];
+      for (size_t q = 1; q < n; ++q) acc += sums[q * kStats + k];
+      totals[k] = acc;
+    }
+    // updateStatistics with the total sums: normalised weights, the mean and covariance (the same
+    // on all devices), and the device's part of the theta variance (:213-217)
+    s.rc = ndt2d_pf_finalize_totals_launch(m->devs[r], sh.d_poses, nr, sh.d_weights, totals);
+    if (s.rc != NDT2D_OK) return fail("ndt2d_pf_finalize_totals_launch", true);
+    s.rc = ndt2d_copy_to_host_async(m->devs[r], scores_out + begin[r], sh.d_weights, nr * sizeof(double));
+    if (s.rc == NDT2D_OK) s.rc = ndt2d_synchronize(m->devs[r]);
+    if (s.rc != NDT2D_OK) return fail("ndt2d_copy_to_host_async", true);
+    if ((s.rc = ndt2d_pf_result_read(m->devs[r], results.data() + r * kStats)) != NDT2D_OK) return fail("ndt2d_pf_result_read", false);
+  };
+  m->workers->run(share);
+  if ((rc = first_failure(m, st)) != NDT2D_OK) return rc;
+  if (host_measure)
+  {
+    for (size_t k = 0; k < NDT2D_PF_RESULT_DOUBLES; ++k) stats_out[k] = results[k];
+    for (size_t r = 1; r < n; ++r) stats_out[7] += results[r * kStats + 7];
+    note_variant(m, true, false);
+    return NDT2D_OK;
+  }
+  if (stats_out == nullptr)
+  {
+    note_variant(m, true, false);
+    return NDT2D_OK;
+  }
+
+  // RCCL exchange.  On any failure from here on every device is waited out before the error returns.
+  auto give_in = [&](int code, const std::string & msg) {
+    const int frc = mfail(m, code, msg);
+    drain_devices(m);
+    return frc;
+  };
+  std::vector<double *> tables(n);
+  std::vector<void *> streams(n);
+  for (size_t r = 0; r < n; ++r)
+  {
+    tables[r] = m->shards[r].d_table;
+    streams[r] = ndt2d_get_stream(m->devs[r]);
+  }
+  std::string why;
+  // the "total particle weight" all-reduce (src/particle_filter.cpp:166-174) with the other
+  // seven moment sums: [n, 8], every device its own row; then the rows summed in device order
+  rc = ndt2d::exchange_all_reduce(m->exchange, tables.data(), n * kStats, streams.data(), &why);
+  if (rc != NDT2D_OK) return give_in(rc, why);
+  for (size_t r = 0; r < n; ++r)
+  {
+    rc = ndt2d::sum_rows_launch(m->device_ids[r], tables[r], static_cast<int>(n), static_cast<int>(kStats),
+                                m->shards[r].d_sum, streams[r], &why);
+    if (rc != NDT2D_OK) return give_in(rc, why);
+    // (the table serves the second exchange: cleared behind the summation)
+    rc = ndt2d_copy_to_device_async(m->devs[r], tables[r], zeros, n * kStats * sizeof(double));
+    if (rc != NDT2D_OK) return give_in(rc, std::string("ndt2d_copy_to_device_async: ") + ndt2d_last_error(m->devs[r]));
+  }
   for (size_t r = 0; r < n; ++r)
   {
     MatcherShard & sh = m->shards[r];
-    const size_t nr = end[r] - begin[r];
-    rc = ndt2d_copy_to_device_async(m->devs[r], sh.d_poses, poses_xyt + 3 * begin[r], 3 * nr * sizeof(double));
-    if (rc == NDT2D_OK && rccl)
-    {
-      rc = ndt2d_copy_to_device_async(m->devs[r], sh.d_table, zeros, n * kStats * sizeof(double));
-    }
-    if (rc != NDT2D_OK) return dev_fail_at(m, r, rc, "ndt2d_copy_to_device_async");
-    double * d_stats = stats_out == nullptr ? nullptr : (rccl ? sh.d_table + r * kStats : sh.d_sum + kStats);
-    rc = ndt2d_score_poses_launch(m->devs[r], sh.d_poses, nr, sh.d_weights, d_stats);
-    if (rc != NDT2D_OK) return dev_fail_at(m, r, rc, "ndt2d_score_poses_launch");
+    rc = ndt2d_pf_finalize_launch(m->devs[r], sh.d_poses, end[r] - begin[r], sh.d_weights, sh.d_sum, sh.d_table + r * kStats);
+    if (rc != NDT2D_OK) return give_in(rc, std::string("ndt2d_pf_finalize_launch: ") + ndt2d_last_error(m->devs[r]));
   }
-  if (stats_out != nullptr)
-  {
-    std::vector<double *> tables(n);
-    std::vector<void *> streams(n);
-    for (size_t r = 0; r < n; ++r)
-    {
-      tables[r] = m->shards[r].d_table;
-      streams[r] = ndt2d_get_stream(m->devs[r]);
-    }
-    std::string why;
-    if (rccl)
-    {
-      // the "total particle weight" all-reduce (src/particle_filter.cpp:166-174) with the other
-      // seven moment sums: [n, 8], every device its own row; then the rows summed in device order
-      rc = ndt2d::exchange_all_reduce(m->exchange, tables.data(), n * kStats, streams.data(), &why);
-      if (rc != NDT2D_OK) return mfail(m, rc, why);
-      for (size_t r = 0; r < n; ++r)
-      {
-        rc = ndt2d::sum_rows_launch(m->device_ids[r], tables[r], static_cast<int>(n), static_cast<int>(kStats),
-                                    m->shards[r].d_sum, streams[r], &why);
-        if (rc != NDT2D_OK) return mfail(m, rc, why);
-        // (the table serves the second exchange: cleared behind the summation)
-        rc = ndt2d_copy_to_device_async(m->devs[r], tables[r], zeros, n * kStats * sizeof(double));
-        if (rc != NDT2D_OK) return dev_fail_at(m, r, rc, "ndt2d_copy_to_device_async");
-      }
-    }
-    else
-    {
-      for (size_t r = 0; r < n; ++r)
-      {
-        rc = ndt2d_copy_to_host_async(m->devs[r], rows + r * kStats, m->shards[r].d_sum + kStats, kStats * sizeof(double));
-        if (rc != NDT2D_OK) return dev_fail_at(m, r, rc, "ndt2d_copy_to_host_async");
-      }
-      for (size_t r = 0; r < n; ++r)
-      {
-        rc = ndt2d_synchronize(m->devs[r]);
-        if (rc != NDT2D_OK) return dev_fail_at(m, r, rc, "ndt2d_synchronize");
-      }
-      double * sum = m->pinned + pinned_sum_off(n);
-      for (size_t k = 0; k < kStats; ++k)
-      {
-        double acc = rows[k];
-        for (size_t r = 1; r < n; ++r) acc += rows[r * kStats + k];
-        sum[k] = acc;
-      }
-      for (size_t r = 0; r < n; ++r)
-      {
-        rc = ndt2d_copy_to_device_async(m->devs[r], m->shards[r].d_sum, sum, kStats * sizeof(double));
-        if (rc != NDT2D_OK) return dev_fail_at(m, r, rc, "ndt2d_copy_to_device_async");
-      }
-    }
-    // updateStatistics on every device with the total sums: normalised weights, the mean and
-    // covariance (the same on all), and the device's part of the theta variance (:213-217)
-    for (size_t r = 0; r < n; ++r)
-    {
-      MatcherShard & sh = m->shards[r];
-      double * d_out = rccl ? sh.d_table + r * kStats : sh.d_sum + kStats;
-      rc = ndt2d_pf_finalize_launch(m->devs[r], sh.d_poses, end[r] - begin[r], sh.d_weights, sh.d_sum, d_out);
-      if (rc != NDT2D_OK) return dev_fail_at(m, r, rc, "ndt2d_pf_finalize_launch");
-    }
-    if (rccl)
-    {
-      rc = ndt2d::exchange_all_reduce(m->exchange, tables.data(), n * kStats, streams.data(), &why);
-      if (rc != NDT2D_OK) return mfail(m, rc, why);
-      rc = ndt2d_copy_to_host_async(m->dev, rows, tables[0], n * kStats * sizeof(double));
-      if (rc != NDT2D_OK) return dev_fail_at(m, 0, rc, "ndt2d_copy_to_host_async");
-    }
-    else
-    {
-      for (size_t r = 0; r < n; ++r)
-      {
-        rc = ndt2d_copy_to_host_async(m->devs[r], rows + r * kStats, m->shards[r].d_sum + kStats, kStats * sizeof(double));
-        if (rc != NDT2D_OK) return dev_fail_at(m, r, rc, "ndt2d_copy_to_host_async");
-      }
-    }
-  }
-  for (size_t r = 0; r < n; ++r)
-  {
-    rc = ndt2d_copy_to_host_async(m->devs[r], scores_out + begin[r], m->shards[r].d_weights,
-                                  (end[r] - begin[r]) * sizeof(double));
-    if (rc != NDT2D_OK) return dev_fail_at(m, r, rc, "ndt2d_copy_to_host_async");
-  }
-  for (size_t r = 0; r < n; ++r)
-  {
-    rc = ndt2d_synchronize(m->devs[r]);
-    if (rc != NDT2D_OK) return dev_fail_at(m, r, rc, "ndt2d_synchronize");
-  }
-  if (stats_out != nullptr)
-  {
-    for (size_t k = 0; k < NDT2D_PF_RESULT_DOUBLES; ++k) stats_out[k] = rows[k];
-    for (size_t r = 1; r < n; ++r) stats_out[7] += rows[r * kStats + 7];
-  }
-  note_variant(m, true, rccl);
+  rc = ndt2d::exchange_all_reduce(m->exchange, tables.data(), n * kStats, streams.data(), &why);
+  if (rc != NDT2D_OK) return give_in(rc, why);
+  rc = ndt2d_copy_to_host_async(m->dev, rows, tables[0], n * kStats * sizeof(double));
+  if (rc != NDT2D_OK) return give_in(rc, std::string("ndt2d_copy_to_host_async: ") + ndt2d_last_error(m->dev));
+  // the weights' way back, every device on its own thread again
+  for (RankStatus & s : st) s = RankStatus();
+  auto back = [&](size_t r) {
+    RankStatus & s = st[r];
+    s.what = "ndt2d_copy_to_host_async";
+    s.rc = ndt2d_copy_to_host_async(m->devs[r], scores_out + begin[r], m->shards[r].d_weights,
+                                    (end[r] - begin[r]) * sizeof(double));
+    const int src = ndt2d_synchronize(m->devs[r]);
+    if (s.rc == NDT2D_OK) s.rc = src;
+  };
+  m->workers->run(back);
+  if ((rc = first_failure(m, st)) != NDT2D_OK) return rc;
+  for (size_t k = 0; k < NDT2D_PF_RESULT_DOUBLES; ++k) stats_out[k] = rows[k];
+  for (size_t r = 1; r < n; ++r) stats_out[7] += rows[r * kStats + 7];
+  note_variant(m, true, true);
   return NDT2D_OK;
 }
 
 void destroy_matcher(ndt2d_matcher * m)
 {
+  m->workers.reset();   // (the threads end before the contexts they drive)
   // (a matcher whose creation failed half-way has contexts but no shard records yet)
   for (size_t r = 0; r < m->devs.size() && r < m->shards.size(); ++r)
   {
@@ -1127,6 +1267,15 @@ int ndt2d_matcher_create_multi(ndt2d_matcher ** out, const int * device_ids, int
   }
   m->shards.resize(m->devs.size());
   m->dev = m->devs[0];
+  try
+  {
+    m->workers.reset(new ndt2d::DeviceWorkers(m->devs.size()));
+  }
+  catch (...)
+  {
+    destroy_matcher(m);
+    return NDT2D_ERR_INVALID;   // (no thread could be started)
+  }
   m->dth = search_offsets(m->angular_size, m->angular_res);
   m->dlin = search_offsets(m->linear_size, m->linear_res);
   *out = m;
@@ -1165,8 +1314,30 @@ int ndt2d_matcher_set_exchange(ndt2d_matcher * m, const char * mode)
 
 int ndt2d_matcher_set_multi_min_units(ndt2d_matcher * m, double units)
 {
-  if (m == nullptr || !(units >= 0.0)) return NDT2D_ERR_INVALID;
-  m->multi_min_units = units;
+  return ndt2d_matcher_set_multi_thresholds(m, units, units);
+}
+
+int ndt2d_matcher_set_multi_thresholds(ndt2d_matcher * m, double min_search_units, double min_pose_units)
+{
+  if (m == nullptr || !(min_search_units >= 0.0) || !(min_pose_units >= 0.0)) return NDT2D_ERR_INVALID;
+  m->multi_min_units = min_search_units;
+  m->multi_min_pose_units = min_pose_units;
+  return NDT2D_OK;
+}
+
+int ndt2d_matcher_get_multi_thresholds(ndt2d_matcher * m, double * min_search_units, double * min_pose_units)
+{
+  if (m == nullptr) return NDT2D_ERR_INVALID;
+  if (min_search_units != nullptr) *min_search_units = m->multi_min_units;
+  if (min_pose_units != nullptr) *min_pose_units = m->multi_min_pose_units;
+  return NDT2D_OK;
+}
+
+int ndt2d_matcher_last_fanout_us(ndt2d_matcher * m, double * out_us, size_t capacity, size_t * n_out)
+{
+  if (m == nullptr || (capacity > 0 && out_us == nullptr)) return NDT2D_ERR_INVALID;
+  if (n_out != nullptr) *n_out = m->fanout_us.size();
+  for (size_t r = 0; r < m->fanout_us.size() && r < capacity; ++r) out_us[r] = m->fanout_us[r];
   return NDT2D_OK;
 }
 
@@ -1258,7 +1429,7 @@ int ndt2d_matcher_add_scans(ndt2d_matcher * m, const double * poses_xyt,
   }
   if (m->ndt) m->spare = std::move(m->ndt);
   m->ndt = build_ndt(m->resolution, m->range_max, poses_xyt, points_xy, offsets, n_scans,
-                     std::move(m->spare));
+                     std::move(m->spare), m->eigen_form);
   const size_t ncell = m->ndt->ncell();
   if (ncell == 0 || m->ndt->size_x() > 0xffffffffull || m->ndt->size_y() > 0xffffffffull)
   {
@@ -1293,6 +1464,18 @@ int ndt2d_matcher_add_scans(ndt2d_matcher * m, const double * poses_xyt,
     }
   }
   m->have_ndt = true;
+  return NDT2D_OK;
+}
+
+int ndt2d_matcher_set_eigenvalue_form(ndt2d_matcher * m, const char * form)
+{
+  if (m == nullptr || form == nullptr) return NDT2D_ERR_INVALID;
+  for (ndt2d_handle h : m->devs)
+  {
+    const int rc = ndt2d_set_eigenvalue_form(h, form);
+    if (rc != NDT2D_OK) return mfail(m, rc, "set_eigenvalue_form: unknown form (eigen, closed)");
+  }
+  m->eigen_form = std::strcmp(form, "closed") == 0 ? ndt2d::kEigenFormClosed : ndt2d::kEigenFormSchur;
   return NDT2D_OK;
 }
 
@@ -1345,6 +1528,7 @@ static int prepare_search_impl(ndt2d_matcher * m, const double * scan_pose_xyt,
   if (!same)
   {
     m->beams.swap(m->scratch_beams);
+    ++m->beams_epoch;
     m->beams_on_device = false;
   }
   return prepare_tables(m, scan_pose_xyt, use, same ? nullptr : m->beams.data(), same, n_th_out,
@@ -1565,6 +1749,7 @@ int ndt2d_matcher_match_laser_scan(ndt2d_matcher * m, const double * scan_pose_x
   if (rc != NDT2D_OK) return dev_fail(m, rc, "ndt2d_set_beams_from_ranges");
   if (n_points_out != nullptr) *n_points_out = n_points;
   m->beams.clear();
+  ++m->beams_epoch;
   m->beams_on_device = false;   // the device holds beams the host has no copy of
   m->n_use = use;
   size_t n_th = 0, n_lin = 0;
@@ -1677,7 +1862,7 @@ int ndt2d_matcher_score_points(ndt2d_matcher * m, const double * points_xy, size
     // NDT, in the reference's order ("the unchanged node + unchanged ParticleFilter
     // keep working via per-pose scorePoints").  Nothing on the device is touched: a search
     // launched ahead by scoreScan stays pending.
-    if (const HostNdt * ndt = host_ndt(m))
+    if (const HostNdt * ndt = host_ndt(m, true))
     {
       *score_out = host_score_points(*ndt, points_xy, n_points, m->laser_max_beams, pose_xyt);
       return NDT2D_OK;
@@ -1699,7 +1884,7 @@ int ndt2d_matcher_score_scan(ndt2d_matcher * m, const double * scan_pose_xyt,
   if (m->single_pose_host && m->have_ndt && n_points > 0 && points_xy != nullptr && m->laser_max_beams > 0 &&
       std::min(m->laser_max_beams, n_points) <= m->single_pose_max_beams)
   {
-    if (const HostNdt * ndt = host_ndt(m))
+    if (const HostNdt * ndt = host_ndt(m, true))
     {
       // The host scores the pose (see ndt2d_matcher_score_points) -- and when the matchScan of
       // this scan is coming (`ahead`), its search is launched first and runs meanwhile.

@@ -411,8 +411,13 @@ __global__ void __launch_bounds__(THREADS) score_poses_kernel(const PosesArgs a)
   }
 }
 
+// host_out (optional, host-coherent memory as the device addresses it): the eight sums are
+// stored there as well, system scope, followed by `seq` at host_out[kPoseSumsFlagOffset] -- a
+// host thread spins on it instead of synchronising the stream (the sharded particle path:
+// every device's sums meet on the host between its two launches).
 __global__ void __launch_bounds__(256) poses_reduce_kernel(const double * partials,
-                                                           uint32_t n_blocks, double * stats)
+                                                           uint32_t n_blocks, double * stats,
+                                                           double * host_out, unsigned long long seq)
 {
   __shared__ double sh[256 * 8];
   const int t = threadIdx.x;
@@ -437,6 +442,16 @@ __global__ void __launch_bounds__(256) poses_reduce_kernel(const double * partia
     __syncthreads();
   }
   if (t < 8) stats[t] = sh[t];
+  if (host_out != nullptr)
+  {
+    // (the eight stores and the flag come from ONE lane, in program order, each waited for)
+    if (t == 0)
+    {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) store_host(host_out + k, sh[k]);
+      raise_host_flag(host_out + kPoseSumsFlagOffset, seq);
+    }
+  }
 }
 
 constexpr uint32_t kMaxMatchBlocks = 512;
@@ -804,13 +819,18 @@ namespace
 //   stats = {sum w, sum w x, sum w y, sum w cos, sum w sin, sum w xx, sum w xy, sum w yy}:
 // every weight is normalised in place (:171-174) and the weighted squared angular
 // distance to the circular mean (:213-217) is reduced per block.
+// totals.by_value: the moment sums arrive as kernel arguments (the sharded particle path sums
+// the devices' rows on the host and launches with the totals -- no upload) instead of `stats`.
 __global__ void __launch_bounds__(256) pf_finalize_kernel(const double * poses_xyt, uint64_t n,
                                                           double * weights, const double * stats,
-                                                          double * partials)
+                                                          const PoseTotals totals, double * partials)
 {
   __shared__ double sh[4];
-  const double sum_w = stats[0];
-  const double mean_th = atan2(stats[4] / sum_w, stats[3] / sum_w);
+  // (read member by member: a pointer to the argument would put the struct in scratch memory)
+  const double sum_w = totals.by_value ? totals.v[0] : stats[0];
+  const double sum_c = totals.by_value ? totals.v[3] : stats[3];
+  const double sum_s = totals.by_value ? totals.v[4] : stats[4];
+  const double mean_th = atan2(sum_s / sum_w, sum_c / sum_w);
   double acc = 0.0;
   for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x; i < n;
        i += static_cast<uint64_t>(gridDim.x) * 256)
@@ -827,9 +847,12 @@ __global__ void __launch_bounds__(256) pf_finalize_kernel(const double * poses_x
 }
 
 // out = {sum w, mean x, mean y, mean theta, cov xx, cov xy, cov yy, theta variance increment}
+// host_out (optional): the eight results also go to host-coherent memory (system-scope stores;
+// the caller synchronises the stream behind its weight copy, so no flag follows).
 __global__ void __launch_bounds__(256) pf_finalize_reduce_kernel(const double * partials,
                                                                  uint32_t n_blocks,
-                                                                 const double * stats, double * out)
+                                                                 const double * stats, const PoseTotals totals,
+                                                                 double * out, double * host_out)
 {
   __shared__ double sh[256];
   double v = 0.0;
@@ -843,16 +866,25 @@ __global__ void __launch_bounds__(256) pf_finalize_reduce_kernel(const double * 
   }
   if (threadIdx.x == 0)
   {
-    const double sum_w = stats[0];
-    const double mean_x = stats[1] / sum_w, mean_y = stats[2] / sum_w;
+    double st[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) st[k] = totals.by_value ? totals.v[k] : stats[k];
+    const double sum_w = st[0];
+    const double mean_x = st[1] / sum_w, mean_y = st[2] / sum_w;
     out[0] = sum_w;
     out[1] = mean_x;
     out[2] = mean_y;
-    out[3] = atan2(stats[4] / sum_w, stats[3] / sum_w);
-    out[4] = stats[5] / sum_w - mean_x * mean_x;
-    out[5] = stats[6] / sum_w - mean_x * mean_y;
-    out[6] = stats[7] / sum_w - mean_y * mean_y;
+    out[3] = atan2(st[4] / sum_w, st[3] / sum_w);
+    out[4] = st[5] / sum_w - mean_x * mean_x;
+    out[5] = st[6] / sum_w - mean_x * mean_y;
+    out[6] = st[7] / sum_w - mean_y * mean_y;
     out[7] = sh[0];
+    if (host_out != nullptr)
+    {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) store_host(host_out + k, out[k]);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
   }
 }
 
@@ -870,18 +902,24 @@ hipError_t launch_collect_near(const double * scores, uint64_t n, uint64_t hi, c
 }
 
 hipError_t launch_pf_finalize(const double * poses_xyt, uint64_t n_poses, double * weights,
-                              const double * stats, double * workspace, double * out,
-                              hipStream_t stream)
+                              const double * stats, const double * totals_by_value, double * workspace,
+                              double * out, double * host_out, hipStream_t stream)
 {
-  if (n_poses == 0) return hipErrorInvalidValue;
+  if (n_poses == 0 || (stats == nullptr && totals_by_value == nullptr)) return hipErrorInvalidValue;
+  PoseTotals totals{};
+  if (totals_by_value != nullptr)
+  {
+    for (int k = 0; k < 8; ++k) totals.v[k] = totals_by_value[k];
+    totals.by_value = 1;
+  }
   uint64_t need = (n_poses + 255) / 256;
   const uint32_t blocks = static_cast<uint32_t>(need < kMaxPosesBlocks ? need : kMaxPosesBlocks);
   hipLaunchKernelGGL(pf_finalize_kernel, dim3(blocks), dim3(256), 0, stream, poses_xyt, n_poses,
-                     weights, stats, workspace);
+                     weights, stats, totals, workspace);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(pf_finalize_reduce_kernel, dim3(1), dim3(256), 0, stream, workspace, blocks,
-                     stats, out);
+                     stats, totals, out, host_out);
   return hipGetLastError();
 }
 
@@ -915,7 +953,7 @@ size_t poses_lds_per_block() { return device_limits().lds_per_block; }
 
 hipError_t launch_score_poses(const PosesArgs & args_in, double * workspace, double * stats_out,
                               int force_variant, hipStream_t stream, hipEvent_t ev_main_done,
-                              LaunchInfo * info)
+                              LaunchInfo * info, double * host_sums, unsigned long long host_seq)
 {
   PosesArgs args = args_in;
   if (args.n_beams == 0 || args.n_poses == 0) return hipErrorInvalidValue;
@@ -970,7 +1008,7 @@ hipError_t launch_score_poses(const PosesArgs & args_in, double * workspace, dou
   if (stats_out != nullptr)
   {
     hipLaunchKernelGGL(poses_reduce_kernel, dim3(1), dim3(256), 0, stream, workspace, blocks,
-                       stats_out);
+                       stats_out, host_sums, host_seq);
     e = hipGetLastError();
     n_kernels = 2;
   }

@@ -121,19 +121,26 @@ __device__ __forceinline__ void small_final_reduction(const MatchArgs & a, const
   double acc[10];
 #pragma unroll
   for (int k = 0; k < 10; ++k) acc[k] = 0.0;
+  bool gave_up = false;
   for (uint32_t r = threadIdx.x; r < n_records; r += n_threads)
   {
     // Forward progress: this block is the launch's LAST (index search_blocks), and workgroups are
     // dispatched in index order on this hardware, so every producer is resident or done before
     // the first poll -- an assumption of the design (HIP does not promise it; kSmallMaxItems keeps
     // the launch far below the chip's resident-block capacity).  Should it ever fail, the poll
-    // gives up after ~1 s and traps: the host's wait then returns NDT2D_ERR_HIP instead of hanging.
+    // gives up after ~1 s: the block then publishes "gave up" instead of a record (below) and the
+    // host's wait returns NDT2D_ERR_HIP for this call -- no trap, the context stays usable.
     uint32_t polls = 0;
     while (__hip_atomic_load(fin.done + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != fin.seq)
     {
       __builtin_amdgcn_s_sleep(2);
-      if (++polls > (1u << 24)) __builtin_trap();
+      if (++polls > kDonePollLimit)
+      {
+        gave_up = true;
+        break;
+      }
     }
+    if (gave_up) break;
     // the record's words are read only after its `done` word has been seen (acquire)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     const double * p = a.partials + static_cast<size_t>(r) * kRecord;
@@ -143,6 +150,37 @@ __device__ __forceinline__ void small_final_reduction(const MatchArgs & a, const
     merge_best(v[0], v[1], bs, bi);
 #pragma unroll
     for (int k = 0; k < 10; ++k) acc[k] += v[2 + k];
+  }
+  // did any thread give up?  (Not __syncthreads_or(): the device library's workgroup reduction
+  // brings static LDS of its own, and this kernel's map must start at LDS offset 0.)  One word
+  // per wave behind the records' scratch, written by every wave, read by all after the barrier.
+  {
+    uint32_t * wave_gave_up = reinterpret_cast<uint32_t *>(scratch + static_cast<size_t>(kSmallMaxWaves) * kRecord);
+    const bool wave_flag = __builtin_amdgcn_ballot_w64(gave_up) != 0ull;
+    if (lane == 0) wave_gave_up[wave] = wave_flag ? 1u : 0u;
+    __syncthreads();
+    bool any = false;
+    for (uint32_t w = 0; w < n_waves; ++w) any |= wave_gave_up[w] != 0u;
+    gave_up = any;
+    __syncthreads();   // (the words are read before the records' scratch is written below)
+  }
+  if (gave_up)
+  {
+    // a record never came: no result -- NaN score, no index -- and the flag says why
+    if (threadIdx.x < kRecord)
+    {
+      const double val = threadIdx.x == 1 ? -1.0 : __longlong_as_double(0x7ff8000000000000ll);
+      fin.record_out[threadIdx.x] = val;
+      if (fin.record_out2 != nullptr) fin.record_out2[threadIdx.x] = val;
+      if (fin.host_out != nullptr) store_host(fin.host_out + threadIdx.x, val);
+    }
+    if (fin.host_out != nullptr && wave == 0)
+    {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      if (lane == 0) raise_host_flag(fin.host_out + kHostFlagSlot, fin.seq | kHostFlagGaveUp);
+    }
+    return;
   }
   wave_best_to_last_lane(bs, bi);
 #pragma unroll
@@ -498,7 +536,7 @@ match_small_kernel(const MatchArgs a,
     }
     // the record is in L2 (its stores acknowledged) before its `done` word says so
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == kWave - 1)
+    if (lane == kWave - 1 && !NDT2D_TEST_DROPS_DONE(static_cast<size_t>(t_local) * plan.tiles + tile))
     {
       __hip_atomic_store(fin.done + (static_cast<size_t>(t_local) * plan.tiles + tile), fin.seq, __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
@@ -745,3 +783,13 @@ hipError_t launch_match_small(const MatchArgs & args_in, double * workspace, uns
 }
 
 }  // namespace ndt2d
+
+#ifdef NDT2D_TEST_HOOKS
+// Test builds only (libndt2d_hip_hooks.so; not declared in include/ndt2d_hip.h): make the producer
+// of record / pose `which - 1` of this translation unit's kernels withhold its `done` word
+// (0: normal operation) -- tests/test_gpu_bounded_poll.py.
+extern "C" int ndt2d_test_drop_done_small(int which)
+{
+  return hipMemcpyToSymbol(HIP_SYMBOL(ndt2d::g_test_drop_done), &which, sizeof(int)) == hipSuccess ? 0 : 3;
+}
+#endif

@@ -528,7 +528,8 @@ __global__ void __launch_bounds__(kFewThreads) score_few_kernel(const PosesArgs 
   // round trip on the path of the block that happened to finish last.
   if (i == n)   // (n > 1 and a flag: see first_side)
   {
-    for (uint32_t k = threadIdx.x; k < n; k += kFewThreads)
+    bool gave_up = false;
+    for (uint32_t k = threadIdx.x; k < n && !gave_up; k += kFewThreads)
     {
       // (the last block of the launch, dispatched after all the others -- the assumption and the
       // bounded poll of ndt2d_match_small.hip's reducing block: kFewPosesMax keeps the launch far
@@ -537,12 +538,34 @@ __global__ void __launch_bounds__(kFewThreads) score_few_kernel(const PosesArgs 
       while (__hip_atomic_load(f.done + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != f.seq)
       {
         __builtin_amdgcn_s_sleep(2);
-        if (++polls > (1u << 24)) __builtin_trap();
+        if (++polls > kDonePollLimit)
+        {
+          gave_up = true;
+          break;
+        }
       }
     }
     // what the other blocks wrote before their `done` words is read after this point only
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    __syncthreads();
+    // (any thread?  through the block's scratch row -- one word per wave -- rather than the
+    // device library's workgroup reduction, which brings static LDS of its own)
+    {
+      uint32_t * wave_gave_up = reinterpret_cast<uint32_t *>(chunk_sums + kChunks);
+      const bool wave_flag = __builtin_amdgcn_ballot_w64(gave_up) != 0ull;
+      if ((threadIdx.x & (kWave - 1)) == 0) wave_gave_up[threadIdx.x >> 6] = wave_flag ? 1u : 0u;
+      __syncthreads();
+      bool any = false;
+      for (uint32_t w = 0; w < kFewThreads / kWave; ++w) any |= wave_gave_up[w] != 0u;
+      gave_up = any;
+      __syncthreads();
+    }
+    if (gave_up)
+    {
+      // a pose's score never came: the flag says so (the host's wait returns NDT2D_ERR_HIP for
+      // this call; no trap -- the context stays usable)
+      if (threadIdx.x == 0) raise_host_flag(reinterpret_cast<double *>(f.flag), f.seq | kHostFlagGaveUp);
+      return;
+    }
     if (!f.stats)
     {
       if (threadIdx.x == 0) raise_host_flag(reinterpret_cast<double *>(f.flag), f.seq);
@@ -621,7 +644,7 @@ __global__ void __launch_bounds__(kFewThreads) score_few_kernel(const PosesArgs 
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (n > 1)
       {
-        __hip_atomic_store(f.done + i, f.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!NDT2D_TEST_DROPS_DONE(i)) __hip_atomic_store(f.done + i, f.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       else if (!f.stats)
       {
@@ -989,3 +1012,13 @@ hipError_t launch_poses_compact(const PosesArgs & args_in, int cus, bool screen,
 }
 
 }  // namespace ndt2d
+
+#ifdef NDT2D_TEST_HOOKS
+// Test builds only (libndt2d_hip_hooks.so; not declared in include/ndt2d_hip.h): make the producer
+// of record / pose `which - 1` of this translation unit's kernels withhold its `done` word
+// (0: normal operation) -- tests/test_gpu_bounded_poll.py.
+extern "C" int ndt2d_test_drop_done_few(int which)
+{
+  return hipMemcpyToSymbol(HIP_SYMBOL(ndt2d::g_test_drop_done), &which, sizeof(int)) == hipSuccess ? 0 : 3;
+}
+#endif

@@ -58,6 +58,13 @@ void ScanMatcherNDTHip::initialize(const std::string & name, rclcpp::Node * node
     node->declare_parameter<std::vector<int64_t>>(name + ".device_ids", std::vector<int64_t>());
   // "auto" | "rccl" (one all-reduce of the record table) | "host" (no collective)
   const std::string exchange = node->declare_parameter<std::string>(name + ".exchange", "auto");
+  // Work below these stays on the first device (candidates x beams of a search; particles x
+  // beams of a batch -- BatchPoseScorer::scorePoses / measurePoses, the batched counterpart of
+  // src/particle_filter.cpp:78-89).  The defaults are the library's (1e9 / 2e8: the
+  // 1,000,000-particle global localisation of BASELINE configs[4], 7.2e8, is sharded);
+  // negative = keep the library's default.
+  const double multi_min_units = node->declare_parameter<double>(name + ".multi_min_units", -1.0);
+  const double multi_min_pose_units = node->declare_parameter<double>(name + ".multi_min_pose_units", -1.0);
 
   std::vector<int> ids(device_ids.begin(), device_ids.end());
   if (ids.empty()) ids.push_back(device_id);
@@ -68,6 +75,13 @@ void ScanMatcherNDTHip::initialize(const std::string & name, rclcpp::Node * node
     return;
   }
   ok(ndt2d_matcher_set_exchange(matcher_, exchange.c_str()), "ndt2d_matcher_set_exchange");
+  {
+    double search_units = 0.0, pose_units = 0.0;
+    ndt2d_matcher_get_multi_thresholds(matcher_, &search_units, &pose_units);
+    if (multi_min_units >= 0.0) search_units = multi_min_units;
+    if (multi_min_pose_units >= 0.0) pose_units = multi_min_pose_units;
+    ok(ndt2d_matcher_set_multi_thresholds(matcher_, search_units, pose_units), "ndt2d_matcher_set_multi_thresholds");
+  }
   // no per-launch timing events in production: they cost ~4.5 us of every call
   ndt2d_matcher_set_timing(matcher_, 0);
   ok(ndt2d_matcher_initialize(matcher_, resolution, angular_res, angular_size, linear_res,

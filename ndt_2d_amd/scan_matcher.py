@@ -106,6 +106,26 @@ class ScanMatcherNDT:
         self._check(self._L.ndt2d_matcher_set_multi_min_units(self._m, float(units)),
                     "set_multi_min_units")
 
+    def set_multi_thresholds(self, min_search_units, min_pose_units):
+        """The two thresholds apart: candidates x beams of a search (default 1e9), particles x
+        beams of a pose batch (default 2e8)."""
+        self._check(self._L.ndt2d_matcher_set_multi_thresholds(self._m, float(min_search_units),
+                                                               float(min_pose_units)), "set_multi_thresholds")
+
+    def multi_thresholds(self):
+        a, b = _capi.C.c_double(0.0), _capi.C.c_double(0.0)
+        self._check(self._L.ndt2d_matcher_get_multi_thresholds(self._m, _capi.C.byref(a), _capi.C.byref(b)),
+                    "get_multi_thresholds")
+        return a.value, b.value
+
+    def last_fanout_us(self):
+        """Of the last dealt call: when each device's launch had been queued (us from the call's start)."""
+        out = np.zeros(64, dtype=np.float64)
+        n = _capi.C.c_size_t(0)
+        self._check(self._L.ndt2d_matcher_last_fanout_us(self._m, _capi.dptr(out), 64, _capi.C.byref(n)),
+                    "last_fanout_us")
+        return out[:min(n.value, 64)].copy()
+
     def matcher_variant(self):
         """ndt2d_matcher_last_variant: "multi[n]/rccl/..." when the last call was dealt out."""
         v = self._L.ndt2d_matcher_last_variant(self._m)
@@ -320,6 +340,11 @@ class ScanMatcherNDT:
     def set_build_mode(self, mode):
         """Where addScans builds the NDT: "host", "device" or "auto" (bit-identical grids)."""
         self._check(self._L.ndt2d_matcher_set_build_mode(self._m, mode.encode()), "set_build_mode")
+
+    def set_eigenvalue_form(self, form):
+        """How Cell::compute's eigenvalues (src/ndt_model.cpp:84-85) are formed: "eigen" (default:
+        Eigen 3.4.0's EigenSolver transcribed) or "closed" (the closed form of rounds 1-4)."""
+        self._check(self._L.ndt2d_matcher_set_eigenvalue_form(self._m, form.encode()), "set_eigenvalue_form")
 
     # -- additive batched interface ------------------------------------------------
 

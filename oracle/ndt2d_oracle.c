@@ -62,17 +62,65 @@ void orc_cell_add_point(orc_cell * c, double x, double y)
   c->valid = 0;
 }
 
-/* Eigenvalues of the (symmetric) 2x2 covariance, standing in for
- * Eigen::EigenSolver<Matrix2d>(covariance).eigenvalues().real()
- * (src/ndt_model.cpp:84-85).  Eigen's real-Schur path: the 2x2 Hessenberg
- * form is the matrix itself; if the sub-diagonal is negligible
- * (|b| <= max(eps*(|a|+|d|), norm*eps^2)) the diagonal entries are the
- * eigenvalues exactly; otherwise the 2x2 block is split with
- * p = (a-d)/2, z = sqrt(p^2 + b*c).  Eigen then applies a Givens rotation and
- * reads the diagonal; here the closed form d + p +/- z is used instead, which
- * can differ from Eigen in the last ulps (it only feeds the clamp-branch
- * determinant, src/ndt_model.cpp:91). */
-static void eigenvalues_2x2(const double * m, double * e0, double * e1)
+/* Eigenvalues of the 2x2 covariance as
+ * Eigen::EigenSolver<Matrix2d>(covariance).eigenvalues().real() arrives at them
+ * (src/ndt_model.cpp:84-85).  Eigen is a third-party dependency absent from this image
+ * (find_package(Eigen3), CMakeLists.txt:17; ROS 2 Humble: 3.4.0); this is a transcription of
+ * Eigen 3.4.0 for a real 2x2 input, operation by operation:
+ *   RealSchur::compute (Eigenvalues/RealSchur.h): scale = matrix.cwiseAbs().maxCoeff(); the
+ *     Schur form T is computed of matrix / scale and multiplied by scale at the end; a 2x2
+ *     matrix is its own Hessenberg form (the Householder step has tau = 0).
+ *   computeFromHessenberg: norm = sum over columns of |entries on and above the sub-diagonal|,
+ *     considerAsZero = max(norm * eps^2, DBL_MIN); findSmallSubdiagEntry:
+ *     |t10| <= max(eps * (|t00| + |t11|), considerAsZero)  =>  the diagonal is the result.
+ *   splitOffTwoRows: p = (t00 - t11) / 2, q = p*p + t10*t01; q >= 0: z = sqrt|q|, a Givens
+ *     rotation of (p + z, t10) (p >= 0) or (p - z, t10) applied as rot.adjoint() from the left
+ *     and rot from the right, then t10 = 0.
+ *   JacobiRotation::makeGivens (Jacobi/Jacobi.h, real case) and apply_rotation_in_the_plane:
+ *     x' = c x + s y, y' = -s x + c y with separate multiplies and add (no FMA on x86-64).
+ *   EigenSolver::compute (Eigenvalues/EigenSolver.h): t10 == 0: the diagonal of T; else a
+ *     complex pair whose real part t11 + (t00 - t11) / 2 is returned twice.
+ * PARITY UNPINNED at this level: the reference holds no vector for the eigenvalues themselves
+ * and Eigen cannot be run here; test/ndt_model_tests.cpp pins only what follows from them
+ * (tests/test_oracle_reference_vectors.py).  orc_set_eigen_form(1) selects the closed form
+ * d + p +- z that rounds 1-4 used (ulps apart; tests/test_eigen_form.py counts the cells it
+ * changes). */
+static int g_eigen_form = 0;
+
+void orc_set_eigen_form(int form) { g_eigen_form = form; }
+int orc_get_eigen_form(void) { return g_eigen_form; }
+
+static void make_givens(double p, double q, double * c, double * s)
+{
+  if (q == 0.0)
+  {
+    *c = p < 0.0 ? -1.0 : 1.0;
+    *s = 0.0;
+  }
+  else if (p == 0.0)
+  {
+    *c = 0.0;
+    *s = q < 0.0 ? 1.0 : -1.0;
+  }
+  else if (fabs(p) > fabs(q))
+  {
+    const double t = q / p;
+    double u = sqrt(1.0 + t * t);
+    if (p < 0.0) u = -u;
+    *c = 1.0 / u;
+    *s = -t * *c;
+  }
+  else
+  {
+    const double t = p / q;
+    double u = sqrt(1.0 + t * t);
+    if (q < 0.0) u = -u;
+    *s = -1.0 / u;
+    *c = -t * *s;
+  }
+}
+
+static void eigenvalues_closed_form(const double * m, double * e0, double * e1)
 {
   const double a = m[0], b = m[1], c = m[2], d = m[3];
   const double norm = fabs(a) + fabs(b) + fabs(c) + fabs(d);
@@ -105,6 +153,93 @@ static void eigenvalues_2x2(const double * m, double * e0, double * e1)
     /* complex pair: .real() of both is d + p */
     *e0 = d + p;
     *e1 = d + p;
+  }
+}
+
+static void eigenvalues_2x2(const double * m, double * e0, double * e1)
+{
+  if (g_eigen_form == 1)
+  {
+    eigenvalues_closed_form(m, e0, e1);
+    return;
+  }
+  /* RealSchur::compute */
+  double scale = fabs(m[0]);
+  if (fabs(m[2]) > scale) scale = fabs(m[2]);
+  if (fabs(m[1]) > scale) scale = fabs(m[1]);
+  if (fabs(m[3]) > scale) scale = fabs(m[3]);
+  if (scale < DBL_MIN)
+  {
+    *e0 = 0.0; /* m_matT.setZero() */
+    *e1 = 0.0;
+    return;
+  }
+  double t00 = m[0] / scale, t01 = m[1] / scale, t10 = m[2] / scale, t11 = m[3] / scale;
+  /* computeNormOfT */
+  double norm = 0.0;
+  norm += fabs(t00) + fabs(t10);
+  norm += fabs(t01) + fabs(t11);
+  if (norm != 0.0)
+  {
+    double consider_as_zero = norm * (DBL_EPSILON * DBL_EPSILON);
+    if (consider_as_zero < DBL_MIN) consider_as_zero = DBL_MIN;
+    /* findSmallSubdiagEntry */
+    double s = fabs(t00) + fabs(t11);
+    s = s * DBL_EPSILON;
+    if (s < consider_as_zero) s = consider_as_zero;
+    if (fabs(t10) <= s)
+    {
+      t10 = 0.0;
+    }
+    else
+    {
+      /* splitOffTwoRows */
+      const double p = 0.5 * (t00 - t11);
+      const double q = p * p + t10 * t01;
+      if (q >= 0.0)
+      {
+        const double z = sqrt(fabs(q));
+        double c, sn;
+        if (p >= 0.0) make_givens(p + z, t10, &c, &sn);
+        else make_givens(p - z, t10, &c, &sn);
+        const double jc = c, js = -sn; /* rot.adjoint() and rot.transpose(), real case */
+        if (!(jc == 1.0 && js == 0.0))
+        {
+          double x, y;
+          /* applyOnTheLeft(0, 1, rot.adjoint()) */
+          x = t00; y = t10;
+          t00 = jc * x + js * y;
+          t10 = -js * x + jc * y;
+          x = t01; y = t11;
+          t01 = jc * x + js * y;
+          t11 = -js * x + jc * y;
+          /* applyOnTheRight(0, 1, rot) */
+          x = t00; y = t01;
+          t00 = jc * x + js * y;
+          t01 = -js * x + jc * y;
+          x = t10; y = t11;
+          t10 = jc * x + js * y;
+          t11 = -js * x + jc * y;
+        }
+        t10 = 0.0;
+      }
+    }
+  }
+  /* m_matT *= scale */
+  t00 *= scale;
+  t10 *= scale;
+  t11 *= scale;
+  /* EigenSolver::compute */
+  if (t10 == 0.0)
+  {
+    *e0 = t00;
+    *e1 = t11;
+  }
+  else
+  {
+    const double p = 0.5 * (t00 - t11);
+    *e0 = t11 + p;
+    *e1 = t11 + p;
   }
 }
 

@@ -58,6 +58,10 @@ typedef struct orc_cell
 void orc_cell_init(orc_cell * c);                                /* ndt_model.cpp:40-48 */
 void orc_cell_add_point(orc_cell * c, double x, double y);       /* ndt_model.cpp:50-63 */
 void orc_cell_compute(orc_cell * c);                             /* ndt_model.cpp:65-103 */
+/* How orc_cell_compute forms the eigenvalues of :84-85: 0 (default) = Eigen 3.4.0's
+ * EigenSolver<Matrix2d> transcribed, 1 = the closed form d + p +- z (see ndt2d_oracle.c). */
+void orc_set_eigen_form(int form);
+int orc_get_eigen_form(void);
 double orc_cell_score(const orc_cell * c, double x, double y);   /* ndt_model.cpp:105-116 */
 
 /* class NDT, reference include/ndt_2d/ndt_model.hpp:67-134 */

@@ -59,6 +59,8 @@ def lib():
     sig("orc_cell_init", None, [C.POINTER(OrcCell)])
     sig("orc_cell_add_point", None, [C.POINTER(OrcCell), d, d])
     sig("orc_cell_compute", None, [C.POINTER(OrcCell)])
+    sig("orc_set_eigen_form", None, [C.c_int])
+    sig("orc_get_eigen_form", C.c_int, [])
     sig("orc_cell_score", d, [C.POINTER(OrcCell), d, d])
     sig("orc_ndt_create", vp, [d, d, d, d, d])
     sig("orc_ndt_destroy", None, [vp])
@@ -101,6 +103,11 @@ def lib():
     sig("orc_shortest_angular_distance", d, [d, d])
     _lib = L
     return L
+
+
+def set_eigen_form(form):
+    """"eigen" (default): Eigen 3.4.0's EigenSolver transcribed; "closed": the closed form."""
+    lib().orc_set_eigen_form({"eigen": 0, "closed": 1}[form])
 
 
 def _arr(a):

@@ -46,6 +46,24 @@ def test_c_host_multi_device_equals_single_device(tmp_path, ids, exchange, label
     assert out["pf_measure"]["variant"].startswith(label)
 
 
+def test_c_host_cfg5_is_sharded_by_the_default_thresholds(tmp_path):
+    """BASELINE.json configs[4] -- 1,000,000 particles x 720 beams, 801 x 801 NDT -- through
+    eight contexts and the host exchange WITHOUT touching the thresholds (the reference's call
+    site: src/ndt_mapper.cpp:474 -> src/particle_filter.cpp:78-89): the call is dealt out, raw
+    scores are bit for bit the single-device ones, weights and statistics agree to rounding."""
+    exe = _build(tmp_path)
+    r = subprocess.run([exe, "0,0,0,0,0,0,0,0", "host", "cfg5"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["ok"] is True and out["devices"] == 8
+    c = out["cfg5"]
+    assert c["grid"] == [801, 801] and c["particles"] == 1000000
+    assert c["units"] >= c["default_min_pose_units"]
+    assert c["raw_scores_bit_identical"] is True
+    assert c["max_rel_weight_diff"] < 1e-12
+    assert c["variant"].startswith("multi[8]/host/") and c["score_poses_variant"].startswith("multi[8]/host/")
+
+
 def test_multi_device_all_scores_against_the_oracle():
     """Every one of cfg-1's 17,640 scores from three contexts (theta steps interleaved)
     against the CPU oracle, and the golden result."""
