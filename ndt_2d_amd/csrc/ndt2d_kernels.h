@@ -136,6 +136,7 @@ struct BuildArgs
   double * cells_global;      // [ncell + 1][kCellStrideGlobal] out
   uint32_t * occ_bits;        // out
   uint8_t * cell_bytes;       // out: [size_y + 2][size_x + 2]
+  int eigen_form;             // ndt2d_eigen2.h: 0 = Eigen's EigenSolver transcribed, 1 = closed form
 };
 size_t build_sort_temp_bytes(uint32_t n_points, uint32_t ncell);
 hipError_t launch_build_grid(const BuildArgs & args, hipStream_t stream);
@@ -203,6 +204,9 @@ size_t match_workspace_head_doubles();   // counters + first-stage records in fr
 // then, at host_record[kHostFlagSlot], `seq` as a 64-bit integer -- a host may spin on
 // it instead of synchronising the stream.
 constexpr int kHostFlagSlot = 16;
+// ... or seq | kHostFlagGaveUp: the launch's last block waited in vain for another block's
+// result (its bounded poll, ndt2d_device_fn.h); the call has no result (NDT2D_ERR_HIP).
+constexpr unsigned long long kHostFlagGaveUp = 1ull << 63;
 // Whether launch_match with these arguments reads the search tables from device memory
 // (false: the small-lattice search takes them as kernel arguments from args.host_tables).
 bool match_needs_device_tables(const MatchArgs & args, bool outer_available, int force_variant);
@@ -222,16 +226,30 @@ size_t poses_workspace_doubles(uint64_t n_poses);
 // particular order; only the first cap to arrive are kept).
 hipError_t launch_collect_near(const double * scores, uint64_t n, uint64_t hi, const double * record, double rel,
                                double abs_tol, unsigned long long * out, uint32_t cap, hipStream_t stream);
+// host_sums (optional, with stats_out): host-coherent memory as the device addresses it; the
+// reduction stores the eight sums there too and then `host_seq` at
+// host_sums[kPoseSumsFlagOffset] for a host thread that spins on it.
+constexpr int kPoseSumsFlagOffset = 8;
 hipError_t launch_score_poses(const PosesArgs & args, double * workspace, double * stats_out,
                               int force_variant, hipStream_t stream, hipEvent_t ev_main_done,
-                              LaunchInfo * info);
+                              LaunchInfo * info, double * host_sums = nullptr,
+                              unsigned long long host_seq = 0);
+
+// The moment sums of updateStatistics as a kernel argument (by_value != 0) -- see launch_pf_finalize.
+struct PoseTotals
+{
+  double v[8];
+  int by_value;
+};
 
 // ParticleFilter::updateStatistics from the moment sums: normalises weights in
 // place and writes out = {sum w, mean x, mean y, mean theta, cov xx, cov xy, cov yy,
 // theta-variance increment}.  workspace: poses_workspace_doubles() doubles.
+// The sums come from device memory (`stats`) or, totals_by_value != nullptr, as eight host
+// values that travel as kernel arguments.  host_out (optional): `out` in host-coherent memory too.
 hipError_t launch_pf_finalize(const double * poses_xyt, uint64_t n_poses, double * weights,
-                              const double * stats, double * workspace, double * out,
-                              hipStream_t stream);
+                              const double * stats, const double * totals_by_value, double * workspace,
+                              double * out, double * host_out, hipStream_t stream);
 
 // Particle-filter steps around `measure` (ndt2d_motion.hip).  The float fields are
 // the parameters std::normal_distribution<float>(mean, sigma) holds
