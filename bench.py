@@ -165,13 +165,28 @@ def source_hash():
     return h.hexdigest()
 
 
+def library_identity():
+    """Which sources the loaded libndt2d_hip.so was compiled from (ndt2d_build_info) and whether
+    that is the tree this script runs from (ndt_2d_amd/build.py source_sha256)."""
+    try:
+        from ndt_2d_amd import _capi
+        from ndt_2d_amd import build as _build
+        have, want = _capi.lib_source_sha256(), _build.source_sha256()
+        return {"path": _capi.LIB_PATH, "build_info": _capi.build_info(), "source_sha256_of_tree": want,
+                "lib_matches_source": have == want}
+    except Exception as exc:   # noqa: BLE001 -- a missing figure, not a failed bench
+        return {"error": str(exc), "lib_matches_source": None}
+
+
 def pmc_matches_source(pmc):
     return bool(pmc) and pmc.get("source_sha256") == source_hash()
 
 
 SHARE_COUNTERS = ("SQ_INSTS_VALU", "SQ_BUSY_CU_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU",
                   "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64",
-                  "SQ_INSTS_VALU_TRANS_F64", "SQ_INSTS_VALU_FMA_F32", "FETCH_SIZE", "WRITE_SIZE")
+                  "SQ_INSTS_VALU_TRANS_F64", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32",
+                  "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_INT64", "SQ_INSTS_VALU_CVT",
+                  "FETCH_SIZE", "WRITE_SIZE")
 
 
 def share_counters(pmc, workload, rank, world):
@@ -310,6 +325,7 @@ def roofline(kernel, kernel_ms, units, n_cu, pmc, expected_dispatch_note, counte
                   "frac_bracket = the two mixed classes all at 2 cycles .. all at 4"
                   % (n_simd, MAX_CLOCK_HZ / 1e9, cycles_per_inst),
         issue_pricing=pricing["table"],
+        valu_mix_matches_source=(_load_json(MIX_FILE) or {}).get("source_sha256") == source_hash(),
         issue_slot_occupancy_pmc=k["SQ_INSTS_VALU"] * cycles_per_inst / (4.0 * k["SQ_BUSY_CU_CYCLES"]),
         sustained_clock_GHz_est=clock / 1e9,
         clock_in_pmc_pass_GHz=(busy_cycles / (dur_pmc * 1e-9) / 1e9) if dur_pmc else None,
@@ -998,6 +1014,7 @@ def main():
             "prewarm": {"seconds": args.prewarm, "steps": n_prewarm,
                         "what": "untimed launches before --warmup (clocks reach their sustained level)"},
             "shader_clock_MHz_sysfs": clock_mhz,
+            "library": library_identity(),
             "rank_kernel_ms": {"max": max(rank_kernel_ms), "mean": sum(rank_kernel_ms) / len(rank_kernel_ms),
                                "per_rank": rank_kernel_ms},
         }
@@ -1233,11 +1250,11 @@ def c_host_multi_device(ids):
 
     def run(exchange):
         try:
-            r = subprocess.run([probe, "--devices", ",".join(str(i) for i in ids), "--exchange", exchange],
-                               capture_output=True, text=True, timeout=150, env=env)
+            r = subprocess.run([probe, "--devices", ",".join(str(i) for i in ids), "--exchange", exchange,
+                                "--workload", "all"], capture_output=True, text=True, timeout=400, env=env)
         except subprocess.TimeoutExpired as exc:
             tail = exc.stdout.decode(errors="replace") if isinstance(exc.stdout, bytes) else (exc.stdout or "")
-            return {"error": "probe timed out (150 s)", "exchange_requested": exchange, "stdout_tail": tail[-1500:]}
+            return {"error": "probe timed out (400 s)", "exchange_requested": exchange, "stdout_tail": tail[-1500:]}
         if r.returncode != 0:
             return {"error": "probe exit %d: %s" % (r.returncode, r.stderr[-500:]), "exchange_requested": exchange}
         try:   # (RCCL writes its own lines to stdout: the probe's is the one that opens the object)
@@ -1255,8 +1272,11 @@ def c_host_multi_device(ids):
     if len(set(ids)) == len(ids):
         out["rccl"] = run("rccl")
     out["what"] = ("one ndt2d_matcher over devices %s (ndt2d_matcher_create_multi), plain-C host: median "
-                   "wall time of the whole ndt2d_matcher_match_scan call; host exchange at the top level, "
-                   "the RCCL exchange under `rccl`" % ids)
+                   "wall time of the whole ndt2d_matcher_match_scan call (cfg2, cfg4) and of the whole "
+                   "ndt2d_matcher_pf_measure call with the DEFAULT thresholds (cfg5: BASELINE.json configs[4], host "
+                   "particles in, host weights out); fanout_us = when each device's launch had been queued; "
+                   "dealing_overhead = the dealt call against the one-device call on workloads too small to matter; "
+                   "host exchange at the top level, the RCCL exchange under `rccl`" % ids)
     return out
 
 

@@ -2,7 +2,7 @@
 # search, and the SQ counters of the search kernel, for three lattices on cfg-2's map and scan.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/pmc_midsize
+O=$R/gpurun_out/r05/pmc_midsize
 rm -rf $O && mkdir -p $O
 for c in "1.0 0.02" "1.0 0.1" "1.0 0.35" "1.0 0.5"; do
   t=$(echo $c | tr ' ' '_')

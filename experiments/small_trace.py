@@ -4,7 +4,7 @@
 built with -DNDT2D_SMALL_TRACE (experiments/build_trace_lib.sh -> experiments/bin/trace.so;
 run with NDT2D_HIP_LIB pointing at it).
 
-    NDT2D_HIP_LIB=experiments/bin/trace.so python experiments/small_trace.py [defaults|d720|cfg1]
+    NDT2D_HIP_LIB=experiments/bin/trace.so python experiments/small_trace.py [defaults|d720|cfg1|mid1352]
 """
 import os
 import sys
@@ -22,6 +22,8 @@ DEFAULTS = dict(search_linear_size=0.05, search_linear_resolution=0.005, search_
 over = {"defaults": DEFAULTS, "real30": DEFAULTS,
         "d720": dict(search_linear_size=0.05, search_linear_resolution=0.005, search_angular_size=0.1,
                      search_angular_resolution=0.0025),
+        "mid1352": dict(search_linear_size=1.0, search_linear_resolution=0.02, search_angular_size=0.02,
+                        search_angular_resolution=0.005),
         "cfg1": {}}[which]
 m = ScanMatcherNDT(0)
 if which == "real30":
@@ -81,3 +83,15 @@ print("  per wave: setup %.2f (max %.2f)  beams %.2f (min %.2f max %.2f)  waitin
       "  combine + record %.2f (max %.2f) us"
       % (d_setup.mean(), d_setup.max(), d_main.mean(), d_main.min(), d_main.max(), d_wait.mean(), d_wait.max(),
          d_rec.mean(), d_rec.max()))
+# when the blocks start and how long they run: the launch's shape (a mid-size lattice needs more
+# than one round of block slots; its time is the rounds' critical path)
+dur = ends - starts
+order = np.argsort(starts)
+print("  blocks started by: 25 %% %.1f  50 %% %.1f  75 %% %.1f  100 %% %.1f us; durations: p10 %.1f  p50 %.1f  p90 %.1f  max %.1f us"
+      % tuple(list(np.percentile(late, [25, 50, 75, 100])) + list(np.percentile(dur, [10, 50, 90, 100]))))
+slow = np.argsort(dur)[-8:]
+print("  the eight longest blocks: " + ", ".join("start %.1f dur %.1f" % (late[b], dur[b]) for b in slow))
+last = np.argsort(ends)[-8:]
+print("  the eight blocks that end last: " + ", ".join("start %.1f dur %.1f end %.1f" % (late[b], dur[b], ends[b] - t0) for b in last))
+running = [(int(((starts <= t0 + x) & (ends > t0 + x)).sum())) for x in np.arange(0.0, ends.max() - t0, 5.0)]
+print("  blocks in flight every 5 us: " + " ".join(str(r) for r in running))

@@ -76,7 +76,24 @@ struct SmallPlan
   uint32_t linear;              // tiles are runs of 64 consecutive candidates, not 8 x 8 patches
   uint32_t no_tail;             // (experiments) leave out the final reduction
   uint32_t search_blocks;       // blocks of the search proper; block search_blocks (if launched) reduces
+  // Blocks are dispatched in index order and a mid-size lattice needs more than one round of the
+  // chip's block slots: with centre_first the block index walks the PATCHES from the lattice's
+  // centre outwards (all theta steps of a patch together, the middle step first) instead of
+  // theta by theta, row-major.  The search is centred on the caller's guess, so the patches
+  // around the centre are the ones whose every beam hits the map -- a block of those runs ten
+  // times as long as one at the rim, and must not be in the last round (1,352 blocks of 720 beams:
+  // 85 -> 75 us; dealing one heavy block beside two light ones per CU instead was measured too:
+  // 81 us -- a heavy block's 48 us are its own chain, not its neighbours' issue slots).  Which
+  // block evaluates which tile leaves no trace in the records (indexed by (theta, tile)): same bits.
+  uint32_t centre_first;
 };
+
+// j-th element of 0 .. n-1 visited from the middle outwards: mid, mid + 1, mid - 1, mid + 2, ...
+__host__ __device__ inline uint32_t middle_out(uint32_t j, uint32_t n)
+{
+  const uint32_t mid = (n - 1u) / 2u;
+  return (j & 1u) ? mid + (j + 1u) / 2u : mid - j / 2u;
+}
 
 // What the launch's last block needs for the final reduction.
 struct SmallFinal
@@ -128,8 +145,8 @@ __device__ __forceinline__ void small_final_reduction(const MatchArgs & a, const
     // dispatched in index order on this hardware, so every producer is resident or done before
     // the first poll -- an assumption of the design (HIP does not promise it; kSmallMaxItems keeps
     // the launch far below the chip's resident-block capacity).  Should it ever fail, the poll
-    // gives up after ~1 s: the block then publishes "gave up" instead of a record (below) and the
-    // host's wait returns NDT2D_ERR_HIP for this call -- no trap, the context stays usable.
+    // gives up after a second or two: the block then publishes "gave up" instead of a record
+    // (below) and the host's wait returns NDT2D_ERR_HIP for this call -- no trap.
     uint32_t polls = 0;
     while (__hip_atomic_load(fin.done + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != fin.seq)
     {
@@ -151,37 +168,12 @@ __device__ __forceinline__ void small_final_reduction(const MatchArgs & a, const
 #pragma unroll
     for (int k = 0; k < 10; ++k) acc[k] += v[2 + k];
   }
-  // did any thread give up?  (Not __syncthreads_or(): the device library's workgroup reduction
-  // brings static LDS of its own, and this kernel's map must start at LDS offset 0.)  One word
-  // per wave behind the records' scratch, written by every wave, read by all after the barrier.
-  {
-    uint32_t * wave_gave_up = reinterpret_cast<uint32_t *>(scratch + static_cast<size_t>(kSmallMaxWaves) * kRecord);
-    const bool wave_flag = __builtin_amdgcn_ballot_w64(gave_up) != 0ull;
-    if (lane == 0) wave_gave_up[wave] = wave_flag ? 1u : 0u;
-    __syncthreads();
-    bool any = false;
-    for (uint32_t w = 0; w < n_waves; ++w) any |= wave_gave_up[w] != 0u;
-    gave_up = any;
-    __syncthreads();   // (the words are read before the records' scratch is written below)
-  }
-  if (gave_up)
-  {
-    // a record never came: no result -- NaN score, no index -- and the flag says why
-    if (threadIdx.x < kRecord)
-    {
-      const double val = threadIdx.x == 1 ? -1.0 : __longlong_as_double(0x7ff8000000000000ll);
-      fin.record_out[threadIdx.x] = val;
-      if (fin.record_out2 != nullptr) fin.record_out2[threadIdx.x] = val;
-      if (fin.host_out != nullptr) store_host(fin.host_out + threadIdx.x, val);
-    }
-    if (fin.host_out != nullptr && wave == 0)
-    {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_wave_barrier();
-      if (lane == 0) raise_host_flag(fin.host_out + kHostFlagSlot, fin.seq | kHostFlagGaveUp);
-    }
-    return;
-  }
+  // Did any thread give up?  One word per wave behind the records' scratch, written with the
+  // wave's record and read behind the same barrier -- no barrier of its own on the path every
+  // search takes.  (Not __syncthreads_or(): the device library's workgroup reduction brings
+  // static LDS, and this kernel's map must start at LDS offset 0.)
+  uint32_t * wave_gave_up = reinterpret_cast<uint32_t *>(scratch + static_cast<size_t>(kSmallMaxWaves) * kRecord);
+  const bool wave_flag = __builtin_amdgcn_ballot_w64(gave_up) != 0ull;
   wave_best_to_last_lane(bs, bi);
 #pragma unroll
   for (int k = 0; k < 10; ++k) acc[k] = wave_sum_to_last_lane(acc[k]);
@@ -191,8 +183,14 @@ __device__ __forceinline__ void small_final_reduction(const MatchArgs & a, const
     scratch[wave * kRecord + 1] = bi;
 #pragma unroll
     for (int k = 0; k < 10; ++k) scratch[wave * kRecord + 2 + k] = acc[k];
+    wave_gave_up[wave] = wave_flag ? 1u : 0u;
   }
   __syncthreads();
+  bool any_gave_up = false;
+  if (threadIdx.x < kWave)
+  {
+    for (uint32_t w = 0; w < n_waves; ++w) any_gave_up |= wave_gave_up[w] != 0u;
+  }
   if (threadIdx.x < kRecord)
   {
     const uint32_t k = threadIdx.x;
@@ -212,6 +210,9 @@ __device__ __forceinline__ void small_final_reduction(const MatchArgs & a, const
       val = scratch[k];
       for (uint32_t w = 1; w < n_waves; ++w) val += scratch[w * kRecord + k];
     }
+    // a record never came: no result -- NaN score, no index -- and the flag says why (the host's
+    // wait returns NDT2D_ERR_HIP for this call; no trap, the context stays usable)
+    if (any_gave_up) val = k == 1 ? -1.0 : __longlong_as_double(0x7ff8000000000000ll);
     fin.record_out[k] = val;
     if (fin.record_out2 != nullptr) fin.record_out2[k] = val;
     if (fin.host_out != nullptr) store_host(fin.host_out + k, val);
@@ -221,7 +222,7 @@ __device__ __forceinline__ void small_final_reduction(const MatchArgs & a, const
     // the record (lanes 0..11 of this wave) has been acknowledged before the flag leaves
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    if (lane == 0) raise_host_flag(fin.host_out + kHostFlagSlot, fin.seq);
+    if (lane == 0) raise_host_flag(fin.host_out + kHostFlagSlot, any_gave_up ? (fin.seq | kHostFlagGaveUp) : fin.seq);
   }
 #ifdef NDT2D_SMALL_TRACE
   // when the flag had left (final reduction and publish done)
@@ -278,8 +279,18 @@ match_small_kernel(const MatchArgs a,
                                  static_cast<size_t>(kSmallMaxWaves) * kRecord);
 
   const uint32_t n_threads = blockDim.x;
-  const uint32_t t_local = blockIdx.x / plan.blocks_per_theta;
-  const uint32_t first_patch = (blockIdx.x - t_local * plan.blocks_per_theta) * plan.patches_per_block;
+  uint32_t t_local = blockIdx.x / plan.blocks_per_theta;
+  uint32_t first_patch = (blockIdx.x - t_local * plan.blocks_per_theta) * plan.patches_per_block;
+  if (plan.centre_first)
+  {
+    // (one tile per block, 8 x 8 patches: see SmallPlan::centre_first)
+    const uint32_t c = blockIdx.x;
+    const uint32_t n_th_local = plan.search_blocks / plan.blocks_per_theta;
+    const uint32_t patch_rank = c / n_th_local;
+    const uint32_t patches_1d = (a.n_lin + kPatch - 1) / kPatch;
+    t_local = middle_out(c - patch_rank * n_th_local, n_th_local);
+    first_patch = middle_out(patch_rank / patches_1d, patches_1d) * patches_1d + middle_out(patch_rank % patches_1d, patches_1d);
+  }
   const uint32_t ith = a.th_begin + t_local * a.th_stride;
 
   // map window: one byte per grid cell, copied from the grid's extended byte image;
@@ -642,6 +653,13 @@ SmallPlan small_plan(const MatchArgs & args, const LaneGeom & geo, int cus)
   if (p < 1) p = 1;
   plan.patches_per_block = p;
   plan.blocks_per_theta = (plan.tiles + p - 1) / p;
+  {
+    static const bool knob_off = [] {   // A/B knob: NDT2D_SMALL_CENTRE_FIRST=0
+      const char * v = std::getenv("NDT2D_SMALL_CENTRE_FIRST");
+      return v != nullptr && v[0] == '0';
+    }();
+    plan.centre_first = (!knob_off && p == 1 && plan.linear == 0) ? 1u : 0u;
+  }
   return plan;
 }
 

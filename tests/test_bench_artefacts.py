@@ -1,4 +1,4 @@
-"""The committed bench line (profiles/r04_bench.json, written by `python bench.py` on an
+"""The committed bench line (profiles/r05_bench.json, written by `python bench.py` on an
 MI355X) keeps the driver's contract and agrees with the committed counters and golden
 results.  No GPU needed."""
 import json
@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.fixture(scope="module")
 def line():
-    with open(os.path.join(ROOT, "profiles", "r04_bench.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r05_bench.json")) as f:
         return json.load(f)
 
 
@@ -35,21 +35,39 @@ def test_roofline_is_a_fraction_of_something_that_binds(line):
     r = line["roofline"]
     assert r["bound"] == "valu_issue" and 0.0 < r["frac"] <= 1.0
     assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-9)
-    # the peak is the chip's fixed issue peak (1,024 SIMDs x 2.4 GHz / 4 cycles), the time is
-    # the run's own: achieved = committed SQ_INSTS_VALU / live kernel time
-    # (FP32 instructions are priced at 2 cycles: the search kernel holds 12,288 of them in 2.3e8)
-    assert r["peak"] == pytest.approx(1024 * 2.4e9 / 4.0 / 1e9, rel=1e-4)
-    with open(os.path.join(ROOT, "profiles", "r04_pmc.json")) as f:
+    # the peak is the chip's fixed issue peak for THIS kernel's instruction mix: 1,024 SIMDs x 2.4 GHz
+    # over the mean measured issue cycles per instruction (profiles/r05_ubench_issue.json; the two
+    # classes that mix 2- and 4-cycle instructions by the kernel's own static mix, r05_valu_mix.json);
+    # the time is the run's own: achieved = committed SQ_INSTS_VALU / live kernel time
+    table = r["issue_pricing"]
+    total = sum(row["instructions"] for row in table)
+    cycles = sum(row["instructions"] * row["cycles_per_instruction"] for row in table)
+    assert total == pytest.approx(r["valu_insts_per_launch"], rel=1e-9)
+    assert all(2.0 <= row["cycles_per_instruction"] <= 16.0 for row in table)
+    fp64 = [row for row in table if row["class"] in ("ADD_F64", "MUL_F64", "FMA_F64")]
+    assert len(fp64) == 3 and all(row["cycles_per_instruction"] == 4.0 for row in fp64)
+    assert 3.5 < cycles / total < 4.0
+    assert r["peak"] == pytest.approx(1024 * 2.4e9 / (cycles / total) / 1e9, rel=1e-6)
+    # the bracket: every instruction of the two mixed classes at 2 cycles .. at 4
+    lo, hi = r["frac_bracket"]
+    assert lo < r["frac"] < hi <= 1.0 and 0.55 < lo and hi - lo < 0.3
+    with open(os.path.join(ROOT, "profiles", "r05_ubench_issue.json")) as f:
+        issue = json.load(f)
+    assert issue["cycles"]["v_fma_f64"] == 4.0 and issue["cycles"]["v_mov_b32"] == 2.0
+    assert issue["cycles"]["v_perm_b32"] == 4.0 and issue["cycles"]["v_add_u32"] == 2.0
+    assert issue["instructions"]["v_add_u32"]["counted_by"] == ["INT32"]
+    assert issue["instructions"]["v_perm_b32"]["counted_by"] == ["(no class counter)"]
+    with open(os.path.join(ROOT, "profiles", "r05_pmc.json")) as f:
         pmc = json.load(f)
     k = pmc["kernels"][r["kernel"]]
     assert r["achieved"] == pytest.approx(k["SQ_INSTS_VALU"] / (r["kernel_ms_avg"] * 1e-3) / 1e9, rel=1e-9)
     assert r["valu_insts_per_launch"] == pytest.approx(k["SQ_INSTS_VALU"], rel=1e-9)
     # the run-invariant share of the kernel's own issue slots, reproducible from the counters alone
     assert r["issue_slot_occupancy_pmc"] == pytest.approx(
-        k["SQ_INSTS_VALU"] * 4.0 / (4.0 * k["SQ_BUSY_CU_CYCLES"]), rel=1e-4)
+        k["SQ_INSTS_VALU"] * (cycles / total) / (4.0 * k["SQ_BUSY_CU_CYCLES"]), rel=1e-4)
     assert r["frac"] < r["issue_slot_occupancy_pmc"]          # the chip sustains less than 2.4 GHz
     # ... and it does move with the run: the same command with the driver's flags
-    with open(os.path.join(ROOT, "profiles", "r04_bench_driver_flags.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r05_bench_driver_flags.json")) as f:
         other = json.load(f)
     assert other["steps"] == 20 and other["warmup"] == 5
     assert other["roofline"]["frac"] != r["frac"]
@@ -57,7 +75,7 @@ def test_roofline_is_a_fraction_of_something_that_binds(line):
         r["frac"] * r["kernel_ms_avg"], rel=1e-9)
     assert other["value"] == pytest.approx(line["value"], rel=0.03)   # the pre-warm: within 3 %
     # the kernel's average duration under rocprofv3 (--kernel-trace --stats) agrees with the HIP events
-    with open(os.path.join(ROOT, "profiles", "r04_kernel_stats.csv")) as f:
+    with open(os.path.join(ROOT, "profiles", "r05_kernel_stats.csv")) as f:
         row = next(ln for ln in f if "match_lane_compact_kernel" in ln)
     avg_ns = float(row.rsplit('"', 1)[1].split(",")[3])
     assert avg_ns * 1e-6 == pytest.approx(r["kernel_ms_avg"], rel=0.03)
@@ -88,21 +106,32 @@ def test_single_gpu_anchors_of_the_eight_gpu_workloads(line):
     sh = c4["eight_shares_alone_on_this_gpu"]
     assert len(sh["ms"]) == 8 and sh["max_over_mean"] < 1.05 and sh["whole_over_slowest_share"] > 6.0
     assert len(c5["eight_shares_alone_on_this_gpu"]["scoring_kernel_ms"]) == 8
-    # ... and one multi-device matcher through the plain-C host found the cfg-4 winner
-    assert line["c_host_multi_device"]["cfg4"]["best_index"] == 80443810
+    # ... and one multi-device matcher through the plain-C host found the cfg-4 winner, ran
+    # BASELINE configs[4] with its default thresholds and measured what dealing costs
+    mh = line["c_host_multi_device"]
+    assert mh["cfg4"]["best_index"] == 80443810
+    assert mh["cfg5"]["particles"] == 1000000 and mh["cfg5"]["units"] >= mh["cfg5"]["multi_min_pose_units"]
+    assert mh["cfg5"]["max_rel_weight_diff_vs_single"] < 1e-12
+    assert "dealing_overhead" in mh and mh["dealing_overhead"]["search"]["dealt_call_us"] > 0
+    # the library the line was measured with was compiled from the tree it ran in
+    assert line["library"]["lib_matches_source"] is True
 
 
 def test_counters_belong_to_the_kernels_being_shipped(line):
-    """profiles/r04_pmc.json carries the sha256 of csrc/*.hip, *.h it was taken with: a kernel
+    """profiles/r05_pmc.json carries the sha256 of csrc/*.hip, *.h it was taken with: a kernel
     edit without a re-profile makes the committed roofline stale, and this test fail."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    with open(os.path.join(ROOT, "profiles", "r04_pmc.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r05_pmc.json")) as f:
         pmc = json.load(f)
     assert pmc["source_sha256"] == bench.source_hash()
     assert line["roofline"]["pmc_matches_source"] is True
+    # ... and so does the static instruction mix the two mixed classes are priced with
+    with open(os.path.join(ROOT, "profiles", "r05_valu_mix.json")) as f:
+        assert json.load(f)["source_sha256"] == bench.source_hash()
+    assert line["roofline"]["valu_mix_matches_source"] is True
     assert len(pmc["shares"]["cfg4"]) == 8 and len(pmc["shares"]["cfg5"]) == 8
     for sh in pmc["shares"]["cfg4"] + pmc["shares"]["cfg5"]:
         assert sh["SQ_INSTS_VALU"] > 0 and sh["SQ_BUSY_CU_CYCLES"] > 0 and "WRITE_SIZE" in sh
@@ -113,13 +142,17 @@ def test_counters_belong_to_the_kernels_being_shipped(line):
 def test_eight_rank_line_counts_as_measured():
     """`bench.py --gpus 8` (8 ranks on the box's one GPU, gloo): roofline of rank 0's share,
     CPU baseline, and the C-ABI multi-device leg -- none of them null."""
-    with open(os.path.join(ROOT, "profiles", "r04_bench_8ranks_one_gpu_gloo.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r05_bench_8ranks_one_gpu_gloo.json")) as f:
         ln = json.load(f)
     assert ln["n_gpus"] == 8 and ln["scaling"] == "strong" and "configs[3]" in ln["config"]["workload"]
     assert 0.0 < ln["roofline"]["frac"] <= 1.0
     assert ln["cpu_baseline"]["value"] > 0 and ln["cpu_baseline"]["kind"] == "port"
     assert ln["match_result"]["best_index"] == 80443810
-    assert ln["c_host_multi_device"]["devices"] == 8 and ln["c_host_multi_device"]["cfg4"]["best_index"] == 80443810
+    mh = ln["c_host_multi_device"]
+    assert mh["devices"] == 8 and mh["cfg4"]["best_index"] == 80443810
+    # eight contexts behind one handle: cfg-5 dealt out by the default thresholds, the fan-out recorded
+    assert mh["cfg5"]["variant"].startswith("multi[8]/host/") and len(mh["cfg5"]["fanout_us"]) == 8
+    assert len(mh["cfg4"]["fanout_us"]) == 8 and len(mh["cfg4"]["shares_alone_ms"]) == 8
     pf = ln["particle_filter"]
     assert 0.0 < pf["roofline"]["frac"] <= 1.0 and pf["cpu_baseline"]["value"] > 0
 
