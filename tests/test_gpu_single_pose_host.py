@@ -116,3 +116,34 @@ def test_mapper_cycle_with_host_scoring_still_launches_the_search_ahead():
         assert abs(got["score"] - exp["score"]) < 1e-12
     launched, collected = gpu.search_ahead_stats()
     assert launched >= 4 and collected == launched
+
+
+def test_a_large_device_built_grid_is_not_fetched_for_single_poses():
+    """A grid built on the DEVICE (maps of 32,768 points and more) has no host copy; fetching one
+    for a single pose would move the whole dense grid over PCIe (cfg-5: 801 x 801 cells, 31 MB) to
+    save a 30 us launch.  Above 65,536 cells the single-pose calls take the device path instead --
+    same score within the device exp's rounding -- while the cfg-3 grid (40,401 cells) is fetched
+    once and scored on the host, bit for bit the oracle's."""
+    import oracle_lib as O
+    from ndt_2d_amd import ScanMatcherNDT, synth
+    for cfg, on_host in ((3, True), (5, False)):
+        p = synth.matcher_params(cfg, laser_max_beams=100)
+        scans = synth.map_scans(cfg)
+        gpu = ScanMatcherNDT(0)
+        gpu.initialize("m", **p)
+        gpu.set_build_mode("device")
+        gpu.addScans(scans)
+        ref = O.ScanMatcherNDT()
+        ref.initialize(**p)
+        ref.addScans(scans)
+        guess, pts, _ = synth.query_scan(cfg)
+        poses = synth.particles(cfg, 64)
+        got = np.array([gpu.scorePoints(pts, q) for q in poses] + [gpu.scoreScan(guess, pts)])
+        want = np.array([ref.scorePoints(pts, q) for q in poses] + [ref.scoreScan(guess, pts)])
+        assert np.count_nonzero(want) > 3
+        if on_host:
+            assert np.array_equal(got, want), cfg
+        else:
+            assert gpu.last_variant().startswith("poses/block-per-pose"), gpu.last_variant()
+            assert float(np.max(np.abs(got - want))) < 1e-12, cfg
+        gpu.close()
