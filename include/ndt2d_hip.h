@@ -20,8 +20,16 @@
  *      src/particle_filter.cpp:78-89).  The pluginlib shim
  *      (ndt_2d_amd/plugin/scan_matcher_ndt_hip.cpp) is a thin wrapper of it.
  *
- * There is NO CPU fallback behind any compute entry point: without a usable
- * GPU they return NDT2D_ERR_NO_DEVICE / NDT2D_ERR_HIP.
+ * There is NO CPU fallback: nothing in this library exists without a usable GPU
+ * (ndt2d_create / ndt2d_matcher_create return NDT2D_ERR_NO_DEVICE / NDT2D_ERR_HIP),
+ * and every search, every batch of poses and every scan of more than 256 beams is
+ * evaluated on the GPU.  What runs on the HOST, by design and on a live matcher only
+ * (DESIGN.md 3.6): ONE pose of a short scan -- ndt2d_matcher_score_points /
+ * _score_scan as the unchanged ParticleFilter::measure calls them, once per particle
+ * (src/particle_filter.cpp:81-87) -- is scored by the calling thread from the host
+ * copy of the NDT in the reference's order (0.4 us instead of a 9 us launch + PCIe
+ * round trip; ndt2d_matcher_set_single_pose_path(m, "device", 0) turns it off), and
+ * the few candidates of a marked near-tie are rescored in the reference's arithmetic.
  */
 #ifndef NDT2D_HIP_H_
 #define NDT2D_HIP_H_

@@ -160,14 +160,15 @@ def build_all(force=False, verbose=False, jobs=4):
 
 
 HOOKS_LIB_PATH = os.path.join(_PKG, "libndt2d_hip_hooks.so")
-HOOKED_SOURCES = ["ndt2d_match_small.hip", "ndt2d_poses_compact.hip"]
+HOOKED_SOURCES = ["ndt2d_match_small.hip", "ndt2d_poses_compact.hip", "ndt2d_device.hip"]
 
 
 def build_test_hooks(verbose=False):
     """libndt2d_hip_hooks.so: the library with -DNDT2D_TEST_HOOKS in the two translation units
     whose kernels wait for their own blocks (bounded polls) -- their producers can then be told
     to withhold a `done` word (ndt2d_test_drop_done_small / _few), which is how
-    tests/test_gpu_bounded_poll.py makes the polls trip.  Test infrastructure: never loaded by
+    tests/test_gpu_bounded_poll.py makes the polls trip -- and in the device layer, where the k-th
+    launch can be made to fail (ndt2d_test_fail_launch: tests/test_gpu_multi_failure.py).  Test infrastructure: never loaded by
     the package itself (NDT2D_HIP_LIB selects it in the test's subprocess)."""
     lib = build_all(verbose=verbose)
     sha = source_sha256()

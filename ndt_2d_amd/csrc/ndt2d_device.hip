@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -159,6 +160,25 @@ int fail(ndt2d_context * h, int code, const std::string & msg)
   if (h != nullptr) h->err = msg;
   return code;
 }
+
+#ifdef NDT2D_TEST_HOOKS
+// Test builds only (libndt2d_hip_hooks.so): the k-th search launch / particle launch from now on
+// fails with NDT2D_ERR_HIP (ndt2d_test_fail_launch(k); 0: none) -- how tests/test_gpu_multi_failure.py
+// makes ONE device of a multi-device call fail while the others are in flight.
+std::atomic<int> g_test_fail_launch{0};
+bool test_launch_fails()
+{
+  int v = g_test_fail_launch.load();
+  while (v > 0)
+  {
+    if (g_test_fail_launch.compare_exchange_weak(v, v - 1)) return v == 1;
+  }
+  return false;
+}
+#define NDT2D_TEST_MAYBE_FAIL(h, what) do { if (test_launch_fails()) return fail(h, NDT2D_ERR_HIP, what ": failure injected by the test hook"); } while (0)
+#else
+#define NDT2D_TEST_MAYBE_FAIL(h, what) do {} while (0)
+#endif
 
 int fail_hip(ndt2d_context * h, hipError_t e, const char * what)
 {
@@ -1230,6 +1250,7 @@ int ndt2d_match_launch_strided(ndt2d_handle h, size_t th_first, size_t th_stride
     return fail(h, NDT2D_ERR_INVALID, "ndt2d_match_launch: bad theta range");
   }
   const size_t th_begin = th_first, th_end = th_first + th_count;
+  NDT2D_TEST_MAYBE_FAIL(h, "ndt2d_match_launch");
   NDT2D_HIP(h, hipSetDevice(h->device));
   int rc = ensure(h, h->record, NDT2D_MATCH_RECORD_DOUBLES);
   if (rc != NDT2D_OK) return rc;
@@ -1475,6 +1496,7 @@ int ndt2d_score_poses_launch(ndt2d_handle h, const double * d_poses_xyt, size_t 
 int ndt2d_pose_sums_launch(ndt2d_handle h, const double * d_poses_xyt, size_t n_poses, double * d_scores)
 {
   if (h == nullptr) return NDT2D_ERR_INVALID;
+  NDT2D_TEST_MAYBE_FAIL(h, "ndt2d_pose_sums_launch");
   NDT2D_HIP(h, hipSetDevice(h->device));
   int rc = ensure(h, h->stats, NDT2D_POSE_STATS_DOUBLES + NDT2D_PF_RESULT_DOUBLES);
   if (rc != NDT2D_OK) return rc;
@@ -2445,3 +2467,11 @@ int ndt2d_set_variant(ndt2d_handle h, const char * name)
 }
 
 }  // extern "C"
+
+#ifdef NDT2D_TEST_HOOKS
+extern "C" int ndt2d_test_fail_launch(int kth)
+{
+  g_test_fail_launch.store(kth);
+  return 0;
+}
+#endif
