@@ -39,6 +39,7 @@
 
 #include "ndt2d_device_fn.h"
 #include "ndt2d_lane_fn.h"
+#include "ndt2d_poses_fn.h"
 
 namespace ndt2d
 {
@@ -49,12 +50,10 @@ namespace
 constexpr int kQueueCap = 128;          // items per wave (ring); < 64 pending + <= 64 pushed
 constexpr uint32_t kCellBits = 26;      // queue meta word = cell index | lane << 26
 constexpr uint32_t kCellMask = (1u << kCellBits) - 1;
-// The beams are cut into kChunks contiguous chunks.  A lane's score is
-//   ((c_0 + c_1) + c_2) + ... + c_7,   c_j = in-order sum of the terms of chunk j,
-// whatever number of waves (1, 2, 4 or 8) shares the 64 poses of a group, so the
-// result does not depend on the launch geometry or on how a particle set is
-// sharded.  (It differs from the reference's single running sum by a few ulps.)
-constexpr int kChunks = 8;
+// (kChunks, ndt2d_poses_fn.h: a lane's score is the in-order sum of its chunk sums whatever
+// number of waves -- 1, 2, 4 or 8 -- shares the 64 poses of a group, so the result does not
+// depend on the launch geometry or on how a particle set is sharded.  It differs from the
+// reference's single running sum by a few ulps.)
 constexpr int kPhaseA = 2;               // beams per dense step
 constexpr size_t kLdsBudget = 160 * 1024;
 
@@ -71,29 +70,6 @@ struct CompactLayout
   static constexpr size_t kFixedDoubles =
     static_cast<size_t>(kWaves) * 8 + THREADS + 2 * kPointDoubles + static_cast<size_t>(kWaves) * kQueueCap / 2;
 };
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-// The occupancy bitmap starts at LDS offset 0 (checked at kernel entry), so a word's
-// byte offset is its LDS address: no per-look-up add of an array base.
-__device__ __forceinline__ uint32_t lds_word_at(uint32_t address)
-{
-  typedef const __attribute__((address_space(3))) uint32_t * lds_word_ptr;
-  return *reinterpret_cast<lds_word_ptr>(address);
-}
-
-constexpr uint32_t kBeamBits = 26;       // SCREEN queue word = beam index | lane << 26
-constexpr uint32_t kScreenPadFloats = 64; // f32 beam array: one screening block (32 beams) of slack
-
-// Bound (in cells) of |u_f32 - u| for the screening coordinate of a pose whose own
-// cell coordinate is within `reach` cells of the grid: the four fused operations and
-// the rounding of their FP32 inputs each contribute at most 2^-24 of the largest
-// magnitude involved; 16x that, and never less than 2^-12 cell.
-__host__ __device__ inline float screen_guard(float magnitude)
-{
-  const float g = magnitude * (16.0f / 16777216.0f);
-  return g > (1.0f / 4096.0f) ? g : (1.0f / 4096.0f);
-}
 
 // SPLIT waves share the 64 poses of a group; each takes kChunks / SPLIT chunks.
 template <int THREADS, bool POW2, bool SCREEN, bool COARSE = false>
@@ -299,10 +275,8 @@ score_poses_compact_kernel(const PosesArgs a, const uint32_t split)
         int iu, iv;  // floor, one instruction each
         asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(iu) : "v"(uv.x));
         asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(iv) : "v"(uv.y));
-        const bool inside = (static_cast<uint32_t>(iu) < g.size_x) & (static_cast<uint32_t>(iv) < g.size_y);
         Screen r;
-        r.idx = inside ? __umul24(static_cast<uint32_t>(iv) >> k_log2, bits_sx) + (static_cast<uint32_t>(iu) >> k_log2)
-                       : bits_outside;
+        r.idx = screen_bit_index(iu, iv, k_log2, bits_sx, bits_outside);
         // The coordinate carries +guard, so "within guard of a cell boundary" reads
         // fract < 2 guard, and where that is false floor() is the exact point's cell.
         // (Far outside the grid it also fires now and then: a harmless false candidate.)
@@ -960,7 +934,7 @@ hipError_t launch_poses_compact(const PosesArgs & args_in, int cus, bool screen,
     static_cast<double>(args.grid.size_x > args.grid.size_y ? args.grid.size_x : args.grid.size_y) +
     2.0 * reach_cells + 4.0;
   if (!(magnitude < 65536.0)) screen = false;   // also catches NaN / inf reach
-  if (args.grid.size_x >= (1u << 24)) screen = false;  // 24-bit multiply of the bitmap index
+  if (args.grid.size_x >= (1u << 23)) screen = false;  // signed 24-bit multiply of the bitmap index
   args.screen_guard = screen ? screen_guard(static_cast<float>(magnitude)) : 0.0f;
   // Small LDS image: 256-thread blocks, several per CU.  Large occupancy bitmap:
   // one 1024-thread block per CU shares it.
