@@ -228,6 +228,31 @@ __global__ void __launch_bounds__(256) k(double * out, Stamp * stamps, int iters
     if constexpr (OP == 56) { I2("v_xor_b32") }
     if constexpr (OP == 57) { I2("v_lshrrev_b32") }
     if constexpr (OP == 58) { I2("v_max_u32") }
+    // the particle kernel's screening pass (round 5, second table)
+    if constexpr (OP == 80) { I1("v_cvt_flr_i32_f32", "") }
+    if constexpr (OP == 81) { I1("v_fract_f32", "") }
+    if constexpr (OP == 82) { I2("v_min_f32") }
+    if constexpr (OP == 83) { I3("v_alignbit_b32") }
+    if constexpr (OP == 84) { I3("v_mad_i32_i24") }
+    if constexpr (OP == 85)
+    {
+      REP16(asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(i0) : "v"(j) : "vcc"); asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(i1) : "v"(j) : "vcc");
+            asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(i2) : "v"(j) : "vcc"); asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(i3) : "v"(j) : "vcc");
+            asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(i4) : "v"(j) : "vcc"); asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(i5) : "v"(j) : "vcc");
+            asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(i6) : "v"(j) : "vcc"); asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(i7) : "v"(j) : "vcc");)
+    }
+    if constexpr (OP == 86) { CI("v_cmp_lt_f32") }
+    if constexpr (OP == 87) { I1("v_ffbl_b32", "") }
+    if constexpr (OP == 88) { I2("v_bcnt_u32_b32") }
+    if constexpr (OP == 89) { I1("v_bfrev_b32", "") }
+    if constexpr (OP == 90)
+    {
+      // compare + add-with-carry pairs, as the screening pass shifts its "near" bits in
+      REP16(asm volatile("v_cmp_lt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(i0) : "v"(i1), "v"(j) : "vcc");
+            asm volatile("v_cmp_lt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(i2) : "v"(i3), "v"(j) : "vcc");
+            asm volatile("v_cmp_lt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(i4) : "v"(i5), "v"(j) : "vcc");
+            asm volatile("v_cmp_lt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(i6) : "v"(i7), "v"(j) : "vcc");)
+    }
     if constexpr (OP == 59) { I2("v_add_f32") }
     if constexpr (OP == 60) { MOVS("%1") }
     if constexpr (OP == 61) { MOVS("0x85ebc8a0") }
@@ -422,6 +447,17 @@ int main(int argc, char ** argv)
   run<56>("v_xor_b32", "INT32");
   run<57>("v_lshrrev_b32", "INT32");
   run<58>("v_max_u32", "INT32");
+  run<80>("v_cvt_flr_i32_f32", "CVT");
+  run<81>("v_fract_f32", "other");
+  run<82>("v_min_f32", "other");
+  run<83>("v_alignbit_b32", "other");
+  run<84>("v_mad_i32_i24", "INT32");
+  run<85>("v_addc_co_u32 vcc", "INT32");
+  run<86>("v_cmp_lt_f32 vcc", "other");
+  run<87>("v_ffbl_b32", "other");
+  run<88>("v_bcnt_u32_b32", "other");
+  run<89>("v_bfrev_b32", "other");
+  run<90>("v_cmp_lt_f32 vcc + v_addc_co_u32 vcc pairs (64 per 128)", "mix");
   run<59>("v_add_f32", "FP32");
   run<60>("v_mov_b32 from sgpr", "other");
   run<61>("v_mov_b32 literal", "other");

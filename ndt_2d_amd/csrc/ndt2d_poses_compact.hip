@@ -48,6 +48,9 @@ namespace
 {
 
 constexpr int kQueueCap = 128;          // items per wave (ring); < 64 pending + <= 64 pushed
+// The screened kernel appends a whole block of 32 beams' candidates at once (at most 64 pending +
+// what fits; a block with more takes the round-by-round path): a larger ring.
+constexpr int kQueueCapScreen = 256;
 constexpr uint32_t kCellBits = 26;      // queue meta word = cell index | lane << 26
 constexpr uint32_t kCellMask = (1u << kCellBits) - 1;
 // (kChunks, ndt2d_poses_fn.h: a lane's score is the in-order sum of its chunk sums whatever
@@ -61,14 +64,15 @@ template <int THREADS, bool SCREEN>
 struct CompactLayout
 {
   static constexpr int kWaves = THREADS / kWave;
+  static constexpr int kCap = SCREEN ? kQueueCapScreen : kQueueCap;
   // occupancy bitmap (at LDS offset 0), then doubles: [stats kWaves*8][sums THREADS]
   //          [q_px kWaves*cap][q_py kWaves*cap] (unscreened kernel only: the screened one
   //          queues {beam | lane} words)[q_meta (u32) kWaves*cap/2]; then beams (f64), beams
   //          (f32, SCREEN only) and, when several waves share a group, the chunk sums
   //          [groups][kChunks][64].
-  static constexpr size_t kPointDoubles = SCREEN ? 0 : static_cast<size_t>(kWaves) * kQueueCap;
+  static constexpr size_t kPointDoubles = SCREEN ? 0 : static_cast<size_t>(kWaves) * kCap;
   static constexpr size_t kFixedDoubles =
-    static_cast<size_t>(kWaves) * 8 + THREADS + 2 * kPointDoubles + static_cast<size_t>(kWaves) * kQueueCap / 2;
+    static_cast<size_t>(kWaves) * 8 + THREADS + 2 * kPointDoubles + static_cast<size_t>(kWaves) * kCap / 2;
 };
 
 // SPLIT waves share the 64 poses of a group; each takes kChunks / SPLIT chunks.
@@ -101,7 +105,7 @@ score_poses_compact_kernel(const PosesArgs a, const uint32_t split)
   double * q_px_all = sh_sum + THREADS;
   double * q_py_all = q_px_all + L::kPointDoubles;
   uint32_t * q_meta_all = reinterpret_cast<uint32_t *>(q_py_all + L::kPointDoubles);
-  double * lds_beams = reinterpret_cast<double *>(q_meta_all + L::kWaves * kQueueCap);
+  double * lds_beams = reinterpret_cast<double *>(q_meta_all + L::kWaves * L::kCap);
   float * lds_beams_f = reinterpret_cast<float *>(lds_beams + 2 * ((a.n_beams + 1) & ~1u));
   // chunk sums [group][chunk][lane], only used (and allocated) when split > 1
   double * sh_chunk =
@@ -121,9 +125,10 @@ score_poses_compact_kernel(const PosesArgs a, const uint32_t split)
   const uint32_t group = wave / split;          // group of 64 poses inside the block
   const uint32_t part = wave - group * split;   // which share of the chunks
   const uint32_t groups_per_block = L::kWaves / split;
-  double * q_px = q_px_all + (SCREEN ? 0 : wave * kQueueCap);
-  double * q_py = q_py_all + (SCREEN ? 0 : wave * kQueueCap);
-  uint32_t * q_meta = q_meta_all + wave * kQueueCap;
+  constexpr uint32_t kCap = static_cast<uint32_t>(L::kCap);
+  double * q_px = q_px_all + (SCREEN ? 0 : wave * kCap);
+  double * q_py = q_py_all + (SCREEN ? 0 : wave * kCap);
+  uint32_t * q_meta = q_meta_all + wave * kCap;
   double * my_sums = sh_sum + wave * kWave;
   double * my_chunks = sh_chunk + static_cast<size_t>(group) * kChunks * kWave;
   const uint64_t lanes_below = (1ull << lane) - 1ull;
@@ -144,7 +149,7 @@ score_poses_compact_kernel(const PosesArgs a, const uint32_t split)
   auto drain = [&](uint32_t head, uint32_t n) {
     if (SCREEN)
     {
-      const uint32_t slot = (head + lane) & (kQueueCap - 1);
+      const uint32_t slot = (head + lane) & (kCap - 1);
       const uint32_t meta = lane < n ? q_meta[slot] : 0u;
       const int owner = static_cast<int>(meta >> kBeamBits);
       // (all lanes take part in the shuffles)
@@ -164,7 +169,7 @@ score_poses_compact_kernel(const PosesArgs a, const uint32_t split)
     }
     else if (lane < n)
     {
-      const uint32_t slot = (head + lane) & (kQueueCap - 1);
+      const uint32_t slot = (head + lane) & (kCap - 1);
       const double px = q_px[slot];
       const double py = q_py[slot];
       const uint32_t meta = q_meta[slot];
@@ -241,7 +246,7 @@ score_poses_compact_kernel(const PosesArgs a, const uint32_t split)
           if (occ)
           {
             const uint32_t slot =
-              (head + count + static_cast<uint32_t>(__popcll(mask & lanes_below))) & (kQueueCap - 1);
+              (head + count + static_cast<uint32_t>(__popcll(mask & lanes_below))) & (kCap - 1);
             q_px[slot] = px;
             q_py[slot] = py;
             q_meta[slot] = idx | (lane << kCellBits);
@@ -251,7 +256,7 @@ score_poses_compact_kernel(const PosesArgs a, const uint32_t split)
           {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             drain(head, kWave);
-            head = (head + kWave) & (kQueueCap - 1);
+            head = (head + kWave) & (kCap - 1);
             count -= kWave;
           }
         }
@@ -296,7 +301,7 @@ score_poses_compact_kernel(const PosesArgs a, const uint32_t split)
           if (candidate)
           {
             const uint32_t slot =
-              (head + count + static_cast<uint32_t>(__popcll(mask & lanes_below))) & (kQueueCap - 1);
+              (head + count + static_cast<uint32_t>(__popcll(mask & lanes_below))) & (kCap - 1);
             q_meta[slot] = beam | (lane << kBeamBits);
           }
           count += static_cast<uint32_t>(__popcll(mask));
@@ -304,7 +309,7 @@ score_poses_compact_kernel(const PosesArgs a, const uint32_t split)
           {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             drain(head, kWave);
-            head = (head + kWave) & (kQueueCap - 1);
+            head = (head + kWave) & (kCap - 1);
             count -= kWave;
           }
         }
@@ -340,6 +345,12 @@ score_poses_compact_kernel(const PosesArgs a, const uint32_t split)
               sc[u] = screen_address(reinterpret_cast<const float2 *>(lds_beams_f)[k + b0 + u]);
               word[u] = lds_word_at((sc[u].idx >> 3) & ~3u);
             }
+            // All kScreenStep bitmap reads are issued before the first is waited for.  Left to
+            // itself the compiler consumes beam u's word right behind beam u + 1's address
+            // arithmetic -- one LDS round trip per beam on the wave's path instead of one per
+            // step (round 5: cfg-3 - 4 %, cfg-5 - 3 %; also why 2 / 8 / 16 beams per step had
+            // measured the same as 4).  Reading the next step's beams ahead as well: no gain.
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < kScreenStep; ++u)
             {
@@ -350,6 +361,38 @@ score_poses_compact_kernel(const PosesArgs a, const uint32_t split)
           }
           cmask |= __builtin_bitreverse32(near_rev);
           if (k1 - k < static_cast<uint32_t>(kScreenBlock)) cmask &= (1u << (k1 - k)) - 1u;
+          // The block's candidates are appended lane by lane (lane 0's in beam order, then lane
+          // 1's ...: a lane's pairs still enter the queue in beam order): every lane knows its
+          // first slot from a prefix sum of the lanes' counts and writes its own entries -- no
+          // ballot and no rank per entry.  (Round 5; until then the block was appended in rounds,
+          // round r = every lane's r-th candidate: the same number of loop trips, twice the
+          // instructions each and a scalar count per trip.  The rounds remain for a block that
+          // does not fit the ring whole.)
+          const uint32_t mine = static_cast<uint32_t>(__builtin_popcount(cmask));
+          const uint32_t upto = wave_inclusive_scan_u32(mine);
+          const uint32_t total = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(upto), kWave - 1));
+          if (total == 0u) continue;
+          if (count + total <= kCap)
+          {
+            uint32_t slot = head + count + (upto - mine);
+            const uint32_t tag = (lane << kBeamBits) + k;   // + bit index = beam | lane << 26
+            while (cmask != 0u)
+            {
+              const uint32_t lowest = static_cast<uint32_t>(__ffs(static_cast<int>(cmask))) - 1u;
+              q_meta[slot & (kCap - 1)] = tag + lowest;
+              ++slot;
+              cmask &= cmask - 1u;
+            }
+            count += total;
+            while (count >= kWave)
+            {
+              __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+              drain(head, kWave);
+              head = (head + kWave) & (kCap - 1);
+              count -= kWave;
+            }
+            continue;
+          }
           for (uint64_t pending = __builtin_amdgcn_ballot_w64(cmask != 0u); pending != 0ull;
                pending = __builtin_amdgcn_ballot_w64(cmask != 0u))
           {

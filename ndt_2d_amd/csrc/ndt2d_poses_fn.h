@@ -53,6 +53,20 @@ __device__ __forceinline__ uint32_t screen_bit_index(int iu, int iv, uint32_t k_
   return min(static_cast<uint32_t>(idx), bits_outside);
 }
 
+// Inclusive prefix sum of one word per lane over the wave (DPP: a Kogge-Stone scan inside
+// each row of 16 lanes, then the rows' totals handed on with row_bcast15 / row_bcast31).
+__device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v)
+{
+  int x = static_cast<int>(v);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);    // row_shr:1
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);    // row_shr:2
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);    // row_shr:4
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);    // row_shr:8
+  x += __builtin_amdgcn_update_dpp(0, x, kDppRowBcast15, 0xa, 0xf, false);
+  x += __builtin_amdgcn_update_dpp(0, x, kDppRowBcast31, 0xc, 0xf, false);
+  return static_cast<uint32_t>(x);
+}
+
 }  // namespace
 
 }  // namespace ndt2d
