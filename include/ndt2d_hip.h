@@ -460,6 +460,15 @@ const char * ndt2d_last_variant(ndt2d_handle h);
  * scoring without compaction), "compact-exact" (particle scoring with the exact
  * FP64 phase A: the bit-exactness control of the FP32 screen). */
 int ndt2d_set_variant(ndt2d_handle h, const char * name);
+/* A batch of 131,072 poses or more handed over in ordinary host memory (ndt2d_score_poses,
+ * ndt2d_pf_measure: ParticleFilter::measure of a large filter, reference
+ * src/particle_filter.cpp:78-89) is cut into pieces: piece k + 1 is uploaded on a stream of its own
+ * while piece k is scored, raw scores travel back under the piece after.  The raw scores do not
+ * depend on the cut (bit-identical), the pieces' moment sums are added in piece order.
+ * pieces: 0 = default (4), 1 = off (one upload, one launch, one download), at most 16. */
+int ndt2d_set_pipeline_pieces(ndt2d_handle h, int pieces);
+/* Pieces the last ndt2d_score_poses / ndt2d_pf_measure was cut into (1: not pipelined). */
+int ndt2d_last_pipeline_pieces(ndt2d_handle h);
 
 /* ------------------------------------------------------------------------ */
 /* (2) matcher layer: ndt_2d::ScanMatcherNDT restated over the device layer  */

@@ -135,6 +135,8 @@ SIGNATURES = {
     "ndt2d_last_launch_ms": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "ndt2d_last_variant": (C.c_char_p, [_vp]),
     "ndt2d_set_variant": (C.c_int, [_vp, C.c_char_p]),
+    "ndt2d_set_pipeline_pieces": (C.c_int, [_vp, C.c_int]),
+    "ndt2d_last_pipeline_pieces": (C.c_int, [_vp]),
     "ndt2d_matcher_create": (C.c_int, [C.POINTER(_vp), C.c_int]),
     "ndt2d_matcher_create_multi": (C.c_int, [C.POINTER(_vp), C.POINTER(C.c_int), C.c_int]),
     "ndt2d_matcher_device_count": (C.c_int, [_vp]),

@@ -40,6 +40,9 @@ struct PinnedStage
   uint64_t needed = 0;
 };
 
+// Pieces a large pose batch from host memory is cut into (see pipelined_pose_batch)
+#define NDT2D_PIPELINE_PIECES 16
+
 struct ndt2d_context
 {
   int device = 0;
@@ -120,6 +123,13 @@ struct ndt2d_context
 
   DeviceBuffer ws_match, ws_poses, record, stats, outer;
   DeviceBuffer tmp_scores, tmp_poses, tmp_noise;
+  // Pipelined pose batches (pipelined_pose_batch): the uploads of a large batch from host memory
+  // run on their own stream, piece by piece, under the scoring of the piece before
+  hipStream_t up_stream = nullptr, down_stream = nullptr;
+  hipEvent_t pipe_up[NDT2D_PIPELINE_PIECES] = {}, pipe_scored[NDT2D_PIPELINE_PIECES] = {}, pipe_idle = nullptr;
+  DeviceBuffer piece_stats;   // [pieces][8] moment sums
+  int pipeline_pieces = 0;    // 0: default (ndt2d_set_pipeline_pieces)
+  int last_pieces = 1;        // pieces of the last host pose batch (ndt2d_last_pipeline_pieces)
   DeviceBuffer near_list;   // ndt2d_match_near_best: {count, indices}
   // LaserScan conversion: ranges (floats), points, {n, rmax | n, use, rmax}
   DeviceBuffer scan_ranges, scan_points, scan_info;
@@ -565,6 +575,15 @@ int ndt2d_destroy(ndt2d_handle h)
   release(h->tmp_scores);
   release(h->tmp_poses);
   release(h->tmp_noise);
+  release(h->piece_stats);
+  for (int i = 0; i < NDT2D_PIPELINE_PIECES; ++i)
+  {
+    if (h->pipe_up[i]) (void)hipEventDestroy(h->pipe_up[i]);
+    if (h->pipe_scored[i]) (void)hipEventDestroy(h->pipe_scored[i]);
+  }
+  if (h->pipe_idle) (void)hipEventDestroy(h->pipe_idle);
+  if (h->up_stream) (void)hipStreamDestroy(h->up_stream);
+  if (h->down_stream) (void)hipStreamDestroy(h->down_stream);
   release(h->near_list);
   release(h->scan_ranges);
   release(h->scan_points);
@@ -1706,6 +1725,146 @@ int ndt2d_score_fetch(ndt2d_handle h, double * h_scores)
   return rc;
 }
 
+// A LARGE batch of poses from (pageable or pinned) host memory -- ParticleFilter::measure of a
+// big filter through the drop-in boundary (reference src/particle_filter.cpp:78-89; BASELINE
+// configs[4]: 10^6 particles = 24 MB in, 8 MB out): the batch is cut into pieces, piece k + 1 is
+// uploaded on a stream of its own while piece k is scored, and (scores only) piece k - 1 travels
+// back on a third.  Sharding a pose set leaves every raw score bit-identical (a lane's score
+// does not depend on the launch geometry), the pieces' moment sums are added in piece order.
+//   measure: weights = scores normalised by the total, h_out = the statistics (updateStatistics)
+//   else:    h_scores = raw scores, h_stats (optional) = the eight moment sums
+constexpr size_t kPipelineFromPoses = 1u << 17;   // 3 MB of poses: below, the pieces cost more than they hide
+
+static int pipeline_pieces_for(const ndt2d_context * h, size_t n_poses)
+{
+  if (h->pipeline_pieces == 1 || n_poses < kPipelineFromPoses) return 1;
+  int pieces = h->pipeline_pieces > 0 ? h->pipeline_pieces : 4;
+  // (no piece below a quarter of the threshold)
+  while (pieces > 1 && n_poses / static_cast<size_t>(pieces) < kPipelineFromPoses / 4) --pieces;
+  return pieces > NDT2D_PIPELINE_PIECES ? NDT2D_PIPELINE_PIECES : pieces;
+}
+
+static int pipelined_pose_batch(ndt2d_context * h, const double * h_poses_xyt, size_t n_poses, int pieces,
+                                bool measure, double * h_scores, double * h_stats_or_out)
+{
+  int rc = ensure(h, h->tmp_poses, 3 * n_poses);
+  if (rc != NDT2D_OK) return rc;
+  rc = ensure(h, h->tmp_scores, n_poses);
+  if (rc != NDT2D_OK) return rc;
+  rc = ensure(h, h->stats, NDT2D_POSE_STATS_DOUBLES + NDT2D_PF_RESULT_DOUBLES);
+  if (rc != NDT2D_OK) return rc;
+  rc = ensure(h, h->piece_stats, static_cast<size_t>(NDT2D_PIPELINE_PIECES) * NDT2D_POSE_STATS_DOUBLES);
+  if (rc != NDT2D_OK) return rc;
+  if (h->up_stream == nullptr) NDT2D_HIP(h, hipStreamCreateWithFlags(&h->up_stream, hipStreamNonBlocking));
+  if (h->down_stream == nullptr) NDT2D_HIP(h, hipStreamCreateWithFlags(&h->down_stream, hipStreamNonBlocking));
+  if (h->pipe_idle == nullptr) NDT2D_HIP(h, hipEventCreateWithFlags(&h->pipe_idle, hipEventDisableTiming));
+  for (int k = 0; k < pieces; ++k)
+  {
+    if (h->pipe_up[k] == nullptr) NDT2D_HIP(h, hipEventCreateWithFlags(&h->pipe_up[k], hipEventDisableTiming));
+    if (h->pipe_scored[k] == nullptr) NDT2D_HIP(h, hipEventCreateWithFlags(&h->pipe_scored[k], hipEventDisableTiming));
+  }
+  // Whatever fails from here on, nothing of this call may still be reading the caller's poses
+  // or writing the caller's scores when it returns.
+  auto drain = [&](int code) -> int {
+    (void)hipStreamSynchronize(h->up_stream);
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipStreamSynchronize(h->down_stream);
+    return code;
+  };
+  // (what the main stream still has queued may read the staging buffers: the uploads wait for it)
+  NDT2D_HIP(h, hipEventRecord(h->pipe_idle, h->stream));
+  NDT2D_HIP(h, hipStreamWaitEvent(h->up_stream, h->pipe_idle, 0));
+  const bool want_sums = measure || h_stats_or_out != nullptr;
+  // Equal pieces of whole groups of 64 poses.  (A smaller first piece -- nothing runs under its
+  // upload -- was measured and lost: the batched kernel's blocks walk their groups in rounds, and
+  // pieces of 1/7 and 2/7 of cfg-5 fall between two round counts, 240 us for what should take 165.)
+  // No event pairs around the pieces' kernels (ndt2d_launch_history_ms): a pair costs the stream
+  // 11 us per piece.
+  const size_t unit = ((n_poses + static_cast<size_t>(pieces) - 1) / static_cast<size_t>(pieces) + 63) / 64 * 64;
+  const bool timing_was = h->timing;
+  h->timing = false;
+  auto finish = [&](int code) -> int {
+    h->timing = timing_was;
+    return code == NDT2D_OK ? code : drain(code);
+  };
+  int n_pieces = 0;
+  hipError_t e = hipSuccess;
+  size_t prev_off = 0, prev_cnt = 0;
+  // raw scores: piece k - 1 travels back once piece k has been queued behind it (a download
+  // into ordinary host memory holds the calling thread until the piece has been scored)
+  auto download = [&](size_t off, size_t cnt, int k) -> hipError_t {
+    hipError_t de = hipStreamWaitEvent(h->down_stream, h->pipe_scored[k], 0);
+    if (de == hipSuccess)
+    {
+      de = hipMemcpyAsync(h_scores + off, h->tmp_scores.ptr + off, cnt * sizeof(double), hipMemcpyDeviceToHost,
+                          h->down_stream);
+    }
+    return de;
+  };
+  for (size_t off = 0; off < n_poses; ++n_pieces)
+  {
+    const size_t cnt = n_poses - off < unit ? n_poses - off : unit;
+    const int k = n_pieces;
+    e = hipMemcpyAsync(h->tmp_poses.ptr + 3 * off, h_poses_xyt + 3 * off, 3 * cnt * sizeof(double),
+                       hipMemcpyHostToDevice, h->up_stream);
+    if (e == hipSuccess) e = hipEventRecord(h->pipe_up[k], h->up_stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(h->stream, h->pipe_up[k], 0);
+    if (e != hipSuccess) return finish(fail_hip(h, e, "pipelined_pose_batch: upload"));
+    rc = score_poses_launch_impl(h, h->tmp_poses.ptr + 3 * off, cnt, h->tmp_scores.ptr + off,
+                                 want_sums ? h->piece_stats.ptr + static_cast<size_t>(k) * NDT2D_POSE_STATS_DOUBLES : nullptr,
+                                 false);
+    if (rc != NDT2D_OK) return finish(rc);
+    if (!measure)
+    {
+      e = hipEventRecord(h->pipe_scored[k], h->stream);
+      if (e == hipSuccess && k > 0) e = download(prev_off, prev_cnt, k - 1);
+      if (e != hipSuccess) return finish(fail_hip(h, e, "pipelined_pose_batch: download"));
+      prev_off = off;
+      prev_cnt = cnt;
+    }
+    off += cnt;
+  }
+  if (!measure)
+  {
+    e = download(prev_off, prev_cnt, n_pieces - 1);
+    if (e != hipSuccess) return finish(fail_hip(h, e, "pipelined_pose_batch: download"));
+  }
+  if (want_sums)
+  {
+    e = ndt2d::launch_sum_moment_rows(h->piece_stats.ptr, static_cast<uint32_t>(n_pieces), h->stats.ptr, h->stream);
+    if (e != hipSuccess) return finish(fail_hip(h, e, "launch_sum_moment_rows"));
+  }
+  if (measure)
+  {
+    double * d_out = h->stats.ptr + NDT2D_POSE_STATS_DOUBLES;
+    rc = ndt2d_pf_finalize_launch(h, h->tmp_poses.ptr, n_poses, h->tmp_scores.ptr, h->stats.ptr, d_out);
+    if (rc != NDT2D_OK) return finish(rc);
+    e = hipMemcpyAsync(h_scores, h->tmp_scores.ptr, n_poses * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess)
+    {
+      e = hipMemcpyAsync(h_stats_or_out, d_out, NDT2D_PF_RESULT_DOUBLES * sizeof(double), hipMemcpyDeviceToHost,
+                         h->stream);
+    }
+  }
+  else if (h_stats_or_out != nullptr)
+  {
+    e = hipMemcpyAsync(h_stats_or_out, h->stats.ptr, NDT2D_POSE_STATS_DOUBLES * sizeof(double),
+                       hipMemcpyDeviceToHost, h->stream);
+  }
+  if (e != hipSuccess) return finish(fail_hip(h, e, "pipelined_pose_batch: results"));
+  e = hipStreamSynchronize(h->down_stream);
+  if (e != hipSuccess) return finish(fail_hip(h, e, "hipStreamSynchronize"));
+  {
+    const uint64_t q_ = h->queued;
+    e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) return finish(fail_hip(h, e, "hipStreamSynchronize"));
+    if (h->reached < q_) h->reached = q_;
+  }
+  h->timing = timing_was;
+  h->last_pieces = n_pieces;
+  return NDT2D_OK;
+}
+
 int ndt2d_score_poses(ndt2d_handle h, const double * h_poses_xyt, size_t n_poses,
                       double * h_scores, double * h_stats)
 {
@@ -1741,6 +1900,13 @@ int ndt2d_score_poses(ndt2d_handle h, const double * h_poses_xyt, size_t n_poses
   // poses are read over PCIe once, the scores written once, no copy is queued.
   const double * d_poses = device_view(h_poses_xyt);
   double * d_scores = device_view(h_scores);
+  h->last_pieces = 1;
+  if (d_poses == nullptr && d_scores == nullptr)
+  {
+    // a large batch from ordinary host memory: uploads, scoring and downloads piece by piece, overlapped
+    const int pieces = pipeline_pieces_for(h, n_poses);
+    if (pieces > 1) return pipelined_pose_batch(h, h_poses_xyt, n_poses, pieces, false, h_scores, h_stats);
+  }
   if (d_poses == nullptr)
   {
     rc = ensure(h, h->tmp_poses, 3 * n_poses);
@@ -1812,6 +1978,12 @@ int ndt2d_pf_measure(ndt2d_handle h, const double * h_poses_xyt, size_t n_poses,
     {
       return run_few(h, nullptr, h->n_beams, h_poses_xyt, n_poses, true, h_weights, h_out);
     }
+  }
+  h->last_pieces = 1;
+  {
+    // a large filter: the particles go up piece by piece under the scoring of the piece before
+    const int pieces = pipeline_pieces_for(h, n_poses);
+    if (pieces > 1) return pipelined_pose_batch(h, h_poses_xyt, n_poses, pieces, true, h_weights, h_out);
   }
   int rc = ensure(h, h->tmp_poses, 3 * n_poses);
   if (rc != NDT2D_OK) return rc;
@@ -2444,6 +2616,18 @@ int ndt2d_launch_history_ms(ndt2d_handle h, float * ms_out, size_t capacity, siz
 }
 
 const char * ndt2d_last_variant(ndt2d_handle h) { return h != nullptr ? h->last_variant : ""; }
+
+int ndt2d_set_pipeline_pieces(ndt2d_handle h, int pieces)
+{
+  if (h == nullptr || pieces < 0 || pieces > NDT2D_PIPELINE_PIECES) return NDT2D_ERR_INVALID;
+  h->pipeline_pieces = pieces;
+  return NDT2D_OK;
+}
+
+int ndt2d_last_pipeline_pieces(ndt2d_handle h)
+{
+  return h == nullptr ? 0 : h->last_pieces;
+}
 
 int ndt2d_set_variant(ndt2d_handle h, const char * name)
 {

@@ -235,6 +235,10 @@ hipError_t launch_score_poses(const PosesArgs & args, double * workspace, double
                               LaunchInfo * info, double * host_sums = nullptr,
                               unsigned long long host_seq = 0);
 
+// out[k] = ((rows[0][k] + rows[1][k]) + rows[2][k]) + ... for the 8 moment sums of n_rows pieces of
+// a particle set scored piece by piece (the pipelined pose batches of ndt2d_device.hip).
+hipError_t launch_sum_moment_rows(const double * rows, uint32_t n_rows, double * out, hipStream_t stream);
+
 // The moment sums of updateStatistics as a kernel argument (by_value != 0) -- see launch_pf_finalize.
 struct PoseTotals
 {

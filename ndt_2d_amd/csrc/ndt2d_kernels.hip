@@ -454,6 +454,14 @@ __global__ void __launch_bounds__(256) poses_reduce_kernel(const double * partia
   }
 }
 
+__global__ void __launch_bounds__(64) sum_moment_rows_kernel(const double * rows, uint32_t n_rows, double * out)
+{
+  if (threadIdx.x >= 8) return;
+  double v = rows[threadIdx.x];
+  for (uint32_t r = 1; r < n_rows; ++r) v += rows[static_cast<size_t>(r) * 8 + threadIdx.x];
+  out[threadIdx.x] = v;
+}
+
 constexpr uint32_t kMaxMatchBlocks = 512;
 constexpr uint32_t kMaxPosesBlocks = 4096;
 constexpr size_t kLdsPerCu = 160 * 1024;
@@ -920,6 +928,12 @@ hipError_t launch_pf_finalize(const double * poses_xyt, uint64_t n_poses, double
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(pf_finalize_reduce_kernel, dim3(1), dim3(256), 0, stream, workspace, blocks,
                      stats, totals, out, host_out);
+  return hipGetLastError();
+}
+
+hipError_t launch_sum_moment_rows(const double * rows, uint32_t n_rows, double * out, hipStream_t stream)
+{
+  hipLaunchKernelGGL(sum_moment_rows_kernel, dim3(1), dim3(64), 0, stream, rows, n_rows, out);
   return hipGetLastError();
 }
 

@@ -512,6 +512,16 @@ class ScanMatcherNDT:
         v = self._L.ndt2d_last_variant(self.device_handle)
         return v.decode() if v else ""
 
+    def set_pipeline_pieces(self, pieces):
+        """ndt2d_set_pipeline_pieces: how a large pose batch from host memory is cut into
+        overlapped upload / scoring / download pieces (0 default, 1 off)."""
+        rc = self._L.ndt2d_set_pipeline_pieces(self.device_handle, int(pieces))
+        if rc != 0:
+            raise Ndt2dError(rc, "ndt2d_set_pipeline_pieces")
+
+    def last_pipeline_pieces(self):
+        return int(self._L.ndt2d_last_pipeline_pieces(self.device_handle))
+
     def set_variant(self, name):
         rc = self._L.ndt2d_set_variant(self.device_handle, name.encode())
         if rc != _capi.OK:
