@@ -141,12 +141,15 @@ __device__ __forceinline__ void small_final_reduction(const MatchArgs & a, const
   bool gave_up = false;
   for (uint32_t r = threadIdx.x; r < n_records; r += n_threads)
   {
-    // Forward progress: this block is the launch's LAST (index search_blocks), and workgroups are
-    // dispatched in index order on this hardware, so every producer is resident or done before
-    // the first poll -- an assumption of the design (HIP does not promise it; kSmallMaxItems keeps
-    // the launch far below the chip's resident-block capacity).  Should it ever fail, the poll
-    // gives up after a second or two: the block then publishes "gave up" instead of a record
-    // (below) and the host's wait returns NDT2D_ERR_HIP for this call -- no trap.
+    // Forward progress does NOT rest on the order workgroups are dispatched in (which HIP leaves
+    // undefined): the producers wait for nothing, and this block holds ONE of the chip's block
+    // slots (hundreds of this kernel's size) while it polls -- whatever the order, the producers still
+    // pending are dispatched into the others and finish.  What the index order this hardware
+    // does dispatch in buys is efficiency only: the reducer (index search_blocks, the last) takes
+    // its slot when every producer is resident or done, not before.  The bound below is for what
+    // cannot be reasoned away (another process holding the chip for seconds): the block then
+    // publishes "gave up" instead of a record and the host's wait returns NDT2D_ERR_HIP for this
+    // call -- no trap, the context stays usable.
     uint32_t polls = 0;
     while (__hip_atomic_load(fin.done + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != fin.seq)
     {

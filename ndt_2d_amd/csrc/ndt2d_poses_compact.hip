@@ -548,9 +548,9 @@ __global__ void __launch_bounds__(kFewThreads) score_few_kernel(const PosesArgs 
     bool gave_up = false;
     for (uint32_t k = threadIdx.x; k < n && !gave_up; k += kFewThreads)
     {
-      // (the last block of the launch, dispatched after all the others -- the assumption and the
-      // bounded poll of ndt2d_match_small.hip's reducing block: kFewPosesMax keeps the launch far
-      // below the chip's resident-block capacity)
+      // (forward progress as for ndt2d_match_small.hip's reducing block: the poses' blocks wait for
+      // nothing and this block holds one slot while it polls, so the dispatch order is a matter
+      // of efficiency, not of correctness; the poll is bounded all the same)
       uint32_t polls = 0;
       while (__hip_atomic_load(f.done + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != f.seq)
       {

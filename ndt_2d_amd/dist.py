@@ -118,7 +118,7 @@ def match_scan_sharded(matcher, scan_pose, points, rank, world, dist, pose=None)
     rec = np.concatenate([[best_score, -1.0 if best_index is None else float(best_index) + (0.5 if marked else 0.0)],
                           acc])
     if marked:
-        # a rival within 1e-9 of the winner: every rank settles it for itself on the whole lattice
+        # a rival within the near-tie tolerance (2^-36 relative) of the winner: every rank settles it for itself on the whole lattice
         # (same data, same arithmetic, same verdict -- no further exchange)
         rec = matcher.settle_near_tie(scan_pose, rec)
         best_index = int(rec[1]) if rec[1] >= 0.0 else None

@@ -302,7 +302,7 @@ class ScanMatcherNDT:
         return a.value, b.value
 
     def set_adjudication(self, enabled):
-        """Near-tie adjudication of matchScan (on by default): candidates within 1e-11 (relative) of the
+        """Near-tie adjudication of matchScan (on by default): candidates within 2^-36 (1.5e-11, relative) of the
         best are rescored on the host with the reference's arithmetic and its first-wins rule."""
         self._check(self._L.ndt2d_matcher_set_adjudication(self._m, 1 if enabled else 0), "set_adjudication")
 
