@@ -1133,7 +1133,7 @@ def particle_bench_sharded(matcher_cls, synth, shard, torch, dist, dev, dev_inde
     table = torch.zeros((world, shard.POSE_STATS), dtype=torch.float64, device=dev)
     d_sum = torch.zeros(shard.POSE_STATS, dtype=torch.float64, device=dev)
     d_out = torch.zeros(8, dtype=torch.float64, device=dev)
-    d_var = torch.zeros(1, dtype=torch.float64, device=dev)
+    d_var = d_out[7:8]          # the theta-variance increment where pf_finalize leaves it
 
     def step():
         table.zero_()
@@ -1145,9 +1145,8 @@ def particle_bench_sharded(matcher_cls, synth, shard, torch, dist, dev, dev_inde
         if n_local:
             m.pf_finalize_launch(d_parts.data_ptr(), n_local, d_w.data_ptr(), d_sum.data_ptr(),
                                  d_out.data_ptr())
-        d_var.copy_(d_out[7:8])
         if all_reduce is not None:
-            all_reduce(d_var, dist.ReduceOp.SUM)                # theta variance, second pass
+            all_reduce(d_var, dist.ReduceOp.SUM)                # theta variance, second pass (in place in d_out)
 
     for _ in range(warmup):
         step()
