@@ -1876,6 +1876,7 @@ int ndt2d_score_poses(ndt2d_handle h, const double * h_poses_xyt, size_t n_poses
   if (!h->has_grid) return fail(h, NDT2D_ERR_NO_GRID, "ndt2d_score_poses: no grid");
   if (h->n_beams == 0) return fail(h, NDT2D_ERR_STATE, "ndt2d_score_poses: set_beams first");
   NDT2D_HIP(h, hipSetDevice(h->device));
+  h->last_pieces = 1;
   int rc;
 
   // A small batch (scorePoints / scoreScan: ONE pose; a particle filter of the node's
@@ -1900,7 +1901,6 @@ int ndt2d_score_poses(ndt2d_handle h, const double * h_poses_xyt, size_t n_poses
   // poses are read over PCIe once, the scores written once, no copy is queued.
   const double * d_poses = device_view(h_poses_xyt);
   double * d_scores = device_view(h_scores);
-  h->last_pieces = 1;
   if (d_poses == nullptr && d_scores == nullptr)
   {
     // a large batch from ordinary host memory: uploads, scoring and downloads piece by piece, overlapped
@@ -1967,6 +1967,7 @@ int ndt2d_pf_measure(ndt2d_handle h, const double * h_poses_xyt, size_t n_poses,
   if (!h->has_grid) return fail(h, NDT2D_ERR_NO_GRID, "ndt2d_pf_measure: no grid");
   if (h->n_beams == 0) return fail(h, NDT2D_ERR_STATE, "ndt2d_pf_measure: set_beams first");
   NDT2D_HIP(h, hipSetDevice(h->device));
+  h->last_pieces = 1;
   if (n_poses <= ndt2d::kFewPosesMax && h->force_variant == ndt2d::kVariantAuto && !h->batched_only)
   {
     // a filter of the node's size (<= 500 particles by default): scoring and
@@ -1979,7 +1980,6 @@ int ndt2d_pf_measure(ndt2d_handle h, const double * h_poses_xyt, size_t n_poses,
       return run_few(h, nullptr, h->n_beams, h_poses_xyt, n_poses, true, h_weights, h_out);
     }
   }
-  h->last_pieces = 1;
   {
     // a large filter: the particles go up piece by piece under the scoring of the piece before
     const int pieces = pipeline_pieces_for(h, n_poses);
