@@ -111,10 +111,7 @@ __global__ void __launch_bounds__(256) cells_kernel(const BuildArgs a, const uin
   {
     // Cell::addPoint in the reference's point order (src/ndt_model.cpp:50-63)
     const uint32_t b = seg_begin[cell], e = seg_end[cell];
-    for (uint32_t j = b; j < e; ++j)
-    {
-      const size_t i = sorted_vals[j];
-      const double x = a.world_xy[2 * i], y = a.world_xy[2 * i + 1];
+    auto add_point = [&](double x, double y) {
       const double n1 = n + 1;
       mean_x = (mean_x * n + x) / n1;
       mean_y = (mean_y * n + y) / n1;
@@ -122,6 +119,27 @@ __global__ void __launch_bounds__(256) cells_kernel(const BuildArgs a, const uin
       cxy = (cxy * n + x * y) / n1;
       cyy = (cyy * n + y * y) / n1;
       n += 1;
+    };
+    // The recurrence is one dependent chain per cell (a wall cell seen from hundreds of scans holds
+    // thousands of points): its two gathers per point -- the point's index, then the point -- are
+    // taken off that chain, kBatch points' worth in flight ahead of the arithmetic.
+    constexpr uint32_t kBatch = 8;
+    uint32_t j = b;
+    for (; j + kBatch <= e; j += kBatch)
+    {
+      size_t idx[kBatch];
+      double2 p[kBatch];
+#pragma unroll
+      for (uint32_t u = 0; u < kBatch; ++u) idx[u] = sorted_vals[j + u];
+#pragma unroll
+      for (uint32_t u = 0; u < kBatch; ++u) p[u] = reinterpret_cast<const double2 *>(a.world_xy)[idx[u]];
+#pragma unroll
+      for (uint32_t u = 0; u < kBatch; ++u) add_point(p[u].x, p[u].y);
+    }
+    for (; j < e; ++j)
+    {
+      const size_t i = sorted_vals[j];
+      add_point(a.world_xy[2 * i], a.world_xy[2 * i + 1]);
     }
     // Cell::compute (src/ndt_model.cpp:65-103)
     if (!(n < 3))
