@@ -9,7 +9,7 @@
 //   1. points_kernel   one thread per point: transform by its scan's pose
 //                      (:139-141, cos/sin from the host libm as in :135-136),
 //                      NDT::getIndex (:203-218) -> sort key = cell (ncell = outside)
-//   2. stable radix sort of (cell, point index)  [hipcub::DeviceRadixSort]: points
+//   2. stable radix sort of (cell, point index)  [rocprim::radix_sort_pairs, onesweep]: points
 //                      of one cell stay in their original order
 //   3. segments_kernel first / one-past-last sorted position of every cell
 //   4. cells_kernel    one thread per cell walks its points in order: addPoint,
@@ -21,7 +21,8 @@
 //
 // Everything is IEEE double with the reference's operation order (file compiled
 // with -ffp-contract=off; '/' and sqrt are correctly rounded).
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include "ndt2d_eigen2.h"
 #include "ndt2d_lane_fn.h"
@@ -409,13 +410,20 @@ int key_bits(uint32_t ncell)
 
 }  // namespace
 
+// The library's radix sort hands anything below a million keys to its merge sort -- 21 launches
+// of ~6 us each for the 378,000 points of cfg-3's map, a third of the whole device build.  With the
+// limit lowered the one-sweep radix sort takes them: a histogram, its scan and one pass per 8 key
+// bits (the keys are cell indices: 16 bits at cfg-3, 20 at cfg-5).  Both are stable.
+using BuildSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                                   rocprim::default_config, 16384>;
+
 size_t build_sort_temp_bytes(uint32_t n_points, uint32_t ncell)
 {
   size_t bytes = 0;
-  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, static_cast<const uint32_t *>(nullptr),
-                                     static_cast<uint32_t *>(nullptr),
-                                     static_cast<const uint32_t *>(nullptr),
-                                     static_cast<uint32_t *>(nullptr), n_points, 0, key_bits(ncell));
+  (void)rocprim::radix_sort_pairs<BuildSortConfig>(nullptr, bytes, static_cast<const uint32_t *>(nullptr),
+                                                   static_cast<uint32_t *>(nullptr),
+                                                   static_cast<const uint32_t *>(nullptr),
+                                                   static_cast<uint32_t *>(nullptr), n_points, 0u, key_bits(ncell));
   return bytes;
 }
 
@@ -432,8 +440,8 @@ hipError_t launch_build_grid(const BuildArgs & a, hipStream_t stream)
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     size_t temp = a.sort_temp_bytes;
-    e = hipcub::DeviceRadixSort::SortPairs(a.sort_temp, temp, a.keys_in, a.keys_out, a.vals_in,
-                                           a.vals_out, a.n_points, 0, key_bits(ncell), stream);
+    e = rocprim::radix_sort_pairs<BuildSortConfig>(a.sort_temp, temp, a.keys_in, a.keys_out, a.vals_in,
+                                                   a.vals_out, a.n_points, 0u, key_bits(ncell), stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(segments_kernel, dim3(pb), dim3(256), 0, stream, a.keys_out, a.n_points,
                        a.seg_begin, a.seg_begin + (ncell + 1));
