@@ -12,7 +12,7 @@
 //   2. stable radix sort of (cell, point index)  [rocprim::radix_sort_pairs, onesweep]: points
 //                      of one cell stay in their original order
 //   3. segments_kernel first / one-past-last sorted position of every cell
-//   4. cells_kernel    one thread per cell walks its points in order: addPoint,
+//   4. cell_sums_kernel + cells_kernel   a lane per (cell, quantity) walks the cell's points in order: addPoint,
 //                      then Cell::compute (:65-103), and writes the cell in all the
 //                      layouts the scorers read (cells6, LDS image, 64-byte gather
 //                      copy)
@@ -99,6 +99,54 @@ __device__ __forceinline__ void write_scorer_record(uint32_t ncell, uint32_t cel
   if (lane == 1 && word + 1 < n_words) occ_bits[word + 1] = static_cast<uint32_t>(mask >> 32);
 }
 
+// Cell::addPoint in the reference's point order (src/ndt_model.cpp:50-63): five recurrences per
+// cell -- the mean's two components and the upper triangle of the second moment, each
+// v = (v * n + t) / (n + 1) with its own t -- that share nothing but n.  The recurrence is a
+// chain (a wall cell seen from hundreds of scans holds hundreds of points) and with a lane per
+// CELL that lane issues all five, ~135 FP64 instructions per point, less than one wave to a SIMD.
+// So: a lane per (cell, quantity), eight lanes to a cell of which five work -- the same
+// arithmetic on every quantity, a fifth of the instructions on the longest chain.  The sums
+// are left in cells6[cell] = {mean_x, mean_y, cxx, cxy, cyy, n} for cells_kernel below.
+__global__ void __launch_bounds__(256) cell_sums_kernel(const BuildArgs a, const uint32_t * sorted_vals,
+                                                        const uint32_t * seg_begin,
+                                                        const uint32_t * seg_end)
+{
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t cell = t >> 3, q = t & 7u;
+  if (cell >= a.grid.ncell || q >= 5u) return;
+  const uint32_t b = seg_begin[cell], e = seg_end[cell];
+  const double2 * xy = reinterpret_cast<const double2 *>(a.world_xy);
+  double n = 0.0, v = 0.0;
+  auto add_point = [&](double2 p) {
+    const double term = q == 0u ? p.x : q == 1u ? p.y : q == 2u ? p.x * p.x : q == 3u ? p.x * p.y : p.y * p.y;
+    v = (v * n + term) / (n + 1);
+    n += 1;
+  };
+  // (the two gathers per point -- its index, then the point -- eight points ahead of the chain)
+  constexpr uint32_t kBatch = 8;
+  uint32_t j = b;
+  for (; j + kBatch <= e; j += kBatch)
+  {
+    uint32_t idx[kBatch];
+    double2 p[kBatch];
+#pragma unroll
+    for (uint32_t u = 0; u < kBatch; ++u) idx[u] = sorted_vals[j + u];
+#pragma unroll
+    for (uint32_t u = 0; u < kBatch; ++u) p[u] = xy[idx[u]];
+#pragma unroll
+    for (uint32_t u = 0; u < kBatch; ++u) add_point(p[u]);
+  }
+  for (; j < e; ++j) add_point(xy[sorted_vals[j]]);
+  double * c6 = a.cells6 + static_cast<size_t>(cell) * 6;
+  c6[q] = v;
+  if (q == 0u) c6[5] = n;
+}
+
+// Cell::compute (src/ndt_model.cpp:65-103), a lane per cell.  OWN_SUMS: the lane also walks its
+// cell's points itself (all five recurrences: the form for sparse grids -- cfg-5's 641,601 cells
+// hold 1.7 points each on average, and eight lanes per cell would be five million threads with
+// nothing to do); otherwise from the sums cell_sums_kernel left in cells6.
+template <bool OWN_SUMS>
 __global__ void __launch_bounds__(256) cells_kernel(const BuildArgs a, const uint32_t * sorted_vals,
                                                     const uint32_t * seg_begin,
                                                     const uint32_t * seg_end)
@@ -110,37 +158,43 @@ __global__ void __launch_bounds__(256) cells_kernel(const BuildArgs a, const uin
   double ixx = 0.0, ixy = 0.0, iyy = 0.0;
   if (cell < a.grid.ncell)
   {
-    // Cell::addPoint in the reference's point order (src/ndt_model.cpp:50-63)
-    const uint32_t b = seg_begin[cell], e = seg_end[cell];
-    auto add_point = [&](double x, double y) {
-      const double n1 = n + 1;
-      mean_x = (mean_x * n + x) / n1;
-      mean_y = (mean_y * n + y) / n1;
-      cxx = (cxx * n + x * x) / n1;
-      cxy = (cxy * n + x * y) / n1;
-      cyy = (cyy * n + y * y) / n1;
-      n += 1;
-    };
-    // The recurrence is one dependent chain per cell (a wall cell seen from hundreds of scans holds
-    // thousands of points): its two gathers per point -- the point's index, then the point -- are
-    // taken off that chain, kBatch points' worth in flight ahead of the arithmetic.
-    constexpr uint32_t kBatch = 8;
-    uint32_t j = b;
-    for (; j + kBatch <= e; j += kBatch)
+    if (OWN_SUMS)
     {
-      size_t idx[kBatch];
-      double2 p[kBatch];
+      const uint32_t b = seg_begin[cell], e = seg_end[cell];
+      const double2 * xy = reinterpret_cast<const double2 *>(a.world_xy);
+      auto add_point = [&](double2 p) {
+        const double n1 = n + 1;
+        mean_x = (mean_x * n + p.x) / n1;
+        mean_y = (mean_y * n + p.y) / n1;
+        cxx = (cxx * n + p.x * p.x) / n1;
+        cxy = (cxy * n + p.x * p.y) / n1;
+        cyy = (cyy * n + p.y * p.y) / n1;
+        n += 1;
+      };
+      constexpr uint32_t kBatch = 8;
+      uint32_t j = b;
+      for (; j + kBatch <= e; j += kBatch)
+      {
+        uint32_t idx[kBatch];
+        double2 p[kBatch];
 #pragma unroll
-      for (uint32_t u = 0; u < kBatch; ++u) idx[u] = sorted_vals[j + u];
+        for (uint32_t u = 0; u < kBatch; ++u) idx[u] = sorted_vals[j + u];
 #pragma unroll
-      for (uint32_t u = 0; u < kBatch; ++u) p[u] = reinterpret_cast<const double2 *>(a.world_xy)[idx[u]];
+        for (uint32_t u = 0; u < kBatch; ++u) p[u] = xy[idx[u]];
 #pragma unroll
-      for (uint32_t u = 0; u < kBatch; ++u) add_point(p[u].x, p[u].y);
+        for (uint32_t u = 0; u < kBatch; ++u) add_point(p[u]);
+      }
+      for (; j < e; ++j) add_point(xy[sorted_vals[j]]);
     }
-    for (; j < e; ++j)
+    else
     {
-      const size_t i = sorted_vals[j];
-      add_point(a.world_xy[2 * i], a.world_xy[2 * i + 1]);
+      const double * s6 = a.cells6 + static_cast<size_t>(cell) * 6;
+      mean_x = s6[0];
+      mean_y = s6[1];
+      cxx = s6[2];
+      cxy = s6[3];
+      cyy = s6[4];
+      n = s6[5];
     }
     // Cell::compute (src/ndt_model.cpp:65-103)
     if (!(n < 3))
@@ -448,8 +502,22 @@ hipError_t launch_build_grid(const BuildArgs & a, hipStream_t stream)
     e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(cells_kernel, dim3((ncell + 1 + 255) / 256), dim3(256), 0, stream, a,
-                     a.vals_out, a.seg_begin, a.seg_begin + (ncell + 1));
+  // a lane per (cell, quantity) where cells hold points by the dozen (local and loop-closure maps,
+  // cfg-3: 9 per cell on average, hundreds in a wall's cells); a lane per cell on sparse grids
+  if (static_cast<uint64_t>(a.n_points) >= 4ull * ncell)
+  {
+    hipLaunchKernelGGL(cell_sums_kernel, dim3((ncell * 8 + 255) / 256), dim3(256), 0, stream, a,
+                       a.vals_out, a.seg_begin, a.seg_begin + (ncell + 1));
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(cells_kernel<false>, dim3((ncell + 1 + 255) / 256), dim3(256), 0, stream, a,
+                       a.vals_out, a.seg_begin, a.seg_begin + (ncell + 1));
+  }
+  else
+  {
+    hipLaunchKernelGGL(cells_kernel<true>, dim3((ncell + 1 + 255) / 256), dim3(256), 0, stream, a,
+                       a.vals_out, a.seg_begin, a.seg_begin + (ncell + 1));
+  }
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   return launch_grid_tail(a.grid, a.cells_lds_image, a.occ_bits, a.cell_bytes, stream);
