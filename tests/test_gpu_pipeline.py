@@ -1,76 +1,83 @@
-"""A large pose batch handed over in ordinary host memory is cut into pieces whose uploads,
-scoring and downloads overlap (ndt2d_set_pipeline_pieces; ParticleFilter::measure of a big filter
-through the drop-in boundary, reference src/particle_filter.cpp:78-89).  The cut must not show:
-raw scores bit for bit, normalised weights and statistics to rounding, and the oracle's weights."""
-import os
-
+"""One localisation + mapping step through every device entry point in sequence, the
+oracle walking the same steps on the CPU: LaserScan conversion -> matchScan against the
+map -> particle filter update / measure -> the scan joins the map (NDT rebuilt) ->
+occupancy grid.  Each stage has its own parity tests; this one checks that they
+compose (state left on the device by one stage is what the next one needs)."""
 import numpy as np
 import pytest
 
-from ndt_2d_amd import ScanMatcherNDT, pf_measure, synth
-
 import oracle_lib as O
+from ndt_2d_amd import MotionModel, ParticleFilter, ScanMatcherNDT, synth
+from ndt_2d_amd.occupancy_grid import OccupancyGrid
 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def big_filter():
-    cfg = 3
-    gpu = ScanMatcherNDT(0)
-    gpu.initialize("pf", **synth.matcher_params(cfg))
+def test_one_slam_step_composes():
+    import torch
+    cfg = 1
     scans = synth.map_scans(cfg)
+    params = synth.matcher_params(cfg)
+    gpu = ScanMatcherNDT(0)
+    gpu.initialize("pipeline", **params)
+    gpu.set_build_mode("device")
     gpu.addScans(scans)
     ref = O.ScanMatcherNDT()
-    ref.initialize(**synth.matcher_params(cfg))
+    ref.initialize(**params)
     ref.addScans(scans)
-    _, pts, _ = synth.query_scan(cfg)
-    rng = np.random.default_rng(7)
-    pa = synth.particles(cfg)
-    # 300,017 particles: above the pipelining threshold, not a multiple of anything
-    parts = np.concatenate([pa, pa[:100000] + rng.normal(0, 0.05, (100000, 3)), np.tile(pa, (2, 1))[:100017] + rng.normal(0, 0.3, (100017, 3))])
-    return gpu, ref, pts, parts
+    assert np.array_equal(gpu.grid()[0], ref.ndt.cells6(), equal_nan=True)
 
+    # 1. the sensor message: ranges of the cfg-1 query scan, with drop-outs, taken while moving
+    guess, pts, _ = synth.query_scan(cfg)
+    n = len(pts)
+    ranges = np.hypot(pts[:, 0], pts[:, 1]).astype(np.float32)
+    ranges[::37] = np.nan
+    conv = dict(angle_min=-np.pi, angle_increment=2.0 * np.pi / n, range_max=params["range_max"],
+                laser=(0.03, 0.0, 0.0), motion=(0.01, 0.0, 0.005))
+    points_ref = O.convert_scan(ranges, **conv)
+    points_gpu = gpu.convertScan(ranges, **conv)
+    assert points_gpu.shape == points_ref.shape and np.max(np.abs(points_gpu - points_ref)) < 1e-12
 
-@pytest.mark.parametrize("pieces", [0, 2, 3, 4, 7, 16])
-def test_pipelined_batch_leaves_no_trace(big_filter, pieces):
-    gpu, ref, pts, parts = big_filter
-    try:
-        gpu.set_pipeline_pieces(1)
-        s1 = gpu.scorePoses(pts, parts)
-        assert gpu.last_pipeline_pieces() == 1
-        w1, mean1, cov1 = pf_measure(gpu, parts, pts)
-        gpu.set_pipeline_pieces(pieces)
-        s = gpu.scorePoses(pts, parts)
-        used = gpu.last_pipeline_pieces()
-        # (no piece below 32,768 poses: 300,017 poses are cut into nine at most)
-        assert used == min(4 if pieces == 0 else pieces, len(parts) // 32768), (pieces, used)
-        w, mean, cov = pf_measure(gpu, parts, pts)
-        assert gpu.last_pipeline_pieces() == used
-    finally:
-        gpu.set_pipeline_pieces(0)
-    assert np.array_equal(s, s1)
-    assert np.max(np.abs(w - w1)) <= 1e-15 * np.max(np.abs(w1)) * 64
-    assert np.allclose(mean, mean1, rtol=0, atol=1e-12)
-    assert np.allclose(cov, cov1, rtol=1e-11, atol=1e-13)
+    # 2. match it against the map, from the raw ranges
+    exp = ref.matchScan(guess, points_ref, pose=[0.0, 0.0, 0.0])
+    got = gpu.matchLaserScan(guess, ranges, pose=[0.0, 0.0, 0.0], **conv)
+    assert np.array_equal(got["pose"], exp["pose"]) and abs(got["score"] - exp["score"]) < 1e-9
+    corrected = np.array(guess) + got["pose"]          # reference src/ndt_mapper.cpp:521-524
 
+    # 3. particle filter: init around the corrected pose, odometry update, measurement
+    seed, n_p = 7, 2000
+    pf = ParticleFilter(n_p, 4000, MotionModel(0.1, 0.1, 0.1, 0.1, 0.0), gpu, seed=seed)
+    pf.init(corrected[0], corrected[1], corrected[2], 0.1, 0.1, 0.05)
+    pf.update(0.02, 0.0, 0.01)
+    pf.measure(gpu, points_gpu)
 
-def test_pipelined_measure_matches_the_oracle(big_filter):
-    gpu, ref, pts, parts = big_filter
-    gpu.set_pipeline_pieces(0)
-    w, mean, cov = pf_measure(gpu, parts, pts)
-    assert gpu.last_pipeline_pieces() == 4
-    raw = O.pf_measure(ref, parts, pts, omp_threads=os.cpu_count())
-    want = raw / raw.sum()
-    assert np.max(np.abs(w - want)) < 1e-9 * np.max(np.abs(want))
-    # a small batch is not cut
-    gpu.scorePoses(pts, parts[:5000])
-    assert gpu.last_pipeline_pieces() == 1
+    def noise(step):
+        z = torch.empty((n_p, 3), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        gpu.pf_noise_launch(seed, step, 0, n_p, z.data_ptr())
+        gpu.synchronize()
+        return z.cpu().numpy()
 
+    p = O.pf_init(corrected[0], corrected[1], corrected[2], 0.1, 0.1, 0.05, noise(1))
+    cov = np.zeros((3, 3))
+    w, _, cov = O.pf_update_statistics(p, np.full(n_p, 1.0 / n_p), cov)
+    p, _ = O.motion_sample(0.02, 0.0, 0.01, [0.1, 0.1, 0.1, 0.1, 0.0], p, noise(2))
+    w, _, cov = O.pf_update_statistics(p, w, cov)
+    w, mean, cov = O.pf_update_statistics(p, O.pf_measure(ref, p, points_ref), cov)
+    assert np.allclose(pf.getMean(), mean, rtol=1e-9, atol=1e-11)
+    assert np.allclose(pf.getCovariance(), cov, rtol=1e-7, atol=1e-10)
+    assert np.linalg.norm(pf.getMean()[:2] - corrected[:2]) < 0.2
 
-def test_pipeline_pieces_argument_is_checked(big_filter):
-    gpu = big_filter[0]
-    from ndt_2d_amd import Ndt2dError
-    for bad in (-1, 17):
-        with pytest.raises(Ndt2dError):
-            gpu.set_pipeline_pieces(bad)
+    # 4. the scan joins the map: NDT rebuilt on the device, bit-identical to the oracle's
+    new_scans = scans + [(tuple(corrected), points_ref)]
+    gpu.reset()
+    gpu.addScans(new_scans)
+    ref.reset()
+    ref.addScans(new_scans)
+    assert np.array_equal(gpu.grid()[0], ref.ndt.cells6(), equal_nan=True)
+
+    # 5. the published map
+    want = O.OccupancyGrid(0.05, 0.25).getMsg(new_scans)
+    have = OccupancyGrid(0.05, 0.25, gpu).getMsg(new_scans)
+    assert (have["width"], have["height"]) == (want["width"], want["height"])
+    assert np.array_equal(have["data"], want["data"])
