@@ -39,6 +39,8 @@ out = {"lib": os.environ.get("NDT2D_HIP_LIB", "in-tree")}
 for name, search in CASES:
     m = ScanMatcherNDT(0)
     m.initialize(name, **synth.matcher_params(2, **search))
+    if os.environ.get("NDT2D_AB_BUILD_MODE"):   # "device": the grid as a loop closure's addScans of many scans builds it
+        m.set_build_mode(os.environ["NDT2D_AB_BUILD_MODE"])
     m.addScans(scans)
     big = name == "cfg4"
     for _ in range(1 if big else 5):

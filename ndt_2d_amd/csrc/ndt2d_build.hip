@@ -464,6 +464,71 @@ int key_bits(uint32_t ncell)
 
 }  // namespace
 
+// The compacted form of a device-built grid (what the host install of a small grid prepares on
+// the CPU, ndt2d_device.hip ndt2d_set_grid): the records of the cells that can score, in cell
+// order, followed by the sentinel's, and the cell -> record table (uint16; cells that cannot score
+// and entry ncell, "outside", point at the sentinel).  The searches keep both in LDS -- 15 KB
+// instead of 81 at cfg-2, two blocks to a CU -- and were 8-20 % slower on a device-built grid
+// (a loop closure's addScans of many scans) for want of them.  One block: the occupancy bitmap's
+// words (bit = the cell can score, written by cells_kernel's ballots) are counted and scanned in
+// LDS, a cell's rank is its word's prefix plus the set bits below it.  ncell < 65,535.
+constexpr int kCompactThreads = 1024;
+__global__ void __launch_bounds__(kCompactThreads) compact_grid_kernel(uint32_t ncell, const double * cells_lds_image,
+                                                                       const uint32_t * occ_bits, double * records,
+                                                                       uint16_t * ranks, uint32_t * n_occ_out)
+{
+  __shared__ uint32_t prefix[2048 + 1];
+  __shared__ uint32_t wave_total[kCompactThreads / 64];
+  const uint32_t n_words = (ncell + 31) / 32;           // words that hold cells (<= 2048)
+  const uint32_t t = threadIdx.x;
+  // two consecutive words per thread: their counts, scanned over the block
+  uint32_t w0 = 0, w1 = 0;
+  if (2 * t < n_words) w0 = occ_bits[2 * t];
+  if (2 * t + 1 < n_words) w1 = occ_bits[2 * t + 1];
+  // (bits at and beyond ncell are zero: write_scorer_record's ballot tests cell < ncell)
+  const uint32_t c0 = static_cast<uint32_t>(__builtin_popcount(w0)), c1 = static_cast<uint32_t>(__builtin_popcount(w1));
+  uint32_t incl = c0 + c1;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1)
+  {
+    const uint32_t up = __shfl_up(incl, off, 64);
+    if ((t & 63u) >= static_cast<uint32_t>(off)) incl += up;
+  }
+  if ((t & 63u) == 63u) wave_total[t >> 6] = incl;
+  __syncthreads();
+  uint32_t base = 0;
+  for (uint32_t w = 0; w < (t >> 6); ++w) base += wave_total[w];
+  const uint32_t excl = base + incl - (c0 + c1);
+  prefix[2 * t] = excl;
+  prefix[2 * t + 1] = excl + c0;
+  if (t == kCompactThreads - 1) prefix[2048] = base + incl;
+  __syncthreads();
+  const uint32_t n_occ = prefix[2048];
+  for (uint32_t cell = t; cell < ncell; cell += kCompactThreads)
+  {
+    const uint32_t word = occ_bits[cell >> 5], bit = cell & 31u;
+    const bool occ = ((word >> bit) & 1u) != 0u;
+    const uint32_t rank = occ ? prefix[cell >> 5] + static_cast<uint32_t>(__builtin_popcount(word & ((1u << bit) - 1u))) : n_occ;
+    ranks[cell] = static_cast<uint16_t>(rank);
+    if (occ)
+    {
+      const double * src = cells_lds_image + static_cast<size_t>(cell) * kCellDoubles;
+      double * dst = records + static_cast<size_t>(rank) * kCellDoubles;
+#pragma unroll
+      for (int k = 0; k < kCellDoubles; ++k) dst[k] = src[k];
+    }
+  }
+  if (t == 0)
+  {
+    ranks[ncell] = static_cast<uint16_t>(n_occ);
+    const double * src = cells_lds_image + static_cast<size_t>(ncell) * kCellDoubles;   // the sentinel record
+    double * dst = records + static_cast<size_t>(n_occ) * kCellDoubles;
+#pragma unroll
+    for (int k = 0; k < kCellDoubles; ++k) dst[k] = src[k];
+    *n_occ_out = n_occ;
+  }
+}
+
 // The library's radix sort hands anything below a million keys to its merge sort -- 21 launches
 // of ~6 us each for the 378,000 points of cfg-3's map, a third of the whole device build.  With the
 // limit lowered the one-sweep radix sort takes them: a histogram, its scan and one pass per 8 key
@@ -579,6 +644,15 @@ hipError_t launch_grid_sparse_to_dense(const uint32_t * cell_index, const double
   if (e != hipSuccess || n == 0) return e;
   hipLaunchKernelGGL(grid_scatter_raw_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, cell_index, cells6,
                      n, ncell, dense6);
+  return hipGetLastError();
+}
+
+hipError_t launch_compact_grid(uint32_t ncell, const double * cells_lds_image, const uint32_t * occ_bits,
+                               double * records, uint16_t * ranks, uint32_t * n_occ_out, hipStream_t stream)
+{
+  if (ncell >= 65535u) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(compact_grid_kernel, dim3(1), dim3(kCompactThreads), 0, stream, ncell, cells_lds_image,
+                     occ_bits, records, ranks, n_occ_out);
   return hipGetLastError();
 }
 

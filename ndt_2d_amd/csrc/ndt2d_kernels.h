@@ -140,6 +140,11 @@ struct BuildArgs
 };
 size_t build_sort_temp_bytes(uint32_t n_points, uint32_t ncell);
 hipError_t launch_build_grid(const BuildArgs & args, hipStream_t stream);
+// The compacted records + cell -> record table of a device-built grid (ncell < 65,535), from the
+// packed records and the occupancy bitmap launch_build_grid left: records[(n_occ + 1)][6] (at most
+// ncell + 1 rows), ranks[ncell + 1], *n_occ_out = the cells that can score.
+hipError_t launch_compact_grid(uint32_t ncell, const double * cells_lds_image, const uint32_t * occ_bits,
+                               double * records, uint16_t * ranks, uint32_t * n_occ_out, hipStream_t stream);
 // The scorer layouts of a grid uploaded as cells6 records (ndt2d_set_grid): packed
 // records in both strides, occupancy bitmap, per-cell map bytes.  `geometry` carries
 // size / cell size / origin only.
