@@ -555,7 +555,7 @@ int ndt2d_matcher_initialize(ndt2d_matcher * m, double ndt_resolution,
 int ndt2d_matcher_add_scans(ndt2d_matcher * m, const double * poses_xyt,
                             const double * points_xy, const size_t * offsets, size_t n_scans);
 /* Where addScans builds the NDT: "host" (C++ on the host, then upload), "device"
- * (ndt2d_build_grid) or "auto" (device from 32768 map points up).  Both give
+ * (ndt2d_build_grid) or "auto" (device from 73,728 map points up: ~100 scans of 720 beams).  Both give
  * bit-identical grids. */
 int ndt2d_matcher_set_build_mode(ndt2d_matcher * m, const char * mode);
 /* ndt2d_set_eigenvalue_form for the host build and every device of the matcher. */

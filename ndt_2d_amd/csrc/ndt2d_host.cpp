@@ -556,7 +556,7 @@ void discard_ahead(ndt2d_matcher * m)
 }
 
 // The host NDT the single-pose path and the near-tie adjudication score against: the one
-// addScans built on the host, or -- for a grid built on the DEVICE (maps of 32768 points and
+// addScans built on the host, or -- for a grid built on the DEVICE (maps of 73,728 points and
 // more) -- its records fetched back once per addScans.  That fetch is the whole dense grid
 // (48 bytes per cell, synchronous) plus a host pool of the same size: worth it for the grids
 // the single-pose path exists for, not for a loop-closure map of a million cells, where it
@@ -1404,11 +1404,15 @@ int ndt2d_matcher_add_scans(ndt2d_matcher * m, const double * poses_xyt,
   if (offsets == nullptr) offsets = no_offsets;
   m->have_ndt = false;
   // Device build (N1): the whole of addScans on the GPU, bit-identical to the host
-  // build; "auto" uses it from 32768 map points up, where it beats the host build
-  // (measured: 0.12 vs 0.14 ms at 6.5 k points, 2.7 vs 1.0 ms at 378 k, 58.6 vs 2.1 ms at 1.1 M).
+  // build; "auto" uses it from kDeviceBuildFromPoints map points up, where it beats the host build
+  // (round 5, whole addScans call, host / device: 0.068 / 0.134 ms at 6,480 points, 0.192 / 0.252
+  // at 32,400, 0.324 / 0.340 at 64,800, 0.409 / 0.346 at 86,400, 0.64 / 0.44 at 144,000, 1.72 /
+  // 0.79 at 378,000 -- experiments/build_crossover.py; the device build is ~130 us of launches
+  // and a synchronisation plus 3.4 ns per point, the host build 40 us plus 4.4 ns per point).
+  constexpr size_t kDeviceBuildFromPoints = 73728;   // ~100 scans of 720 beams (32,768 until round 5)
   const size_t n_map_points = n_scans > 0 ? offsets[n_scans] : 0;
   const bool on_device =
-    n_scans > 0 && (m->build_mode == 2 || (m->build_mode == 0 && n_map_points >= 32768));
+    n_scans > 0 && (m->build_mode == 2 || (m->build_mode == 0 && n_map_points >= kDeviceBuildFromPoints));
   if (on_device)
   {
     m->ndt.reset();

@@ -119,7 +119,7 @@ def test_mapper_cycle_with_host_scoring_still_launches_the_search_ahead():
 
 
 def test_a_large_device_built_grid_is_not_fetched_for_single_poses():
-    """A grid built on the DEVICE (maps of 32,768 points and more) has no host copy; fetching one
+    """A grid built on the DEVICE (maps of 73,728 points and more) has no host copy; fetching one
     for a single pose would move the whole dense grid over PCIe (cfg-5: 801 x 801 cells, 31 MB) to
     save a 30 us launch.  Above 65,536 cells the single-pose calls take the device path instead --
     same score within the device exp's rounding -- while the cfg-3 grid (40,401 cells) is fetched
