@@ -442,7 +442,16 @@ constexpr uint64_t kMaxLaneItems = 1ull << 24;
 // small-lattice search (beams split across the waves of a block); it can hold
 // kSmallMaxItems.  Above, the lane-per-candidate search; the wave-per-candidate mapping
 // serves what neither can (windows beyond 1,024 cells, > 2^24 items).
-constexpr uint64_t kSmallBelowItems = 2560;
+// Round 5, whole matchScan calls with the event pairs off (experiments/small_crossover.py; small /
+// large form, ms): 100 beams 2,704 items 0.068 / 0.088, 3,380 items 0.082 / 0.073; 360 beams 2,704
+// 0.100 / 0.140, 4,056 0.136 / 0.159, 5,070 0.164 / 0.166; 720 beams 2,704 0.143 / 0.173, 3,380 0.168 /
+// 0.193, 4,056 0.191 / 0.197, 5,070 0.220 / 0.209 -- the crossover lies near 3,000 items for the
+// node's own 100-beam scans and past 4,000 for longer ones (2,560 for all until then: the small form
+// has gained since -- centre-first blocks -- and the large form's extra launches cost every call 30 us).
+constexpr uint64_t kSmallBelowItemsShortScan = 3072;   // scans of at most kShortScanBeams beams
+constexpr uint64_t kSmallBelowItemsLongScan = 4096;
+constexpr uint32_t kShortScanBeams = 128;
+constexpr uint64_t kWaveBelowItems = 2560;             // (the wave mapping's range where the small form cannot run)
 constexpr uint64_t kSmallMaxItems = 8192;
 // Lane search: lattices (whole, not a launch's share) below these many work items have a
 // candidate's beams cut into four / two parts (MatchArgs::beam_parts): one expensive item

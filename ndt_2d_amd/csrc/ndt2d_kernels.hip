@@ -591,8 +591,8 @@ const char * lane_variant_name(int records, bool block_map, bool pow2, bool part
 // Candidate mapping.  Lane-per-candidate (64 translations of one theta step per wave,
 // occupancy-map look-up, bit-exact skipping) whenever its LDS image fits: the
 // small-lattice form (a block per theta step and up to P tiles, beams split across its
-// waves, no pre-kernel, final reduction in the same launch) below kSmallBelowItems work
-// items, the persistent large-lattice form above.  Otherwise wave-per-candidate.
+// waves, no pre-kernel, final reduction in the same launch) below kSmallBelowItems... work
+// items (by the scan's length), the persistent large-lattice form above.  Otherwise wave-per-candidate.
 // (The choice follows the whole lattice, so every shard of a search makes the same one
 // and a candidate's score has the same bits whichever rank evaluates it.)
 Mapping choose_mapping(const MatchArgs & args, bool outer_available, int force_variant,
@@ -607,11 +607,12 @@ Mapping choose_mapping(const MatchArgs & args, bool outer_available, int force_v
   if (force_variant & kVariantWave) use_lane = use_small = false;
   if (force_variant & kVariantSmall) return use_small ? Mapping::kSmall : Mapping::kInvalid;
   if (force_variant & kVariantLane) return use_lane ? Mapping::kLane : Mapping::kInvalid;
-  if (use_small && use_lane) return items < kSmallBelowItems ? Mapping::kSmall : Mapping::kLane;
+  const uint64_t small_below = args.n_beams <= kShortScanBeams ? kSmallBelowItemsShortScan : kSmallBelowItemsLongScan;
+  if (use_small && use_lane) return items < small_below ? Mapping::kSmall : Mapping::kLane;
   if (use_small) return Mapping::kSmall;
   // (a small lattice the small-lattice form cannot take -- a window wider than 256 cells:
   // a wave alone with one expensive work item takes 0.2 ms, the wave mapping is the faster one)
-  if (use_lane) return items < kSmallBelowItems ? Mapping::kWave : Mapping::kLane;
+  if (use_lane) return items < kWaveBelowItems ? Mapping::kWave : Mapping::kLane;
   return Mapping::kWave;
 }
 
