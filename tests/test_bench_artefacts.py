@@ -184,3 +184,60 @@ def test_bench_gpus_n_run_directly_starts_its_ranks_as_a_child_job():
         pytest.skip("a GPU box runs this for real (tests/test_gpu_dist_sharded.py)")
     assert r.returncode != 0
     assert "no GPU visible" in r.stderr and "torch.distributed" in r.stderr
+
+
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    return bench
+
+
+@pytest.mark.parametrize("name", ["r05_bench.json", "r05_bench_driver_flags.json",
+                                  "r05_bench_8ranks_one_gpu_gloo.json"])
+def test_stdout_line_stays_under_the_drivers_limit(name):
+    """Round 5's line was 33,034 bytes and the driver recorded `parsed: null`.  bench.py now prints
+    compact_line(full record): built here from the committed FULL records of round 5 (the largest
+    the script has produced), it keeps every contract field and stays under 12 KiB."""
+    bench = _bench_module()
+    with open(os.path.join(ROOT, "profiles", name)) as f:
+        full = json.load(f)
+    assert len(json.dumps(full)) > 12288                      # the canned record is the oversized one
+    short = bench.compact_line(full, ["bench_detail.json"])
+    text = json.dumps(short, separators=(",", ":"))
+    assert len(text) < 12288 and "\n" not in text
+    assert bench.MAX_LINE_BYTES <= 12288
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "roofline_hbm", "cpu_baseline",
+                "match_result", "library"):
+        assert key in short, key
+        if key not in ("config", "roofline", "roofline_hbm", "cpu_baseline", "library"):
+            assert short[key] == full[key]
+    r = short["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms_avg"):
+        assert r[key] == full["roofline"][key], key
+    assert "issue_pricing" not in r and "dropped_for_size" not in short
+    c = short["cpu_baseline"]
+    assert c["value"] == full["cpu_baseline"]["value"] and c["cores"] == full["cpu_baseline"]["cores"]
+    assert c["kind"] == "port" and c["sample"]
+    assert "workload" in short["config"] and "model" not in short["config"]
+    if full["n_gpus"] == 1:
+        assert short["default_search"]["mapper_cycle_us"] == full["default_search"]["c_host"]["mapper_cycle_us"]
+        assert short["cfg4_single_gpu"]["best_index"] == 80443810
+        assert short["cfg5_single_gpu"]["roofline_frac"] == full["cfg5_single_gpu"]["roofline"]["frac"]
+        assert short["particle_filter"]["roofline_frac"] == full["particle_filter"]["roofline"]["frac"]
+
+
+def test_stdout_line_sheds_side_legs_rather_than_grow():
+    """Whatever a future leg adds, the line never passes the limit: legs are dropped from the end
+    and named in `dropped_for_size`; the contract's own fields are never dropped."""
+    bench = _bench_module()
+    with open(os.path.join(ROOT, "profiles", "r05_bench.json")) as f:
+        full = json.load(f)
+    full["default_search"]["c_host"]["real_lidar_map"]["match_scan_us"] = "x" * 20000
+    short = bench.compact_line(full, [])
+    assert len(json.dumps(short, separators=(",", ":"))) < 12288
+    assert "default_search" in short["dropped_for_size"]
+    assert short["value"] == full["value"] and short["roofline"]["frac"] == full["roofline"]["frac"]
+    assert short["cpu_baseline"]["value"] == full["cpu_baseline"]["value"]
