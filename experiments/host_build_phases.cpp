@@ -8,6 +8,7 @@ static double now_us() { return std::chrono::duration<double, std::micro>(std::c
 int main(int argc, char ** argv)
 {
   const int toy = argc > 1 ? atoi(argv[1]) : 1;
+  const int eform = argc > 2 ? atoi(argv[2]) : ndt2d::kEigenFormSchur;
   const int N = 9, B = 720;
   static double poses[3 * N], pts[2 * B * N];
   static size_t off[N + 1];
@@ -35,12 +36,13 @@ int main(int argc, char ** argv)
     double min_x = 1e300, max_x = -1e300, min_y = 1e300, max_y = -1e300;
     for (size_t k = 0; k < n; ++k) { min_x = std::min(poses[3*k] - rmax, min_x); max_x = std::max(poses[3*k] + rmax, max_x); min_y = std::min(poses[3*k+1] - rmax, min_y); max_y = std::max(poses[3*k+1] + rmax, max_y); }
     if (ndt) ndt->reset(0.25, max_x - min_x, max_y - min_y, min_x, min_y); else ndt.reset(new HostNdt(0.25, max_x - min_x, max_y - min_y, min_x, min_y));
+    if (getenv("NOIL")) ndt->set_interleave(false);
     const double b = now_us();
     for (size_t k = 0; k < n; ++k) ndt->add_scan(poses[3*k], poses[3*k+1], poses[3*k+2], pts + 2 * off[k], off[k+1] - off[k]);
     const double c = now_us();
-    ndt->compute();
+    ndt->compute(eform);
     const double d = now_us();
-    ndt->sparse6(idx, c6);
+    idx.resize(ndt->n_touched()); c6.resize(6 * ndt->n_touched()); ndt->sparse6(idx.data(), c6.data());
     const double e = now_us();
     if (r >= 0) { t[0] += b - a; t[1] += c - b; t[2] += d - c; t[3] += e - d; }
   }

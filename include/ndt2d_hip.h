@@ -47,6 +47,8 @@ extern "C" {
 #define NDT2D_ERR_HIP 3        /* a HIP runtime call failed; see ndt2d_last_error */
 #define NDT2D_ERR_NO_DEVICE 4  /* no GPU visible to this process */
 #define NDT2D_ERR_STATE 5      /* call sequence error (e.g. fetch before launch) */
+#define NDT2D_ERR_ALLOC 6      /* host memory could not be had (std::bad_alloc caught at the boundary) */
+#define NDT2D_ERR_INTERNAL 7   /* any other C++ exception caught at the boundary; see ndt2d_last_error */
 
 #define NDT2D_NO_INDEX UINT64_MAX
 
@@ -56,7 +58,13 @@ extern "C" {
 
 typedef struct ndt2d_context * ndt2d_handle;
 
-/* ABI version of this header (bumped on any signature change). */
+/* ABI version of this header: bumped whenever an export is added, a signature changes or a
+ * default changes results.  4 (round 6): + NDT2D_ERR_ALLOC / NDT2D_ERR_INTERNAL,
+ * ndt2d_host_build_grid_ex, and the round-5 additions that had gone out under 3 (pose_sums_*,
+ * pf_finalize_totals_launch, pipeline_pieces, multi_thresholds, eigenvalue_form, build_info).  A
+ * consumer compares ndt2d_abi_version() with the NDT2D_ABI_VERSION it was compiled against
+ * (the pluginlib shim does, in initialize). */
+#define NDT2D_ABI_VERSION 4
 int ndt2d_abi_version(void);
 /* Which sources this library was compiled from: "NDT2D_SOURCE_SHA256=<64 hex digits> arch=...
  * compiler=...".  The hash is ndt_2d_amd/build.py's source_sha256() (csrc/ *.hip, *.cpp, *.h,
@@ -690,6 +698,17 @@ int ndt2d_host_build_grid(double ndt_resolution, double range_max, const double 
                           const double * points_xy, const size_t * offsets, size_t n_scans,
                           double * cells6_out, size_t capacity_cells, uint32_t * size_x,
                           uint32_t * size_y, double * origin_x, double * origin_y);
+/* ... with flags: NDT2D_BUILD_SEQUENTIAL adds every scan's points one after the other, the
+ * reference's loop as it stands (src/ndt_model.cpp:132-152), instead of the four quarters of a
+ * scan side by side (csrc/ndt2d_host.cpp HostNdt::add_scan) -- the two give the same bits, and
+ * tests/test_host_logic.py holds them to it; NDT2D_BUILD_CLOSED_FORM takes the closed-form
+ * eigenvalues (ndt2d_matcher_set_eigenvalue_form "closed"). */
+#define NDT2D_BUILD_SEQUENTIAL 1u
+#define NDT2D_BUILD_CLOSED_FORM 2u
+int ndt2d_host_build_grid_ex(double ndt_resolution, double range_max, const double * poses_xyt,
+                             const double * points_xy, const size_t * offsets, size_t n_scans, unsigned flags,
+                             double * cells6_out, size_t capacity_cells, uint32_t * size_x,
+                             uint32_t * size_y, double * origin_x, double * origin_y);
 
 /* ------------------------------------------------------------------------ */
 /* Synthetic workload generator (BASELINE.md section 3 / SURVEY.md 8d)       */

@@ -17,13 +17,15 @@ ERR_NO_GRID = 2
 ERR_HIP = 3
 ERR_NO_DEVICE = 4
 ERR_STATE = 5
+ERR_ALLOC = 6
+ERR_INTERNAL = 7
 NO_INDEX = (1 << 64) - 1
 MATCH_RECORD_DOUBLES = 12
 POSE_STATS_DOUBLES = 8
 PF_RESULT_DOUBLES = 8
 
 _ERR_NAMES = {1: "NDT2D_ERR_INVALID", 2: "NDT2D_ERR_NO_GRID", 3: "NDT2D_ERR_HIP",
-              4: "NDT2D_ERR_NO_DEVICE", 5: "NDT2D_ERR_STATE"}
+              4: "NDT2D_ERR_NO_DEVICE", 5: "NDT2D_ERR_STATE", 6: "NDT2D_ERR_ALLOC", 7: "NDT2D_ERR_INTERNAL"}
 
 
 class Ndt2dError(RuntimeError):
@@ -183,6 +185,8 @@ SIGNATURES = {
                                      C.POINTER(_u32), _szp]),
     "ndt2d_host_build_grid": (C.c_int, [_d, _d, _dp, _dp, _szp, _sz, _dp, _sz,
                                        C.POINTER(_u32), C.POINTER(_u32), _dp, _dp]),
+    "ndt2d_host_build_grid_ex": (C.c_int, [_d, _d, _dp, _dp, _szp, _sz, C.c_uint, _dp, _sz,
+                                          C.POINTER(_u32), C.POINTER(_u32), _dp, _dp]),
     "ndt2d_synth_scan": (C.c_int, [C.POINTER(World), _dp, _sz, _d, C.c_uint64, _dp]),
     "ndt2d_synth_pose_blocked": (C.c_int, [C.POINTER(World), _d, _d, _d]),
     "ndt2d_synth_uniform": (C.c_int, [C.c_uint64, _sz, _dp]),

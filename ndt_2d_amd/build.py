@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_PKG, "libndt2d_hip.so")
 # ndt2d_build_info.cpp is compiled apart (it receives the hash of all the others as a macro)
 BUILD_INFO_SOURCE = "ndt2d_build_info.cpp"
 SOURCES = ["ndt2d_kernels.hip", "ndt2d_match_lane.hip", "ndt2d_match_small.hip", "ndt2d_poses_compact.hip", "ndt2d_build.hip", "ndt2d_motion.hip", "ndt2d_scan.hip", "ndt2d_occupancy.hip", "ndt2d_device.hip", "ndt2d_exchange.hip", "ndt2d_host.cpp"]
-HEADERS = [os.path.join(_CSRC, "ndt2d_kernels.h"), os.path.join(_CSRC, "ndt2d_device_fn.h"), os.path.join(_CSRC, "ndt2d_lane_fn.h"), os.path.join(_CSRC, "ndt2d_poses_fn.h"), os.path.join(_CSRC, "ndt2d_exchange.h"), os.path.join(_CSRC, "ndt2d_eigen2.h"), os.path.join(_CSRC, "ndt2d_workers.h"), os.path.join(_ROOT, "include", "ndt2d_hip.h")]
+HEADERS = [os.path.join(_CSRC, "ndt2d_kernels.h"), os.path.join(_CSRC, "ndt2d_device_fn.h"), os.path.join(_CSRC, "ndt2d_lane_fn.h"), os.path.join(_CSRC, "ndt2d_poses_fn.h"), os.path.join(_CSRC, "ndt2d_exchange.h"), os.path.join(_CSRC, "ndt2d_eigen2.h"), os.path.join(_CSRC, "ndt2d_workers.h"), os.path.join(_CSRC, "ndt2d_guard.h"), os.path.join(_ROOT, "include", "ndt2d_hip.h")]
 ARCH = "gfx950"
 # -ffp-contract=off: the reference's x86-64 build has no fused multiply-add; the
 # kernels keep its separate roundings (see DESIGN.md "Numerics").

@@ -203,13 +203,16 @@ __global__ void __launch_bounds__(256) cells_kernel(const BuildArgs a, const uin
       const double vxx = (cxx - (mean_x * mean_x)) * scale;
       const double vxy = (cxy - (mean_x * mean_y)) * scale;
       const double vyy = (cyy - (mean_y * mean_y)) * scale;
-      double small, large;
-      covariance_eigenvalues(a.eigen_form, vxx, vxy, vyy, &small, &large);   // (:84-85, ndt2d_eigen2.h)
-      if (small > large)
+      double small = 1.0, large = 1.0;
+      if (!clamp_test_surely_false(vxx, vxy, vyy))   // (else: the branch of :99 whatever their last bits)
       {
-        const double t = small;
-        small = large;
-        large = t;
+        covariance_eigenvalues(a.eigen_form, vxx, vxy, vyy, &small, &large);   // (:84-85, ndt2d_eigen2.h)
+        if (small > large)
+        {
+          const double t = small;
+          small = large;
+          large = t;
+        }
       }
       if (small < 0.001 * large)
       {

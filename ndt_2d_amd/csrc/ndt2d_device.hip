@@ -14,6 +14,7 @@
 #include <string>
 #include <vector>
 
+#include "ndt2d_guard.h"
 #include "ndt2d_hip.h"
 #include "ndt2d_kernels.h"
 
@@ -189,6 +190,20 @@ bool test_launch_fails()
 #else
 #define NDT2D_TEST_MAYBE_FAIL(h, what) do {} while (0)
 #endif
+
+// ndt2d_guard.h: where the text of an exception caught at the C boundary goes
+void guard_note(ndt2d_context * h, const char * what) noexcept
+{
+  if (h == nullptr) return;
+  try
+  {
+    h->err = what;
+  }
+  catch (...)
+  {
+  }
+}
+void guard_note(std::nullptr_t, const char *) noexcept {}
 
 int fail_hip(ndt2d_context * h, hipError_t e, const char * what)
 {
@@ -507,10 +522,11 @@ bool is_pow2(double v)
 
 extern "C" {
 
-int ndt2d_abi_version(void) { return 3; }
+int ndt2d_abi_version(void) { return NDT2D_ABI_VERSION; }
 
 int ndt2d_create(ndt2d_handle * out, int device_id)
 {
+  NDT2D_C_TRY
   if (out == nullptr) return NDT2D_ERR_INVALID;
   *out = nullptr;
   int count = 0;
@@ -534,10 +550,12 @@ int ndt2d_create(ndt2d_handle * out, int device_id)
   h->stream = h->own_stream;
   *out = h;
   return NDT2D_OK;
+  NDT2D_C_CATCH(nullptr)
 }
 
 int ndt2d_destroy(ndt2d_handle h)
 {
+  NDT2D_C_TRY
   if (h == nullptr) return NDT2D_ERR_INVALID;
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
@@ -596,6 +614,7 @@ int ndt2d_destroy(ndt2d_handle h)
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
   return NDT2D_OK;
+  NDT2D_C_CATCH(h)
 }
 
 const char * ndt2d_last_error(ndt2d_handle h)
@@ -605,12 +624,14 @@ const char * ndt2d_last_error(ndt2d_handle h)
 
 int ndt2d_set_stream(ndt2d_handle h, void * hip_stream)
 {
+  NDT2D_C_TRY
   if (h == nullptr) return NDT2D_ERR_INVALID;
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
   h->stream = hip_stream != nullptr ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
   h->stage_cap = 0;
   return NDT2D_OK;
+  NDT2D_C_CATCH(h)
 }
 
 void * ndt2d_get_stream(ndt2d_handle h) { return h != nullptr ? h->stream : nullptr; }
@@ -620,6 +641,7 @@ int ndt2d_device_id(ndt2d_handle h) { return h != nullptr ? h->device : -1; }
 int ndt2d_set_grid(ndt2d_handle h, const double * cells6, uint32_t size_x, uint32_t size_y,
                    double cell_size, double origin_x, double origin_y)
 {
+  NDT2D_C_TRY
   if (h == nullptr) return NDT2D_ERR_INVALID;
   if (cells6 == nullptr || size_x == 0 || size_y == 0 || !(cell_size > 0.0))
   {
@@ -725,12 +747,14 @@ int ndt2d_set_grid(ndt2d_handle h, const double * cells6, uint32_t size_x, uint3
   h->block_bytes_log2 = -1;
   h->has_grid = true;
   return NDT2D_OK;
+  NDT2D_C_CATCH(h)
 }
 
 int ndt2d_build_grid(ndt2d_handle h, double ndt_resolution, double range_max,
                      const double * poses_xyt, const double * points_xy, const size_t * offsets,
                      size_t n_scans)
 {
+  NDT2D_C_TRY
   if (h == nullptr) return NDT2D_ERR_INVALID;
   if (!(ndt_resolution > 0.0) || n_scans == 0 || poses_xyt == nullptr || offsets == nullptr ||
       n_scans > (1u << 30))
@@ -886,6 +910,7 @@ int ndt2d_build_grid(ndt2d_handle h, double ndt_resolution, double range_max,
   h->block_bytes_log2 = -1;
   h->has_grid = true;
   return NDT2D_OK;
+  NDT2D_C_CATCH(h)
 }
 
 // Largest [rank table | compacted records] image any search kernel would keep in LDS
@@ -919,6 +944,7 @@ static StageLayout stage_layout(size_t cap, uint32_t ncell, bool with_compact)
 int ndt2d_grid_stage_begin(ndt2d_handle h, uint32_t size_x, uint32_t size_y, size_t capacity,
                            uint32_t ** cell_index_out, double ** cells6_out)
 {
+  NDT2D_C_TRY
   if (h == nullptr) return NDT2D_ERR_INVALID;
   h->stage_cap = 0;
   if (cell_index_out == nullptr || cells6_out == nullptr || size_x == 0 || size_y == 0 || capacity >= (1ull << 31))
@@ -951,10 +977,12 @@ int ndt2d_grid_stage_begin(ndt2d_handle h, uint32_t size_x, uint32_t size_y, siz
   *cells6_out = h->stage_grid.ptr;
   *cell_index_out = reinterpret_cast<uint32_t *>(h->stage_grid.ptr + l.n6);
   return NDT2D_OK;
+  NDT2D_C_CATCH(h)
 }
 
 int ndt2d_grid_stage_commit(ndt2d_handle h, size_t n_listed, double cell_size, double origin_x, double origin_y)
 {
+  NDT2D_C_TRY
   if (h == nullptr) return NDT2D_ERR_INVALID;
   if (h->stage_cap == 0) return fail(h, NDT2D_ERR_STATE, "ndt2d_grid_stage_commit: no ndt2d_grid_stage_begin before it");
   const size_t cap = h->stage_cap;
@@ -1088,12 +1116,14 @@ int ndt2d_grid_stage_commit(ndt2d_handle h, size_t n_listed, double cell_size, d
   h->block_bytes_log2 = -1;
   h->has_grid = true;
   return NDT2D_OK;
+  NDT2D_C_CATCH(h)
 }
 
 int ndt2d_set_grid_sparse(ndt2d_handle h, const uint32_t * cell_index, const double * cells6,
                           size_t n_listed, uint32_t size_x, uint32_t size_y, double cell_size,
                           double origin_x, double origin_y)
 {
+  NDT2D_C_TRY
   if (h == nullptr) return NDT2D_ERR_INVALID;
   if ((n_listed > 0 && (cell_index == nullptr || cells6 == nullptr)) || size_x == 0 || size_y == 0 ||
       !(cell_size > 0.0) || n_listed >= (1ull << 31))
@@ -1110,20 +1140,24 @@ int ndt2d_set_grid_sparse(ndt2d_handle h, const uint32_t * cell_index, const dou
     std::memcpy(st_idx, cell_index, n_listed * sizeof(uint32_t));
   }
   return ndt2d_grid_stage_commit(h, n_listed, cell_size, origin_x, origin_y);
+  NDT2D_C_CATCH(h)
 }
 
 int ndt2d_set_eigenvalue_form(ndt2d_handle h, const char * form)
 {
+  NDT2D_C_TRY
   if (h == nullptr || form == nullptr) return NDT2D_ERR_INVALID;
   if (std::strcmp(form, "eigen") == 0) h->eigen_form = 0;
   else if (std::strcmp(form, "closed") == 0) h->eigen_form = 1;
   else return fail(h, NDT2D_ERR_INVALID, "ndt2d_set_eigenvalue_form: unknown form (eigen, closed)");
   return NDT2D_OK;
+  NDT2D_C_CATCH(h)
 }
 
 int ndt2d_get_grid(ndt2d_handle h, double * cells6_out, size_t capacity_cells, uint32_t * size_x,
                    uint32_t * size_y, double * cell_size, double * origin_x, double * origin_y)
 {
+  NDT2D_C_TRY
   if (h == nullptr) return NDT2D_ERR_INVALID;
   if (!h->has_grid) return fail(h, NDT2D_ERR_NO_GRID, "ndt2d_get_grid: no grid");
   if (size_x) *size_x = h->grid.size_x;
@@ -1151,21 +1185,25 @@ int ndt2d_get_grid(ndt2d_handle h, double * cells6_out, size_t capacity_cells, u
     NDT2D_SYNC(h);
   }
   return NDT2D_OK;
+  NDT2D_C_CATCH(h)
 }
 
 int ndt2d_clear_grid(ndt2d_handle h)
 {
+  NDT2D_C_TRY
   if (h == nullptr) return NDT2D_ERR_INVALID;
   h->has_grid = false;
   h->bytes_job.n = 0;
   h->stage_cap = 0;   // (an open list is dropped with the grid it was for)
   return NDT2D_OK;
+  NDT2D_C_CATCH(h)
 }
 
 int ndt2d_has_grid(ndt2d_handle h) { return (h != nullptr && h->has_grid) ? 1 : 0; }
 
 int ndt2d_set_beams(ndt2d_handle h, const double * beams_xy, size_t n_beams)
 {
+  NDT2D_C_TRY
   if (h == nullptr) return NDT2D_ERR_INVALID;
   if (beams_xy == nullptr || n_beams == 0 || n_beams > (1u << 20))
   {
@@ -1186,12 +1224,14 @@ int ndt2d_set_beams(ndt2d_handle h, const double * beams_xy, size_t n_beams)
   h->has_search = false;
   h->beam_rmax = beam_reach(beams_xy, n_beams);
   return NDT2D_OK;
+  NDT2D_C_CATCH(h)
 }
 
 int ndt2d_set_search(ndt2d_handle h, double pose_x, double pose_y, const double * dth,
                      const double * cos_th, const double * sin_th, size_t n_th,
                      const double * dlin, size_t n_lin)
 {
+  NDT2D_C_TRY
   if (h == nullptr) return NDT2D_ERR_INVALID;
   if (dth == nullptr || cos_th == nullptr || sin_th == nullptr || dlin == nullptr || n_th == 0 ||
       n_lin == 0 || n_th > (1u << 24) || n_lin > 46340)
@@ -1218,12 +1258,14 @@ int ndt2d_set_search(ndt2d_handle h, double pose_x, double pose_y, const double 
   h->tables_ptr = h->tables.ptr;
   h->has_search = true;
   return NDT2D_OK;
+  NDT2D_C_CATCH(h)
 }
 
 int ndt2d_set_search_beams(ndt2d_handle h, const double * beams_xy, size_t n_beams, double pose_x,
                            double pose_y, const double * dth, const double * cos_th,
                            const double * sin_th, size_t n_th, const double * dlin, size_t n_lin)
 {
+  NDT2D_C_TRY
   if (h == nullptr) return NDT2D_ERR_INVALID;
   if (beams_xy == nullptr)
   {
@@ -1269,19 +1311,23 @@ int ndt2d_set_search_beams(ndt2d_handle h, const double * beams_xy, size_t n_bea
   h->pose_y = pose_y;
   h->has_search = true;
   return NDT2D_OK;
+  NDT2D_C_CATCH(h)
 }
 
 int ndt2d_match_launch(ndt2d_handle h, size_t th_begin, size_t th_end, double * d_scores,
                        double * d_record)
 {
+  NDT2D_C_TRY
   if (h == nullptr) return NDT2D_ERR_INVALID;
   if (th_begin >= th_end) return fail(h, NDT2D_ERR_INVALID, "ndt2d_match_launch: bad theta range");
   return ndt2d_match_launch_strided(h, th_begin, 1, th_end - th_begin, d_scores, d_record);
+  NDT2D_C_CATCH(h)
 }
 
 int ndt2d_match_launch_strided(ndt2d_handle h, size_t th_first, size_t th_stride, size_t th_count,
                                double * d_scores, double * d_record)
 {
+  NDT2D_C_TRY
   if (h == nullptr) return NDT2D_ERR_INVALID;
   if (!h->has_grid) return fail(h, NDT2D_ERR_NO_GRID, "ndt2d_match_launch: no grid");
   if (!h->has_search || h->n_beams == 0)
@@ -1403,10 +1449,12 @@ int ndt2d_match_launch_strided(ndt2d_handle h, size_t th_first, size_t th_stride
   ++h->match_launches;
   h->last_candidates = static_cast<uint64_t>(th_end - th_begin) * h->n_lin * h->n_lin;
   return NDT2D_OK;
+  NDT2D_C_CATCH(h)
 }
 
 int ndt2d_match_fetch(ndt2d_handle h, ndt2d_match_result * out)
 {
+  NDT2D_C_TRY
   if (h == nullptr || out == nullptr) return NDT2D_ERR_INVALID;
   if (!h->match_pending) return fail(h, NDT2D_ERR_STATE, "ndt2d_match_fetch: nothing launched");
   NDT2D_HIP(h, hipSetDevice(h->device));
@@ -1426,11 +1474,13 @@ int ndt2d_match_fetch(ndt2d_handle h, ndt2d_match_result * out)
   for (int k = 0; k < 10; ++k) out->acc[k] = rec[2 + k];
   out->n_candidates = h->last_candidates;
   return NDT2D_OK;
+  NDT2D_C_CATCH(h)
 }
 
 int ndt2d_match_near_best(ndt2d_handle h, size_t th_begin, size_t th_end, double rel, uint64_t * index_out,
                           size_t capacity, size_t * n_out, ndt2d_match_result * result_out)
 {
+  NDT2D_C_TRY
   if (h == nullptr || n_out == nullptr || (capacity > 0 && index_out == nullptr)) return NDT2D_ERR_INVALID;
   *n_out = 0;
   if (!(rel >= 0.0) || th_begin >= th_end || th_end > h->n_th || capacity > 65536)
@@ -1482,19 +1532,23 @@ int ndt2d_match_near_best(ndt2d_handle h, size_t th_begin, size_t th_end, double
   for (size_t k = 0; k < kept; ++k) index_out[k] = base + host[1 + k];
   std::sort(index_out, index_out + kept);
   return NDT2D_OK;
+  NDT2D_C_CATCH(h)
 }
 
 int ndt2d_match_status(ndt2d_handle h, uint64_t * n_launched, uint64_t * n_fetched)
 {
+  NDT2D_C_TRY
   if (h == nullptr) return NDT2D_ERR_INVALID;
   if (n_launched != nullptr) *n_launched = h->match_launches;
   if (n_fetched != nullptr) *n_fetched = h->match_fetches;
   return NDT2D_OK;
+  NDT2D_C_CATCH(h)
 }
 
 int ndt2d_match(ndt2d_handle h, size_t th_begin, size_t th_end, double * h_scores,
                 ndt2d_match_result * out)
 {
+  NDT2D_C_TRY
   if (h == nullptr || out == nullptr) return NDT2D_ERR_INVALID;
   double * d_scores = nullptr;
   size_t n_scores = 0;
@@ -1519,6 +1573,7 @@ int ndt2d_match(ndt2d_handle h, size_t th_begin, size_t th_end, double * h_score
     NDT2D_SYNC(h);
   }
   return ndt2d_match_fetch(h, out);
+  NDT2D_C_CATCH(h)
 }
 
 // slots of the host-coherent block the sharded particle path uses (behind the few-pose path's
@@ -1534,11 +1589,14 @@ static int score_poses_launch_impl(ndt2d_handle h, const double * d_poses_xyt, s
 int ndt2d_score_poses_launch(ndt2d_handle h, const double * d_poses_xyt, size_t n_poses,
                              double * d_scores, double * d_stats)
 {
+  NDT2D_C_TRY
   return score_poses_launch_impl(h, d_poses_xyt, n_poses, d_scores, d_stats, false);
+  NDT2D_C_CATCH(h)
 }
 
 int ndt2d_pose_sums_launch(ndt2d_handle h, const double * d_poses_xyt, size_t n_poses, double * d_scores)
 {
+  NDT2D_C_TRY
   if (h == nullptr) return NDT2D_ERR_INVALID;
   NDT2D_TEST_MAYBE_FAIL(h, "ndt2d_pose_sums_launch");
   NDT2D_HIP(h, hipSetDevice(h->device));
@@ -1546,10 +1604,12 @@ int ndt2d_pose_sums_launch(ndt2d_handle h, const double * d_poses_xyt, size_t n_
   if (rc != NDT2D_OK) return rc;
   if ((rc = ensure_host_res(h)) != NDT2D_OK) return rc;
   return score_poses_launch_impl(h, d_poses_xyt, n_poses, d_scores, h->stats.ptr, true);
+  NDT2D_C_CATCH(h)
 }
 
 int ndt2d_pose_sums_fetch(ndt2d_handle h, double * sums_out)
 {
+  NDT2D_C_TRY
   if (h == nullptr || sums_out == nullptr) return NDT2D_ERR_INVALID;
   if (!h->sums_pending) return fail(h, NDT2D_ERR_STATE, "ndt2d_pose_sums_fetch: nothing launched");
   NDT2D_HIP(h, hipSetDevice(h->device));
@@ -1558,11 +1618,13 @@ int ndt2d_pose_sums_fetch(ndt2d_handle h, double * sums_out)
   if (rc != NDT2D_OK) return rc;
   for (int k = 0; k < NDT2D_POSE_STATS_DOUBLES; ++k) sums_out[k] = h->host_res[kPoseSumsSlot + k];
   return NDT2D_OK;
+  NDT2D_C_CATCH(h)
 }
 
 int ndt2d_pf_finalize_totals_launch(ndt2d_handle h, const double * d_poses_xyt, size_t n_poses,
                                     double * d_weights, const double * totals)
 {
+  NDT2D_C_TRY
   if (h == nullptr) return NDT2D_ERR_INVALID;
   if (d_poses_xyt == nullptr || d_weights == nullptr || totals == nullptr || n_poses == 0)
   {
@@ -1578,15 +1640,18 @@ int ndt2d_pf_finalize_totals_launch(ndt2d_handle h, const double * d_poses_xyt, 
                                            h->host_res_dev + kPfShardOutSlot, h->stream);
   if (e != hipSuccess) return fail_hip(h, e, "launch_pf_finalize");
   return NDT2D_OK;
+  NDT2D_C_CATCH(h)
 }
 
 int ndt2d_pf_result_read(ndt2d_handle h, double * out)
 {
+  NDT2D_C_TRY
   if (h == nullptr || out == nullptr) return NDT2D_ERR_INVALID;
   if (h->host_res == nullptr) return fail(h, NDT2D_ERR_STATE, "ndt2d_pf_result_read: nothing launched");
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
   for (int k = 0; k < NDT2D_PF_RESULT_DOUBLES; ++k) out[k] = h->host_res[kPfShardOutSlot + k];
   return NDT2D_OK;
+  NDT2D_C_CATCH(h)
 }
 
 static int score_poses_launch_impl(ndt2d_handle h, const double * d_poses_xyt, size_t n_poses,
@@ -1660,6 +1725,7 @@ static int score_poses_launch_impl(ndt2d_handle h, const double * d_poses_xyt, s
 int ndt2d_score_poses_beams(ndt2d_handle h, const double * beams_xy, size_t n_beams,
                             const double * h_poses_xyt, size_t n_poses, double * h_scores)
 {
+  NDT2D_C_TRY
   if (h == nullptr) return NDT2D_ERR_INVALID;
   if (beams_xy == nullptr || n_beams == 0 || n_beams > (1u << 20) || h_poses_xyt == nullptr ||
       h_scores == nullptr || n_poses == 0)
@@ -1698,11 +1764,13 @@ int ndt2d_score_poses_beams(ndt2d_handle h, const double * beams_xy, size_t n_be
   int rc = ndt2d_set_beams(h, beams_xy, n_beams);
   if (rc != NDT2D_OK) return rc;
   return ndt2d_score_poses(h, h_poses_xyt, n_poses, h_scores, nullptr);
+  NDT2D_C_CATCH(h)
 }
 
 int ndt2d_score_poses_beams_launch(ndt2d_handle h, const double * beams_xy, size_t n_beams,
                                    const double * h_poses_xyt, size_t n_poses)
 {
+  NDT2D_C_TRY
   if (h == nullptr) return NDT2D_ERR_INVALID;
   if (h_poses_xyt == nullptr || n_poses == 0 || (beams_xy != nullptr && n_beams == 0))
   {
@@ -1734,10 +1802,12 @@ int ndt2d_score_poses_beams_launch(ndt2d_handle h, const double * beams_xy, size
   h->beams_ptr = h->beams.ptr;
   h->beam_rmax = beam_reach(beams_xy, n_beams);
   return NDT2D_OK;
+  NDT2D_C_CATCH(h)
 }
 
 int ndt2d_score_fetch(ndt2d_handle h, double * h_scores)
 {
+  NDT2D_C_TRY
   if (h == nullptr) return NDT2D_ERR_INVALID;
   if (h_scores == nullptr) return fail(h, NDT2D_ERR_INVALID, "ndt2d_score_fetch: bad argument");
   const int rc = run_few_fetch(h, h_scores, nullptr);
@@ -1748,6 +1818,7 @@ int ndt2d_score_fetch(ndt2d_handle h, double * h_scores)
     h->has_search = false;
   }
   return rc;
+  NDT2D_C_CATCH(h)
 }
 
 // A LARGE batch of poses from (pageable or pinned) host memory -- ParticleFilter::measure of a
@@ -1893,6 +1964,7 @@ static int pipelined_pose_batch(ndt2d_context * h, const double * h_poses_xyt, s
 int ndt2d_score_poses(ndt2d_handle h, const double * h_poses_xyt, size_t n_poses,
                       double * h_scores, double * h_stats)
 {
+  NDT2D_C_TRY
   if (h == nullptr) return NDT2D_ERR_INVALID;
   if (h_poses_xyt == nullptr || h_scores == nullptr || n_poses == 0)
   {
@@ -1961,11 +2033,13 @@ int ndt2d_score_poses(ndt2d_handle h, const double * h_poses_xyt, size_t n_poses
   }
   NDT2D_SYNC(h);
   return NDT2D_OK;
+  NDT2D_C_CATCH(h)
 }
 
 int ndt2d_pf_finalize_launch(ndt2d_handle h, const double * d_poses_xyt, size_t n_poses,
                              double * d_weights, const double * d_stats, double * d_out)
 {
+  NDT2D_C_TRY
   if (h == nullptr) return NDT2D_ERR_INVALID;
   if (d_poses_xyt == nullptr || d_weights == nullptr || d_stats == nullptr || d_out == nullptr ||
       n_poses == 0)
@@ -1979,11 +2053,13 @@ int ndt2d_pf_finalize_launch(ndt2d_handle h, const double * d_poses_xyt, size_t 
                                            h->ws_poses.ptr, d_out, nullptr, h->stream);
   if (e != hipSuccess) return fail_hip(h, e, "launch_pf_finalize");
   return NDT2D_OK;
+  NDT2D_C_CATCH(h)
 }
 
 int ndt2d_pf_measure(ndt2d_handle h, const double * h_poses_xyt, size_t n_poses,
                      double * h_weights, double * h_out)
 {
+  NDT2D_C_TRY
   if (h == nullptr) return NDT2D_ERR_INVALID;
   if (h_poses_xyt == nullptr || h_weights == nullptr || h_out == nullptr || n_poses == 0)
   {
@@ -2029,11 +2105,13 @@ int ndt2d_pf_measure(ndt2d_handle h, const double * h_poses_xyt, size_t n_poses,
                               hipMemcpyDeviceToHost, h->stream));
   NDT2D_SYNC(h);
   return NDT2D_OK;
+  NDT2D_C_CATCH(h)
 }
 
 int ndt2d_pf_noise_launch(ndt2d_handle h, uint64_t seed, uint64_t step, uint64_t first_index,
                           size_t n, float * d_noise_out)
 {
+  NDT2D_C_TRY
   if (h == nullptr) return NDT2D_ERR_INVALID;
   if (d_noise_out == nullptr || n == 0)
   {
@@ -2043,12 +2121,14 @@ int ndt2d_pf_noise_launch(ndt2d_handle h, uint64_t seed, uint64_t step, uint64_t
   hipError_t e = ndt2d::launch_pf_noise(d_noise_out, n, seed, first_index, step, h->stream);
   if (e != hipSuccess) return fail_hip(h, e, "launch_pf_noise");
   return NDT2D_OK;
+  NDT2D_C_CATCH(h)
 }
 
 int ndt2d_pf_motion_launch(ndt2d_handle h, double * d_poses_xyt, size_t n, double dx, double dy,
                            double dth, const double * alphas5, const float * d_noise,
                            uint64_t seed, uint64_t step, uint64_t first_index)
 {
+  NDT2D_C_TRY
   if (h == nullptr) return NDT2D_ERR_INVALID;
   if (d_poses_xyt == nullptr || alphas5 == nullptr || n == 0)
   {
@@ -2060,6 +2140,7 @@ int ndt2d_pf_motion_launch(ndt2d_handle h, double * d_poses_xyt, size_t n, doubl
     ndt2d::launch_pf_motion(d_poses_xyt, n, p, d_noise, seed, first_index, step, h->stream);
   if (e != hipSuccess) return fail_hip(h, e, "launch_pf_motion");
   return NDT2D_OK;
+  NDT2D_C_CATCH(h)
 }
 
 int ndt2d_pf_init_launch(ndt2d_handle h, double * d_poses_xyt, size_t n, double x, double y,
@@ -2067,6 +2148,7 @@ int ndt2d_pf_init_launch(ndt2d_handle h, double * d_poses_xyt, size_t n, double 
                          const float * d_noise, uint64_t seed, uint64_t step,
                          uint64_t first_index)
 {
+  NDT2D_C_TRY
   if (h == nullptr) return NDT2D_ERR_INVALID;
   if (d_poses_xyt == nullptr || n == 0)
   {
@@ -2084,11 +2166,13 @@ int ndt2d_pf_init_launch(ndt2d_handle h, double * d_poses_xyt, size_t n, double 
     ndt2d::launch_pf_init(d_poses_xyt, n, p, d_noise, seed, first_index, step, h->stream);
   if (e != hipSuccess) return fail_hip(h, e, "launch_pf_init");
   return NDT2D_OK;
+  NDT2D_C_CATCH(h)
 }
 
 int ndt2d_pose_moments_launch(ndt2d_handle h, const double * d_poses_xyt, size_t n,
                               const double * d_weights, double * d_stats)
 {
+  NDT2D_C_TRY
   if (h == nullptr) return NDT2D_ERR_INVALID;
   if (d_poses_xyt == nullptr || d_stats == nullptr || n == 0)
   {
@@ -2101,12 +2185,14 @@ int ndt2d_pose_moments_launch(ndt2d_handle h, const double * d_poses_xyt, size_t
     ndt2d::launch_pose_moments(d_poses_xyt, n, d_weights, h->ws_poses.ptr, d_stats, h->stream);
   if (e != hipSuccess) return fail_hip(h, e, "launch_pose_moments");
   return NDT2D_OK;
+  NDT2D_C_CATCH(h)
 }
 
 int ndt2d_pf_update(ndt2d_handle h, double * h_poses_xyt, size_t n, double dx, double dy,
                     double dth, const double * alphas5, const float * h_noise, uint64_t seed,
                     uint64_t step, double * h_weights, double * h_out)
 {
+  NDT2D_C_TRY
   if (h == nullptr) return NDT2D_ERR_INVALID;
   if (h_poses_xyt == nullptr || alphas5 == nullptr || h_weights == nullptr || h_out == nullptr ||
       n == 0)
@@ -2148,6 +2234,7 @@ int ndt2d_pf_update(ndt2d_handle h, double * h_poses_xyt, size_t n, double dx, d
                               hipMemcpyDeviceToHost, h->stream));
   NDT2D_SYNC(h);
   return NDT2D_OK;
+  NDT2D_C_CATCH(h)
 }
 
 }  // extern "C"
@@ -2295,6 +2382,7 @@ int ndt2d_convert_scan_launch(ndt2d_handle h, const float * d_ranges, size_t n_r
                               const ndt2d_laser_scan * scan, double * d_points_xy_out,
                               double * d_info_out)
 {
+  NDT2D_C_TRY
   if (h == nullptr) return NDT2D_ERR_INVALID;
   if (d_ranges == nullptr || scan == nullptr || d_points_xy_out == nullptr ||
       d_info_out == nullptr || n_ranges == 0 || n_ranges > (1u << 24))
@@ -2307,12 +2395,14 @@ int ndt2d_convert_scan_launch(ndt2d_handle h, const float * d_ranges, size_t n_r
                                             h->stream);
   if (e != hipSuccess) return fail_hip(h, e, "launch_convert_scan");
   return NDT2D_OK;
+  NDT2D_C_CATCH(h)
 }
 
 int ndt2d_convert_scan(ndt2d_handle h, const float * h_ranges, size_t n_ranges,
                        const ndt2d_laser_scan * scan, double * h_points_xy_out,
                        size_t * n_points_out)
 {
+  NDT2D_C_TRY
   if (h == nullptr) return NDT2D_ERR_INVALID;
   if (scan == nullptr || n_points_out == nullptr || (n_ranges > 0 && h_ranges == nullptr) ||
       (n_ranges > 0 && h_points_xy_out == nullptr))
@@ -2337,12 +2427,14 @@ int ndt2d_convert_scan(ndt2d_handle h, const float * h_ranges, size_t n_ranges,
   }
   *n_points_out = n;
   return NDT2D_OK;
+  NDT2D_C_CATCH(h)
 }
 
 int ndt2d_set_beams_from_ranges(ndt2d_handle h, const float * h_ranges, size_t n_ranges,
                                 const ndt2d_laser_scan * scan, size_t laser_max_beams,
                                 size_t * n_points_out, size_t * n_beams_out)
 {
+  NDT2D_C_TRY
   if (h == nullptr) return NDT2D_ERR_INVALID;
   if (scan == nullptr || n_beams_out == nullptr || (n_ranges > 0 && h_ranges == nullptr) ||
       laser_max_beams > (1u << 20))
@@ -2379,6 +2471,7 @@ int ndt2d_set_beams_from_ranges(ndt2d_handle h, const float * h_ranges, size_t n
     h->beam_rmax = info[2];
   }
   return NDT2D_OK;
+  NDT2D_C_CATCH(h)
 }
 
 const double * ndt2d_scan_points(ndt2d_handle h, size_t * n_points_out)
@@ -2394,6 +2487,7 @@ int ndt2d_occupancy_grid(ndt2d_handle h, double resolution, double occ_thresh,
                          double * bounds_inout, ndt2d_occupancy_info * info_out,
                          signed char * data_out, size_t data_capacity)
 {
+  NDT2D_C_TRY
   if (h == nullptr) return NDT2D_ERR_INVALID;
   if (!(resolution > 0.0) || bounds_inout == nullptr || info_out == nullptr ||
       n_scans_bounded > n_scans || n_scans > (1u << 30) ||
@@ -2506,30 +2600,36 @@ int ndt2d_occupancy_grid(ndt2d_handle h, double resolution, double occ_thresh,
   NDT2D_HIP(h, hipMemcpyAsync(data_out, d_data, n_cells, hipMemcpyDeviceToHost, h->stream));
   NDT2D_SYNC(h);
   return NDT2D_OK;
+  NDT2D_C_CATCH(h)
 }
 
 int ndt2d_device_alloc(ndt2d_handle h, size_t bytes, void ** d_out)
 {
+  NDT2D_C_TRY
   if (h == nullptr || d_out == nullptr) return NDT2D_ERR_INVALID;
   *d_out = nullptr;
   if (bytes == 0) return fail(h, NDT2D_ERR_INVALID, "ndt2d_device_alloc: zero size");
   NDT2D_HIP(h, hipSetDevice(h->device));
   NDT2D_HIP(h, hipMalloc(d_out, bytes));
   return NDT2D_OK;
+  NDT2D_C_CATCH(h)
 }
 
 int ndt2d_device_free(ndt2d_handle h, void * d_ptr)
 {
+  NDT2D_C_TRY
   if (h == nullptr) return NDT2D_ERR_INVALID;
   if (d_ptr == nullptr) return NDT2D_OK;
   NDT2D_HIP(h, hipSetDevice(h->device));
   NDT2D_SYNC(h);  // nothing in flight may still use it
   NDT2D_HIP(h, hipFree(d_ptr));
   return NDT2D_OK;
+  NDT2D_C_CATCH(h)
 }
 
 int ndt2d_copy_to_device(ndt2d_handle h, void * d_dst, const void * h_src, size_t bytes)
 {
+  NDT2D_C_TRY
   if (h == nullptr) return NDT2D_ERR_INVALID;
   if (bytes == 0) return NDT2D_OK;
   if (d_dst == nullptr || h_src == nullptr) return fail(h, NDT2D_ERR_INVALID, "ndt2d_copy_to_device: null pointer");
@@ -2537,10 +2637,12 @@ int ndt2d_copy_to_device(ndt2d_handle h, void * d_dst, const void * h_src, size_
   NDT2D_HIP(h, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, h->stream));
   NDT2D_SYNC(h);
   return NDT2D_OK;
+  NDT2D_C_CATCH(h)
 }
 
 int ndt2d_copy_to_host(ndt2d_handle h, void * h_dst, const void * d_src, size_t bytes)
 {
+  NDT2D_C_TRY
   if (h == nullptr) return NDT2D_ERR_INVALID;
   if (bytes == 0) return NDT2D_OK;
   if (h_dst == nullptr || d_src == nullptr) return fail(h, NDT2D_ERR_INVALID, "ndt2d_copy_to_host: null pointer");
@@ -2548,48 +2650,58 @@ int ndt2d_copy_to_host(ndt2d_handle h, void * h_dst, const void * d_src, size_t 
   NDT2D_HIP(h, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, h->stream));
   NDT2D_SYNC(h);
   return NDT2D_OK;
+  NDT2D_C_CATCH(h)
 }
 
 int ndt2d_copy_to_device_async(ndt2d_handle h, void * d_dst, const void * h_src, size_t bytes)
 {
+  NDT2D_C_TRY
   if (h == nullptr) return NDT2D_ERR_INVALID;
   if (bytes == 0) return NDT2D_OK;
   if (d_dst == nullptr || h_src == nullptr) return fail(h, NDT2D_ERR_INVALID, "ndt2d_copy_to_device_async: null pointer");
   NDT2D_HIP(h, hipSetDevice(h->device));
   NDT2D_HIP(h, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, h->stream));
   return NDT2D_OK;
+  NDT2D_C_CATCH(h)
 }
 
 int ndt2d_copy_to_host_async(ndt2d_handle h, void * h_dst, const void * d_src, size_t bytes)
 {
+  NDT2D_C_TRY
   if (h == nullptr) return NDT2D_ERR_INVALID;
   if (bytes == 0) return NDT2D_OK;
   if (h_dst == nullptr || d_src == nullptr) return fail(h, NDT2D_ERR_INVALID, "ndt2d_copy_to_host_async: null pointer");
   NDT2D_HIP(h, hipSetDevice(h->device));
   NDT2D_HIP(h, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, h->stream));
   return NDT2D_OK;
+  NDT2D_C_CATCH(h)
 }
 
 int ndt2d_set_timing(ndt2d_handle h, int enabled)
 {
+  NDT2D_C_TRY
   if (h == nullptr) return NDT2D_ERR_INVALID;
   h->timing = enabled != 0;
   if (!h->timing) h->timed = false;
   return NDT2D_OK;
+  NDT2D_C_CATCH(h)
 }
 
 int ndt2d_host_alloc(ndt2d_handle h, size_t bytes, void ** out)
 {
+  NDT2D_C_TRY
   if (h == nullptr || out == nullptr) return NDT2D_ERR_INVALID;
   *out = nullptr;
   if (bytes == 0) return fail(h, NDT2D_ERR_INVALID, "ndt2d_host_alloc: zero size");
   NDT2D_HIP(h, hipSetDevice(h->device));
   NDT2D_HIP(h, hipHostMalloc(out, bytes, hipHostMallocMapped | hipHostMallocPortable));
   return NDT2D_OK;
+  NDT2D_C_CATCH(h)
 }
 
 int ndt2d_host_free(ndt2d_handle h, void * ptr)
 {
+  NDT2D_C_TRY
   if (ptr == nullptr) return h != nullptr ? NDT2D_OK : NDT2D_ERR_INVALID;
   if (h == nullptr)   // the owning context is gone, and with it everything that could use ptr
   {
@@ -2601,18 +2713,22 @@ int ndt2d_host_free(ndt2d_handle h, void * ptr)
   NDT2D_SYNC(h);  // nothing in flight may still use it
   NDT2D_HIP(h, hipHostFree(ptr));
   return NDT2D_OK;
+  NDT2D_C_CATCH(h)
 }
 
 int ndt2d_synchronize(ndt2d_handle h)
 {
+  NDT2D_C_TRY
   if (h == nullptr) return NDT2D_ERR_INVALID;
   NDT2D_HIP(h, hipSetDevice(h->device));
   NDT2D_SYNC(h);
   return NDT2D_OK;
+  NDT2D_C_CATCH(h)
 }
 
 int ndt2d_last_launch_ms(ndt2d_handle h, float * ms, int * n_kernels)
 {
+  NDT2D_C_TRY
   if (h == nullptr || ms == nullptr) return NDT2D_ERR_INVALID;
   if (!h->timed) return fail(h, NDT2D_ERR_STATE, "ndt2d_last_launch_ms: nothing launched");
   NDT2D_HIP(h, hipSetDevice(h->device));
@@ -2620,10 +2736,12 @@ int ndt2d_last_launch_ms(ndt2d_handle h, float * ms, int * n_kernels)
   NDT2D_HIP(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
   if (n_kernels != nullptr) *n_kernels = h->last_kernels;
   return NDT2D_OK;
+  NDT2D_C_CATCH(h)
 }
 
 int ndt2d_launch_history_ms(ndt2d_handle h, float * ms_out, size_t capacity, size_t * n_out)
 {
+  NDT2D_C_TRY
   if (h == nullptr || n_out == nullptr || (capacity > 0 && ms_out == nullptr)) return NDT2D_ERR_INVALID;
   *n_out = 0;
   NDT2D_HIP(h, hipSetDevice(h->device));
@@ -2638,24 +2756,30 @@ int ndt2d_launch_history_ms(ndt2d_handle h, float * ms_out, size_t capacity, siz
   }
   *n_out = n;
   return NDT2D_OK;
+  NDT2D_C_CATCH(h)
 }
 
 const char * ndt2d_last_variant(ndt2d_handle h) { return h != nullptr ? h->last_variant : ""; }
 
 int ndt2d_set_pipeline_pieces(ndt2d_handle h, int pieces)
 {
+  NDT2D_C_TRY
   if (h == nullptr || pieces < 0 || pieces > NDT2D_PIPELINE_PIECES) return NDT2D_ERR_INVALID;
   h->pipeline_pieces = pieces;
   return NDT2D_OK;
+  NDT2D_C_CATCH(h)
 }
 
 int ndt2d_last_pipeline_pieces(ndt2d_handle h)
 {
+  NDT2D_C_TRY
   return h == nullptr ? 0 : h->last_pieces;
+  NDT2D_C_CATCH(h)
 }
 
 int ndt2d_set_variant(ndt2d_handle h, const char * name)
 {
+  NDT2D_C_TRY
   if (h == nullptr || name == nullptr) return NDT2D_ERR_INVALID;
   h->batched_only = false;
   if (std::strcmp(name, "auto") == 0) h->force_variant = ndt2d::kVariantAuto;
@@ -2673,6 +2797,7 @@ int ndt2d_set_variant(ndt2d_handle h, const char * name)
   else if (std::strcmp(name, "compact-exact") == 0) h->force_variant = ndt2d::kVariantNoSkip;
   else return fail(h, NDT2D_ERR_INVALID, "ndt2d_set_variant: unknown variant");
   return NDT2D_OK;
+  NDT2D_C_CATCH(h)
 }
 
 }  // extern "C"
@@ -2680,7 +2805,9 @@ int ndt2d_set_variant(ndt2d_handle h, const char * name)
 #ifdef NDT2D_TEST_HOOKS
 extern "C" int ndt2d_test_fail_launch(int kth)
 {
+  NDT2D_C_TRY
   g_test_fail_launch.store(kth);
   return 0;
+  NDT2D_C_CATCH(nullptr)
 }
 #endif

@@ -32,6 +32,7 @@
 
 #include "ndt2d_eigen2.h"
 #include "ndt2d_exchange.h"
+#include "ndt2d_guard.h"
 #include "ndt2d_hip.h"
 #include "ndt2d_workers.h"
 
@@ -91,9 +92,14 @@ struct HostCell
     cov_xy = (corr_xy - (mean_x * mean_y)) * scale;
     cov_yy = (corr_yy - (mean_y * mean_y)) * scale;
 
-    double small, large;
-    ndt2d::covariance_eigenvalues(eigen_form, cov_xx, cov_xy, cov_yy, &small, &large);
-    if (small > large) std::swap(small, large);
+    // (the eigenvalues decide the branch and feed the clamp's determinant: a covariance far from
+    // the threshold does not need them, ndt2d_eigen2.h clamp_test_surely_false)
+    double small = 1.0, large = 1.0;
+    if (!ndt2d::clamp_test_surely_false(cov_xx, cov_xy, cov_yy))
+    {
+      ndt2d::covariance_eigenvalues(eigen_form, cov_xx, cov_xy, cov_yy, &small, &large);
+      if (small > large) std::swap(small, large);
+    }
     if (small < 0.001 * large)
     {
       // eigenvalue clamp (:88-96)
@@ -142,7 +148,7 @@ public:
     // follows the scan poses, so its size changes by a cell now and then; a real lidar's
     // grid is tens of thousands of cells, 6 MB, of which a scan touches a thousand).
     for (const uint32_t i : touched_) cells_[i] = HostCell();
-    if (cells_.size() < sx * sy) cells_.resize(sx * sy);
+    if (cells_.size() < sx * sy + 1) cells_.resize(sx * sy + 1);   // (+ 1: add_scan's scratch cell)
     n_cells_ = sx * sy;
     touched_.clear();
     {
@@ -172,30 +178,213 @@ public:
     return static_cast<long>(gy * size_x_ + gx);
   }
 
-  // NDT::addScan, reference src/ndt_model.cpp:132-152
+  // NDT::addScan, reference src/ndt_model.cpp:132-152.
+  //
+  // Cell::addPoint is a recurrence -- v = (v * n + t) / (n + 1) on five running values -- and
+  // consecutive beams of a scan fall into the same cell more often than not: one dependent chain
+  // of multiply, add, DIVIDE and a store-to-load round trip per point (~20 cycles; the whole of
+  // addScans' host time, 4.3 ns per point on the GPU box's EPYC 9575F).  Round 6: a scan is cut
+  // into four quarters of consecutive beams and the quarters advance side by side -- four chains
+  // in flight, and the four corr_yy updates of a step share ONE packed divide (five 256-bit
+  // divides per four points instead of eight divide operations).  A cell's values depend on the
+  // ORDER of its points (the reference's: scan after scan, beam after beam): pass 1 transforms the
+  // points and looks their cells up (branch-free, vectorised by the compiler), then stamps every
+  // cell with the first quarter of the scan that reaches it; the points of a LATER quarter in
+  // such a cell (the cell a quarter boundary falls into; a robot boxed in closer than a cell) are
+  // taken out of their quarter and added behind the quarters, in beam order.  So every cell
+  // still receives its points in the reference's order, and every lane of a packed operation is
+  // the IEEE operation of the scalar code: bit-identical cells (tests/test_host_logic.py, and
+  // every host-build == oracle test).  Points outside the grid go to a scratch cell behind it.
 #if defined(__x86_64__) && defined(__GNUC__) && !defined(__clang__)
   __attribute__((target_clones("avx2", "default")))
 #endif
   void add_scan(double pose_x, double pose_y, double pose_theta, const double * pts, size_t n)
   {
+    typedef double v4d __attribute__((vector_size(32)));
     double cos_th, sin_th;
     ndt2d_cos_sin(pose_theta, &cos_th, &sin_th);  // :135-136
-    for (size_t k = 0; k < n; ++k)
+    const size_t quarter = n / 4;
+    const bool side_by_side = quarter >= 8 && interleave_;   // (shorter scans: nothing to gain)
+    if (!side_by_side)
     {
-      const double px = pts[2 * k], py = pts[2 * k + 1];
-      double wx = pose_x;
-      double wy = pose_y;
-      wx += px * cos_th - py * sin_th;
-      wy += px * sin_th + py * cos_th;
-      const long i = index(wx, wy);
-      if (i >= 0)
+      // the reference's loop as it stands
+      for (size_t k = 0; k < n; ++k)
       {
-        HostCell & c = cells_[static_cast<size_t>(i)];
-        if (c.n == 0.0) touched_.push_back(static_cast<uint32_t>(i));
-        c.add(wx, wy);
+        const double px = pts[2 * k], py = pts[2 * k + 1];
+        double wx = pose_x;
+        double wy = pose_y;
+        wx += px * cos_th - py * sin_th;
+        wy += px * sin_th + py * cos_th;
+        const long i = index(wx, wy);
+        if (i >= 0)
+        {
+          HostCell & c = cells_[static_cast<size_t>(i)];
+          if (c.n == 0.0) touched_.push_back(static_cast<uint32_t>(i));
+          c.add(wx, wy);
+        }
+      }
+      return;
+    }
+    if (scan_idx_.size() < n)
+    {
+      scan_idx_.resize(n);
+      scan_xy_.resize(2 * n);
+    }
+    if (cells_.size() < n_cells_ + 1) cells_.resize(n_cells_ + 1);
+    if (stamp_.size() < cells_.size()) stamp_.resize(cells_.size(), 0u);
+    if (epoch_ > 0xfffffff0u)
+    {
+      std::fill(stamp_.begin(), stamp_.end(), 0u);
+      epoch_ = 0;
+    }
+    const uint32_t scan_first = epoch_ + 1;
+    epoch_ += 4;
+    int32_t * const idx = scan_idx_.data();
+    double * const xy = scan_xy_.data();
+    const int32_t outside = static_cast<int32_t>(n_cells_);   // the scratch cell
+    // pass 1a: points_world (:138-143) and NDT::getIndex (:203-218).  For a point that passed
+    // `x >= origin`, trunc(f) < size  <=>  f < size, so the four comparisons are getIndex's.
+    // (Everything the loop reads of *this is copied out first: its stores could alias members.)
+    {
+      const double ox = origin_x_, oy = origin_y_, inv = inv_cell_size_, cs = cell_size_;
+      const double fsx = static_cast<double>(size_x_), fsy = static_cast<double>(size_y_);
+      const int32_t sx = static_cast<int32_t>(size_x_);
+      if (pow2_)
+      {
+        for (size_t k = 0; k < n; ++k)
+        {
+          const double px = pts[2 * k], py = pts[2 * k + 1];
+          double wx = pose_x;
+          double wy = pose_y;
+          wx += px * cos_th - py * sin_th;
+          wy += px * sin_th + py * cos_th;
+          xy[2 * k] = wx;
+          xy[2 * k + 1] = wy;
+          const double fx = (wx - ox) * inv, fy = (wy - oy) * inv;   // (exact reciprocal: == the divide)
+          const bool in = (wx >= ox) & (wy >= oy) & (fx < fsx) & (fy < fsy);
+          const int32_t gx = static_cast<int32_t>(in ? fx : 0.0), gy = static_cast<int32_t>(in ? fy : 0.0);
+          idx[k] = in ? gy * sx + gx : outside;
+        }
+      }
+      else
+      {
+        for (size_t k = 0; k < n; ++k)
+        {
+          const double px = pts[2 * k], py = pts[2 * k + 1];
+          double wx = pose_x;
+          double wy = pose_y;
+          wx += px * cos_th - py * sin_th;
+          wy += px * sin_th + py * cos_th;
+          xy[2 * k] = wx;
+          xy[2 * k + 1] = wy;
+          const double fx = (wx - ox) / cs, fy = (wy - oy) / cs;
+          const bool in = (wx >= ox) & (wy >= oy) & (fx < fsx) & (fy < fsy);
+          const int32_t gx = static_cast<int32_t>(in ? fx : 0.0), gy = static_cast<int32_t>(in ? fy : 0.0);
+          idx[k] = in ? gy * sx + gx : outside;
+        }
       }
     }
+    // pass 1b: first touches (in beam order: `touched_` keeps the order the sequential loop gave
+    // it) and the quarter stamps.  A point whose cell an EARLIER quarter of this scan has reached
+    // (the cell a quarter boundary falls into, mostly) leaves its quarter: it is added after the
+    // quarters, in beam order -- every point of that cell from the later quarter does, so the
+    // cell still sees its points in the reference's order.  The n % 4 beams behind the fourth
+    // quarter go the same way.
+    size_t n_late = 0;
+    {
+      const size_t n_touched_before = touched_.size();
+      touched_.resize(n_touched_before + n);
+      if (late_.size() < n) late_.resize(n);
+      uint32_t * touched_out = touched_.data() + n_touched_before;
+      uint32_t * const stamp = stamp_.data();
+      uint32_t * const late = late_.data();
+      const HostCell * const cells = cells_.data();
+      for (size_t part = 0; part < 4; ++part)
+      {
+        const size_t k_end = part == 3 ? n : (part + 1) * quarter;
+        const uint32_t mine = scan_first + static_cast<uint32_t>(part);
+        for (size_t k = part * quarter; k < k_end; ++k)
+        {
+          const int32_t i = idx[k];
+          if (i == outside) continue;
+          const uint32_t seen = stamp[i];
+          if (seen < scan_first)
+          {
+            stamp[i] = mine;
+            *touched_out = static_cast<uint32_t>(i);
+            touched_out += cells[i].n == 0.0 ? 1 : 0;
+          }
+          if ((seen >= scan_first && seen != mine) || k >= 4 * quarter)
+          {
+            late[n_late++] = static_cast<uint32_t>(k);
+          }
+        }
+      }
+      touched_.resize(static_cast<size_t>(touched_out - touched_.data()));
+    }
+    // pass 2: Cell::addPoint (:50-63)
+    HostCell * const cells = cells_.data();
+    {
+      const size_t q = quarter;
+      // (the late points step aside: their quarter adds to the scratch cell in their place)
+      if (late_cell_.size() < n_late) late_cell_.resize(n_late);
+      for (size_t l = 0; l < n_late; ++l)
+      {
+        const uint32_t k = late_[l];
+        late_cell_[l] = idx[k];
+        idx[k] = outside;
+      }
+      for (size_t j = 0; j < q; ++j)
+      {
+        HostCell & c0 = cells[idx[j]];
+        HostCell & c1 = cells[idx[j + q]];
+        HostCell & c2 = cells[idx[j + 2 * q]];
+        HostCell & c3 = cells[idx[j + 3 * q]];
+        const double x0 = xy[2 * j], y0 = xy[2 * j + 1];
+        const double x1 = xy[2 * (j + q)], y1 = xy[2 * (j + q) + 1];
+        const double x2 = xy[2 * (j + 2 * q)], y2 = xy[2 * (j + 2 * q) + 1];
+        const double x3 = xy[2 * (j + 3 * q)], y3 = xy[2 * (j + 3 * q) + 1];
+        const v4d nn = {c0.n, c1.n, c2.n, c3.n};
+        const v4d n1 = nn + 1.0;
+        v4d yy = {c0.corr_yy, c1.corr_yy, c2.corr_yy, c3.corr_yy};
+        const v4d ty = {y0 * y0, y1 * y1, y2 * y2, y3 * y3};
+        yy = (yy * nn + ty) / n1;
+        v4d v0, v1, v2, v3;
+        std::memcpy(&v0, &c0.mean_x, sizeof(v4d));     // mean_x, mean_y, corr_xx, corr_xy
+        std::memcpy(&v1, &c1.mean_x, sizeof(v4d));
+        std::memcpy(&v2, &c2.mean_x, sizeof(v4d));
+        std::memcpy(&v3, &c3.mean_x, sizeof(v4d));
+        const v4d t0 = {x0, y0, x0 * x0, x0 * y0}, t1 = {x1, y1, x1 * x1, x1 * y1};
+        const v4d t2 = {x2, y2, x2 * x2, x2 * y2}, t3 = {x3, y3, x3 * x3, x3 * y3};
+        v0 = (v0 * nn[0] + t0) / n1[0];
+        v1 = (v1 * nn[1] + t1) / n1[1];
+        v2 = (v2 * nn[2] + t2) / n1[2];
+        v3 = (v3 * nn[3] + t3) / n1[3];
+        std::memcpy(&c0.mean_x, &v0, sizeof(v4d));
+        std::memcpy(&c1.mean_x, &v1, sizeof(v4d));
+        std::memcpy(&c2.mean_x, &v2, sizeof(v4d));
+        std::memcpy(&c3.mean_x, &v3, sizeof(v4d));
+        c0.corr_yy = yy[0];
+        c1.corr_yy = yy[1];
+        c2.corr_yy = yy[2];
+        c3.corr_yy = yy[3];
+        c0.n = n1[0];
+        c1.n = n1[1];
+        c2.n = n1[2];
+        c3.n = n1[3];
+        c0.valid = c1.valid = c2.valid = c3.valid = false;
+      }
+      for (size_t l = 0; l < n_late; ++l)
+      {
+        const uint32_t k = late_[l];
+        cells[late_cell_[l]].add(xy[2 * k], xy[2 * k + 1]);
+      }
+    }
+    cells[outside] = HostCell();
   }
+
+  // (tests: the sequential order for every scan -- the two must agree bit for bit)
+  void set_interleave(bool on) { interleave_ = on; }
 
   // NDT::likelihood(Vector2d) (reference src/ndt_model.cpp:162-170) with Cell::score (:105-116)
   // inlined: exp(((-0.5 * q^T) * information) * q) in that order, libm's exp.  Used by the
@@ -286,13 +475,23 @@ private:
   std::vector<HostCell> cells_;     // a pool: the first n_cells_ are the grid
   size_t n_cells_ = 0;
   std::vector<uint32_t> touched_;   // cells that hold at least one point
+  // add_scan: world points and cell indices of the scan being added; per-cell stamp = the
+  // (scan, quarter) that last reached the cell (ids from a running counter: never cleared)
+  std::vector<double> scan_xy_;
+  std::vector<int32_t> scan_idx_;
+  std::vector<uint32_t> stamp_;
+  std::vector<uint32_t> late_;      // beams of the scan that are added after the quarters ...
+  std::vector<int32_t> late_cell_;  // ... and their cells
+  uint32_t epoch_ = 0;
+  bool interleave_ = true;
 };
 
 // ScanMatcherNDT::addScans' extent + NDT build, reference src/scan_matcher_ndt.cpp:49-74.
 // max_x_/max_y_ start at numeric_limits<double>::min(), as the reference has it.
 std::unique_ptr<HostNdt> build_ndt(double resolution, double range_max, const double * poses,
                                    const double * pts, const size_t * offsets, size_t n_scans,
-                                   std::unique_ptr<HostNdt> reuse = nullptr, int eigen_form = ndt2d::kEigenFormSchur)
+                                   std::unique_ptr<HostNdt> reuse = nullptr, int eigen_form = ndt2d::kEigenFormSchur,
+                                   bool side_by_side = true)
 {
   double min_x = std::numeric_limits<double>::max();
   double max_x = std::numeric_limits<double>::min();
@@ -305,6 +504,13 @@ std::unique_ptr<HostNdt> build_ndt(double resolution, double range_max, const do
     min_y = std::min(poses[3 * k + 1] - range_max, min_y);
     max_y = std::max(poses[3 * k + 1] + range_max, max_y);
   }
+  // NDT::NDT (src/ndt_model.cpp:118-126) sizes the grid (size_t)(extent / cell_size + 1) per axis:
+  // a pose of 1e15 or a NaN makes that a count no allocation can serve (or, cast from NaN, undefined
+  // behaviour).  Refused here, before any storage is asked for: nullptr.
+  {
+    const double fsx = ((max_x - min_x) / resolution) + 1, fsy = ((max_y - min_y) / resolution) + 1;
+    if (!(fsx >= 1.0) || !(fsy >= 1.0) || !(fsx * fsy < 2147483648.0)) return nullptr;
+  }
   std::unique_ptr<HostNdt> ndt = std::move(reuse);
   if (ndt)
   {
@@ -314,6 +520,7 @@ std::unique_ptr<HostNdt> build_ndt(double resolution, double range_max, const do
   {
     ndt.reset(new HostNdt(resolution, (max_x - min_x), (max_y - min_y), min_x, min_y));
   }
+  ndt->set_interleave(side_by_side);
   for (size_t k = 0; k < n_scans; ++k)
   {
     ndt->add_scan(poses[3 * k], poses[3 * k + 1], poses[3 * k + 2], pts + 2 * offsets[k],
@@ -335,6 +542,15 @@ std::vector<double> search_offsets(double size, double res)
   }
   for (double v = -size; v < size; v += res) out.push_back(v);
   return out;
+}
+
+// Whether search_offsets(size, res) ends and stays within `limit` values.
+bool offsets_fit(double size, double res, size_t limit)
+{
+  if (!std::isfinite(size) || !std::isfinite(res)) return false;
+  if (!(res > 0.0)) return true;                  // (search_offsets: at most one value)
+  if (!(size > 0.0)) return true;                 // (-size < size fails at once: no value)
+  return 2.0 * size / res <= static_cast<double>(limit) - 2.0;
 }
 
 // Subsampling of matchScan / scorePoints, reference src/scan_matcher_ndt.cpp:95-96,110.
@@ -450,6 +666,20 @@ struct ndt2d_matcher
 
 namespace
 {
+
+// ndt2d_guard.h: where the text of an exception caught at the C boundary goes
+void guard_note(ndt2d_matcher * m, const char * what) noexcept
+{
+  if (m == nullptr) return;
+  try
+  {
+    m->err = what;
+  }
+  catch (...)
+  {
+  }
+}
+void guard_note(std::nullptr_t, const char *) noexcept {}
 
 int mfail(ndt2d_matcher * m, int code, const std::string & msg)
 {
@@ -1252,47 +1482,58 @@ int ndt2d_matcher_create_multi(ndt2d_matcher ** out, const int * device_ids, int
   *out = nullptr;
   if (device_ids == nullptr || n_dev <= 0 || n_dev > 64) return NDT2D_ERR_INVALID;
   ndt2d_matcher * m = new (std::nothrow) ndt2d_matcher();
-  if (m == nullptr) return NDT2D_ERR_INVALID;
-  for (int r = 0; r < n_dev; ++r)
-  {
-    ndt2d_handle dev = nullptr;
-    const int rc = ndt2d_create(&dev, device_ids[r]);
-    if (rc != NDT2D_OK)
-    {
-      destroy_matcher(m);
-      return rc;
-    }
-    m->devs.push_back(dev);
-    m->device_ids.push_back(device_ids[r]);
-  }
-  m->shards.resize(m->devs.size());
-  m->dev = m->devs[0];
+  if (m == nullptr) return NDT2D_ERR_ALLOC;
   try
   {
+    m->devs.reserve(static_cast<size_t>(n_dev));
+    m->device_ids.reserve(static_cast<size_t>(n_dev));
+    for (int r = 0; r < n_dev; ++r)
+    {
+      ndt2d_handle dev = nullptr;
+      const int rc = ndt2d_create(&dev, device_ids[r]);
+      if (rc != NDT2D_OK)
+      {
+        destroy_matcher(m);
+        return rc;
+      }
+      m->devs.push_back(dev);
+      m->device_ids.push_back(device_ids[r]);
+    }
+    m->shards.resize(m->devs.size());
+    m->dev = m->devs[0];
     m->workers.reset(new ndt2d::DeviceWorkers(m->devs.size()));
+    m->dth = search_offsets(m->angular_size, m->angular_res);
+    m->dlin = search_offsets(m->linear_size, m->linear_res);
+  }
+  catch (const std::bad_alloc &)
+  {
+    destroy_matcher(m);
+    return NDT2D_ERR_ALLOC;
   }
   catch (...)
   {
     destroy_matcher(m);
-    return NDT2D_ERR_INVALID;   // (no thread could be started)
+    return NDT2D_ERR_INTERNAL;   // (no thread could be started)
   }
-  m->dth = search_offsets(m->angular_size, m->angular_res);
-  m->dlin = search_offsets(m->linear_size, m->linear_res);
   *out = m;
   return NDT2D_OK;
 }
 
 int ndt2d_matcher_create(ndt2d_matcher ** out, int device_id)
 {
+  NDT2D_C_TRY
   return ndt2d_matcher_create_multi(out, &device_id, 1);
+  NDT2D_C_CATCH(nullptr)
 }
 
 int ndt2d_matcher_destroy(ndt2d_matcher * m)
 {
+  NDT2D_C_TRY
   if (m == nullptr) return NDT2D_ERR_INVALID;
   discard_ahead(m);
   destroy_matcher(m);
   return NDT2D_OK;
+  NDT2D_C_CATCH(m)
 }
 
 int ndt2d_matcher_device_count(ndt2d_matcher * m) { return m != nullptr ? static_cast<int>(m->devs.size()) : 0; }
@@ -1304,52 +1545,70 @@ ndt2d_handle ndt2d_matcher_device_at(ndt2d_matcher * m, int rank)
 
 int ndt2d_matcher_set_exchange(ndt2d_matcher * m, const char * mode)
 {
+  NDT2D_C_TRY
   if (m == nullptr || mode == nullptr) return NDT2D_ERR_INVALID;
   if (std::strcmp(mode, "auto") == 0) m->exchange_mode = 0;
   else if (std::strcmp(mode, "host") == 0) m->exchange_mode = 1;
   else if (std::strcmp(mode, "rccl") == 0) m->exchange_mode = 2;
   else return mfail(m, NDT2D_ERR_INVALID, "set_exchange: unknown mode (auto, host, rccl)");
   return NDT2D_OK;
+  NDT2D_C_CATCH(m)
 }
 
 int ndt2d_matcher_set_multi_min_units(ndt2d_matcher * m, double units)
 {
+  NDT2D_C_TRY
   return ndt2d_matcher_set_multi_thresholds(m, units, units);
+  NDT2D_C_CATCH(m)
 }
 
 int ndt2d_matcher_set_multi_thresholds(ndt2d_matcher * m, double min_search_units, double min_pose_units)
 {
+  NDT2D_C_TRY
   if (m == nullptr || !(min_search_units >= 0.0) || !(min_pose_units >= 0.0)) return NDT2D_ERR_INVALID;
   m->multi_min_units = min_search_units;
   m->multi_min_pose_units = min_pose_units;
   return NDT2D_OK;
+  NDT2D_C_CATCH(m)
 }
 
 int ndt2d_matcher_get_multi_thresholds(ndt2d_matcher * m, double * min_search_units, double * min_pose_units)
 {
+  NDT2D_C_TRY
   if (m == nullptr) return NDT2D_ERR_INVALID;
   if (min_search_units != nullptr) *min_search_units = m->multi_min_units;
   if (min_pose_units != nullptr) *min_pose_units = m->multi_min_pose_units;
   return NDT2D_OK;
+  NDT2D_C_CATCH(m)
 }
 
 int ndt2d_matcher_last_fanout_us(ndt2d_matcher * m, double * out_us, size_t capacity, size_t * n_out)
 {
+  NDT2D_C_TRY
   if (m == nullptr || (capacity > 0 && out_us == nullptr)) return NDT2D_ERR_INVALID;
   if (n_out != nullptr) *n_out = m->fanout_us.size();
   for (size_t r = 0; r < m->fanout_us.size() && r < capacity; ++r) out_us[r] = m->fanout_us[r];
   return NDT2D_OK;
+  NDT2D_C_CATCH(m)
 }
 
 const char * ndt2d_matcher_last_variant(ndt2d_matcher * m)
 {
   if (m == nullptr) return "";
-  if (!m->last_multi) note_variant(m, false, false);   // whatever the first device ran last
+  try
+  {
+    if (!m->last_multi) note_variant(m, false, false);   // whatever the first device ran last
+  }
+  catch (...)
+  {
+    return "";
+  }
   return m->variant.c_str();
 }
 
 int ndt2d_matcher_set_timing(ndt2d_matcher * m, int enabled)
 {
+  NDT2D_C_TRY
   if (m == nullptr) return NDT2D_ERR_INVALID;
   for (ndt2d_handle h : m->devs)
   {
@@ -1357,6 +1616,7 @@ int ndt2d_matcher_set_timing(ndt2d_matcher * m, int enabled)
     if (rc != NDT2D_OK) return rc;
   }
   return NDT2D_OK;
+  NDT2D_C_CATCH(m)
 }
 
 const char * ndt2d_matcher_last_error(ndt2d_matcher * m)
@@ -1371,8 +1631,23 @@ int ndt2d_matcher_initialize(ndt2d_matcher * m, double ndt_resolution,
                              double search_linear_resolution, double search_linear_size,
                              size_t laser_max_beams, double range_max)
 {
+  NDT2D_C_TRY
   if (m == nullptr) return NDT2D_ERR_INVALID;
-  if (!(ndt_resolution > 0.0)) return mfail(m, NDT2D_ERR_INVALID, "ndt_resolution must be > 0");
+  if (!(ndt_resolution > 0.0) || !std::isfinite(ndt_resolution))
+  {
+    return mfail(m, NDT2D_ERR_INVALID, "ndt_resolution must be a finite number > 0");
+  }
+  if (!std::isfinite(range_max)) return mfail(m, NDT2D_ERR_INVALID, "range_max must be finite");
+  // The lattice is visited by `for (v = -size; v < size; v += res)` (src/scan_matcher_ndt.cpp:103,
+  // 117,119): a step the range never gets past would not end there, and one that needs more steps
+  // than a search can take (ndt2d_set_search: 2^24 angular, 46,340 linear) would only fill memory
+  // here -- refused before a single offset is stored.
+  if (!offsets_fit(search_angular_size, search_angular_resolution, 1u << 24) ||
+      !offsets_fit(search_linear_size, search_linear_resolution, 46340))
+  {
+    return mfail(m, NDT2D_ERR_INVALID, "search lattice: size / resolution must be finite, the resolution > 0, at most "
+                                       "2^24 angular and 46,340 linear steps");
+  }
   discard_ahead(m);
   m->pair_seen = false;
   m->resolution = ndt_resolution;
@@ -1386,15 +1661,25 @@ int ndt2d_matcher_initialize(ndt2d_matcher * m, double ndt_resolution,
   m->dlin = search_offsets(m->linear_size, m->linear_res);
   m->search_ready = false;
   return NDT2D_OK;
+  NDT2D_C_CATCH(m)
 }
 
 int ndt2d_matcher_add_scans(ndt2d_matcher * m, const double * poses_xyt,
                             const double * points_xy, const size_t * offsets, size_t n_scans)
 {
+  NDT2D_C_TRY
   if (m == nullptr) return NDT2D_ERR_INVALID;
   if (n_scans > 0 && (poses_xyt == nullptr || offsets == nullptr))
   {
     return mfail(m, NDT2D_ERR_INVALID, "add_scans: null input");
+  }
+  for (size_t k = 0; k < 3 * n_scans; ++k)
+  {
+    if (!std::isfinite(poses_xyt[k])) return mfail(m, NDT2D_ERR_INVALID, "add_scans: a scan pose is not finite");
+  }
+  for (size_t k = 0; k < n_scans; ++k)
+  {
+    if (offsets[k + 1] < offsets[k]) return mfail(m, NDT2D_ERR_INVALID, "add_scans: offsets must not decrease");
   }
   discard_ahead(m);
   m->fetched.reset();
@@ -1434,12 +1719,12 @@ int ndt2d_matcher_add_scans(ndt2d_matcher * m, const double * poses_xyt,
   if (m->ndt) m->spare = std::move(m->ndt);
   m->ndt = build_ndt(m->resolution, m->range_max, poses_xyt, points_xy, offsets, n_scans,
                      std::move(m->spare), m->eigen_form);
-  const size_t ncell = m->ndt->ncell();
-  if (ncell == 0 || m->ndt->size_x() > 0xffffffffull || m->ndt->size_y() > 0xffffffffull)
+  if (!m->ndt || m->ndt->ncell() == 0)
   {
     m->ndt.reset();
     for (ndt2d_handle h : m->devs) ndt2d_clear_grid(h);
-    return mfail(m, NDT2D_ERR_INVALID, "add_scans: degenerate grid extent");
+    return mfail(m, NDT2D_ERR_INVALID, "add_scans: degenerate grid extent (scan poses +- range_max must span a "
+                                       "finite grid of fewer than 2^31 cells)");
   }
   // The cells that hold points travel, not the grid (ndt2d_set_grid_sparse: the install kernel
   // reads the staged list in place, two launches and no copy; 245 x 245 cells: 297 us dense ->
@@ -1469,10 +1754,12 @@ int ndt2d_matcher_add_scans(ndt2d_matcher * m, const double * poses_xyt,
   }
   m->have_ndt = true;
   return NDT2D_OK;
+  NDT2D_C_CATCH(m)
 }
 
 int ndt2d_matcher_set_eigenvalue_form(ndt2d_matcher * m, const char * form)
 {
+  NDT2D_C_TRY
   if (m == nullptr || form == nullptr) return NDT2D_ERR_INVALID;
   for (ndt2d_handle h : m->devs)
   {
@@ -1481,20 +1768,24 @@ int ndt2d_matcher_set_eigenvalue_form(ndt2d_matcher * m, const char * form)
   }
   m->eigen_form = std::strcmp(form, "closed") == 0 ? ndt2d::kEigenFormClosed : ndt2d::kEigenFormSchur;
   return NDT2D_OK;
+  NDT2D_C_CATCH(m)
 }
 
 int ndt2d_matcher_set_build_mode(ndt2d_matcher * m, const char * mode)
 {
+  NDT2D_C_TRY
   if (m == nullptr || mode == nullptr) return NDT2D_ERR_INVALID;
   if (std::strcmp(mode, "auto") == 0) m->build_mode = 0;
   else if (std::strcmp(mode, "host") == 0) m->build_mode = 1;
   else if (std::strcmp(mode, "device") == 0) m->build_mode = 2;
   else return mfail(m, NDT2D_ERR_INVALID, "set_build_mode: unknown mode");
   return NDT2D_OK;
+  NDT2D_C_CATCH(m)
 }
 
 int ndt2d_matcher_reset(ndt2d_matcher * m)
 {
+  NDT2D_C_TRY
   if (m == nullptr) return NDT2D_ERR_INVALID;
   discard_ahead(m);
   if (m->ndt) m->spare = std::move(m->ndt);   // `ndt_.reset()`; the storage serves the next addScans
@@ -1507,6 +1798,7 @@ int ndt2d_matcher_reset(ndt2d_matcher * m)
     if (rc == NDT2D_OK) rc = crc;
   }
   return rc;
+  NDT2D_C_CATCH(m)
 }
 
 int ndt2d_matcher_has_ndt(ndt2d_matcher * m) { return (m != nullptr && m->have_ndt) ? 1 : 0; }
@@ -1543,14 +1835,17 @@ int ndt2d_matcher_prepare_search(ndt2d_matcher * m, const double * scan_pose_xyt
                                  const double * points_xy, size_t n_points, size_t * n_th_out,
                                  size_t * n_lin_out, size_t * n_beams_out)
 {
+  NDT2D_C_TRY
   if (m != nullptr) discard_ahead(m);
   return prepare_search_impl(m, scan_pose_xyt, points_xy, n_points, n_th_out, n_lin_out, n_beams_out,
                              nullptr);
+  NDT2D_C_CATCH(m)
 }
 
 int ndt2d_matcher_finish_match(ndt2d_matcher * m, const double * record, double * pose_inout,
                                double * covariance_out, double * score_out)
 {
+  NDT2D_C_TRY
   if (m == nullptr || record == nullptr || score_out == nullptr) return NDT2D_ERR_INVALID;
   // n_use is the N of the search prepared last (prepare_search / match_laser_scan);
   // scoring calls in between replace the device beams but leave it alone
@@ -1590,6 +1885,7 @@ int ndt2d_matcher_finish_match(ndt2d_matcher * m, const double * record, double 
   // :148
   *score_out = best_score / use;
   return NDT2D_OK;
+  NDT2D_C_CATCH(m)
 }
 
 int ndt2d_matcher_match_scan_ex(ndt2d_matcher * m, const double * scan_pose_xyt,
@@ -1599,6 +1895,7 @@ int ndt2d_matcher_match_scan_ex(ndt2d_matcher * m, const double * scan_pose_xyt,
                                 size_t all_scores_cap, size_t * n_candidates_out,
                                 uint64_t * best_index_out)
 {
+  NDT2D_C_TRY
   if (m == nullptr || score_out == nullptr || scan_pose_xyt == nullptr)
   {
     return NDT2D_ERR_INVALID;
@@ -1718,14 +2015,17 @@ int ndt2d_matcher_match_scan_ex(ndt2d_matcher * m, const double * scan_pose_xyt,
     if (best_index_out != nullptr) *best_index_out = record[1] < 0.0 ? NDT2D_NO_INDEX : static_cast<uint64_t>(record[1]);
   }
   return ndt2d_matcher_finish_match(m, record, pose_inout, covariance_out, score_out);
+  NDT2D_C_CATCH(m)
 }
 
 int ndt2d_matcher_match_scan(ndt2d_matcher * m, const double * scan_pose_xyt,
                              const double * points_xy, size_t n_points, double * pose_inout,
                              double * covariance_out, double * score_out)
 {
+  NDT2D_C_TRY
   return ndt2d_matcher_match_scan_ex(m, scan_pose_xyt, points_xy, n_points, pose_inout,
                                      covariance_out, score_out, nullptr, 0, nullptr, nullptr);
+  NDT2D_C_CATCH(m)
 }
 
 int ndt2d_matcher_match_laser_scan(ndt2d_matcher * m, const double * scan_pose_xyt,
@@ -1734,6 +2034,7 @@ int ndt2d_matcher_match_laser_scan(ndt2d_matcher * m, const double * scan_pose_x
                                    double * covariance_out, double * score_out,
                                    size_t * n_points_out)
 {
+  NDT2D_C_TRY
   if (m == nullptr || score_out == nullptr || scan_pose_xyt == nullptr || scan == nullptr)
   {
     return NDT2D_ERR_INVALID;
@@ -1788,11 +2089,13 @@ int ndt2d_matcher_match_laser_scan(ndt2d_matcher * m, const double * scan_pose_x
     if (res.near_tie) ++m->adj_marked;
   }
   return ndt2d_matcher_finish_match(m, record, pose_inout, covariance_out, score_out);
+  NDT2D_C_CATCH(m)
 }
 
 int ndt2d_matcher_score_poses(ndt2d_matcher * m, const double * points_xy, size_t n_points,
                               const double * poses_xyt, size_t n_poses, double * scores_out)
 {
+  NDT2D_C_TRY
   if (m == nullptr || scores_out == nullptr || (n_poses > 0 && poses_xyt == nullptr))
   {
     return NDT2D_ERR_INVALID;
@@ -1839,11 +2142,13 @@ int ndt2d_matcher_score_poses(ndt2d_matcher * m, const double * points_xy, size_
   rc = ndt2d_score_poses(m->dev, poses_xyt, n_poses, scores_out, nullptr);
   if (rc != NDT2D_OK) return dev_fail(m, rc, "ndt2d_score_poses");
   return NDT2D_OK;
+  NDT2D_C_CATCH(m)
 }
 
 int ndt2d_matcher_prepare_beams(ndt2d_matcher * m, const double * points_xy, size_t n_points,
                                 size_t * n_beams_out)
 {
+  NDT2D_C_TRY
   if (m == nullptr) return NDT2D_ERR_INVALID;
   if (n_points > 0 && points_xy == nullptr) return mfail(m, NDT2D_ERR_INVALID, "null points");
   discard_ahead(m);
@@ -1851,11 +2156,13 @@ int ndt2d_matcher_prepare_beams(ndt2d_matcher * m, const double * points_xy, siz
   int rc = stage_beams(m, points_xy, n_points, &use);
   if (n_beams_out != nullptr) *n_beams_out = use;
   return rc;
+  NDT2D_C_CATCH(m)
 }
 
 int ndt2d_matcher_score_points(ndt2d_matcher * m, const double * points_xy, size_t n_points,
                                const double * pose_xyt, double * score_out)
 {
+  NDT2D_C_TRY
   if (pose_xyt == nullptr || score_out == nullptr) return NDT2D_ERR_INVALID;
   if (m != nullptr && m->single_pose_host && m->have_ndt && n_points > 0 && points_xy != nullptr &&
       m->laser_max_beams > 0 && std::min(m->laser_max_beams, n_points) <= m->single_pose_max_beams)
@@ -1873,11 +2180,13 @@ int ndt2d_matcher_score_points(ndt2d_matcher * m, const double * points_xy, size
     }
   }
   return ndt2d_matcher_score_poses(m, points_xy, n_points, pose_xyt, 1, score_out);
+  NDT2D_C_CATCH(m)
 }
 
 int ndt2d_matcher_score_scan(ndt2d_matcher * m, const double * scan_pose_xyt,
                              const double * points_xy, size_t n_points, double * score_out)
 {
+  NDT2D_C_TRY
   // scoreScan(scan) = scorePoints(scan->getPoints(), scan->getPose()) (:151-154)
   if (m == nullptr || scan_pose_xyt == nullptr || score_out == nullptr) return NDT2D_ERR_INVALID;
   discard_ahead(m);
@@ -1973,63 +2282,77 @@ int ndt2d_matcher_score_scan(ndt2d_matcher * m, const double * scan_pose_xyt,
     std::memcpy(m->score_scan_pose, scan_pose_xyt, sizeof(m->score_scan_pose));
   }
   return rc;
+  NDT2D_C_CATCH(m)
 }
 
 int ndt2d_matcher_settle_near_tie(ndt2d_matcher * m, const double * scan_pose_xyt, double * record_inout)
 {
+  NDT2D_C_TRY
   if (m == nullptr || scan_pose_xyt == nullptr || record_inout == nullptr) return NDT2D_ERR_INVALID;
   if (!m->search_ready) return mfail(m, NDT2D_ERR_STATE, "settle_near_tie: ndt2d_matcher_prepare_search first");
   discard_ahead(m);
   return settle_near_tie(m, scan_pose_xyt, m->dth.size(), m->dlin.size(), m->n_use, record_inout);
+  NDT2D_C_CATCH(m)
 }
 
 int ndt2d_matcher_set_adjudication(ndt2d_matcher * m, int enabled)
 {
+  NDT2D_C_TRY
   if (m == nullptr) return NDT2D_ERR_INVALID;
   m->adjudicate = enabled != 0;
   return NDT2D_OK;
+  NDT2D_C_CATCH(m)
 }
 
 int ndt2d_matcher_adjudication_stats(ndt2d_matcher * m, uint64_t * marked, uint64_t * changed, uint64_t * truncated)
 {
+  NDT2D_C_TRY
   if (m == nullptr) return NDT2D_ERR_INVALID;
   if (marked != nullptr) *marked = m->adj_marked;
   if (changed != nullptr) *changed = m->adj_changed;
   if (truncated != nullptr) *truncated = m->adj_truncated;
   return NDT2D_OK;
+  NDT2D_C_CATCH(m)
 }
 
 int ndt2d_matcher_set_single_pose_path(ndt2d_matcher * m, const char * where, size_t max_beams)
 {
+  NDT2D_C_TRY
   if (m == nullptr || where == nullptr) return NDT2D_ERR_INVALID;
   if (std::strcmp(where, "host") == 0) m->single_pose_host = true;
   else if (std::strcmp(where, "device") == 0) m->single_pose_host = false;
   else return mfail(m, NDT2D_ERR_INVALID, "set_single_pose_path: unknown path (host, device)");
   if (max_beams > 0) m->single_pose_max_beams = max_beams;
   return NDT2D_OK;
+  NDT2D_C_CATCH(m)
 }
 
 int ndt2d_matcher_search_ahead_stats(ndt2d_matcher * m, uint64_t * launched, uint64_t * collected)
 {
+  NDT2D_C_TRY
   if (m == nullptr) return NDT2D_ERR_INVALID;
   if (launched != nullptr) *launched = m->ahead_launched;
   if (collected != nullptr) *collected = m->ahead_collected;
   return NDT2D_OK;
+  NDT2D_C_CATCH(m)
 }
 
 int ndt2d_matcher_set_search_ahead(ndt2d_matcher * m, int enabled)
 {
+  NDT2D_C_TRY
   if (m == nullptr) return NDT2D_ERR_INVALID;
   discard_ahead(m);
   m->ahead_enabled = enabled != 0 ? 1 : 0;
   m->pair_seen = false;
   return NDT2D_OK;
+  NDT2D_C_CATCH(m)
 }
 
 int ndt2d_matcher_pf_measure(ndt2d_matcher * m, const double * particles_xyt,
                              size_t n_particles, const double * points_xy, size_t n_points,
                              double * weights_out, double * mean_out, double * cov_inout)
 {
+  NDT2D_C_TRY
   if (m == nullptr || weights_out == nullptr || mean_out == nullptr || cov_inout == nullptr ||
       (n_particles > 0 && particles_xyt == nullptr))
   {
@@ -2108,19 +2431,23 @@ int ndt2d_matcher_pf_measure(ndt2d_matcher * m, const double * particles_xyt,
     cov_inout[8] += weights_out[i] * d * d;
   }
   return NDT2D_OK;
+  NDT2D_C_CATCH(m)
 }
 
 int ndt2d_matcher_grid_info(ndt2d_matcher * m, uint32_t * size_x, uint32_t * size_y,
                             double * cell_size, double * origin_x, double * origin_y)
 {
+  NDT2D_C_TRY
   if (m == nullptr) return NDT2D_ERR_INVALID;
   if (!m->have_ndt) return mfail(m, NDT2D_ERR_NO_GRID, "no NDT");
   int rc = ndt2d_get_grid(m->dev, nullptr, 0, size_x, size_y, cell_size, origin_x, origin_y);
   return rc == NDT2D_OK ? rc : dev_fail(m, rc, "ndt2d_get_grid");
+  NDT2D_C_CATCH(m)
 }
 
 int ndt2d_matcher_grid_cells6(ndt2d_matcher * m, double * cells6_out, size_t capacity_cells)
 {
+  NDT2D_C_TRY
   if (m == nullptr || cells6_out == nullptr) return NDT2D_ERR_INVALID;
   if (!m->have_ndt) return mfail(m, NDT2D_ERR_NO_GRID, "no NDT");
   discard_ahead(m);
@@ -2133,10 +2460,13 @@ int ndt2d_matcher_grid_cells6(ndt2d_matcher * m, double * cells6_out, size_t cap
   int rc = ndt2d_get_grid(m->dev, cells6_out, capacity_cells, nullptr, nullptr, nullptr, nullptr,
                           nullptr);
   return rc == NDT2D_OK ? rc : dev_fail(m, rc, "ndt2d_get_grid");
+  NDT2D_C_CATCH(m)
 }
 
 int ndt2d_search_offsets(double size, double res, double * out, size_t cap, size_t * n_out)
 {
+  NDT2D_C_TRY
+  if (!offsets_fit(size, res, 1u << 24)) return NDT2D_ERR_INVALID;   // (a loop that would not end, or only fill memory)
   const std::vector<double> v = search_offsets(size, res);
   if (n_out != nullptr) *n_out = v.size();
   if (out != nullptr)
@@ -2144,6 +2474,7 @@ int ndt2d_search_offsets(double size, double res, double * out, size_t cap, size
     for (size_t i = 0; i < v.size() && i < cap; ++i) out[i] = v[i];
   }
   return NDT2D_OK;
+  NDT2D_C_CATCH(nullptr)
 }
 
 int ndt2d_kld_resample(const double * particles_xyt, const double * weights, size_t n,
@@ -2151,6 +2482,7 @@ int ndt2d_kld_resample(const double * particles_xyt, const double * weights, siz
                        const double * leaf_size3, const double * uniforms, size_t n_uniforms,
                        uint32_t * indices_out, size_t * n_out)
 {
+  NDT2D_C_TRY
   if (n_out == nullptr) return NDT2D_ERR_INVALID;
   *n_out = 0;
   if (max_particles == 0) return NDT2D_OK;
@@ -2221,6 +2553,7 @@ int ndt2d_kld_resample(const double * particles_xyt, const double * weights, siz
   }
   *n_out = count;
   return NDT2D_OK;
+  NDT2D_C_CATCH(nullptr)
 }
 
 int ndt2d_host_build_grid(double ndt_resolution, double range_max, const double * poses_xyt,
@@ -2228,6 +2561,18 @@ int ndt2d_host_build_grid(double ndt_resolution, double range_max, const double 
                           double * cells6_out, size_t capacity_cells, uint32_t * size_x,
                           uint32_t * size_y, double * origin_x, double * origin_y)
 {
+  NDT2D_C_TRY
+  return ndt2d_host_build_grid_ex(ndt_resolution, range_max, poses_xyt, points_xy, offsets, n_scans, 0u, cells6_out,
+                                  capacity_cells, size_x, size_y, origin_x, origin_y);
+  NDT2D_C_CATCH(nullptr)
+}
+
+int ndt2d_host_build_grid_ex(double ndt_resolution, double range_max, const double * poses_xyt,
+                             const double * points_xy, const size_t * offsets, size_t n_scans, unsigned flags,
+                             double * cells6_out, size_t capacity_cells, uint32_t * size_x,
+                             uint32_t * size_y, double * origin_x, double * origin_y)
+{
+  NDT2D_C_TRY
   if (!(ndt_resolution > 0.0) || (n_scans > 0 && (poses_xyt == nullptr || offsets == nullptr)))
   {
     return NDT2D_ERR_INVALID;
@@ -2236,7 +2581,11 @@ int ndt2d_host_build_grid(double ndt_resolution, double range_max, const double 
   static const size_t no_offsets[1] = {0};
   std::unique_ptr<HostNdt> ndt = build_ndt(ndt_resolution, range_max, poses_xyt,
                                            points_xy ? points_xy : no_points,
-                                           offsets ? offsets : no_offsets, n_scans);
+                                           offsets ? offsets : no_offsets, n_scans, nullptr,
+                                           (flags & NDT2D_BUILD_CLOSED_FORM) ? ndt2d::kEigenFormClosed
+                                                                             : ndt2d::kEigenFormSchur,
+                                           (flags & NDT2D_BUILD_SEQUENTIAL) == 0);
+  if (!ndt) return NDT2D_ERR_INVALID;   // (degenerate extent: non-finite poses / range_max, >= 2^31 cells)
   if (size_x) *size_x = static_cast<uint32_t>(ndt->size_x());
   if (size_y) *size_y = static_cast<uint32_t>(ndt->size_y());
   if (origin_x) *origin_x = ndt->origin_x();
@@ -2247,6 +2596,7 @@ int ndt2d_host_build_grid(double ndt_resolution, double range_max, const double 
     ndt->pack6(cells6_out);
   }
   return NDT2D_OK;
+  NDT2D_C_CATCH(nullptr)
 }
 
 // ---------------------------------------------------------------------------
@@ -2359,6 +2709,7 @@ extern "C" {
 int ndt2d_synth_scan(const ndt2d_world * world, const double * pose_xyt, size_t n_beams,
                      double noise_sigma, uint64_t seed, double * points_xy)
 {
+  NDT2D_C_TRY
   if (world == nullptr || pose_xyt == nullptr || points_xy == nullptr || n_beams == 0)
   {
     return NDT2D_ERR_INVALID;
@@ -2379,10 +2730,12 @@ int ndt2d_synth_scan(const ndt2d_world * world, const double * pose_xyt, size_t 
     points_xy[2 * k + 1] = r * std::sin(ang);
   }
   return NDT2D_OK;
+  NDT2D_C_CATCH(nullptr)
 }
 
 int ndt2d_synth_pose_blocked(const ndt2d_world * world, double x, double y, double margin)
 {
+  NDT2D_C_TRY
   if (world == nullptr || !(world->pillar_pitch > 0.0)) return 0;
   const long ci = static_cast<long>(std::floor(x / world->pillar_pitch));
   const long cj = static_cast<long>(std::floor(y / world->pillar_pitch));
@@ -2392,14 +2745,17 @@ int ndt2d_synth_pose_blocked(const ndt2d_world * world, double x, double y, doub
           std::fabs(y - cy) <= world->pillar_half + margin)
            ? 1
            : 0;
+  NDT2D_C_CATCH(nullptr)
 }
 
 int ndt2d_synth_uniform(uint64_t seed, size_t n, double * out)
 {
+  NDT2D_C_TRY
   if (out == nullptr) return NDT2D_ERR_INVALID;
   SplitMix64 rng(seed);
   for (size_t i = 0; i < n; ++i) out[i] = rng.uniform();
   return NDT2D_OK;
+  NDT2D_C_CATCH(nullptr)
 }
 
 }  // extern "C"

@@ -66,6 +66,15 @@ void ScanMatcherNDTHip::initialize(const std::string & name, rclcpp::Node * node
   const double multi_min_units = node->declare_parameter<double>(name + ".multi_min_units", -1.0);
   const double multi_min_pose_units = node->declare_parameter<double>(name + ".multi_min_pose_units", -1.0);
 
+  // the library found at run time must be the one this shim was compiled against: an older
+  // libndt2d_hip.so on the loader's path would otherwise fail at some later symbol, not here
+  if (ndt2d_abi_version() != NDT2D_ABI_VERSION)
+  {
+    RCLCPP_ERROR(node_->get_logger(), "%s: libndt2d_hip.so has ABI %d, this plugin was built against %d (%s)",
+                 name_.c_str(), ndt2d_abi_version(), NDT2D_ABI_VERSION, ndt2d_build_info());
+    matcher_ = nullptr;
+    return;
+  }
   std::vector<int> ids(device_ids.begin(), device_ids.end());
   if (ids.empty()) ids.push_back(device_id);
   if (!ok(ndt2d_matcher_create_multi(&matcher_, ids.data(), static_cast<int>(ids.size())),

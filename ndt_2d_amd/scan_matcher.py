@@ -46,22 +46,28 @@ def _pack_scans(scans):
     return poses, allpts, offsets
 
 
-def host_build_grid(ndt_resolution, range_max, scans):
-    """addScans' NDT build on the host only (no GPU): (cells6, size_x, size_y, ox, oy)."""
+BUILD_SEQUENTIAL = 1      # include/ndt2d_hip.h NDT2D_BUILD_SEQUENTIAL
+BUILD_CLOSED_FORM = 2     # NDT2D_BUILD_CLOSED_FORM
+
+
+def host_build_grid(ndt_resolution, range_max, scans, flags=0):
+    """addScans' NDT build on the host only (no GPU): (cells6, size_x, size_y, ox, oy).
+    flags: BUILD_SEQUENTIAL (the reference's loop as it stands instead of a scan's four
+    quarters side by side: same bits), BUILD_CLOSED_FORM."""
     L = _capi.lib()
     poses, allpts, offsets = _pack_scans(scans)
     sx, sy = C.c_uint32(0), C.c_uint32(0)
     ox, oy = C.c_double(0), C.c_double(0)
     off_p = offsets.ctypes.data_as(C.POINTER(C.c_size_t))
-    rc = L.ndt2d_host_build_grid(ndt_resolution, range_max, dptr(poses), dptr(allpts), off_p,
-                                 len(scans), None, 0, C.byref(sx), C.byref(sy), C.byref(ox),
-                                 C.byref(oy))
+    rc = L.ndt2d_host_build_grid_ex(ndt_resolution, range_max, dptr(poses), dptr(allpts), off_p,
+                                    len(scans), flags, None, 0, C.byref(sx), C.byref(sy), C.byref(ox),
+                                    C.byref(oy))
     if rc != _capi.OK:
         raise Ndt2dError(rc, "ndt2d_host_build_grid")
     cells = np.zeros((sx.value * sy.value, 6), dtype=np.float64)
-    rc = L.ndt2d_host_build_grid(ndt_resolution, range_max, dptr(poses), dptr(allpts), off_p,
-                                 len(scans), dptr(cells), len(cells), C.byref(sx), C.byref(sy),
-                                 C.byref(ox), C.byref(oy))
+    rc = L.ndt2d_host_build_grid_ex(ndt_resolution, range_max, dptr(poses), dptr(allpts), off_p,
+                                    len(scans), flags, dptr(cells), len(cells), C.byref(sx), C.byref(sy),
+                                    C.byref(ox), C.byref(oy))
     if rc != _capi.OK:
         raise Ndt2dError(rc, "ndt2d_host_build_grid")
     return cells, sx.value, sy.value, ox.value, oy.value

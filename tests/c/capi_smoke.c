@@ -15,7 +15,7 @@ int main(void)
   double off[64];
   size_t n = 0;
   if (ndt2d_search_offsets(0.05, 0.005, off, 64, &n) != NDT2D_OK || n != 21) return 10;
-  if (ndt2d_abi_version() != 3) return 11;
+  if (ndt2d_abi_version() != NDT2D_ABI_VERSION || NDT2D_ABI_VERSION != 4) return 11;
 
   const double poses[3] = {0.0, 0.0, 0.0};
   const double pts[10] = {3.5, 3.5, 3.45, 3.4, 3.55, 3.6, 3.45, 3.6, 3.45, 3.6};

@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
 def test_python_binding_covers_every_declared_symbol():
     from ndt_2d_amd import _capi
     assert sorted(_capi.SIGNATURES) == declared_functions()
-    assert _capi.lib().ndt2d_abi_version() == 3
+    assert _capi.lib().ndt2d_abi_version() == 4
 
 
 def test_library_is_built_from_these_sources():

@@ -113,3 +113,24 @@ def test_host_and_device_builds_follow_the_oracle_in_both_forms(cfg, form):
         gpu.addScans(scans)
         assert np.array_equal(gpu.grid()[0], exp), (cfg, form, mode)
         gpu.close()
+
+
+def test_clamp_screen_never_skips_a_cell_that_needs_its_eigenvalues(tmp_path):
+    """Round 6: Cell::compute on the host and on the device asks ndt2d::clamp_test_surely_false
+    first and computes the eigenvalues only when the answer is no (csrc/ndt2d_eigen2.h).  Compiled
+    from the product's header: on 4 million covariances -- half of them within a decade of the
+    threshold -- a `yes` never meets a cell that either eigenvalue form sends to the clamp branch,
+    and the smallest eigenvalue ratio it lets through is four times the threshold."""
+    import json
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "eigen_screen_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-I", os.path.join(root, "ndt_2d_amd", "csrc"),
+                           os.path.join(root, "tests", "cpp", "eigen_screen_check.cpp"), "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    out = json.loads(r.stdout)
+    assert r.returncode == 0 and out["violations"] == 0, out
+    assert out["screened"] > 0.2 * out["cases"] and out["clamp_branch"] > 0.2 * out["cases"]
+    assert out["near_threshold"] > 0.1 * out["cases"]
+    assert out["least_ratio_screened"] > 0.0039

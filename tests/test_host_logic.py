@@ -118,3 +118,103 @@ def test_shard_strided_partitions():
                 seen += [first + stride * k for k in range(count)]
             assert sorted(seen) == list(range(n))
     assert shard.decode_index(1065647, 100) == (106, 56, 47)
+
+
+# ---- round 6: addScans' host build adds a scan's four quarters side by side ----
+
+def _random_scans(rng, n_scans, n_beams, spread, reach):
+    scans = []
+    for _ in range(n_scans):
+        pose = (float(rng.uniform(-spread, spread)), float(rng.uniform(-spread, spread)),
+                float(rng.uniform(-math.pi, math.pi)))
+        ang = np.linspace(-math.pi, math.pi, n_beams, endpoint=False)
+        r = rng.uniform(0.0, reach, n_beams)
+        scans.append((pose, np.stack([r * np.cos(ang), r * np.sin(ang)], axis=1)))
+    return scans
+
+
+@pytest.mark.parametrize("cfg", [1, 3])
+def test_quarters_side_by_side_give_the_sequential_bits(cfg):
+    """HostNdt::add_scan (csrc/ndt2d_host.cpp): four chains of Cell::addPoint in flight, the points
+    of a cell still in the reference's order -- every cell bit for bit the sequential loop's."""
+    from ndt_2d_amd.scan_matcher import BUILD_SEQUENTIAL
+    scans = synth.map_scans(cfg)
+    p = synth.matcher_params(cfg)
+    a = host_build_grid(p["ndt_resolution"], p["range_max"], scans)
+    b = host_build_grid(p["ndt_resolution"], p["range_max"], scans, BUILD_SEQUENTIAL)
+    assert a[1:] == b[1:] and np.array_equal(a[0], b[0])
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_quarters_that_share_cells_keep_the_order(seed):
+    """Adversarial scans: ranges shorter than a cell (EVERY quarter lands in the robot's own cell
+    and its neighbours), beams beyond the grid, beam counts that are no multiple of four, a
+    non-power-of-two cell size (true divide in getIndex), scans too short to be cut."""
+    from ndt_2d_amd.scan_matcher import BUILD_SEQUENTIAL
+    rng = np.random.default_rng(600 + seed)
+    n_beams = [720, 719, 37, 33, 31, 1001, 64, 5, 360, 722, 90, 128][seed]
+    reach = [0.3, 6.0, 0.1, 2.0, 1.0, 12.0, 0.6, 3.0, 0.25, 40.0, 0.05, 1.5][seed]
+    res = [0.25, 0.25, 0.25, 0.1, 0.25, 0.3, 0.25, 0.25, 0.5, 0.25, 0.25, 0.07][seed]
+    scans = _random_scans(rng, 7, n_beams, 0.6, reach)
+    if seed == 9:
+        scans[3] = (scans[3][0], scans[3][1][:0])           # an empty scan among the others
+    a = host_build_grid(res, 3.0, scans)
+    b = host_build_grid(res, 3.0, scans, BUILD_SEQUENTIAL)
+    assert a[1:] == b[1:] and np.array_equal(a[0], b[0])
+    assert (a[0][:, 5] > 0).sum() > 0
+    # ... and both are the oracle's
+    m = O.ScanMatcherNDT()
+    m.initialize(ndt_resolution=res, range_max=3.0)
+    m.addScans(scans)
+    assert np.array_equal(a[0], m.ndt.cells6())
+
+
+def test_builds_reuse_their_storage_across_geometries():
+    """The matcher rebuilds its NDT in the storage of the one before (the cell stamps of
+    add_scan are never cleared: ids from a running counter): a sequence of different maps
+    through ONE library instance gives what each gives alone."""
+    from ndt_2d_amd.scan_matcher import BUILD_SEQUENTIAL
+    rng = np.random.default_rng(77)
+    for i in range(6):
+        scans = _random_scans(rng, 3 + i, 200 + 40 * i, 1.0 + i, 2.0 + i)
+        a = host_build_grid(0.25, 4.0 + i, scans)
+        b = host_build_grid(0.25, 4.0 + i, scans, BUILD_SEQUENTIAL)
+        assert np.array_equal(a[0], b[0])
+
+
+# ---- round 6: nothing unwinds through the C boundary (csrc/ndt2d_guard.h) ----
+
+@pytest.mark.parametrize("pose,range_max", [
+    ((1e15, 0.0, 0.0), 4.75), ((0.0, -1e15, 0.0), 4.75), ((float("nan"), 0.0, 0.0), 4.75),
+    ((0.0, float("inf"), 0.0), 4.75), ((0.0, 0.0, 0.0), float("inf")), ((0.0, 0.0, 0.0), float("nan")),
+    ((0.0, 0.0, 0.0), 1e12), ((3e5, 3e5, 0.0), 3e5)])
+def test_a_grid_no_memory_could_hold_is_an_error_code(pose, range_max):
+    """addScans sizes its NDT by the scan poses +- range_max (reference src/scan_matcher_ndt.cpp:52-66):
+    a pose of 1e15, an infinite range_max or a NaN must come back as a status -- not as a
+    std::bad_alloc / std::length_error unwinding into the caller, not as a size_t cast from NaN."""
+    import ctypes as C
+    from ndt_2d_amd import _capi
+    from ndt_2d_amd._capi import dptr
+    L = _capi.lib()
+    poses = np.array([[0.0, 0.0, 0.0], list(pose)], dtype=np.float64)
+    pts = np.zeros((4, 2))
+    off = np.array([0, 2, 4], dtype=np.uint64)
+    sx, sy = C.c_uint32(0), C.c_uint32(0)
+    ox, oy = C.c_double(0), C.c_double(0)
+    for flags in (0, 1):
+        rc = L.ndt2d_host_build_grid_ex(0.25, range_max, dptr(poses), dptr(pts), off.ctypes.data_as(C.POINTER(C.c_size_t)),
+                                        2, flags, None, 0, C.byref(sx), C.byref(sy), C.byref(ox), C.byref(oy))
+        assert rc == _capi.ERR_INVALID
+    # ... and the library goes on working
+    cells, gx, gy, _, _ = host_build_grid(0.25, 4.75, synth.map_scans(1))
+    assert (gx, gy) == (41, 41) and (cells[:, 5] > 0).any()
+
+
+@pytest.mark.parametrize("size,res", [(1e9, 1e-9), (float("inf"), 0.01), (1.0, 1e-300), (float("nan"), 0.1),
+                                      (1.0, float("nan")), (1e308, 1.0)])
+def test_a_lattice_that_would_not_end_is_an_error_code(size, res):
+    import ctypes as C
+    from ndt_2d_amd import _capi
+    n = C.c_size_t(0)
+    assert _capi.lib().ndt2d_search_offsets(size, res, None, 0, C.byref(n)) == _capi.ERR_INVALID
+    assert len(search_offsets(0.05, 0.005)) == 21
