@@ -19,11 +19,14 @@ all-reduce of the [N, 12] record table (it runs on RCCL's stream while the next 
 search runs; all of them have completed when the timed region ends).  The same line
 carries `particle_filter` = BASELINE.json configs[4] (cfg-5): 1,000,000 particles x 720
 beams on the 801x801 NDT, particles sharded contiguously, one all-reduce of the [N, 8]
-moment sums (the total particle weight of ParticleFilter::updateStatistics), then the
-statistics on the device and the 1-double all-reduce of the theta variance (the
-reference's second pass, src/particle_filter.cpp:213-217).
+moment sums (the total particle weight of ParticleFilter::updateStatistics) -- the ONE
+collective of a step; the statistics then run on the device, and a rank's share of the theta
+variance (the reference's second pass, src/particle_filter.cpp:213-217) stays with its
+weights: whoever collects the weights (the resampler) adds the N shares in rank order.
 
-Rank 0 prints one JSON line.  `roofline` is the resource that binds the dominant kernel
+Rank 0 prints one JSON line: the contract's fields and one summary per side leg (compact_line);
+the full record -- per-class issue table, per-share arrays, probe output -- goes to
+bench_detail.json (--detail-file) and stderr.  `roofline` is the resource that binds the dominant kernel
 -- VALU issue -- as a fraction <= 1; `roofline_hbm` holds the measured HBM-side traffic
 against the 8 TB/s peak and, separately, the declared algorithmic 64 B/unit figure.
 """
@@ -171,9 +174,10 @@ def library_identity():
     try:
         from ndt_2d_amd import _capi
         from ndt_2d_amd import build as _build
-        have, want = _capi.lib_source_sha256(), _build.source_sha256()
-        return {"path": _capi.LIB_PATH, "build_info": _capi.build_info(), "source_sha256_of_tree": want,
-                "lib_matches_source": have == want}
+        have, want, info = _capi.lib_source_sha256(), _build.source_sha256(), _capi.build_info()
+        # (hooks=1 marks the test build with fault-injection hooks: same sources, never the product)
+        return {"path": _capi.LIB_PATH, "build_info": info, "source_sha256_of_tree": want,
+                "lib_matches_source": have == want and " hooks=1" not in info}
     except Exception as exc:   # noqa: BLE001 -- a missing figure, not a failed bench
         return {"error": str(exc), "lib_matches_source": None}
 
@@ -881,15 +885,15 @@ def compact_line(d, detail_paths=()):
     return line
 
 
-def write_detail(d):
-    """The full record: bench_detail.json beside this script (and under gpurun_out/ when that
-    exists, so that it comes back from the GPU box), and one line on stderr.  Returns the paths
-    written, relative to the repository."""
+def write_detail(d, where=None):
+    """The full record: `where`, or bench_detail.json beside this script (and under gpurun_out/
+    when that exists, so that it comes back from the GPU box), and one line on stderr.  Returns
+    the paths written (relative to the repository unless `where` was given)."""
     text = json.dumps(d)
     paths = []
-    for rel in (DETAIL_NAME, os.path.join("gpurun_out", DETAIL_NAME)):
+    for rel in ((where,) if where else (DETAIL_NAME, os.path.join("gpurun_out", DETAIL_NAME))):
         path = os.path.join(_ROOT, rel)
-        if not os.path.isdir(os.path.dirname(path)):
+        if not os.path.isdir(os.path.dirname(path) or "."):
             continue
         try:
             with open(path, "w") as f:
@@ -924,6 +928,9 @@ def main():
                     help="(profiling aid, N = 1) one launch per 1-of-8 share of cfg-4 and cfg-5 on this GPU, "
                          "in rank order; prints the dispatch plan (experiments/profile_r04.sh)")
     ap.add_argument("--print-source-hash", action="store_true")
+    ap.add_argument("--detail-file", default=None,
+                    help="where the FULL record goes (default: bench_detail.json beside this script, and "
+                         "gpurun_out/bench_detail.json when that directory exists); stdout carries the short line")
     ap.add_argument("--prewarm", type=float, default=PREWARM_SECONDS,
                     help="seconds of untimed launches before --warmup (profiler passes use 0)")
     args = ap.parse_args()
@@ -1265,7 +1272,7 @@ def main():
                 line["config"]["kernel_variant"] = c4["variant"]
         # `line` is the FULL record (33 KB in round 5 -- past what the driver keeps of a line): it goes to
         # bench_detail.json and stderr; stdout gets the contract's fields + one summary per side leg
-        detail_paths = write_detail(line)
+        detail_paths = write_detail(line, args.detail_file)
         short = compact_line(line, detail_paths)
         os.write(json_fd, (json.dumps(short, separators=(",", ":")) + "\n").encode())
         if collective:
@@ -1289,9 +1296,12 @@ def particle_bench_sharded(matcher_cls, synth, shard, torch, dist, dev, dev_inde
     NDT, particles sharded contiguously over the ranks.  One step = ParticleFilter::measure
     (reference src/particle_filter.cpp:78-89 + updateStatistics :163-218): every rank scores
     its range and reduces its 8 moment sums on the device, ONE all-reduce of the [N, 8]
-    table gives every rank the total particle weight and the moments, the rank normalises
-    its weights and forms mean / covariance on the device, and the theta variance -- the
-    reference's second pass -- is a 1-double all-reduce.  KLD resampling is host code
+    table gives every rank the total particle weight and the moments -- the only collective
+    of the step -- the rank normalises its weights and forms mean / covariance
+    on the device.  The theta variance is the reference's second pass (:213-217: it needs the
+    circular mean): every rank reduces ITS particles' share on the device and keeps it beside
+    its weights; cov(2,2) = the N shares added in rank order by whoever collects the weights
+    (here: once, after the timed region, for the result check).  KLD resampling is host code
     outside the timed region, as BASELINE.json says."""
     import numpy as np
     m = matcher_cls(dev_index)
@@ -1322,8 +1332,7 @@ def particle_bench_sharded(matcher_cls, synth, shard, torch, dist, dev, dev_inde
         if n_local:
             m.pf_finalize_launch(d_parts.data_ptr(), n_local, d_w.data_ptr(), d_sum.data_ptr(),
                                  d_out.data_ptr())
-        if all_reduce is not None:
-            all_reduce(d_var, dist.ReduceOp.SUM)                # theta variance, second pass (in place in d_out)
+        # (d_out[7] = this rank's share of the theta variance: it stays here, with the weights)
 
     for _ in range(warmup):
         step()
@@ -1338,17 +1347,26 @@ def particle_bench_sharded(matcher_cls, synth, shard, torch, dist, dev, dev_inde
         all_reduce(t, dist.ReduceOp.MAX)
     ms = float(t[0]) / steps * 1e3
     out_h = d_out.cpu().numpy()
+    # outside the timed region: the N shares of the theta variance, one slot per rank, added in rank order
+    shares = torch.zeros(world, dtype=torch.float64, device=dev)
+    shares[rank] = d_var[0]
+    if all_reduce is not None:
+        all_reduce(shares, dist.ReduceOp.SUM)
+    theta_variance = 0.0
+    for v in shares.cpu().numpy():
+        theta_variance += float(v)
     units = n_total * n_beams
     res = {"workload": "cfg-5 (BASELINE.json configs[4]): 1000000 particles x 720 beams, 801x801 NDT @0.25 m, "
                        "particles sharded over %d GPU(s) + weight-sum all-reduce" % world,
            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": ms,
            "value": units / (ms * 1e-3), "unit": "candidate-beams/s", "scaling": "strong",
            "units_per_step": units, "variant": m.last_variant(),
-           "collectives_per_step": ("all-reduce [N,8] moment sums + all-reduce [1] theta variance"
-                                    if all_reduce is not None else "none (one GPU, no process group)"),
+           "collectives_per_step": 1 if all_reduce is not None else 0,
+           "collective": ("one all-reduce of the [N,8] moment sums per step; the theta-variance shares stay "
+                          "with the weights" if all_reduce is not None else "none (one GPU, no process group)"),
            "result": {"sum_w": float(out_h[0]), "mean": [float(v) for v in out_h[1:4]],
                       "cov_xx_xy_yy": [float(v) for v in out_h[4:7]],
-                      "theta_variance": float(d_var.cpu()[0])}}
+                      "theta_variance": theta_variance}}
     # roofline of this rank's scoring kernel: live HIP-event time of its launches, counters of its
     # share of the particle set from the committed per-share passes
     try:

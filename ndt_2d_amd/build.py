@@ -179,9 +179,25 @@ def build_test_hooks(verbose=False):
                 return HOOKS_LIB_PATH
     except OSError:
         pass
+    # the plain objects of the non-hooked sources are linked as they are: build_all() returns early
+    # when the .so already carries the tree's hash, without looking at them -- a box that received
+    # the library but not the (git-ignored) objects gets them compiled here
+    if any(not os.path.exists(_obj(s)) for s in SOURCES if s not in HOOKED_SOURCES):
+        lib = build_all(force=True, verbose=verbose)
     objs = []
     for src in SOURCES + [BUILD_INFO_SOURCE]:
-        if src in HOOKED_SOURCES:
+        if src == BUILD_INFO_SOURCE:
+            # its own build-info object: the same source hash, marked hooks=1, so that
+            # ndt2d_build_info() / lib_matches_source() tell the two libraries apart
+            obj = os.path.join(_CSRC, "ndt2d_build_info.hooks.o")
+            cmd = ["g++"] + FLAGS + ["-DNDT2D_SOURCE_SHA=\"" + sha + "\"", "-DNDT2D_BUILD_ARCH=\"" + ARCH + "\"",
+                                     "-DNDT2D_BUILD_HOOKS=1", "-I", os.path.join(_ROOT, "include"), "-c",
+                                     os.path.join(_CSRC, BUILD_INFO_SOURCE), "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+            objs.append(obj)
+        elif src in HOOKED_SOURCES:
             obj = os.path.join(_CSRC, os.path.splitext(src)[0] + ".hooks.o")
             cmd = [hipcc(), "--offload-arch=" + ARCH] + FLAGS + ["-DNDT2D_TEST_HOOKS", "-I", os.path.join(_ROOT, "include"),
                                                                  "-I", _CSRC, "-c", os.path.join(_CSRC, src), "-o", obj]

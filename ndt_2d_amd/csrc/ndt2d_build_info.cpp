@@ -16,5 +16,10 @@
 extern "C" const char * ndt2d_build_info(void)
 {
   // (the marker is what build.embedded_sha256() looks for in the file)
-  return "NDT2D_SOURCE_SHA256=" NDT2D_SOURCE_SHA " arch=" NDT2D_BUILD_ARCH " compiler=" __VERSION__;
+  // (hooks=1: libndt2d_hip_hooks.so, the test build with -DNDT2D_TEST_HOOKS -- never the product)
+#ifdef NDT2D_BUILD_HOOKS
+  return "NDT2D_SOURCE_SHA256=" NDT2D_SOURCE_SHA " arch=" NDT2D_BUILD_ARCH " compiler=" __VERSION__ " hooks=1";
+#else
+  return "NDT2D_SOURCE_SHA256=" NDT2D_SOURCE_SHA " arch=" NDT2D_BUILD_ARCH " compiler=" __VERSION__ " hooks=0";
+#endif
 }

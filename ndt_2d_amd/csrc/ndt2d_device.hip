@@ -1091,16 +1091,27 @@ int ndt2d_grid_stage_commit(ndt2d_handle h, size_t n_listed, double cell_size, d
     reinterpret_cast<uint8_t *>(h->cell_bytes.ptr),
     compactable ? reinterpret_cast<uint16_t *>(h->ranks.ptr) : nullptr, n_occ, h->stream);
   if (e != hipSuccess) return fail_hip(h, e, "launch_grid_install");
-  h->bytes_job.cell_index = d_idx;
-  h->bytes_job.cells6 = d_cells6;
-  h->bytes_job.n = n;
-  h->bytes_job.bytes = reinterpret_cast<uint8_t *>(h->cell_bytes.ptr);
-  // (behind the install kernel, which reads the buffer in place)
-  if ((rc = stage_mark(h, h->stage_grid)) != NDT2D_OK) return rc;
+  // The map bytes around the listed cells (they read the records the install has just written):
+  // queued right behind it.  Until round 6 the job waited for the next few-pose launch to carry
+  // it -- the mapper's scoreScan -- or ran ahead of the next search; since a short scan's single
+  // pose is scored on the host (round 4) it always ended up in front of the search, on the
+  // critical path of the mapper's cycle.  Here it runs while the host prepares that search.
   g.cells_lds_image = h->cells_lds_image.ptr;
   g.cells_global = h->cells_global.ptr;
   g.occ_bits = reinterpret_cast<const uint32_t *>(h->occ_bits.ptr);
   g.cell_bytes = reinterpret_cast<const uint8_t *>(h->cell_bytes.ptr);
+  {
+    ndt2d::SparseBytesJob job{};
+    job.cell_index = d_idx;
+    job.cells6 = d_cells6;
+    job.n = n;
+    job.bytes = reinterpret_cast<uint8_t *>(h->cell_bytes.ptr);
+    e = ndt2d::launch_sparse_bytes(g, job, h->stream);
+    if (e != hipSuccess) return fail_hip(h, e, "launch_sparse_bytes");
+    h->bytes_job.n = 0;
+  }
+  // (behind the install kernel, which reads the buffer in place)
+  if ((rc = stage_mark(h, h->stage_grid)) != NDT2D_OK) return rc;
   if (compactable)
   {
     g.compact_records = h->compact.ptr + n6 + n_idx + n_rk;

@@ -313,7 +313,33 @@ __device__ __forceinline__ void raise_host_flag(double * flag_slot, unsigned lon
 // process: the flag leaves as seq | kHostFlagGaveUp, which the host's wait turns into
 // NDT2D_ERR_HIP for THIS call only (ndt2d_device.hip wait_host_flag).
 // (kHostFlagGaveUp itself: ndt2d_kernels.h, the host reads it too)
-constexpr uint32_t kDonePollLimit = 1u << 21;   // x (one L2 load + s_sleep(2), ~1 us): a second or two
+// The bound is TIME, read from the chip's 100 MHz wall clock (round 6; until then a count of
+// poll trips, nominally two seconds -- but trips are not time: on a time-sliced or oversubscribed
+// GPU a healthy launch could have run out of them).  Ten seconds in the product; the test build
+// (NDT2D_TEST_HOOKS), whose tests force the poll to run out, waits half a second.  The clock is
+// read once per 1,024 trips.
+#ifdef NDT2D_TEST_HOOKS
+constexpr unsigned long long kDonePollTicks = 50ull * 1000 * 1000;
+#else
+constexpr unsigned long long kDonePollTicks = 1000ull * 1000 * 1000;
+#endif
+struct BoundedPoll
+{
+  uint32_t trips = 0;
+  unsigned long long since = 0;
+  // one more trip: true when the wait has lasted longer than kDonePollTicks
+  __device__ __forceinline__ bool expired()
+  {
+    if ((++trips & 1023u) != 0u) return false;
+    const unsigned long long now = wall_clock64();
+    if (since == 0)
+    {
+      since = now | 1ull;
+      return false;
+    }
+    return now - since > kDonePollTicks;
+  }
+};
 
 #ifdef NDT2D_TEST_HOOKS
 // Test builds only (python -m ndt_2d_amd.build --test-hooks -> libndt2d_hip_hooks.so): the

@@ -204,7 +204,11 @@ public:
     double cos_th, sin_th;
     ndt2d_cos_sin(pose_theta, &cos_th, &sin_th);  // :135-136
     const size_t quarter = n / 4;
-    const bool side_by_side = quarter >= 8 && interleave_;   // (shorter scans: nothing to gain)
+    // (shorter scans: nothing to gain.  Nor on a grid whose cells do not stay in the host's L2:
+    // there the sequential loop's cache misses overlap by themselves and the stamps only add
+    // to them -- GPU box's EPYC 9575F, nine 720-beam scans: 41 x 41 cells 24.3 -> 20.8 us side by
+    // side, 245 x 245 cells 17.3 -> 20.5 us)
+    const bool side_by_side = quarter >= 8 && interleave_ && n_cells_ * sizeof(HostCell) <= (1u << 20);
     if (!side_by_side)
     {
       // the reference's loop as it stands
@@ -1412,39 +1416,41 @@ int multi_score_poses(ndt2d_matcher * m, const double * poses_xyt, size_t n_pose
   }
   std::string why;
   // the "total particle weight" all-reduce (src/particle_filter.cpp:166-174) with the other
-  // seven moment sums: [n, 8], every device its own row; then the rows summed in device order
+  // seven moment sums: [n, 8], every device its own row -- the ONE collective of the call
+  // (until round 6 the devices' theta-variance parts went through a second one)
   rc = ndt2d::exchange_all_reduce(m->exchange, tables.data(), n * kStats, streams.data(), &why);
   if (rc != NDT2D_OK) return give_in(rc, why);
-  for (size_t r = 0; r < n; ++r)
-  {
-    rc = ndt2d::sum_rows_launch(m->device_ids[r], tables[r], static_cast<int>(n), static_cast<int>(kStats),
-                                m->shards[r].d_sum, streams[r], &why);
-    if (rc != NDT2D_OK) return give_in(rc, why);
-    // (the table serves the second exchange: cleared behind the summation)
-    rc = ndt2d_copy_to_device_async(m->devs[r], tables[r], zeros, n * kStats * sizeof(double));
-    if (rc != NDT2D_OK) return give_in(rc, std::string("ndt2d_copy_to_device_async: ") + ndt2d_last_error(m->devs[r]));
-  }
-  for (size_t r = 0; r < n; ++r)
-  {
-    MatcherShard & sh = m->shards[r];
-    rc = ndt2d_pf_finalize_launch(m->devs[r], sh.d_poses, end[r] - begin[r], sh.d_weights, sh.d_sum, sh.d_table + r * kStats);
-    if (rc != NDT2D_OK) return give_in(rc, std::string("ndt2d_pf_finalize_launch: ") + ndt2d_last_error(m->devs[r]));
-  }
-  rc = ndt2d::exchange_all_reduce(m->exchange, tables.data(), n * kStats, streams.data(), &why);
-  if (rc != NDT2D_OK) return give_in(rc, why);
-  rc = ndt2d_copy_to_host_async(m->dev, rows, tables[0], n * kStats * sizeof(double));
-  if (rc != NDT2D_OK) return give_in(rc, std::string("ndt2d_copy_to_host_async: ") + ndt2d_last_error(m->dev));
-  // the weights' way back, every device on its own thread again
+  // Behind it every device goes on by itself, on its own thread: the rows summed in device order
+  // (the same bits everywhere), updateStatistics with them -- normalised weights, mean and
+  // covariance, and the device's OWN part of the theta variance (:213-217) -- then the weights and
+  // the eight results travel home together; the parts are added below, in device order.
   for (RankStatus & s : st) s = RankStatus();
-  auto back = [&](size_t r) {
+  std::vector<std::string> whys(n);
+  auto finish = [&](size_t r) {
     RankStatus & s = st[r];
-    s.what = "ndt2d_copy_to_host_async";
-    s.rc = ndt2d_copy_to_host_async(m->devs[r], scores_out + begin[r], m->shards[r].d_weights,
-                                    (end[r] - begin[r]) * sizeof(double));
-    const int src = ndt2d_synchronize(m->devs[r]);
+    MatcherShard & sh = m->shards[r];
+    const size_t nr = end[r] - begin[r];
+    s.what = "sum_rows_launch";
+    s.rc = ndt2d::sum_rows_launch(m->device_ids[r], tables[r], static_cast<int>(n), static_cast<int>(kStats), sh.d_sum,
+                                  streams[r], &whys[r]);
+    if (s.rc == NDT2D_OK)
+    {
+      s.what = "ndt2d_pf_finalize_launch";
+      s.rc = ndt2d_pf_finalize_launch(m->devs[r], sh.d_poses, nr, sh.d_weights, sh.d_sum, sh.d_sum + kStats);
+    }
+    if (s.rc == NDT2D_OK)
+    {
+      s.what = "ndt2d_copy_to_host_async";
+      s.rc = ndt2d_copy_to_host_async(m->devs[r], scores_out + begin[r], sh.d_weights, nr * sizeof(double));
+    }
+    if (s.rc == NDT2D_OK)
+    {
+      s.rc = ndt2d_copy_to_host_async(m->devs[r], rows + r * kStats, sh.d_sum + kStats, kStats * sizeof(double));
+    }
+    const int src = ndt2d_synchronize(m->devs[r]);   // (whatever happened: nothing of this device stays in flight)
     if (s.rc == NDT2D_OK) s.rc = src;
   };
-  m->workers->run(back);
+  m->workers->run(finish);
   if ((rc = first_failure(m, st)) != NDT2D_OK) return rc;
   for (size_t k = 0; k < NDT2D_PF_RESULT_DOUBLES; ++k) stats_out[k] = rows[k];
   for (size_t r = 1; r < n; ++r) stats_out[7] += rows[r * kStats + 7];

@@ -462,6 +462,16 @@ constexpr uint64_t kSmallMaxItems = 8192;
 constexpr uint64_t kPartsFourBelow = 10240;
 constexpr uint64_t kPartsTwoBelow = 18432;
 
+// The searches and the particle kernel address their LDS map ABSOLUTELY (lds_byte_at, ndt2d_lane_fn.h:
+// the packed cell bytes are the LDS address), which is right only while the kernel's dynamic block
+// starts at LDS offset 0, i.e. while the kernel has no static __shared__ of its own.  Checked on the
+// host, once per kernel: hipFuncGetAttributes(...).sharedSizeBytes must be 0 (until round 6 the
+// kernels checked it themselves and trapped -- which takes the whole context down with them).
+// hipErrorInvalidDeviceFunction when it is not: the launch does not happen, the call returns an error.
+// (also remembers the largest dynamic LDS size granted to the kernel, so that hipFuncSetAttribute
+// is not called again on every launch)
+hipError_t prepare_absolute_lds_kernel(const void * kernel, size_t dynamic_lds_bytes);
+
 }  // namespace ndt2d
 
 #endif  // NDT2D_KERNELS_H_

@@ -537,6 +537,39 @@ hipError_t dispatch_match_nbl(const MatchArgs & args, uint32_t blocks, size_t ld
 
 }  // namespace
 
+hipError_t prepare_absolute_lds_kernel(const void * kernel, size_t dynamic_lds_bytes)
+{
+  struct Seen
+  {
+    hipError_t status;
+    size_t granted[64];   // per device: the dynamic LDS size hipFuncSetAttribute has been given
+  };
+  static std::mutex mu;
+  static std::unordered_map<const void *, Seen> seen;
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 64) device = 0;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = seen.find(kernel);
+  if (it == seen.end())
+  {
+    Seen s{};
+    hipFuncAttributes attr{};
+    s.status = hipFuncGetAttributes(&attr, kernel);
+    if (s.status == hipSuccess && attr.sharedSizeBytes != 0) s.status = hipErrorInvalidDeviceFunction;
+    it = seen.emplace(kernel, s).first;
+  }
+  if (it->second.status != hipSuccess) return it->second.status;
+  if (dynamic_lds_bytes > 48 * 1024 && dynamic_lds_bytes > it->second.granted[device])
+  {
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             static_cast<int>(dynamic_lds_bytes));
+    if (e != hipSuccess) return e;
+    it->second.granted[device] = dynamic_lds_bytes;
+  }
+  return hipSuccess;
+}
+
+
 // Workspace layout: [work-item counters, 2 KB][256 records of the first reduction
 // stage for each of up to kMaxLaneSlabs slabs][partial records: one per wave (wave
 // mapping) or per work item of a slab (lane mapping)]

@@ -181,8 +181,8 @@ __device__ __forceinline__ void match_lane_body(
   if (blockIdx.x == 0 && threadIdx.x == 0) g_lane_hist = a.scores;   // (set before any block uses it: see the experiment)
 #endif
   uint8_t * lds_map = reinterpret_cast<uint8_t *>(lds);
-  // lds_byte_at() addresses the map absolutely: it must start at LDS offset 0
-  if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();
+  // lds_byte_at() addresses the map absolutely: it must start at LDS offset 0 -- no static
+  // __shared__ in this kernel (the launcher checks: prepare_absolute_lds_kernel)
   const uint32_t map_bytes = static_cast<uint32_t>(geo.map_h) * kMapStride;
   const uint32_t rank_bytes = COMPACT ? compact_rank_bytes(g.ncell) : 0u;
   double * lds_cells = lds + (map_bytes + rank_bytes) / sizeof(double);
@@ -767,13 +767,9 @@ hipError_t launch_match_lane(const MatchArgs & args_in, double * outer, double *
     if (e != hipSuccess) return e;
   }
   auto launch = [&](auto kernel, int threads) -> hipError_t {
-    if (lds_bytes > 48 * 1024)
-    {
-      hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          static_cast<int>(lds_bytes));
-      if (e2 != hipSuccess) return e2;
-    }
+    // (no static LDS in front of the map: prepare_absolute_lds_kernel, ndt2d_kernels.h)
+    const hipError_t e2 = prepare_absolute_lds_kernel(reinterpret_cast<const void *>(kernel), lds_bytes);
+    if (e2 != hipSuccess) return e2;
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), lds_bytes, stream, args,
                        reinterpret_cast<const double4 *>(outer),
                        static_cast<const uint8_t *>(map_image), geo);

@@ -150,11 +150,11 @@ __device__ __forceinline__ void small_final_reduction(const MatchArgs & a, const
     // cannot be reasoned away (another process holding the chip for seconds): the block then
     // publishes "gave up" instead of a record and the host's wait returns NDT2D_ERR_HIP for this
     // call -- no trap, the context stays usable.
-    uint32_t polls = 0;
+    BoundedPoll poll;
     while (__hip_atomic_load(fin.done + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != fin.seq)
     {
       __builtin_amdgcn_s_sleep(2);
-      if (++polls > kDonePollLimit)
+      if (poll.expired())
       {
         gave_up = true;
         break;
@@ -266,7 +266,8 @@ match_small_kernel(const MatchArgs a,
   const unsigned long long w_start = wall_clock64();   // 100 MHz, one time base for the chip
 #endif
   const GridDesc & g = a.grid;
-  if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();
+  // (the map is addressed absolutely, from LDS offset 0: no static __shared__ here -- the
+  // launcher checks, prepare_absolute_lds_kernel)
   if (blockIdx.x == plan.search_blocks)
   {
     // the launch's last block reduces (every search block has been dispatched before it)
@@ -774,13 +775,9 @@ hipError_t launch_match_small(const MatchArgs & args_in, double * workspace, uns
   const bool compact = small_use_compact(args, geo);
   const size_t lds_bytes = small_lds_bytes(args, geo, waves, compact);
   auto launch = [&](auto kernel) -> hipError_t {
-    if (lds_bytes > 48 * 1024)
-    {
-      hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          static_cast<int>(lds_bytes));
-      if (e2 != hipSuccess) return e2;
-    }
+    // (no static LDS in front of the map: prepare_absolute_lds_kernel, ndt2d_kernels.h)
+    const hipError_t e2 = prepare_absolute_lds_kernel(reinterpret_cast<const void *>(kernel), lds_bytes);
+    if (e2 != hipSuccess) return e2;
     if (std::getenv("NDT2D_SMALL_DEBUG") != nullptr)
     {
       int per_cu = -1;

@@ -90,8 +90,8 @@ score_poses_compact_kernel(const PosesArgs a, const uint32_t split)
   extern __shared__ __align__(16) double lds[];
   const GridDesc & g = a.grid;
   // The occupancy bitmap comes first: lds_word_at() addresses it absolutely, so it
-  // must start at LDS offset 0.
-  if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();
+  // must start at LDS offset 0 -- no static __shared__ in this kernel (the launcher checks:
+  // prepare_absolute_lds_kernel, ndt2d_kernels.h).
   uint32_t * lds_bits = reinterpret_cast<uint32_t *>(lds);
   // COARSE: one bit per block of 2^k x 2^k cells (PosesArgs::coarse_bits) instead of one per cell
   const uint32_t k_log2 = COARSE ? a.coarse_log2 : 0u;
@@ -551,11 +551,11 @@ __global__ void __launch_bounds__(kFewThreads) score_few_kernel(const PosesArgs 
       // (forward progress as for ndt2d_match_small.hip's reducing block: the poses' blocks wait for
       // nothing and this block holds one slot while it polls, so the dispatch order is a matter
       // of efficiency, not of correctness; the poll is bounded all the same)
-      uint32_t polls = 0;
+      BoundedPoll poll;
       while (__hip_atomic_load(f.done + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != f.seq)
       {
         __builtin_amdgcn_s_sleep(2);
-        if (++polls > kDonePollLimit)
+        if (poll.expired())
         {
           gave_up = true;
           break;
@@ -815,13 +815,8 @@ hipError_t launch_compact(const PosesArgs & args, uint32_t blocks, uint32_t spli
                           size_t lds_bytes, bool screen, hipStream_t stream)
 {
   auto launch = [&](auto kernel) -> hipError_t {
-    if (lds_bytes > 48 * 1024)
-    {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         static_cast<int>(lds_bytes));
-      if (e != hipSuccess) return e;
-    }
+    const hipError_t e = prepare_absolute_lds_kernel(reinterpret_cast<const void *>(kernel), lds_bytes);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(THREADS), lds_bytes, stream, args, split);
     return hipGetLastError();
   };

@@ -18,9 +18,12 @@ lower flat index = the candidate the reference's loops visit first.
 ParticleFilter::measure: particles are split into contiguous ranges; each rank
 scores its range and reduces {sum w, sum w*x, ...} (8 doubles); one
 all-reduce(sum) of a [world, 8] buffer gives every rank the total particle
-weight (reference src/particle_filter.cpp:166-174) and the moment sums; the theta
-variance is the reference's second pass (:213-217, it needs the circular mean the
-first pass produces) and costs a second, 1-double all-reduce.
+weight (reference src/particle_filter.cpp:166-174) and the moment sums -- the ONE
+collective of a step.  The theta variance is the reference's second pass
+(:213-217: it needs the circular mean, which every rank has after that all-reduce): each
+rank sums w d^2 over ITS particles and the share stays with the rank's weights;
+cov(2,2) is the shares added in rank order (combine_theta_shares) by whoever collects the
+weights -- the resampler, which needs all of them anyway (src/particle_filter.cpp:91-137).
 """
 import math
 
@@ -161,15 +164,14 @@ def allreduce_rows(row, rank, world, dist, device=None):
     return table
 
 
-def finish_particle_statistics(stats_table, weights_local, particles_local, cov22_prev=0.0,
-                               dist=None, device=None):
-    """updateStatistics (reference src/particle_filter.cpp:163-218) from the
-    all-reduced moment sums.  stats_table[world][8] un-normalised sums per rank.
-    Returns (normalised local weights, mean[3], cov[3,3]).  The theta variance is the
-    reference's SECOND pass over the particles (:213-217: it needs the circular mean,
-    which needs the first pass's sums), so a sharded filter needs a second, 1-double
-    all-reduce for it -- done here when `dist` is given.  With the nccl (RCCL) backend
-    the tensor lives on `device` (default: the current GPU); gloo takes a host tensor."""
+def finish_particle_statistics(stats_table, weights_local, particles_local, cov22_prev=0.0):
+    """updateStatistics (reference src/particle_filter.cpp:163-218) from the all-reduced
+    moment sums.  stats_table[world][8]: un-normalised sums per rank.  Returns (normalised
+    local weights, mean[3], cov[3,3], theta_share): cov is complete but for cov[2, 2], which
+    holds cov22_prev -- the reference never zeroes it (:216) -- and still lacks the second
+    pass (:213-217); theta_share is this rank's part of that pass, sum w d^2 over its own
+    particles, d = shortest_angular_distance(theta_i, mean theta).  No collective here: the
+    share travels with the weights, and combine_theta_shares() adds the ranks' shares."""
     st = np.asarray(stats_table, dtype=np.float64).reshape(-1, POSE_STATS).sum(axis=0)
     sum_w = st[0]
     with np.errstate(divide="ignore", invalid="ignore"):
@@ -184,15 +186,17 @@ def finish_particle_statistics(stats_table, weights_local, particles_local, cov2
     # angles::shortest_angular_distance(theta_i, mean_theta)
     r = np.fmod((mean_th - th) + math.pi, 2.0 * math.pi)
     d = np.where(r <= 0.0, r + math.pi, r - math.pi)
-    local = float(np.sum(w * d * d))
-    if dist is not None:
-        import torch
-        if dist.get_backend() == "gloo":
-            t = torch.tensor([local], dtype=torch.float64)
-        else:
-            dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
-            t = torch.tensor([local], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        local = float(t.cpu()[0])
-    cov[2, 2] = cov22_prev + local
-    return w, np.array([mean_x, mean_y, mean_th]), cov
+    share = float(np.sum(w * d * d))
+    cov[2, 2] = cov22_prev
+    return w, np.array([mean_x, mean_y, mean_th]), cov, share
+
+
+def combine_theta_shares(cov, shares):
+    """cov(2,2) += the ranks' theta-variance shares, added in rank order (every consumer the
+    same bits).  `shares`: one value per rank, in rank order.  Returns cov."""
+    total = 0.0
+    for v in shares:
+        total += float(v)
+    cov = np.array(cov, dtype=np.float64)
+    cov[2, 2] += total
+    return cov

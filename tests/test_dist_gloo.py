@@ -46,6 +46,22 @@ def _share_record(scores, dth, dlin, th_first, th_stride, th_count):
     return rec
 
 
+_N_COLLECTIVES = [0]
+
+
+def _count_collectives(dist):
+    """Collectives issued so far in this process (all_reduce is wrapped once, on first use)."""
+    if not getattr(dist, "_ndt2d_counted", False):
+        real = dist.all_reduce
+
+        def counted(*a, **k):
+            _N_COLLECTIVES[0] += 1
+            return real(*a, **k)
+        dist.all_reduce = counted
+        dist._ndt2d_counted = True
+    return _N_COLLECTIVES[0]
+
+
 def _worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
@@ -79,12 +95,16 @@ def _worker(rank, world, port, out_dir):
                    (wl * np.cos(pl[:, 2])).sum(), (wl * np.sin(pl[:, 2])).sum(),
                    (wl * pl[:, 0] * pl[:, 0]).sum(), (wl * pl[:, 0] * pl[:, 1]).sum(),
                    (wl * pl[:, 1] * pl[:, 1]).sum()])
+    # ONE collective per particle step: the [world, 8] table.  The theta variance
+    # share of this rank leaves with its weights (here: into the rank's file)
+    n_before = _count_collectives(dist)
     stats = shard.allreduce_rows(torch.from_numpy(st), rank, world, dist).numpy()
-    w, mean, pcov = shard.finish_particle_statistics(stats, wl, pl, 0.0, dist)
+    w, mean, pcov, share = shard.finish_particle_statistics(stats, wl, pl, 0.0)
+    assert _count_collectives(dist) == n_before + 1
 
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), table=table, best_score=best_score,
              best_index=-1 if best_index is None else best_index, acc=acc, cov=cov,
-             w=w, mean=mean, pcov=pcov, pb=pb, pe=pe)
+             w=w, mean=mean, pcov=pcov, share=share, pb=pb, pe=pe)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -103,6 +123,10 @@ def test_two_rank_sharding_reproduces_the_unsharded_result(tmp_path):
         assert float(o["best_score"]) / 720 == float(g["score"])
         assert np.allclose(o["cov"], g["covariance"], rtol=1e-10, atol=0)
         assert np.allclose(o["mean"], gp["mean"], rtol=1e-10, atol=1e-13)
-        assert np.allclose(o["pcov"], gp["cov"], rtol=1e-9, atol=1e-13)
+        # whoever collects the weights adds the ranks' theta shares, in rank order
+        from ndt_2d_amd import dist as shard
+        pcov = shard.combine_theta_shares(o["pcov"], [float(q["share"]) for q in outs])
+        assert o["pcov"][2, 2] == 0.0 and pcov[2, 2] > 0.0
+        assert np.allclose(pcov, gp["cov"], rtol=1e-9, atol=1e-13)
     w = np.concatenate([o["w"] for o in outs])
     assert np.allclose(w, gp["weights"], rtol=1e-12, atol=0)

@@ -85,5 +85,5 @@ def test_bounded_polls_trip_and_the_context_survives(tmp_path):
         assert isinstance(fault, dict), (key, fault)
         assert fault["code"] == _capi.ERR_HIP, (key, fault)
         assert "gave up" in fault["message"], (key, fault)
-        assert fault["seconds"] < 30.0, (key, fault)          # the bound: a second or two
+        assert fault["seconds"] < 30.0, (key, fault)          # the bound: half a second of the chip clock in the test build (ten in the product)
     assert out["search_recovers"] and out["few_recovers"] and out["search_after_few"], out

@@ -91,8 +91,8 @@ def _nccl_worker(out_path):
     m.synchronize()
     dist.all_reduce(table, op=dist.ReduceOp.SUM)
     rec = table.cpu().numpy()[0]
-    # sharded particle statistics: [1, 8] all-reduce + the 1-double theta-variance
-    # all-reduce of finish_particle_statistics on a DEVICE tensor
+    # sharded particle statistics: the [1, 8] all-reduce on a DEVICE tensor -- the one collective
+    # of a step; the theta-variance share stays with the weights (combine_theta_shares)
     parts = synth.particles(3, 4096)
     parts[:, :2] *= 4.0 / 23.0
     d_parts = torch.from_numpy(parts).cuda()
@@ -102,8 +102,8 @@ def _nccl_worker(out_path):
     m.score_poses_launch(d_parts.data_ptr(), len(parts), d_w.data_ptr(), stats[0].data_ptr())
     m.synchronize()
     dist.all_reduce(stats, op=dist.ReduceOp.SUM)
-    w, mean, cov = shard.finish_particle_statistics(stats.cpu().numpy(), d_w.cpu().numpy(), parts, 0.0,
-                                                    dist=dist, device=torch.device("cuda", 0))
+    w, mean, cov, share = shard.finish_particle_statistics(stats.cpu().numpy(), d_w.cpu().numpy(), parts, 0.0)
+    cov = shard.combine_theta_shares(cov, [share])
     w1, mean1, cov1 = pf_measure(m, parts, pts)
     np.savez(out_path, score=res["score"], pose=res["pose"], best_index=res["best_index"],
              covariance=res["covariance"], rec=rec, w=w, mean=mean, cov=cov, w1=w1, mean1=mean1, cov1=cov1)
@@ -136,7 +136,7 @@ def test_rccl_single_rank_runs_the_production_collectives(tmp_path):
     assert np.allclose(got["cov"], got["cov1"], rtol=1e-9, atol=1e-13)
 
 
-def test_bench_with_eight_ranks_on_one_gpu_finds_the_cfg4_winner():
+def test_bench_with_eight_ranks_on_one_gpu_finds_the_cfg4_winner(tmp_path):
     """Plain `python bench.py --gpus 8`: bench.py starts the driver's own launch command
     (torch.distributed.run, 8 ranks) as a child process and relays rank 0's line; here
     the ranks share this box's one GPU and exchange through gloo
@@ -148,10 +148,20 @@ def test_bench_with_eight_ranks_on_one_gpu_finds_the_cfg4_winner():
     import subprocess
     env = dict(os.environ, NDT2D_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("WORLD_SIZE", None)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1"]
+    detail8 = os.path.join(str(tmp_path), "detail8.json")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+           "--detail-file", detail8]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
-    line = json.loads(r.stdout.strip().splitlines()[-1])
+    # stdout: ONE short line (the driver's contract); the full record is in the detail file
+    assert len(r.stdout.strip().splitlines()) == 1 and len(r.stdout) < 12288
+    short = json.loads(r.stdout)
+    with open(detail8) as f:
+        line = json.load(f)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "dtype"):
+        assert short[key] == line[key]
+    assert short["roofline"]["frac"] == line["roofline"]["frac"] and short["cpu_baseline"]["value"] > 0
+    assert short["particle_filter"]["collectives_per_step"] == 1 and short["detail"]["files"] == [detail8]
     assert len(line["rank_kernel_ms"]["per_rank"]) == 8 and min(line["rank_kernel_ms"]["per_rank"]) > 0
     assert line["speedup_vs_single_gpu_same_workload"] > 0 and line["collective_backend"] == "gloo"
     with open(os.path.join(HERE, "golden", "big_winners.json")) as f:
@@ -176,11 +186,14 @@ def test_bench_with_eight_ranks_on_one_gpu_finds_the_cfg4_winner():
     assert "configs[4]" in pf["workload"] and pf["n_gpus"] == 8
     # the same statistics from one process
     env1 = dict(env, NDT2D_BENCH_FORCE_COLLECTIVE="1")
+    detail1 = os.path.join(str(tmp_path), "detail1.json")
     r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "cfg2", "--steps", "2",
-                         "--warmup", "1", "--no-cpu-baseline", "--no-default-search", "--no-anchors"],
+                         "--warmup", "1", "--no-cpu-baseline", "--no-default-search", "--no-anchors",
+                         "--detail-file", detail1],
                         capture_output=True, text=True, timeout=1200, env=env1, cwd=ROOT)
     assert r1.returncode == 0, r1.stderr[-3000:]
-    one = json.loads(r1.stdout.strip().splitlines()[-1])["particle_filter_cfg5"]["result"]
+    with open(detail1) as f:
+        one = json.load(f)["particle_filter_cfg5"]["result"]
     assert pf["result"]["sum_w"] == pytest.approx(one["sum_w"], rel=1e-12)
     assert np.allclose(pf["result"]["mean"], one["mean"], rtol=1e-10, atol=1e-13)
     assert np.allclose(pf["result"]["cov_xx_xy_yy"], one["cov_xx_xy_yy"], rtol=1e-9)
