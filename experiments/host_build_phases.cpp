@@ -37,6 +37,7 @@ int main(int argc, char ** argv)
     for (size_t k = 0; k < n; ++k) { min_x = std::min(poses[3*k] - rmax, min_x); max_x = std::max(poses[3*k] + rmax, max_x); min_y = std::min(poses[3*k+1] - rmax, min_y); max_y = std::max(poses[3*k+1] + rmax, max_y); }
     if (ndt) ndt->reset(0.25, max_x - min_x, max_y - min_y, min_x, min_y); else ndt.reset(new HostNdt(0.25, max_x - min_x, max_y - min_y, min_x, min_y));
     if (getenv("NOIL")) ndt->set_interleave(false);
+    if (getenv("ILALL")) ndt->set_side_by_side_max_bytes(~size_t(0));
     const double b = now_us();
     for (size_t k = 0; k < n; ++k) ndt->add_scan(poses[3*k], poses[3*k+1], poses[3*k+2], pts + 2 * off[k], off[k+1] - off[k]);
     const double c = now_us();

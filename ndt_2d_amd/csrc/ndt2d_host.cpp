@@ -208,7 +208,7 @@ public:
     // there the sequential loop's cache misses overlap by themselves and the stamps only add
     // to them -- GPU box's EPYC 9575F, nine 720-beam scans: 41 x 41 cells 24.3 -> 20.8 us side by
     // side, 245 x 245 cells 17.3 -> 20.5 us)
-    const bool side_by_side = quarter >= 8 && interleave_ && n_cells_ * sizeof(HostCell) <= (1u << 20);
+    const bool side_by_side = quarter >= 8 && interleave_ && n_cells_ * sizeof(HostCell) <= side_by_side_max_bytes_;
     if (!side_by_side)
     {
       // the reference's loop as it stands
@@ -294,6 +294,9 @@ public:
     // quarters, in beam order -- every point of that cell from the later quarter does, so the
     // cell still sees its points in the reference's order.  The n % 4 beams behind the fourth
     // quarter go the same way.
+    // (Written with selects instead of branches -- stamp, first touch and late list stored for every
+    // point -- the loop is SLOWER: EPYC 9575F, toy map 19.4 -> 26.8 us per addScans; consecutive beams
+    // share cells, and a stamp stored for every point is a store-to-load chain through that cell.)
     size_t n_late = 0;
     {
       const size_t n_touched_before = touched_.size();
@@ -389,6 +392,7 @@ public:
 
   // (tests: the sequential order for every scan -- the two must agree bit for bit)
   void set_interleave(bool on) { interleave_ = on; }
+  void set_side_by_side_max_bytes(size_t bytes) { side_by_side_max_bytes_ = bytes; }   // (experiments)
 
   // NDT::likelihood(Vector2d) (reference src/ndt_model.cpp:162-170) with Cell::score (:105-116)
   // inlined: exp(((-0.5 * q^T) * information) * q) in that order, libm's exp.  Used by the
@@ -488,6 +492,7 @@ private:
   std::vector<int32_t> late_cell_;  // ... and their cells
   uint32_t epoch_ = 0;
   bool interleave_ = true;
+  size_t side_by_side_max_bytes_ = 1u << 20;
 };
 
 // ScanMatcherNDT::addScans' extent + NDT build, reference src/scan_matcher_ndt.cpp:49-74.
