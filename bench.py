@@ -45,9 +45,11 @@ HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MAX_CLOCK_HZ = 2.4e9         # MI355X_MICROARCH.md chip table
 VALU_CYCLES_PER_INST = 4.0   # FP64 / CVT / compare / select / VOP3 wave64 instructions: 4 cycles measured (profiles/r05_ubench_issue.json)
 ISSUE_FILE = os.path.join(_ROOT, "profiles", "r05_ubench_issue.json")   # experiments/ubench_issue.hip
-MIX_FILE = os.path.join(_ROOT, "profiles", "r05_valu_mix.json")         # experiments/asm_loop_mix.py
+MIX_FILE = os.path.join(_ROOT, "profiles", "r06_valu_mix.json")         # experiments/asm_loop_mix.py (static, per kernel)
+# the headline kernel's DYNAMIC mix: path counts x the paths' instruction lists (experiments/lane_path_mix.py)
+PATH_MIX_FILE = os.path.join(_ROOT, "profiles", "r06_lane_path_mix.json")
 FP64_PEAK_TFLOPS = 78.6      # vector FP64
-PMC_CANDIDATES = ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json")   # the newest committed counter passes win
+PMC_CANDIDATES = ("r06_pmc.json", "r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json")   # the newest committed counter passes win
 PMC_NAME = next((n for n in PMC_CANDIDATES if os.path.exists(os.path.join(_ROOT, "profiles", n))),
                 PMC_CANDIDATES[0])
 PMC_FILE = os.path.join(_ROOT, "profiles", PMC_NAME)
@@ -244,6 +246,13 @@ def class_pricing(kernel, k):
     in the bracket."""
     issue = (_load_json(ISSUE_FILE) or {}).get("cycles", {})
     mix = ((_load_json(MIX_FILE) or {}).get("kernels", {}).get(kernel, {}) or {}).get("classes", {})
+    # Round 6, the headline kernel: the two mixed classes are no longer priced by a STATIC count of the
+    # kernel's instructions -- a build with path counters says how often a wave takes each path of the
+    # search (profiles/r06_lane_paths.json), the paths' instruction lists say which forms those are, and
+    # only the per-item remainder no counter covers (12 % of the launch) is bracketed 2 .. 4 cycles.
+    dyn = {}
+    if kernel == "match_lane_compact_kernel" and counters_are_whole_cfg2(k):
+        dyn = (_load_json(PATH_MIX_FILE) or {}).get("mixed_classes", {})
     total = k["SQ_INSTS_VALU"]
     table, cycles, low, high, classified = [], 0.0, 0.0, 0.0, 0.0
     for counter, cls, rep in _CLASS_COUNTERS:
@@ -254,21 +263,37 @@ def class_pricing(kernel, k):
         classified += n
         c = mix.get(cls, {}).get("mean_cycles") or issue.get(rep or "", VALU_CYCLES_PER_INST)
         mixed = cls == "INT32"
+        c_low, c_high, source = (2.0 if mixed else c), (4.0 if mixed else c), ("kernel's static mix" if cls in mix else "ubench")
+        if mixed and "INT32" in dyn:
+            c, c_low, c_high = dyn["INT32"]["mean_cycles"], dyn["INT32"]["mean_cycles_low"], dyn["INT32"]["mean_cycles_high"]
+            source = "path counts x path instruction lists (profiles/r06_lane_path_mix.json)"
         cycles += n * c
-        low += n * (2.0 if mixed else c)
-        high += n * (4.0 if mixed else c)
+        low += n * c_low
+        high += n * c_high
         table.append({"class": cls, "instructions": n, "share": n / total, "cycles_per_instruction": c,
-                      "source": "kernel's static mix" if cls in mix else "ubench"})
+                      "source": source})
     rest = max(total - classified, 0.0)
     if rest > 0:
         c = mix.get("other", {}).get("mean_cycles") or VALU_CYCLES_PER_INST
+        c_low, c_high, source = 2.0, 4.0, ("kernel's static mix" if "other" in mix else "assumed")
+        if "other" in dyn:
+            c, c_low, c_high = dyn["other"]["mean_cycles"], dyn["other"]["mean_cycles_low"], dyn["other"]["mean_cycles_high"]
+            source = "path counts x path instruction lists (profiles/r06_lane_path_mix.json)"
         cycles += rest * c
-        low += rest * 2.0
-        high += rest * 4.0
+        low += rest * c_low
+        high += rest * c_high
         table.append({"class": "other (no class counter: moves, selects, compares, permutes, v_ldexp_f64 ...)",
                       "instructions": rest, "share": rest / total, "cycles_per_instruction": c,
-                      "source": "kernel's static mix" if "other" in mix else "assumed"})
+                      "source": source})
     return {"cycles": cycles, "cycles_low": low, "cycles_high": high, "table": table}
+
+
+def counters_are_whole_cfg2(k):
+    """The path mix was taken on the whole cfg-2 lattice: it prices THAT launch's counters (the file
+    names the instruction count it was checked against), not a share of cfg-4."""
+    doc = _load_json(PATH_MIX_FILE) or {}
+    want = (doc.get("pmc") or {}).get("SQ_INSTS_VALU")
+    return bool(want) and abs(k.get("SQ_INSTS_VALU", 0.0) - want) <= 1e-6 * want
 
 
 def roofline(kernel, kernel_ms, units, n_cu, pmc, expected_dispatch_note, counters=None):
@@ -325,8 +350,9 @@ def roofline(kernel, kernel_ms, units, n_cu, pmc, expected_dispatch_note, counte
         frac_bracket=[k["SQ_INSTS_VALU"] * (pricing["cycles_low"] / k["SQ_INSTS_VALU"]) / t / (n_simd * MAX_CLOCK_HZ),
                       k["SQ_INSTS_VALU"] * (pricing["cycles_high"] / k["SQ_INSTS_VALU"]) / t / (n_simd * MAX_CLOCK_HZ)],
         peak_note="%d SIMDs x %.1f GHz / %.3f cycles per wave-instruction, priced per counter class with the issue cycles "
-                  "measured in profiles/r05_ubench_issue.json (mixed classes: profiles/r05_valu_mix.json); "
-                  "frac_bracket = the two mixed classes all at 2 cycles .. all at 4"
+                  "measured in profiles/r05_ubench_issue.json; the two classes that mix 2- and 4-cycle forms by the "
+                  "kernel's own mix (headline kernel: measured path counts, profiles/r06_lane_path_mix.json; others: static, "
+                  "profiles/r06_valu_mix.json); frac_bracket = what of those classes is not pinned down at 2 cycles .. at 4"
                   % (n_simd, MAX_CLOCK_HZ / 1e9, cycles_per_inst),
         issue_pricing=pricing["table"],
         valu_mix_matches_source=(_load_json(MIX_FILE) or {}).get("source_sha256") == source_hash(),

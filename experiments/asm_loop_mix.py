@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Static VALU instruction mix of the hot kernels' loops, priced with the measured issue cycles
 (profiles/r05_ubench_issue.json) and split the way rocprofv3's SQ_INSTS_VALU_* counters split
-them -> profiles/r05_valu_mix.json, which bench.py's roofline prices a kernel's counters with.
+them -> profiles/r06_valu_mix.json, which bench.py's roofline prices a kernel's counters with.
 
-    python3 experiments/asm_loop_mix.py > profiles/r05_valu_mix.json        (compiles the kernels itself)
+    python3 experiments/asm_loop_mix.py > profiles/r06_valu_mix.json        (compiles the kernels itself)
 
 The hardware counts VALU instructions per CLASS (FP64 add / mul / fma, CVT, INT32, INT64, FP32,
 transcendental; everything else in no class: SQ_INSTS_VALU minus the classes).  Within a class

@@ -290,8 +290,23 @@ __host__ __device__ inline uint32_t compact_rank_bytes(uint32_t ncell)
   return kRankLead + (((ncell + 1u) * 2u + 15u) & ~15u);
 }
 
-#ifdef NDT2D_LANE_HIST
+#if defined(NDT2D_LANE_HIST) || defined(NDT2D_LANE_PATHS)
 __device__ double * g_lane_hist = nullptr;   // set by the kernel from MatchArgs::scores
+#endif
+// experiments/lane_paths.py (-DNDT2D_LANE_PATHS): how often a wave takes each path of the search --
+// the dynamic instruction mix is these counts times the paths' static instruction lists.
+//   [200] work items            [201] 64-beam chunks pre-tested   [202] look-up groups of U beams (x U)
+//   [203] groups with a live lane (per-beam tests run)            [204] beams with a live lane
+//   [205] exact evaluations      [206] ... through the reference's index arithmetic (a lane near a boundary)
+//   [207] evaluations that needed exp()   [208] skip-state refreshes   [209] items reduced (some sum != 0)
+//   [210] single beams through the U = 1 form
+#ifdef NDT2D_LANE_PATHS
+#define NDT2D_PATH(slot, amount)                                                              \
+  do {                                                                                        \
+    if (g_lane_hist != nullptr && (threadIdx.x & 63u) == 0) atomicAdd(g_lane_hist + (slot), static_cast<double>(amount)); \
+  } while (0)
+#else
+#define NDT2D_PATH(slot, amount) do {} while (0)
 #endif
 
 struct LaneCtx
@@ -433,8 +448,10 @@ __device__ __forceinline__ void lane_beams(const GridDesc & g, const LaneCtx & c
     m[u] = lds_byte_at(__builtin_amdgcn_perm(hi[u], lo[u], 0x0c0c0502u));
     top = max(top, m[u]);
   }
+  NDT2D_PATH(U == 1 ? 210 : 202, U);
   if (wave_any(top >= skip_level))
   {
+    NDT2D_PATH(203, 1);
     bool added = false;
     // have the beams' end points on their way before the first exact evaluation needs
     // them (left to itself the compiler loads each pair inside its own branch)
@@ -455,6 +472,7 @@ __device__ __forceinline__ void lane_beams(const GridDesc & g, const LaneCtx & c
       const uint64_t live_mask = __builtin_amdgcn_ballot_w64(m[u] >= skip_level);
       if (live_mask != 0ull)
       {
+        NDT2D_PATH(204, 1);
         // within kNearUnits of a unit boundary on either axis: the beams' coordinates
         // come with both 16-bit fractions biased by kNearUnits (see kNearBias), so that is
         // (frac + 4) mod 2^16 < 8, a 16-bit compare per axis; the y fraction straddles
@@ -472,6 +490,8 @@ __device__ __forceinline__ void lane_beams(const GridDesc & g, const LaneCtx & c
         if ((occ_mask | near_mask) != 0ull)
 #endif
         {
+          NDT2D_PATH(205, 1);
+          if (near_mask != 0ull) NDT2D_PATH(206, 1);
           // points_inner (:121-125) and Cell::score, exact
           const double px = o[u].x + dx;
           const double py = o[u].y + dy;
@@ -521,12 +541,14 @@ __device__ __forceinline__ void lane_beams(const GridDesc & g, const LaneCtx & c
           // !(e < bound) also keeps NaN exponents (degenerate cells) on the exact path
           if (wave_any(!(e < skip_below)))
           {
+            NDT2D_PATH(207, 1);
             sum += exp_score(e);
             added = true;
           }
         }
       }
     }
+    if (added) NDT2D_PATH(208, 1);
     if (added) skip = skip_state(sum, no_skip);
   }
 }

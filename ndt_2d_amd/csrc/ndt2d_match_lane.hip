@@ -177,7 +177,7 @@ __device__ __forceinline__ void match_lane_body(
   // the 64-byte-stride HBM copy (a patch touches 1-4 lines).
   extern __shared__ __align__(16) double lds[];
   const GridDesc & g = a.grid;
-#ifdef NDT2D_LANE_HIST
+#if defined(NDT2D_LANE_HIST) || defined(NDT2D_LANE_PATHS)
   if (blockIdx.x == 0 && threadIdx.x == 0) g_lane_hist = a.scores;   // (set before any block uses it: see the experiment)
 #endif
   uint8_t * lds_map = reinterpret_cast<uint8_t *>(lds);
@@ -289,6 +289,7 @@ __device__ __forceinline__ void match_lane_body(
 
     double sum = 0.0;
     SkipState skip = skip_state(0.0, geo.no_skip);
+    NDT2D_PATH(200, 1);
     // Beams go by in chunks of 64.  First the wave asks, one beam per lane, whether the
     // patch as a whole can reach a distribution with that beam (patch_can_score: four LDS
     // reads for 64 beams); four beams out of five cannot, and the groups of eight
@@ -306,6 +307,7 @@ __device__ __forceinline__ void match_lane_body(
       {
         const double k = row[min(b0 + lane, a.n_beams - 1u)].z;
         can_score = __builtin_amdgcn_ballot_w64(patch_can_score(k + dxy_corner, geo.box_span));
+        NDT2D_PATH(201, 1);
       }
 #ifdef NDT2D_LANE_TRACE
       trace_flagged += static_cast<uint32_t>(__popcll(can_score));
@@ -391,7 +393,7 @@ __device__ __forceinline__ void match_lane_body(
       acc[7] += dy * score;
       acc[8] += dt * score;
       acc[9] += score;
-#if !defined(NDT2D_LANE_HIST) && !defined(NDT2D_LANE_TRACE)
+#if !defined(NDT2D_LANE_HIST) && !defined(NDT2D_LANE_TRACE) && !defined(NDT2D_LANE_PATHS)
       if (a.scores != nullptr) a.scores[local] = score;
 #endif
     }
@@ -408,6 +410,7 @@ __device__ __forceinline__ void match_lane_body(
     // would the reduction: skip it.  cfg-2 - 0.7 %, cfg-4 - 1.3 %)
     if (wave_any(sum != 0.0))
     {
+      NDT2D_PATH(209, 1);
       wave_best_to_last_lane(best_s, best_i);
 #pragma unroll
       for (int k = 0; k < 10; ++k) acc[k] = wave_sum_to_last_lane(acc[k]);
