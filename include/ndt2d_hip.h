@@ -296,7 +296,8 @@ int ndt2d_pf_finalize_totals_launch(ndt2d_handle h, const double * d_poses_xyt, 
 int ndt2d_pf_result_read(ndt2d_handle h, double * out);
 /* Host-pointer convenience = ParticleFilter::measure for the beams of
  * ndt2d_set_beams: H2D particles, score, statistics, D2H normalised weights and
- * the NDT2D_PF_RESULT_DOUBLES result. */
+ * the NDT2D_PF_RESULT_DOUBLES result.  (From 131,072 particles the call is pipelined in pieces:
+ * see ndt2d_set_pipeline_pieces for what that means for the last bits of the statistics.) */
 int ndt2d_pf_measure(ndt2d_handle h, const double * h_poses_xyt, size_t n_poses,
                      double * h_weights, double * h_out);
 
@@ -473,6 +474,13 @@ int ndt2d_set_variant(ndt2d_handle h, const char * name);
  * src/particle_filter.cpp:78-89) is cut into pieces: piece k + 1 is uploaded on a stream of its own
  * while piece k is scored, raw scores travel back under the piece after.  The raw scores do not
  * depend on the cut (bit-identical), the pieces' moment sums are added in piece order.
+ * CONTRACT on the statistics: the eight moment sums (total weight, sum w x, ...) are sums of a
+ * million terms whose ORDER follows the cut -- pieces here, devices in a multi-device matcher
+ * (ndt2d_matcher_set_multi_thresholds), blocks of the one-launch form -- so the normalised weights,
+ * mean and covariance of ndt2d_pf_measure / ndt2d_score_poses(h_stats) agree between any two
+ * settings of this knob (and between one and several devices) to within 64 ulps of the sums'
+ * magnitude, not bit for bit; a caller that needs the same bits every time fixes the knob.
+ * tests/test_gpu_pose_batch_pipeline.py holds every setting to that bound.
  * pieces: 0 = default (4), 1 = off (one upload, one launch, one download), at most 16. */
 int ndt2d_set_pipeline_pieces(ndt2d_handle h, int pieces);
 /* Pieces the last ndt2d_score_poses / ndt2d_pf_measure was cut into (1: not pipelined). */

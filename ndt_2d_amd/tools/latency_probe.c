@@ -61,6 +61,14 @@ static void op_add(void)
   if (ndt2d_matcher_reset(m) != NDT2D_OK) exit(5);
   if (ndt2d_matcher_add_scans(m, map_poses, map_pts, map_off, n_map_scans) != NDT2D_OK) exit(6);
 }
+/* what follows an addScans in the node: scoreScan and matchScan of the new scan (untimed filler
+ * between timed addScans calls -- a scoreScan alone would leave its search-ahead in flight and the
+ * next addScans waiting for it, which is not the node's sequence) */
+static void op_score_and_match(void)
+{
+  op_score_scan();
+  op_match();
+}
 static void op_cycle(void)
 {
   op_add();
@@ -572,10 +580,10 @@ int main(int argc, char ** argv)
   double med[8], p99[8];
   measure(op_match, REPS, &med[0], &p99[0]);
   measure(op_score_scan, REPS, &med[1], &p99[1]);
-  /* reset + addScans as the node issues it: a call that returns a result (scoreScan) follows
-   * every one (untimed here).  Back to back -- nothing fetched in between -- each install first
+  /* reset + addScans as the node issues it: scoreScan + matchScan of the scan follow every one
+   * (untimed here).  Back to back -- nothing fetched in between -- each install first
    * has to ask the stream whether the one before has read the staging buffer. */
-  measure_between(op_add, op_score_scan, REPS / 4, &med[2], &p99[2]);
+  measure_between(op_add, op_score_and_match, REPS / 4, &med[2], &p99[2]);
   double add_b2b, add_b2b_p99;
   measure(op_add, REPS / 4, &add_b2b, &add_b2b_p99);
   measure(op_cycle, REPS / 4, &med[3], &p99[3]);
@@ -630,7 +638,7 @@ int main(int argc, char ** argv)
   double rmed[5], rp99[5];
   measure(op_match, REPS, &rmed[0], &rp99[0]);
   measure(op_score_scan, REPS, &rmed[1], &rp99[1]);
-  measure_between(op_add, op_score_scan, REPS / 4, &rmed[2], &rp99[2]);
+  measure_between(op_add, op_score_and_match, REPS / 4, &rmed[2], &rp99[2]);
   double radd_b2b, radd_b2b_p99;
   measure(op_add, REPS / 4, &radd_b2b, &radd_b2b_p99);
   measure(op_cycle, REPS / 4, &rmed[3], &rp99[3]);

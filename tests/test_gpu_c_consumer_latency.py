@@ -32,3 +32,40 @@ def test_c_probe_matches_the_python_path():
         assert 0.05 < out[key] < 5000.0    # (scoreScan of 100 beams is scored on the host: ~1 us)
     # the unchanged ParticleFilter::measure loop (500 scorePoints calls) through the host path
     assert out["measure_500_particles_unchanged_loop_us"] < 2000.0
+
+
+def test_mapper_cycle_stays_within_2p6_kernel_times():
+    """The node's own workload: reset + addScans + scoreScan + matchScan per accepted scan (reference
+    src/ndt_mapper.cpp:508-515) from the plain-C host.  Rounds 4 and 5 let the host side of that cycle
+    grow while the kernels were tuned (65 -> 72 us with the search kernel unchanged at 26.6 us); this
+    is the tripwire VERDICT r05 asked for: the whole cycle within 2.6 x the search kernel's own time
+    (round 6: 66.8 us against 26.6 = 2.51).  Best of three probe runs; a box whose HOST is plainly
+    slower than the one the bound was set on (its 100-beam host scoreScan above 1.5 us, 0.95 there)
+    skips -- the bound guards the code, not the box."""
+    from ndt_2d_amd import ScanMatcherNDT, build, synth
+    build.build_all()
+    runs = []
+    for _ in range(3):
+        r = subprocess.run([build.PROBE_PATH], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (r.returncode, r.stderr)
+        runs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    best = min(runs, key=lambda o: o["mapper_cycle_us"])
+    m = ScanMatcherNDT(0)
+    m.initialize("probe", **synth.matcher_params(1, search_linear_size=0.05, search_linear_resolution=0.005,
+                                                 search_angular_size=0.1, search_angular_resolution=0.0025,
+                                                 laser_max_beams=100))
+    m.addScans(synth.map_scans(1))
+    _, pts, _ = synth.query_scan(1)
+    kernel_us = []
+    for i in range(30):
+        m.matchScan((0.11, -0.05, 0.02), pts)
+        if i >= 10:
+            kernel_us.append(m.last_launch_ms()[0] * 1e3)
+    kernel = float(np.median(kernel_us))
+    assert "small-lattice" in m.last_variant() and 10.0 < kernel < 60.0
+    if min(o["score_scan_us"] for o in runs) > 1.5:
+        pytest.skip("this box's host is slower than the reference box (host scoreScan %.2f us): cycle %.1f us, kernel %.1f us"
+                    % (min(o["score_scan_us"] for o in runs), best["mapper_cycle_us"], kernel))
+    assert best["mapper_cycle_us"] <= 2.6 * kernel, (best["mapper_cycle_us"], kernel)
+    # addScans itself: the host build of nine 720-beam scans + the list install's two launches
+    assert best["add_scans_us"] <= 1.6 * kernel, (best["add_scans_us"], kernel)

@@ -50,6 +50,11 @@ def test_pipelined_batch_leaves_no_trace(big_filter, pieces):
     finally:
         gpu.set_pipeline_pieces(0)
     assert np.array_equal(s, s1)
+    # the contract of include/ndt2d_hip.h (ndt2d_set_pipeline_pieces): the moment sums are added in
+    # piece order, so the normalised weights agree to within 64 ulps of the sums' magnitude -- every
+    # weight is a raw score over the total, and only the total's last bits move
+    total = float(np.sum(s1))
+    assert np.max(np.abs(w * total - w1 * total)) <= 64 * np.spacing(np.max(np.abs(s1)))
     assert np.max(np.abs(w - w1)) <= 1e-15 * np.max(np.abs(w1)) * 64
     assert np.allclose(mean, mean1, rtol=0, atol=1e-12)
     assert np.allclose(cov, cov1, rtol=1e-11, atol=1e-13)
