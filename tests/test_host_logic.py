@@ -218,3 +218,34 @@ def test_a_lattice_that_would_not_end_is_an_error_code(size, res):
     n = C.c_size_t(0)
     assert _capi.lib().ndt2d_search_offsets(size, res, None, 0, C.byref(n)) == _capi.ERR_INVALID
     assert len(search_offsets(0.05, 0.005)) == 21
+
+
+def test_random_scan_sets_build_bit_for_bit_like_the_sequential_loop_and_the_oracle():
+    """A slice of experiments/fuzz_host_build.py (142,850 cases without a difference in round 6): random
+    scan sets, ranges that make degenerate cells (NaN information) included -- compared as bits."""
+    from ndt_2d_amd.scan_matcher import BUILD_SEQUENTIAL
+    rng = np.random.default_rng(66)
+    for _ in range(250):
+        n_scans = int(rng.integers(1, 8))
+        nb = int(rng.choice([1, 7, 31, 32, 33, 100, 360, 719, 720]))
+        res = float(rng.choice([0.05, 0.1, 0.25, 0.3, 1.0]))
+        rmax = float(rng.choice([0.5, 2.0, 4.75]))
+        spread = float(rng.choice([0.0, 0.01, 0.3, 2.0]))
+        reach = float(rng.choice([0.02, 0.2, 1.0, 5.0, 30.0]))
+        scans = []
+        for _ in range(n_scans):
+            pose = (float(rng.uniform(-spread, spread)), float(rng.uniform(-spread, spread)),
+                    float(rng.uniform(-math.pi, math.pi)))
+            ang = np.linspace(-math.pi, math.pi, nb, endpoint=False)
+            r = [rng.uniform(0, reach, nb), np.full(nb, reach) * rng.uniform(0.99, 1.01, nb),
+                 rng.choice([0.0, reach, reach * 0.5], nb)][int(rng.integers(0, 3))]
+            scans.append((pose, np.stack([r * np.cos(ang), r * np.sin(ang)], axis=1)))
+        a = host_build_grid(res, rmax, scans)
+        b = host_build_grid(res, rmax, scans, BUILD_SEQUENTIAL)
+        m = O.ScanMatcherNDT()
+        m.initialize(ndt_resolution=res, range_max=rmax)
+        m.addScans(scans)
+        c = np.ascontiguousarray(m.ndt.cells6())
+        assert a[1:] == b[1:]
+        assert np.array_equal(a[0].view(np.uint64), b[0].view(np.uint64))
+        assert np.array_equal(a[0].view(np.uint64), c.view(np.uint64))
