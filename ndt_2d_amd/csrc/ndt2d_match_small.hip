@@ -117,10 +117,6 @@ __device__ __forceinline__ void store_agent(double * p, double v)
 {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ double load_agent(const double * p)
-{
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 // The reducing block of a launch (see the header): waits for the n_records records of the
 // launch `fin.seq`, reduces them, publishes the result.  scratch: LDS for one record per wave.
@@ -161,12 +157,33 @@ __device__ __forceinline__ void small_final_reduction(const MatchArgs & a, const
       }
     }
     if (gave_up) break;
-    // the record's words are read only after its `done` word has been seen (acquire)
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    // The record's words are read only after its `done` word has been seen -- in program order, which
+    // is all it takes: the producer stored them with agent-scope (sc1) stores, waited for their
+    // acknowledgement, then stored `done`; the loads below are sc1 loads, served by L2.
+    // (MI355X_MICROARCH.md, inter-workgroup visibility: "sc1 stores AND sc1 loads" need no fence.
+    // Until round 6 an agent-scope acquire -- `buffer_inv sc1` -- stood here.)  The compiler keeps
+    // the order:
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
     const double * p = a.partials + static_cast<size_t>(r) * kRecord;
     double v[kRecord];
-#pragma unroll
-    for (int k = 0; k < kRecord; ++k) v[k] = load_agent(p + k);
+    // six 16-byte sc1 loads per record instead of twelve 8-byte ones: the reducing block pulls all
+    // records through ONE CU's address path, a request per lane and load (round 6)
+    static_assert(kRecord == 12, "a record is six 16-byte pieces");
+    // (ONE statement: the compiler does not know that a hand-written load's register is not ready
+    // until the counter says so)
+    double2 q0, q1, q2, q3, q4, q5;
+    asm volatile("global_load_dwordx4 %0, %6, off sc1\n\t"
+                 "global_load_dwordx4 %1, %6, off offset:16 sc1\n\t"
+                 "global_load_dwordx4 %2, %6, off offset:32 sc1\n\t"
+                 "global_load_dwordx4 %3, %6, off offset:48 sc1\n\t"
+                 "global_load_dwordx4 %4, %6, off offset:64 sc1\n\t"
+                 "global_load_dwordx4 %5, %6, off offset:80 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(q4), "=&v"(q5)
+                 : "v"(p)
+                 : "memory");
+    v[0] = q0.x; v[1] = q0.y; v[2] = q1.x; v[3] = q1.y; v[4] = q2.x; v[5] = q2.y;
+    v[6] = q3.x; v[7] = q3.y; v[8] = q4.x; v[9] = q4.y; v[10] = q5.x; v[11] = q5.y;
     merge_best(v[0], v[1], bs, bi);
 #pragma unroll
     for (int k = 0; k < 10; ++k) acc[k] += v[2 + k];
@@ -177,9 +194,14 @@ __device__ __forceinline__ void small_final_reduction(const MatchArgs & a, const
   // static LDS, and this kernel's map must start at LDS offset 0.)
   uint32_t * wave_gave_up = reinterpret_cast<uint32_t *>(scratch + static_cast<size_t>(kSmallMaxWaves) * kRecord);
   const bool wave_flag = __builtin_amdgcn_ballot_w64(gave_up) != 0ull;
-  wave_best_to_last_lane(bs, bi);
+  // (a wave none of whose lanes holds a record -- six of the fifteen at the plugin's defaults -- has
+  // the neutral record already and leaves its SIMD to the waves that reduce)
+  if (wave * kWave < n_records)
+  {
+    wave_best_to_last_lane(bs, bi);
 #pragma unroll
-  for (int k = 0; k < 10; ++k) acc[k] = wave_sum_to_last_lane(acc[k]);
+    for (int k = 0; k < 10; ++k) acc[k] = wave_sum_to_last_lane(acc[k]);
+  }
   if (lane == kWave - 1)
   {
     scratch[wave * kRecord + 0] = bs;
@@ -636,7 +658,6 @@ SmallPlan small_plan(const MatchArgs & args, const LaneGeom & geo, int cus)
     const uint32_t chunks = (groups + cg - 1) / cg;
     if (cg < 12) best_p = static_cast<uint32_t>(kSmallMaxWaves) / chunks;
   }
-  (void)cus;
   if (const char * env = std::getenv("NDT2D_SMALL_CHUNKS"))   // tuning knobs for
   {                                                             // experiments/small_plan_sweep.py
     const uint32_t c = static_cast<uint32_t>(std::atoi(env));
@@ -655,6 +676,33 @@ SmallPlan small_plan(const MatchArgs & args, const LaneGeom & geo, int cus)
   if (p * plan.chunks > static_cast<uint32_t>(kSmallMaxWaves)) p = kSmallMaxWaves / plan.chunks;
   if (p > plan.tiles) p = plan.tiles;
   if (p < 1) p = 1;
+  // Round 6: fewer tiles per block wherever the whole launch still fits the chip at once (six waves
+  // per SIMD: 24 per CU).  A block ends with its heaviest tile and its waves meet at block-wide
+  // barriers; with every tile a block of its own the light tiles are out of the way at once -- the
+  // plugin's default search (560 tiles of 5 chunks): three tiles per block 24.8 us, one 22.4
+  // (experiments/small_plan_sweep.py).  Which block evaluates a tile leaves no trace in its record:
+  // same bits.  (The chunks -- which DO decide the bits of a score -- stay as they are.)
+  if (best_p > 1 && std::getenv("NDT2D_SMALL_PATCHES") == nullptr && cus > 0)
+  {
+    const uint32_t n_th = args.th_end - args.th_begin;
+    const bool compact = small_use_compact(args, geo);
+    for (uint32_t q = 1; q < p; ++q)
+    {
+      // (blocks of a CU: by its wave slots and by its 160 KB of LDS -- a real lidar's 245 x 245 map is a
+      // 61 KB window per block: two blocks per CU, the launch does not fit, three tiles go on sharing one
+      // copy of it; tried without this test: matchScan on that map 28.6 -> 40 us)
+      uint32_t per_cu = 24u / (q * plan.chunks);
+      const size_t lds = small_lds_bytes(args, geo, q * plan.chunks, compact);
+      const uint32_t by_lds = static_cast<uint32_t>((160u * 1024u) / (lds > 0 ? lds : 1));
+      if (by_lds < per_cu) per_cu = by_lds;
+      const uint64_t blocks = static_cast<uint64_t>(n_th) * ((plan.tiles + q - 1) / q);
+      if (per_cu >= 1 && blocks <= static_cast<uint64_t>(cus) * per_cu)
+      {
+        p = q;
+        break;
+      }
+    }
+  }
   plan.patches_per_block = p;
   plan.blocks_per_theta = (plan.tiles + p - 1) / p;
   {

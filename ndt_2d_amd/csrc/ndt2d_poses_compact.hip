@@ -562,8 +562,11 @@ __global__ void __launch_bounds__(kFewThreads) score_few_kernel(const PosesArgs 
         }
       }
     }
-    // what the other blocks wrote before their `done` words is read after this point only
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    // what the other blocks wrote before their `done` words is read after this point only -- with
+    // agent-scope (sc1) loads of what they stored with agent-scope stores and had acknowledged before
+    // `done`: program order suffices, no cache invalidation (see small_final_reduction,
+    // ndt2d_match_small.hip); the compiler keeps the order:
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
     // (any thread?  through the block's scratch row -- one word per wave -- rather than the
     // device library's workgroup reduction, which brings static LDS of its own)
     {
