@@ -38,8 +38,9 @@ def test_mapper_cycle_stays_within_2p6_kernel_times():
     """The node's own workload: reset + addScans + scoreScan + matchScan per accepted scan (reference
     src/ndt_mapper.cpp:508-515) from the plain-C host.  Rounds 4 and 5 let the host side of that cycle
     grow while the kernels were tuned (65 -> 72 us with the search kernel unchanged at 26.6 us); this
-    is the tripwire VERDICT r05 asked for: the whole cycle within 2.6 x the search kernel's own time
-    (round 6: 66.8 us against 26.6 = 2.51).  Best of three probe runs; a box whose HOST is plainly
+    is the tripwire VERDICT r05 asked for: the whole cycle within 2.6 x the search kernel's own time,
+    plus 3 us of box-to-box noise (round 6: 58.7 us against a kernel of 22.9 us by HIP events = 2.56;
+    round 5's 72.6 us against 26.6 would fail).  Best of three probe runs; a box whose HOST is plainly
     slower than the one the bound was set on (its 100-beam host scoreScan above 1.5 us, 0.95 there)
     skips -- the bound guards the code, not the box."""
     from ndt_2d_amd import ScanMatcherNDT, build, synth
@@ -66,6 +67,6 @@ def test_mapper_cycle_stays_within_2p6_kernel_times():
     if min(o["score_scan_us"] for o in runs) > 1.5:
         pytest.skip("this box's host is slower than the reference box (host scoreScan %.2f us): cycle %.1f us, kernel %.1f us"
                     % (min(o["score_scan_us"] for o in runs), best["mapper_cycle_us"], kernel))
-    assert best["mapper_cycle_us"] <= 2.6 * kernel, (best["mapper_cycle_us"], kernel)
+    assert best["mapper_cycle_us"] <= 2.6 * kernel + 3.0, (best["mapper_cycle_us"], kernel)
     # addScans itself: the host build of nine 720-beam scans + the list install's two launches
-    assert best["add_scans_us"] <= 1.6 * kernel, (best["add_scans_us"], kernel)
+    assert best["add_scans_us"] <= 1.4 * kernel + 3.0, (best["add_scans_us"], kernel)
