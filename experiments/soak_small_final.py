@@ -3,11 +3,15 @@ fence.  A stale read would hand the reducer the PREVIOUS launch's record for a b
 K different scans (every launch's records differ from the launch before it) on the plugin's default lattice and
 holds every result (score, pose, covariance, best index) to the bits of that scan's first result, while a
 second context keeps the chip's other CUs busy with particle batches (its own thread).
-    python experiments/soak_small_final.py <seconds> [scans]"""
+The second leg does the same to the few-pose kernel, whose last block reads the other blocks' scores the same way:
+pf_measure of 500 particles (the node's filter) with K alternating particle sets, weights / mean / covariance to
+the bits of each set's first result.
+    python experiments/soak_small_final.py <seconds per leg> [scans]"""
 import os, sys, threading, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from ndt_2d_amd import ScanMatcherNDT, synth
+from ndt_2d_amd.scan_matcher import pf_measure
 
 seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 5
@@ -49,8 +53,26 @@ while time.time() - t0 < seconds:
         if key(m.matchScan(g, p)) != first[k]:
             bad += 1
         n += 1
-stop = True
-t.join()
 print("%s: %d searches of %d alternating scans in %.0f s beside a second context's particle batches: %d results differ from their scan's first"
       % (variant, n, K, time.time() - t0, bad))
-sys.exit(1 if bad else 0)
+
+sets = [np.column_stack([0.5 * rng.uniform(-1, 1, 500), 0.5 * rng.uniform(-1, 1, 500), 0.2 * rng.uniform(-1, 1, 500)]) for _ in range(K)]
+pts = scans[0][1]
+def pkey(r):
+    return r[0].tobytes() + r[1].tobytes() + r[2].tobytes()
+pfirst = [pkey(pf_measure(m, s_, pts)) for s_ in sets]
+assert len(set(pfirst)) == K
+pvariant = m.last_variant()
+pn = 0
+pbad = 0
+t0 = time.time()
+while time.time() - t0 < seconds:
+    for k, s_ in enumerate(sets):
+        if pkey(pf_measure(m, s_, pts)) != pfirst[k]:
+            pbad += 1
+        pn += 1
+stop = True
+t.join()
+print("%s: %d measures of %d alternating 500-particle sets in %.0f s: %d results differ from their set's first"
+      % (pvariant, pn, K, time.time() - t0, pbad))
+sys.exit(1 if (bad or pbad) else 0)
