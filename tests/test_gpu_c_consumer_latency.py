@@ -34,15 +34,17 @@ def test_c_probe_matches_the_python_path():
     assert out["measure_500_particles_unchanged_loop_us"] < 2000.0
 
 
-def test_mapper_cycle_stays_within_2p6_kernel_times():
+def test_mapper_cycle_stays_within_its_host_budget_and_2p6_kernel_times():
     """The node's own workload: reset + addScans + scoreScan + matchScan per accepted scan (reference
     src/ndt_mapper.cpp:508-515) from the plain-C host.  Rounds 4 and 5 let the host side of that cycle
-    grow while the kernels were tuned (65 -> 72 us with the search kernel unchanged at 26.6 us); this
-    is the tripwire VERDICT r05 asked for: the whole cycle within 2.6 x the search kernel's own time,
-    plus 3 us of box-to-box noise (round 6: 58.7 us against a kernel of 22.9 us by HIP events = 2.56;
-    round 5's 72.6 us against 26.6 would fail).  Best of three probe runs; a box whose HOST is plainly
-    slower than the one the bound was set on (its 100-beam host scoreScan above 1.5 us, 0.95 there)
-    skips -- the bound guards the code, not the box."""
+    grow while the kernels were tuned (65 -> 69 -> 72.6 us with the search kernel unchanged at 26.6 us);
+    this is the tripwire VERDICT r05 asked for.  Two forms: what the cycle spends OUTSIDE the search
+    kernel stays within 41 us (round 3: 38.5, round 4: 42.3 and round 5: 46.0 would fail, round 6: 36.6
+    on four boxes) -- and VERDICT's own form, the cycle within 2.6 x the kernel's time, with 5 us of
+    slack because a ratio tightens whenever the kernel gets faster (round 6: 59.0 us against 22.4 us
+    is already 2.63).  Best of three probe runs; a box whose HOST is plainly slower than the ones the
+    bound was set on (its 100-beam host scoreScan above 1.5 us, 0.95 there) skips -- the bound guards
+    the code, not the box."""
     from ndt_2d_amd import ScanMatcherNDT, build, synth
     build.build_all()
     runs = []
@@ -67,6 +69,7 @@ def test_mapper_cycle_stays_within_2p6_kernel_times():
     if min(o["score_scan_us"] for o in runs) > 1.5:
         pytest.skip("this box's host is slower than the reference box (host scoreScan %.2f us): cycle %.1f us, kernel %.1f us"
                     % (min(o["score_scan_us"] for o in runs), best["mapper_cycle_us"], kernel))
-    assert best["mapper_cycle_us"] <= 2.6 * kernel + 3.0, (best["mapper_cycle_us"], kernel)
+    assert best["mapper_cycle_us"] - kernel <= 41.0, (best["mapper_cycle_us"], kernel)
+    assert best["mapper_cycle_us"] <= 2.6 * kernel + 5.0, (best["mapper_cycle_us"], kernel)
     # addScans itself: the host build of nine 720-beam scans + the list install's two launches
     assert best["add_scans_us"] <= 1.4 * kernel + 3.0, (best["add_scans_us"], kernel)
