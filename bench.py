@@ -1469,12 +1469,16 @@ def c_host_multi_device(ids):
         env.pop(k, None)
 
     def run(exchange):
+        # (the probe takes 2 s with eight contexts on one GPU, 8 s with RCCL set up; the RCCL exchange over more than one
+        # device has never run on hardware -- no multi-GPU node in any round -- so its leg gets the
+        # shorter leash: a hang there must not cost the `--gpus N` line its place in the driver's budget)
+        limit = 150 if exchange == "rccl" else 240
         try:
             r = subprocess.run([probe, "--devices", ",".join(str(i) for i in ids), "--exchange", exchange,
-                                "--workload", "all"], capture_output=True, text=True, timeout=400, env=env)
+                                "--workload", "all"], capture_output=True, text=True, timeout=limit, env=env)
         except subprocess.TimeoutExpired as exc:
             tail = exc.stdout.decode(errors="replace") if isinstance(exc.stdout, bytes) else (exc.stdout or "")
-            return {"error": "probe timed out (400 s)", "exchange_requested": exchange, "stdout_tail": tail[-1500:]}
+            return {"error": "probe timed out (%d s)" % limit, "exchange_requested": exchange, "stdout_tail": tail[-1500:]}
         if r.returncode != 0:
             return {"error": "probe exit %d: %s" % (r.returncode, r.stderr[-500:]), "exchange_requested": exchange}
         try:   # (RCCL writes its own lines to stdout: the probe's is the one that opens the object)
