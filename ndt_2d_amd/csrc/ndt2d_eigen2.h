@@ -181,21 +181,27 @@ NDT2D_HD void closed_form_eigenvalues(double a, double b, double d, double * e0,
 
 // Cell::compute needs the eigenvalues for ONE decision -- `small < 0.001 * large` (src/ndt_model.cpp:88)
 // -- and, only when that holds, for the clamp branch's determinant (:91).  For a covariance that is
-// far from the threshold the decision is known without them, whichever form would compute them:
-// with t = a + d and det = a d - b b the exact eigenvalues l1 <= l2 satisfy l1 / l2 >= l1 l2 / (l1 + l2)^2
-// = det / t^2; the computed det is within a few ulps of a d <= t^2 / 4 of the exact one, and either
-// form returns the eigenvalues within a few tens of ulps OF THE LARGER ONE.  det >= 0.004 t^2 therefore
-// puts the computed `small` above 0.0039 * large: four times the threshold, where the forms' ulps
-// cannot matter.  True = "the test at :88 is false, the branch at :99 is taken"; false = compute them.
-// (Round 6: the transcribed EigenSolver is 34 ns per cell on the host -- 9 us of every addScans of
-// the mapper's cycle -- and 97 % of a map's cells are nowhere near the threshold.)
+// clear of the threshold the decision is known without them, whichever form would compute them:
+// with t = a + d and det = a d - b b the exact eigenvalues l1 <= l2 have r = l1 / l2 with
+// r / (1 + r)^2 = det / t^2 =: q, increasing in r.  The computed det is within eps (a d + b b) <= eps t^2 / 2
+// of the exact one -- a relative 5e2 eps at q = 0.001 -- t^2 within three ulps, and either form
+// returns both eigenvalues within a few tens of ulps OF THE LARGER ONE, i.e. `small` within 1e-12 of
+// itself at this conditioning.  q >= 0.0011 means r >= 0.0011024: a tenth above the threshold, eleven
+// orders of magnitude more than the forms' ulps.  True = "the test at :88 is false, the branch at :99
+// is taken"; false = compute them.
+// (Round 6: the transcribed EigenSolver is 20-34 ns per cell on the host -- 9 us of every addScans of
+// the mapper's cycle.  A lidar map's cells are walls, many seen at a grazing angle and thin: with the
+// first version's limit, 0.004, a third of the 41 x 41 map's cells and half of the 245 x 245 map's
+// still went through the solver -- 93 % / 53 % of those with q in [0.0011, 0.004).  What still does:
+// the cells inside the clamp, whose determinant takes the solver's `large` bit for bit, and a band
+// of a tenth above it.  tests/cpp/eigen_screen_check.cpp samples that band densely.)
 NDT2D_HD bool clamp_test_surely_false(double a, double b, double d)
 {
   const double t = a + d;
   const double tt = t * t;
   const double det = a * d - b * b;
   // (t^2 inside the normal range: no product above has overflowed or lost bits to underflow)
-  return a > 0.0 && d > 0.0 && tt < 1.0e300 && tt > 1.0e-280 && det >= 0.004 * tt;
+  return a > 0.0 && d > 0.0 && tt < 1.0e300 && tt > 1.0e-280 && det >= 0.0011 * tt;
 }
 
 // Eigenvalues of the symmetric covariance [[a, b], [b, d]] in the chosen form.

@@ -32,8 +32,9 @@ int main(int argc, char ** argv)
     const double l2 = std::pow(10.0, -8.0 + 12.0 * uniform());
     double r;
     const double pick = uniform();
-    if (pick < 0.5) r = 0.001 * std::pow(10.0, -1.0 + 2.0 * uniform());         // a decade either side of the threshold
-    else if (pick < 0.7) r = 0.004 * (1.0 + 0.2 * (uniform() - 0.5));            // around the screen's own limit
+    if (pick < 0.35) r = 0.001 * std::pow(10.0, -1.0 + 2.0 * uniform());        // a decade either side of the threshold
+    else if (pick < 0.55) r = 0.0011024 * (1.0 + 0.02 * (uniform() - 0.5));      // around the screen's own limit (q = 0.0011)
+    else if (pick < 0.75) r = 0.001 + 0.00012 * uniform();                       // the band between threshold and limit, and just above
     else r = std::pow(10.0, -12.0 * uniform());
     const double l1 = l2 * r, phi = 6.283185307179586 * uniform();
     const double c = std::cos(phi), s = std::sin(phi);

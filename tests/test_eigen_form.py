@@ -133,4 +133,4 @@ def test_clamp_screen_never_skips_a_cell_that_needs_its_eigenvalues(tmp_path):
     assert r.returncode == 0 and out["violations"] == 0, out
     assert out["screened"] > 0.2 * out["cases"] and out["clamp_branch"] > 0.2 * out["cases"]
     assert out["near_threshold"] > 0.1 * out["cases"]
-    assert out["least_ratio_screened"] > 0.0039
+    assert out["least_ratio_screened"] > 0.00110     # (the screen's limit q = 0.0011 is r = 0.0011024)
